@@ -1,0 +1,41 @@
+// Shared host-side helpers for libemdenoise.so (gfx950 only; no CUDA/HIP dual paths).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/emdenoise.h"
+
+namespace emd {
+
+// thread-local last-error text behind emd_last_error()
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+inline int fail(int code, const char* what) {
+    set_error("%s", what);
+    return code;
+}
+
+// Call after every kernel launch: turns a launch-time HIP error into EMD_E_LAUNCH.
+inline int check_launch(const char* kernel) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", kernel, hipGetErrorString(e));
+        return EMD_E_LAUNCH;
+    }
+    return EMD_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+}  // namespace emd
+
+#define EMD_REQUIRE(cond, code, msg)          \
+    do {                                      \
+        if (!(cond)) return emd::fail(code, msg); \
+    } while (0)

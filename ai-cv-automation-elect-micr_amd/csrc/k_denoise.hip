@@ -1,0 +1,262 @@
+// Graph K: learned symmetric-kernel denoiser (see include/emdenoise.h, emd_kernel_denoise_f32).
+// replaces: misc_py/noise-removal-kernels.py:99-105, :378-399, :409-426.
+//
+// HBM-bound single-channel stencil: 8 algorithmic bytes per pixel (read 4, write 4).
+//
+// k3_rows<MODE,R>  width-3 fast path.  One wavefront owns a strip of R output rows x 512 pixels:
+//   each lane holds 8 consecutive pixels of a row (two 16-B loads, 2 KiB per wave-row, coalesced
+//   along W), gets its two horizontal halo pixels from the neighbouring lanes by wave shuffles
+//   (no LDS image), and rolls three rows through registers down the strip.  Every input row is
+//   turned ONCE into its three row-contributions (as the top / middle / bottom row of a 3x3
+//   window), so the sigmoid work is per INPUT pixel:
+//     MODE_SYM  (D4-symmetric maps, depth 2): 3 sigmoids per input pixel (centre/edge/corner class)
+//               instead of 9 per output pixel, because the weight a tap uses depends only on its
+//               class and the value under it.
+//     MODE_GEN  (any 3x3 maps, depth 2): 9 sigmoids per input pixel.
+//     MODE_LIN  (depth 1): plain 3x3 correlation.
+// k_generic        any odd width <= 15, depth <= 5, any H,W: one thread per pixel.
+#include "emd_common.hpp"
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+// a / (1 + 2^(p*ws + bs))  ==  a * sigmoid(w*p + b)  with ws = -w*log2(e), bs = -b*log2(e)
+__device__ __forceinline__ float sig_term(float p, float ws, float bs, float a) {
+    const float e = __builtin_amdgcn_exp2f(fmaf(p, ws, bs));
+    return a * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_generic(const float* __restrict__ x, float* __restrict__ y,
+                                                 int B, int H, int W, int width, int depth,
+                                                 const float* __restrict__ params) {
+    const int ww = width * width;
+    const float* wm = params;
+    const float* bm = params + depth * ww;
+    const float* sc = params + 2 * depth * ww;
+    const int p = width >> 1;
+    const long total = (long)B * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % W);
+        const long t = idx / W;
+        const int r = (int)(t % H);
+        const float* img = x + (t / H) * (long)H * W;
+        float acc = 0.f;
+        for (int i = 0; i < width; ++i) {
+            const int rr = reflect_idx(r + i - p, H);
+            for (int j = 0; j < width; ++j) {
+                const int cc = reflect_idx(c + j - p, W);
+                const int k = i * width + j;
+                float f = wm[k] * img[(long)rr * W + cc];
+                for (int l = 1; l < depth; ++l) {
+                    const float z = f + bm[l * ww + k];
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * z));
+                    f = wm[l * ww + k] * (sc[l] * sg);
+                }
+                acc += f;
+            }
+        }
+        y[idx] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+enum { MODE_LIN = 0, MODE_SYM = 1, MODE_GEN = 2 };
+
+constexpr int kPx = 8;  // pixels per lane
+
+struct K3Params {  // pre-scaled on the device from the params block (wave-uniform -> SGPRs)
+    float ws[9], bs[9], a[9];
+};
+
+template <int MODE>
+__device__ __forceinline__ K3Params load_k3(const float* __restrict__ params, int depth) {
+    K3Params q;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (MODE == MODE_LIN) {
+            q.ws[k] = params[k];  // plain weights
+            q.bs[k] = 0.f;
+            q.a[k] = 0.f;
+        } else {
+            const float w0 = params[k];
+            const float b1 = params[depth * 9 + 9 + k];
+            const float w1 = params[9 + k];
+            const float s1 = params[2 * depth * 9 + 1];
+            q.ws[k] = -kLog2e * w0;
+            q.bs[k] = -kLog2e * b1;
+            q.a[k] = w1 * s1;
+        }
+    }
+    return q;
+}
+
+// Row contributions of one input row: A[i][j] is what pixel column j of this row adds to the output
+// row for which it is window-row i (0 top, 1 middle, 2 bottom).  p[0..9] = columns -1..8.
+template <int MODE>
+__device__ __forceinline__ void row_terms(const float (&p)[kPx + 2], const K3Params& q,
+                                          float (&A0)[kPx], float (&A1)[kPx], float (&A2)[kPx]) {
+    if (MODE == MODE_SYM) {
+        // classes: centre k=4, edge k=1, corner k=0
+        float E[kPx + 2], C[kPx + 2];
+#pragma unroll
+        for (int j = 0; j < kPx + 2; ++j) {
+            E[j] = sig_term(p[j], q.ws[1], q.bs[1], q.a[1]);
+            C[j] = sig_term(p[j], q.ws[0], q.bs[0], q.a[0]);
+        }
+#pragma unroll
+        for (int j = 0; j < kPx; ++j) {
+            const float Z = sig_term(p[j + 1], q.ws[4], q.bs[4], q.a[4]);
+            A1[j] = Z + (E[j] + E[j + 2]);
+            A0[j] = E[j + 1] + (C[j] + C[j + 2]);
+            A2[j] = A0[j];
+        }
+    } else {
+        float* const A[3] = {A0, A1, A2};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < kPx; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int k = i * 3 + d;
+                    if (MODE == MODE_LIN)
+                        acc = fmaf(q.ws[k], p[j + d], acc);
+                    else
+                        acc += sig_term(p[j + d], q.ws[k], q.bs[k], q.a[k]);
+                }
+                A[i][j] = acc;
+            }
+        }
+    }
+}
+
+template <int MODE, int R>
+__global__ __launch_bounds__(256) void k3_rows(const float* __restrict__ x, float* __restrict__ y,
+                                               int B, int H, int W, int depth,
+                                               const float* __restrict__ params, int nseg,
+                                               int nstrip) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nitems = (long)B * nstrip * nseg;
+    if (item >= nitems) return;  // whole wave exits together
+    const int seg = (int)(item % nseg);
+    const long bs_ = item / nseg;
+    const int strip = (int)(bs_ % nstrip);
+    const int b = (int)(bs_ / nstrip);
+
+    const K3Params q = load_k3<MODE>(params, depth);
+
+    const int px0 = seg * (64 * kPx) + lane * kPx;
+    const bool active = px0 < W;  // W % 8 == 0, so an active lane owns 8 valid pixels
+    const bool first_px = px0 == 0;
+    const bool last_px = px0 + kPx >= W;
+    const float* img = x + (long)b * H * W;
+    float* out = y + (long)b * H * W;
+    const int r0 = strip * R;
+
+    float s0[kPx], s1[kPx];
+#pragma unroll
+    for (int t = 0; t < R + 2; ++t) {
+        int rr = reflect_idx(r0 - 1 + t, H);
+        rr = rr < 0 ? 0 : (rr >= H ? H - 1 : rr);  // rows past a ragged last strip: any valid row
+        const float* row = img + (long)rr * W;
+        float p[kPx + 2];
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (active) {
+            v0 = *reinterpret_cast<const float4*>(row + px0);
+            v1 = *reinterpret_cast<const float4*>(row + px0 + 4);
+        }
+        p[1] = v0.x; p[2] = v0.y; p[3] = v0.z; p[4] = v0.w;
+        p[5] = v1.x; p[6] = v1.y; p[7] = v1.z; p[8] = v1.w;
+        // horizontal halo from the neighbouring lanes
+        float left = __shfl_up(p[8], 1);
+        float right = __shfl_down(p[1], 1);
+        if (first_px) left = p[2];                     // REFLECT: column -1 -> column 1
+        else if (lane == 0 && active) left = row[px0 - 1];
+        if (last_px) right = p[7];                     // REFLECT: column W -> column W-2
+        else if (lane == 63) right = row[px0 + kPx];
+        p[0] = left;
+        p[kPx + 1] = right;
+
+        float A0[kPx], A1[kPx], A2[kPx];
+        row_terms<MODE>(p, q, A0, A1, A2);
+
+        if (t >= 2) {
+            const int orow = r0 + t - 2;
+            if (active && orow < H) {
+                float4 o0, o1;
+                o0.x = s0[0] + A2[0]; o0.y = s0[1] + A2[1]; o0.z = s0[2] + A2[2]; o0.w = s0[3] + A2[3];
+                o1.x = s0[4] + A2[4]; o1.y = s0[5] + A2[5]; o1.z = s0[6] + A2[6]; o1.w = s0[7] + A2[7];
+                float* orow_p = out + (long)orow * W + px0;
+                *reinterpret_cast<float4*>(orow_p) = o0;
+                *reinterpret_cast<float4*>(orow_p + 4) = o1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kPx; ++j) {
+            s0[j] = (t >= 1) ? s1[j] + A1[j] : 0.f;
+            s1[j] = A0[j];
+        }
+    }
+}
+
+template <int MODE, int R>
+int launch_k3(const float* x, float* y, int B, int H, int W, int depth, const float* params,
+              hipStream_t st) {
+    const int nseg = (W + 64 * kPx - 1) / (64 * kPx);
+    const int nstrip = (H + R - 1) / R;
+    const long nitems = (long)B * nstrip * nseg;
+    const long nblk = (nitems + 3) / 4;
+    if (nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "emd_kernel_denoise_f32: grid too large");
+    hipLaunchKernelGGL((k3_rows<MODE, R>), dim3((unsigned)nblk), dim3(256), 0, st, x, y, B, H, W, depth,
+                       params, nseg, nstrip);
+    return emd::check_launch("k3_rows");
+}
+
+}  // namespace
+
+extern "C" size_t emd_kernel_params_count(int width, int depth) {
+    if (width < 1 || depth < 1) return 0;
+    return (size_t)2 * depth * width * width + depth;
+}
+
+extern "C" int emd_kernel_denoise_f32(const float* x, float* y, int B, int H, int W, int width,
+                                      int depth, const float* params, unsigned flags,
+                                      emd_stream_t stream) {
+    EMD_REQUIRE(x && y && params, EMD_E_INVALID, "emd_kernel_denoise_f32: null pointer");
+    EMD_REQUIRE(x != y, EMD_E_INVALID, "emd_kernel_denoise_f32: y must not alias x");
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_kernel_denoise_f32: bad shape");
+    EMD_REQUIRE(width >= 1 && (width & 1) && width <= EMD_K_MAX_WIDTH, EMD_E_INVALID,
+                "emd_kernel_denoise_f32: width must be odd and <= 15");
+    EMD_REQUIRE(depth >= 1 && depth <= EMD_K_MAX_DEPTH, EMD_E_INVALID,
+                "emd_kernel_denoise_f32: depth must be 1..5");
+    EMD_REQUIRE(width / 2 < H && width / 2 < W, EMD_E_INVALID,
+                "emd_kernel_denoise_f32: REFLECT padding needs width/2 < min(H,W)");
+    EMD_REQUIRE((flags & ~EMD_K_SYMMETRIC) == 0, EMD_E_INVALID, "emd_kernel_denoise_f32: unknown flag");
+    if (B == 0) return EMD_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    const bool fast = width == 3 && depth <= 2 && (W % kPx) == 0 && W >= 16 && H >= 2 &&
+                      emd::aligned16(x) && emd::aligned16(y);
+    if (fast) {
+        constexpr int R = 8;
+        if (depth == 1) return launch_k3<MODE_LIN, R>(x, y, B, H, W, depth, params, st);
+        if (flags & EMD_K_SYMMETRIC) return launch_k3<MODE_SYM, R>(x, y, B, H, W, depth, params, st);
+        return launch_k3<MODE_GEN, R>(x, y, B, H, W, depth, params, st);
+    }
+    const long total = (long)B * H * W;
+    long nblk = (total + 255) / 256;
+    if (nblk > 256L * 32) nblk = 256L * 32;  // grid-stride the rest
+    hipLaunchKernelGGL(k_generic, dim3((unsigned)nblk), dim3(256), 0, st, x, y, B, H, W, width, depth,
+                       params);
+    return emd::check_launch("k_generic");
+}

@@ -1,0 +1,210 @@
+"""Graph D oracle: the inference denoiser (oracle; test infrastructure only).
+
+Restates ``architecture()`` of machine_learning/denoiser.py:58-398 with the TF op semantics of
+oracle/tf_ops.py, on PyTorch-CPU tensors (float32, or float64 to measure the oracle's own
+rounding).  PARITY UNPINNED (oracle/__init__.py).
+
+Variables are fetched by their TensorFlow names, generated in graph-construction order under
+``tf.variable_scope('nn')`` (denoiser.py:514): slim layers take the default scopes
+``SeparableConv2d``/``Conv``/``Conv2d_transpose`` and ``tf.contrib.layers.batch_norm`` takes
+``BatchNorm``, each uniquified with ``_1, _2, ...`` inside its parent scope.
+
+``cropsize`` is 512 in the reference (denoiser.py:54) with ``aspp_size = 32 = cropsize/16``
+(:45); the oracle keeps that ratio so that the same graph can be checked at small crops.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import tf_ops as T
+
+# denoiser.py:38-52
+features0, features1, features2, features3, features4 = 64, 128, 256, 728, 728
+aspp_filters = features4
+aspp_output = 256
+aspp_rateSmall, aspp_rateMedium, aspp_rateLarge = 6, 12, 18
+num_extra_blocks = 11
+channels = 1
+
+
+class _Names:
+    """tf.variable_scope default-name uniquifier (one counter per parent scope)."""
+
+    def __init__(self, prefix):
+        self.prefix = prefix
+        self.counts = {}
+
+    def unique(self, base):
+        n = self.counts.get(base, 0)
+        self.counts[base] = n + 1
+        return f"{self.prefix}/{base}" if n == 0 else f"{self.prefix}/{base}_{n}"
+
+
+class _Graph:
+    def __init__(self, get_var, dtype):
+        self.get = get_var
+        self.names = _Names("nn")
+        self.dtype = dtype
+        self.trace = None  # optional list of (tag, tensor) for per-layer statistics
+
+    # ---- denoiser.py:71-84
+    def _batch_norm_fn(self, x, scope=None):
+        scope = scope or self.names.unique("BatchNorm")
+        C = x.shape[-1]
+        beta = self.get(scope + "/beta", (C,))
+        gamma = self.get(scope + "/gamma", (C,))
+        mean = self.get(scope + "/moving_mean", (C,))
+        var = self.get(scope + "/moving_variance", (C,))
+        return T.batch_norm_inference_t(x, gamma, beta, mean, var)
+
+    def batch_then_activ(self, x):
+        y = T.relu6_t(self._batch_norm_fn(x))
+        if self.trace is not None:
+            self.trace.append(y)
+        return y
+
+    # ---- denoiser.py:86-99
+    def conv_block_not_sep(self, x, filters, kernel_size=3, stride=1):
+        scope = self.names.unique("Conv")
+        w = self.get(scope + "/weights", (kernel_size, kernel_size, x.shape[-1], filters))
+        b = self.get(scope + "/biases", (filters,))
+        return self.batch_then_activ(T.conv2d_t(x, w, b, stride=stride))
+
+    # ---- denoiser.py:110-136 (slim.separable_convolution2d: stride and rate act on the
+    #      depthwise stage; no bias because normalizer_fn is set; normalizer BN then outer BN+relu6)
+    def strided_conv_block(self, x, filters, stride, rate=1):
+        scope = self.names.unique("SeparableConv2d")
+        cin = x.shape[-1]
+        dw = self.get(scope + "/depthwise_weights", (3, 3, cin, 1))
+        pw = self.get(scope + "/pointwise_weights", (1, 1, cin, filters))
+        y = T.depthwise_conv2d_t(x, dw, stride=stride, rate=rate)
+        y = T.conv2d_t(y, pw, None)
+        y = self._batch_norm_fn(y, scope + "/BatchNorm")
+        return self.batch_then_activ(y)
+
+    def conv_block(self, x, filters):
+        return self.strided_conv_block(x, filters, 1, 1)
+
+    # ---- denoiser.py:138-150
+    def deconv_block(self, x, filters):
+        scope = self.names.unique("Conv2d_transpose")
+        w = self.get(scope + "/weights", (3, 3, filters, x.shape[-1]))
+        b = self.get(scope + "/biases", (filters,))
+        return self.batch_then_activ(T.conv2d_transpose_s2_t(x, w, b))
+
+    # ---- denoiser.py:152-216
+    def aspp_block(self, x, aspp_size):
+        conv1x1 = self.conv_block_not_sep(x, aspp_filters, 1)
+        small = self.batch_then_activ(self.strided_conv_block(x, aspp_filters, 1, aspp_rateSmall))
+        medium = self.batch_then_activ(self.strided_conv_block(x, aspp_filters, 1, aspp_rateMedium))
+        large = self.batch_then_activ(self.strided_conv_block(x, aspp_filters, 1, aspp_rateLarge))
+        # :185-189 tf.nn.pool result is discarded; :199 replaces it by a resize of the INPUT
+        pooling = T.resize_bilinear_legacy_t(x, aspp_size, aspp_size)
+        pooling = self.batch_then_activ(pooling)
+        cat = torch.cat([conv1x1, small, medium, large, pooling], dim=3)
+        return self.conv_block_not_sep(cat, aspp_output, 1)
+
+    # ---- denoiser.py:218-229
+    def residual_conv(self, x, filters):
+        return self.conv_block_not_sep(x, filters, 1, stride=2)
+
+    # ---- denoiser.py:231-246
+    def xception_middle_block(self, x, features):
+        m = self.strided_conv_block(x, features, 1)
+        m = self.strided_conv_block(m, features, 1)
+        m = self.strided_conv_block(m, features, 1)
+        return m + x
+
+    # ---- denoiser.py:248-398
+    def build(self, inputs, cropsize):
+        aspp_size = cropsize // 16
+        x = inputs.reshape(-1, cropsize, cropsize, channels)
+
+        cnn0 = self.conv_block(x, features0)
+        cnn0_last = self.conv_block(cnn0, features0)
+        cnn0_strided = self.strided_conv_block(cnn0_last, features1, 2)
+        cnn0_strided = cnn0_strided + self.residual_conv(x, features1)
+
+        cnn1 = self.conv_block(cnn0_strided, features1)
+        cnn1_last = self.conv_block(cnn1, features1)
+        cnn1_strided = self.strided_conv_block(cnn1_last, features1, 2)
+        cnn1_strided = cnn1_strided + self.residual_conv(cnn0_strided, features1)
+
+        cnn2 = self.conv_block(cnn1_strided, features2)
+        cnn2_last = self.conv_block(cnn2, features2)
+        cnn2_strided = self.strided_conv_block(cnn2_last, features2, 2)
+        cnn2_strided = cnn2_strided + self.residual_conv(cnn1_strided, features2)
+
+        cnn3 = self.conv_block(cnn2_strided, features3)
+        cnn3_last = self.conv_block(cnn3, features3)
+        cnn3_strided = self.strided_conv_block(cnn3_last, features3, 2)
+        cnn3_strided = cnn3_strided + self.residual_conv(cnn2_strided, features3)
+
+        cnn4 = self.conv_block(cnn3_strided, features4)
+        cnn4 = self.conv_block(cnn4, features4)
+        cnn4_last = self.conv_block(cnn4, features4)
+        cnn4_last = cnn4_last + cnn3_strided
+
+        for _ in range(num_extra_blocks):
+            cnn4_last = self.xception_middle_block(cnn4_last, features4)
+
+        aspp = self.aspp_block(cnn4_last, aspp_size)
+
+        deconv3 = T.resize_bilinear_legacy_t(aspp, aspp_size * 4, aspp_size * 4)
+
+        concat2 = torch.cat([deconv3, cnn1_strided], dim=3)
+        deconv2 = self.conv_block(concat2, features2)
+        deconv2 = self.conv_block(deconv2, features2)
+        deconv2 = deconv2 + self.conv_block_not_sep(concat2, features2, 1)
+
+        deconv2to1 = self.deconv_block(deconv2, features2)
+
+        concat1 = torch.cat([deconv2to1, cnn0_strided], dim=3)
+        deconv1 = self.conv_block(concat1, features1)
+        deconv1 = self.conv_block(deconv1, features1)
+        deconv1 = deconv1 + self.conv_block_not_sep(concat1, features1, 1)
+
+        deconv1to0 = self.deconv_block(deconv1, features1)
+
+        deconv0 = self.conv_block(deconv1to0, features0)
+        deconv0 = self.conv_block(deconv0, features0)
+        deconv0 = deconv0 + self.conv_block_not_sep(deconv1to0, features0, 1)
+
+        # :387 "1x1" in the comment, but kernel_size defaults to 3
+        return self.conv_block_not_sep(deconv0, 1)
+
+
+def variable_specs(cropsize=32) -> "OrderedDict[str, tuple]":
+    """Names and shapes of every variable, in creation order."""
+    specs = OrderedDict()
+
+    def rec(name, shape):
+        specs[name] = tuple(int(s) for s in shape)
+        return torch.zeros(shape, dtype=torch.float32)
+
+    g = _Graph(rec, torch.float32)
+    with torch.no_grad():
+        g.build(torch.zeros(1, cropsize, cropsize, 1), cropsize)
+    return specs
+
+
+def architecture(inputs, weights, cropsize=512, dtype=torch.float32, trace=None):
+    """inputs [B,cropsize,cropsize,1] (numpy or torch) -> torch tensor [B,cropsize,cropsize,1].
+    ``weights``: dict TF-name -> numpy array.  No output clip (denoiser.py:396)."""
+    cache = {}
+
+    def get(name, shape):
+        if name not in cache:
+            w = weights[name]
+            assert tuple(w.shape) == tuple(shape), (name, w.shape, shape)
+            cache[name] = torch.from_numpy(np.ascontiguousarray(w)).to(dtype)
+        return cache[name]
+
+    g = _Graph(get, dtype)
+    g.trace = trace
+    x = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(inputs))
+    with torch.no_grad():
+        return g.build(x.to(dtype), cropsize)

@@ -1,0 +1,77 @@
+"""CPU tests of the drop-in boundary: libemdenoise.so loads, exports every symbol that
+include/emdenoise.h declares, the ctypes table covers them all, and argument validation (which
+runs before any launch) reports errors through the documented channel.  No compute here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import emdenoise
+from emdenoise import _lib
+
+
+def declared_symbols(root):
+    text = open(os.path.join(root, "include", "emdenoise.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(emd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound(repo_root):
+    syms = declared_symbols(repo_root)
+    assert "emd_kernel_denoise_f32" in syms and "emd_last_error" in syms
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in emdenoise.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
+    for s in _lib.SIGNATURES:
+        assert s in syms, f"{s} bound in _lib.py but not declared in emdenoise.h"
+
+
+def test_version_and_params_count():
+    lib = _lib.load()
+    assert lib.emd_version() == 100
+    assert lib.emd_kernel_params_count(3, 2) == 2 * 2 * 9 + 2
+    assert lib.emd_kernel_params_count(0, 2) == 0
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)
+    two = ctypes.c_void_p(32)
+    rc = lib.emd_kernel_denoise_f32(null, one, 1, 8, 8, 3, 1, one, 0, null)
+    assert rc == -1 and b"null" in lib.emd_last_error()
+    rc = lib.emd_kernel_denoise_f32(one, two, 1, 8, 8, 4, 1, one, 0, null)       # even width
+    assert rc == -1 and b"width" in lib.emd_last_error()
+    rc = lib.emd_kernel_denoise_f32(one, two, 1, 8, 8, 3, 9, one, 0, null)       # depth too large
+    assert rc == -1
+    rc = lib.emd_kernel_denoise_f32(one, two, 1, 1, 8, 3, 1, one, 0, null)       # pad >= H
+    assert rc == -1 and b"REFLECT" in lib.emd_last_error()
+    rc = lib.emd_kernel_denoise_f32(one, one, 1, 8, 8, 3, 1, one, 0, null)       # aliasing
+    assert rc == -1
+    rc = lib.emd_kernel_denoise_f32(one, two, 0, 8, 8, 3, 1, one, 0, null)       # empty batch: no-op
+    assert rc == 0
+    with pytest.raises(_lib.EmdError):
+        _lib.check(-1, "x")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.EmdError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_host_param_packing():
+    import numpy as np
+
+    p = emdenoise.KernelParams.from_symmetric([[1, 2, 3], [4, 5, 6]], [[0, 0, 0], [7, 8, 9]], [1.0, 0.5], 3)
+    assert p.symmetric and p.depth == 2 and p.width == 3
+    blk = p.packed()
+    assert blk.shape == (38,)
+    np.testing.assert_array_equal(blk[:9].reshape(3, 3), [[3, 2, 3], [2, 1, 2], [3, 2, 3]])
+    np.testing.assert_array_equal(blk[27:36].reshape(3, 3), [[9, 8, 9], [8, 7, 8], [9, 8, 9]])
+    assert blk[36] == 1.0 and blk[37] == 0.5
+    w = np.arange(9, dtype=np.float32).reshape(1, 3, 3)
+    assert not emdenoise.KernelParams(w, np.zeros_like(w), np.ones(1, np.float32)).symmetric
