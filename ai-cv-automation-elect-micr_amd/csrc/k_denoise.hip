@@ -3,7 +3,8 @@
 //
 // HBM-bound single-channel stencil: 8 algorithmic bytes per pixel (read 4, write 4).
 //
-// k3_rows<MODE,R>  width-3 fast path.  One wavefront owns a strip of R output rows x 512 pixels:
+// k3_tile<R,NW>    width 3, depth 2, D4-symmetric maps (the reference's configuration): see below.
+// k3_rows<MODE,R>  width 3, any maps / depth 1.  One wavefront owns a strip of R output rows x 512 pixels:
 //   each lane holds 8 consecutive pixels of a row (two 16-B loads, 2 KiB per wave-row, coalesced
 //   along W), gets its two horizontal halo pixels from the neighbouring lanes by wave shuffles
 //   (no LDS image), and rolls three rows through registers down the strip.  Every input row is
@@ -222,6 +223,185 @@ int launch_k3(const float* x, float* y, int B, int H, int W, int depth, const fl
     return emd::check_launch("k3_rows");
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k3_tile<R,NW>  (D4-symmetric maps, depth 2 -- the reference's configuration).
+// Built for thread-level parallelism: a wave owns only R rows x 512 pixels, so a batch is tens of
+// thousands of short-lived waves whose loads overlap other waves' sigmoid work (a plain copy of the
+// same bytes needs that many waves to reach the HBM rate on this chip).
+//   * lane l holds pixels [4l,4l+4) and [256+4l,256+4l+4) of a row: both 16-B loads of a wave are
+//     lane-contiguous 1-KiB requests;
+//   * exactly 3 sigmoids per input pixel: a lane evaluates the centre/edge/corner class terms of its
+//     own 8 pixels only and gets the two horizontal neighbours' TERMS (not pixels) by wave shuffles;
+//     the two 256-pixel halves are stitched with v_readlane; REFLECT at the image border reuses the
+//     lane's own terms.  Only when W > 512 do the two outermost lanes evaluate one extra pixel.
+//   * the NW waves of a workgroup own consecutive R-row strips and pass the single row-contribution
+//     that crosses a strip boundary through LDS; only the workgroup's two outer rows are evaluated
+//     twice.
+//   out[r] = V[r-1] + M[r] + V[r+1],  M = centre + horizontal edges,  V = vertical edge + corners.
+template <int R, int NW>
+__global__ __launch_bounds__(NW * 64) void k3_tile(const float* __restrict__ x, float* __restrict__ y,
+                                                    int H, int W, int depth,
+                                                    const float* __restrict__ params) {
+    static_assert(R >= 2 && NW >= 2, "");
+    constexpr int N = 8;
+    __shared__ float4 xch_first[NW][2][64];  // V of a wave's first row
+    __shared__ float4 xch_last[NW][2][64];   // V of a wave's last row
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // grid = (column segments of 512, row strips of NW*R, images): no integer division, and all
+    // in-image offsets are 32-bit (H*W < 2^31 is checked on the host) -- the scalar unit is shared
+    // by the whole CU, so 64-bit index arithmetic per wave is not free.
+    const int seg = blockIdx.x, strip = blockIdx.y;
+    const size_t img_off = (size_t)blockIdx.z * (size_t)(H * W);
+
+    const K3Params q = load_k3<MODE_SYM>(params, depth);
+
+    const int base = seg * 512;
+    const int px[2] = {base + lane * 4, base + 256 + lane * 4};
+    const bool act[2] = {px[0] < W, px[1] < W};
+    const bool has_left = seg > 0;                 // wave-uniform: pixels exist left of this tile
+    const bool has_right = base + 512 < W;         // wave-uniform
+    const float* img = x + img_off;
+    float* out = y + img_off;
+    const int a = strip * (NW * R) + wv * R;
+
+    struct Raw { float4 g[2]; float ext; };
+    auto load_row = [&](int r, Raw& p) {
+        int rr = reflect_idx(r, H);
+        rr = rr < 0 ? 0 : (rr >= H ? H - 1 : rr);
+        const float* row = img + rr * W;
+        p.g[0] = p.g[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        p.ext = 0.f;
+        if (act[0]) p.g[0] = *reinterpret_cast<const float4*>(row + px[0]);
+        if (act[1]) p.g[1] = *reinterpret_cast<const float4*>(row + px[1]);
+        if (has_left && lane == 0) p.ext = row[base - 1];
+        if (has_right && lane == 63) p.ext = row[base + 512];
+    };
+    // V[j], M[j] for this lane's 8 pixels of one input row
+    auto terms = [&](const Raw& p, float (&V)[N], float (&M)[N]) {
+        const float pv[N] = {p.g[0].x, p.g[0].y, p.g[0].z, p.g[0].w, p.g[1].x, p.g[1].y, p.g[1].z, p.g[1].w};
+        float E[N], C[N], Z[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            Z[j] = sig_term(pv[j], q.ws[4], q.bs[4], q.a[4]);
+            E[j] = sig_term(pv[j], q.ws[1], q.bs[1], q.a[1]);
+            C[j] = sig_term(pv[j], q.ws[0], q.bs[0], q.a[0]);
+        }
+        float Eext = 0.f, Cext = 0.f;
+        if (has_left || has_right) {  // wave-uniform; never taken when W <= 512
+            Eext = sig_term(p.ext, q.ws[1], q.bs[1], q.a[1]);
+            Cext = sig_term(p.ext, q.ws[0], q.bs[0], q.a[0]);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int o = 4 * g;
+            float El = __shfl_up(E[o + 3], 1), Cl = __shfl_up(C[o + 3], 1);
+            float Er = __shfl_down(E[o], 1), Cr = __shfl_down(C[o], 1);
+            if (g == 1) {  // stitch the halves: left neighbour of lane 0 is lane 63 of half 0
+                const float e = __shfl(E[3], 63), c = __shfl(C[3], 63);
+                if (lane == 0) { El = e; Cl = c; }
+            } else {
+                const float e = __shfl(E[4], 0), c = __shfl(C[4], 0);
+                if (lane == 63) { Er = e; Cr = c; }
+                if (lane == 0 && has_left) { El = Eext; Cl = Cext; }
+            }
+            if (g == 1 && lane == 63 && has_right) { Er = Eext; Cr = Cext; }
+            if (px[g] == 0) { El = E[o + 1]; Cl = C[o + 1]; }          // REFLECT: column -1 -> column 1
+            if (px[g] + 4 >= W) { Er = E[o + 2]; Cr = C[o + 2]; }      // REFLECT: column W -> column W-2
+            M[o + 0] = Z[o + 0] + (El + E[o + 1]);
+            M[o + 1] = Z[o + 1] + (E[o + 0] + E[o + 2]);
+            M[o + 2] = Z[o + 2] + (E[o + 1] + E[o + 3]);
+            M[o + 3] = Z[o + 3] + (E[o + 2] + Er);
+            V[o + 0] = E[o + 0] + (Cl + C[o + 1]);
+            V[o + 1] = E[o + 1] + (C[o + 0] + C[o + 2]);
+            V[o + 2] = E[o + 2] + (C[o + 1] + C[o + 3]);
+            V[o + 3] = E[o + 3] + (C[o + 2] + Cr);
+        }
+    };
+    auto store_row = [&](int orow, const float (&v)[N]) {
+        if (orow < H) {
+            float* o = out + orow * W;
+            if (act[0]) *reinterpret_cast<float4*>(o + px[0]) = make_float4(v[0], v[1], v[2], v[3]);
+            if (act[1]) *reinterpret_cast<float4*>(o + px[1]) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    };
+
+    Raw praw[R], pedge;
+#pragma unroll
+    for (int t = 0; t < R; ++t) load_row(a + t, praw[t]);
+    const bool top_wave = wv == 0, bot_wave = wv == NW - 1;
+    if (top_wave) load_row(a - 1, pedge);
+    else if (bot_wave) load_row(a + R, pedge);
+
+    float first_part[N], cur[N], carry[N];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        float V[N], M[N];
+        terms(praw[t], V, M);
+        if (t == 0) {
+            xch_first[wv][0][lane] = make_float4(V[0], V[1], V[2], V[3]);
+            xch_first[wv][1][lane] = make_float4(V[4], V[5], V[6], V[7]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) { first_part[j] = M[j]; carry[j] = V[j]; }
+        } else {
+            if (t == 1) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) first_part[j] += V[j];
+            } else {
+                float o[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] = cur[j] + V[j];
+                store_row(a + t - 1, o);
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) { cur[j] = carry[j] + M[j]; carry[j] = V[j]; }
+        }
+    }
+    xch_last[wv][0][lane] = make_float4(carry[0], carry[1], carry[2], carry[3]);
+    xch_last[wv][1][lane] = make_float4(carry[4], carry[5], carry[6], carry[7]);
+
+    float above[N], below[N];
+    if (top_wave || bot_wave) {  // wave-uniform
+        float V[N], M[N];
+        terms(pedge, V, M);
+#pragma unroll
+        for (int j = 0; j < N; ++j) { above[j] = V[j]; below[j] = V[j]; }
+    }
+    __syncthreads();
+    if (!top_wave) {
+        const float4 u0 = xch_last[wv - 1][0][lane], u1 = xch_last[wv - 1][1][lane];
+        above[0] = u0.x; above[1] = u0.y; above[2] = u0.z; above[3] = u0.w;
+        above[4] = u1.x; above[5] = u1.y; above[6] = u1.z; above[7] = u1.w;
+    }
+    if (!bot_wave) {
+        const float4 d0 = xch_first[wv + 1][0][lane], d1 = xch_first[wv + 1][1][lane];
+        below[0] = d0.x; below[1] = d0.y; below[2] = d0.z; below[3] = d0.w;
+        below[4] = d1.x; below[5] = d1.y; below[6] = d1.z; below[7] = d1.w;
+    }
+    float o0[N], o1[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { o0[j] = first_part[j] + above[j]; o1[j] = cur[j] + below[j]; }
+    store_row(a, o0);
+    store_row(a + R - 1, o1);
+}
+
+template <int R, int NW>
+int launch_k3_tile(const float* x, float* y, int B, int H, int W, int depth, const float* params,
+                   hipStream_t st) {
+    const int nseg = (W + 511) / 512;
+    const int nstrip = (H + NW * R - 1) / (NW * R);
+    if ((long)H * W >= 0x7fffffffL || nstrip > 65535)
+        return emd::fail(EMD_E_UNSUPPORTED, "emd_kernel_denoise_f32: image too large for the tiled kernel");
+    for (int b0 = 0; b0 < B; b0 += 65535) {  // gridDim.z limit
+        const int nb = B - b0 < 65535 ? B - b0 : 65535;
+        const size_t off = (size_t)b0 * H * W;
+        hipLaunchKernelGGL((k3_tile<R, NW>), dim3(nseg, nstrip, nb), dim3(NW * 64), 0, st, x + off, y + off, H, W,
+                           depth, params);
+    }
+    return emd::check_launch("k3_tile");
+}
+
 }  // namespace
 
 extern "C" size_t emd_kernel_params_count(int width, int depth) {
@@ -250,7 +430,7 @@ extern "C" int emd_kernel_denoise_f32(const float* x, float* y, int B, int H, in
     if (fast) {
         constexpr int R = 8;
         if (depth == 1) return launch_k3<MODE_LIN, R>(x, y, B, H, W, depth, params, st);
-        if (flags & EMD_K_SYMMETRIC) return launch_k3<MODE_SYM, R>(x, y, B, H, W, depth, params, st);
+        if (flags & EMD_K_SYMMETRIC) return launch_k3_tile<2, 8>(x, y, B, H, W, depth, params, st);
         return launch_k3<MODE_GEN, R>(x, y, B, H, W, depth, params, st);
     }
     const long total = (long)B * H * W;
