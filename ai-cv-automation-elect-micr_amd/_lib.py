@@ -22,6 +22,32 @@ SIGNATURES = {
     "emd_kernel_params_count": (C.c_size_t, [C.c_int, C.c_int]),
     "emd_kernel_denoise_f32": (C.c_int, [_c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          _c_float_p, C.c_uint, C.c_void_p]),
+    "emd_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "emd_pack_weights_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    # x ldx whi wlo scale1 shift1 scale2 shift2 res ldres y ldy B H W Cin Cout stride act precision stream
+    "emd_conv1x1_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p,
+                                  _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "emd_deconv_phase_taps": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    # x ldx whi[4] wlo[4] scale1 shift1 y ldy B H W Cin Cout act precision stream
+    "emd_deconv3x3s2_f32": (C.c_int, [_c_float_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _c_float_p,
+                                      _c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p]),
+    # x ldx w y ldy B H W C stride rate stream
+    "emd_dw3x3_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # x w9 a shift y ldy B H W Cout stride act stream
+    "emd_cin1_f32": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # x ldx w scale shift y B H W Cin act stream
+    "emd_conv3x3_cout1_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_float, C.c_float, _c_float_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # x ldx y ldy B Hi Wi Ho Wo C stream
+    "emd_resize_bilinear_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # x ldx scale shift y ldy npix C act stream
+    "emd_affine_relu6_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_long,
+                                       C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib = None

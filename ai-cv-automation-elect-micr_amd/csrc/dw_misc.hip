@@ -1,0 +1,374 @@
+// Bandwidth-bound NHWC fp32 kernels of graph D (machine_learning/denoiser.py):
+//   emd_dw3x3_f32          depthwise half of slim.separable_convolution2d (:113-131), stride 1/2, any rate
+//   emd_cin1_f32           layers whose input is the 1-channel image: cnn0 (depthwise 3x3 on C=1 then
+//                          1->Cout pointwise, :252) and residual0 (1x1 stride-2 conv 1->128, :263)
+//   emd_conv3x3_cout1_f32  the final slim.conv2d(64->1, kernel 3) + bias + BN + relu6 (:387)
+//   emd_resize_bilinear_f32  tf.image.resize_images, legacy bilinear (:199, :350)
+//   emd_affine_relu6_f32   a lone batch_then_activ (:200)
+// Layout rule for all of them: channels are innermost, a lane owns 4 consecutive channels (one 16-B
+// access) and consecutive lanes own consecutive channel groups, then consecutive pixels along W, so
+// a wavefront's access is one contiguous run of NHWC memory whenever C >= 4*64/pixels-per-wave.
+#include "emd_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise 3x3, stride 1, rate 1: each thread owns (image b, column ox, channel group c4) and rolls
+// down a strip of TH output rows with the three live input rows' horizontal partial sums in registers:
+// an input row is read once per strip (3 shifted 16-B loads) and turned into its contribution as the
+// top / middle / bottom row of a window.  TF SAME: pad 1 on every side.
+template <int TH>
+__global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x, int ldx,
+                                                     const float* __restrict__ w, float* __restrict__ y,
+                                                     int ldy, int H, int W, int C4, long nthreads, int nstrip) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nthreads) return;
+    const int c4 = (int)(tid % C4);
+    long t = tid / C4;
+    const int ox = (int)(t % W);
+    t /= W;
+    const int strip = (int)(t % nstrip);
+    const long b = t / nstrip;
+    const int C = C4 * 4;
+
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(w + k * C + c4 * 4);
+
+    const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
+    float* yb = y + (b * H) * (long)W * ldy + c4 * 4;
+    const int oy0 = strip * TH;
+    const bool hasl = ox > 0, hasr = ox + 1 < W;
+
+    float4 s0 = f4zero(), s1 = f4zero();  // s0: top+mid of output (t-2); s1: top of output (t-1)
+#pragma unroll
+    for (int tt = 0; tt < TH + 2; ++tt) {
+        const int iy = oy0 - 1 + tt;
+        float4 h0 = f4zero(), h1 = f4zero(), h2 = f4zero();
+        if (iy >= 0 && iy < H) {
+            const float* row = xb + ((long)iy * W + ox) * ldx;
+            const float4 c = *reinterpret_cast<const float4*>(row);
+            const float4 l = hasl ? *reinterpret_cast<const float4*>(row - ldx) : f4zero();
+            const float4 r = hasr ? *reinterpret_cast<const float4*>(row + ldx) : f4zero();
+            h0 = fma4(wk[0], l, fma4(wk[1], c, fma4(wk[2], r, h0)));
+            h1 = fma4(wk[3], l, fma4(wk[4], c, fma4(wk[5], r, h1)));
+            h2 = fma4(wk[6], l, fma4(wk[7], c, fma4(wk[8], r, h2)));
+        }
+        if (tt >= 2) {
+            const int oy = oy0 + tt - 2;
+            if (oy < H) *reinterpret_cast<float4*>(yb + ((long)oy * W + ox) * ldy) = add4(s0, h2);
+        }
+        s0 = add4(s1, h1);
+        s1 = h0;
+    }
+}
+
+// Depthwise 3x3, any stride / rate: one output pixel x 4 channels per thread (9 loads).
+__global__ __launch_bounds__(256) void dw3x3_generic(const float* __restrict__ x, int ldx,
+                                                     const float* __restrict__ w, float* __restrict__ y,
+                                                     int ldy, int H, int W, int C4, int Ho, int Wo,
+                                                     int stride, int rate, int pt, int pl, long nthreads) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nthreads) return;
+    const int c4 = (int)(tid % C4);
+    long t = tid / C4;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const long b = t / Ho;
+    const int C = C4 * 4;
+    const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
+    float4 acc = f4zero();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int iy = oy * stride - pt + i * rate;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ix = ox * stride - pl + j * rate;
+            if (ix < 0 || ix >= W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx);
+            const float4 wk = *reinterpret_cast<const float4*>(w + (i * 3 + j) * C + c4 * 4);
+            acc = fma4(wk, v, acc);
+        }
+    }
+    *reinterpret_cast<float4*>(y + ((b * Ho + oy) * (long)Wo + ox) * ldy + c4 * 4) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cin == 1 layers.  out[pix][n] = relu6( d[pix] * a[n] + t[n] ),  d = (3x3 depthwise of the image) or the
+// (strided) sample itself.  A wave first evaluates d for 64 consecutive output pixels (lane = pixel),
+// then writes them out N4 = Cout/4 lanes per pixel so that each store instruction covers one contiguous
+// 1-KiB run of the NHWC output; the pixel's d travels to its writer lanes by wave shuffle.
+__global__ __launch_bounds__(256) void cin1_kernel(const float* __restrict__ x, const float* __restrict__ w9,
+                                                   const float* __restrict__ a, const float* __restrict__ tsh,
+                                                   float* __restrict__ y, int ldy, int H, int W, int Ho, int Wo,
+                                                   int stride, int N4, int use_dw, long npix, int act) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long p0 = wave * 64;
+    if (p0 >= npix) return;
+    const long pix = p0 + lane;
+    float d = 0.f;
+    if (pix < npix) {
+        const int ox = (int)(pix % Wo);
+        const long t = pix / Wo;
+        const int oy = (int)(t % Ho);
+        const long b = t / Ho;
+        const float* img = x + b * (long)H * W;
+        if (use_dw) {  // 3x3, stride 1, SAME (pad 1)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int iy = oy - 1 + i;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int ix = ox - 1 + j;
+                    if (ix < 0 || ix >= W) continue;
+                    d = fmaf(w9[i * 3 + j], img[(long)iy * W + ix], d);
+                }
+            }
+        } else {
+            d = img[(long)(oy * stride) * W + ox * stride];
+        }
+    }
+    const int ppi = 64 / N4;  // pixels written per store instruction
+    const int sub = lane / N4, n4 = lane % N4;
+    const float4 av = *reinterpret_cast<const float4*>(a + n4 * 4);
+    const float4 tv = *reinterpret_cast<const float4*>(tsh + n4 * 4);
+    for (int q = 0; q < 64; q += ppi) {
+        const float dv = __shfl(d, q + sub);
+        const long op = p0 + q + sub;
+        if (op < npix) {
+            float4 o = make_float4(fmaf(dv, av.x, tv.x), fmaf(dv, av.y, tv.y), fmaf(dv, av.z, tv.z), fmaf(dv, av.w, tv.w));
+            if (act) o = make_float4(relu6f(o.x), relu6f(o.y), relu6f(o.z), relu6f(o.w));
+            *reinterpret_cast<float4*>(y + op * ldy + n4 * 4) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense 3x3 conv to ONE output channel: LP = Cin/4 lanes share a pixel (each owns 4 input channels of
+// all 9 taps) and reduce their partial dot products with wave shuffles; 64/LP pixels per wave.
+__global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ w, float scale,
+                                                            float shift, float* __restrict__ y, int H, int W,
+                                                            int LP, long npix, int act) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int ppw = 64 / LP;
+    const int c4 = lane % LP, sub = lane / LP;
+    const int C = LP * 4;
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(w + k * C + c4 * 4);
+    const long pix = wave * ppw + sub;
+    float4 acc = f4zero();
+    if (pix < npix) {
+        const int ox = (int)(pix % W);
+        const long t = pix / W;
+        const int oy = (int)(t % H);
+        const long b = t / H;
+        const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int iy = oy - 1 + i;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ix = ox - 1 + j;
+                if (ix < 0 || ix >= W) continue;
+                acc = fma4(wk[i * 3 + j], *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx), acc);
+            }
+        }
+    }
+    float s = (acc.x + acc.y) + (acc.z + acc.w);
+    for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m);
+    if (c4 == 0 && pix < npix) {
+        float v = fmaf(s, scale, shift);
+        y[pix] = act ? relu6f(v) : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.image.resize_images: bilinear, align_corners=False, legacy sampling src = dst * (in/out).
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ x, int ldx,
+                                                              float* __restrict__ y, int ldy, int Hi, int Wi,
+                                                              int Ho, int Wo, int C4, float sy, float sx,
+                                                              long nthreads) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nthreads) return;
+    const int c4 = (int)(tid % C4);
+    long t = tid / C4;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const long b = t / Ho;
+    const float fy = (float)oy * sy, fx = (float)ox * sx;
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* xb = x + (b * Hi) * (long)Wi * ldx + c4 * 4;
+    const float4 tl = *reinterpret_cast<const float4*>(xb + ((long)y0 * Wi + x0) * ldx);
+    const float4 tr = *reinterpret_cast<const float4*>(xb + ((long)y0 * Wi + x1) * ldx);
+    const float4 bl = *reinterpret_cast<const float4*>(xb + ((long)y1 * Wi + x0) * ldx);
+    const float4 br = *reinterpret_cast<const float4*>(xb + ((long)y1 * Wi + x1) * ldx);
+    auto lerp = [](float a, float b2, float l) { return a + (b2 - a) * l; };
+    float4 o;
+    o.x = lerp(lerp(tl.x, tr.x, lx), lerp(bl.x, br.x, lx), ly);
+    o.y = lerp(lerp(tl.y, tr.y, lx), lerp(bl.y, br.y, lx), ly);
+    o.z = lerp(lerp(tl.z, tr.z, lx), lerp(bl.z, br.z, lx), ly);
+    o.w = lerp(lerp(tl.w, tr.w, lx), lerp(bl.w, br.w, lx), ly);
+    *reinterpret_cast<float4*>(y + ((b * Ho + oy) * (long)Wo + ox) * ldy + c4 * 4) = o;
+}
+
+__global__ __launch_bounds__(256) void affine_relu6_kernel(const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ sc,
+                                                           const float* __restrict__ sh, float* __restrict__ y,
+                                                           int ldy, int C4, long nthreads, int act) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nthreads) return;
+    const int c4 = (int)(tid % C4);
+    const long pix = tid / C4;
+    const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c4 * 4);
+    const float4 s = *reinterpret_cast<const float4*>(sc + c4 * 4);
+    const float4 t = *reinterpret_cast<const float4*>(sh + c4 * 4);
+    float4 o = make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
+    if (act) o = make_float4(relu6f(o.x), relu6f(o.y), relu6f(o.z), relu6f(o.w));
+    *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = o;
+}
+
+inline int same_pad_before(int n, int k, int s, int r, int* out) {
+    const int o = (n + s - 1) / s;
+    const int eff = (k - 1) * r + 1;
+    int total = (o - 1) * s + eff - n;
+    if (total < 0) total = 0;
+    *out = o;
+    return total / 2;
+}
+
+inline int grid_for(long nthreads, unsigned* blocks) {
+    const long nb = (nthreads + 255) / 256;
+    if (nb <= 0 || nb > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "grid too large");
+    *blocks = (unsigned)nb;
+    return EMD_OK;
+}
+
+}  // namespace
+
+extern "C" int emd_dw3x3_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W,
+                             int C, int stride, int rate, emd_stream_t stream) {
+    EMD_REQUIRE(x && w && y, EMD_E_INVALID, "emd_dw3x3_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1 && C >= 4, EMD_E_INVALID, "emd_dw3x3_f32: bad shape");
+    EMD_REQUIRE(stride == 1 || stride == 2, EMD_E_UNSUPPORTED, "emd_dw3x3_f32: stride must be 1 or 2");
+    EMD_REQUIRE(rate >= 1 && (rate == 1 || stride == 1), EMD_E_UNSUPPORTED, "emd_dw3x3_f32: rate > 1 needs stride 1");
+    EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C, EMD_E_ALIGN,
+                "emd_dw3x3_f32: C, ldx, ldy must be multiples of 4 and ld >= C");
+    EMD_REQUIRE(emd::aligned16(x) && emd::aligned16(y) && emd::aligned16(w), EMD_E_ALIGN,
+                "emd_dw3x3_f32: pointers must be 16-byte aligned");
+    if (B == 0) return EMD_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int Ho, Wo;
+    const int pt = same_pad_before(H, 3, stride, rate, &Ho);
+    const int pl = same_pad_before(W, 3, stride, rate, &Wo);
+    const int C4 = C / 4;
+    unsigned nb;
+    if (stride == 1 && rate == 1) {
+        constexpr int TH = 8;
+        const int nstrip = (H + TH - 1) / TH;
+        const long nthreads = (long)B * nstrip * W * C4;
+        int rc = grid_for(nthreads, &nb);
+        if (rc != EMD_OK) return rc;
+        hipLaunchKernelGGL(dw3x3_s1_roll<TH>, dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip);
+        return emd::check_launch("dw3x3_s1_roll");
+    }
+    const long nthreads = (long)B * Ho * Wo * C4;
+    int rc = grid_for(nthreads, &nb);
+    if (rc != EMD_OK) return rc;
+    hipLaunchKernelGGL(dw3x3_generic, dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, Ho, Wo, stride, rate, pt,
+                       pl, nthreads);
+    return emd::check_launch("dw3x3_generic");
+}
+
+extern "C" int emd_cin1_f32(const float* x, const float* w9, const float* a, const float* shift, float* y, int ldy,
+                            int B, int H, int W, int Cout, int stride, int act, emd_stream_t stream) {
+    EMD_REQUIRE(x && a && shift && y, EMD_E_INVALID, "emd_cin1_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_cin1_f32: bad shape");
+    EMD_REQUIRE(stride == 1 || stride == 2, EMD_E_UNSUPPORTED, "emd_cin1_f32: stride must be 1 or 2");
+    EMD_REQUIRE(!(w9 && stride != 1), EMD_E_UNSUPPORTED, "emd_cin1_f32: the depthwise form is stride 1 only");
+    const int N4 = Cout / 4;
+    EMD_REQUIRE(Cout % 4 == 0 && N4 >= 1 && N4 <= 64 && (64 % N4) == 0, EMD_E_UNSUPPORTED,
+                "emd_cin1_f32: Cout/4 must divide 64");
+    EMD_REQUIRE(ldy % 4 == 0 && ldy >= Cout && emd::aligned16(y) && emd::aligned16(a) && emd::aligned16(shift),
+                EMD_E_ALIGN, "emd_cin1_f32: alignment");
+    if (B == 0) return EMD_OK;
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    const long npix = (long)B * Ho * Wo;
+    unsigned nb;
+    int rc = grid_for((npix + 63) / 64 * 64, &nb);
+    if (rc != EMD_OK) return rc;
+    hipLaunchKernelGGL(cin1_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, w9, a, shift, y, ldy, H,
+                       W, Ho, Wo, stride, N4, w9 ? 1 : 0, npix, act ? 1 : 0);
+    return emd::check_launch("cin1_kernel");
+}
+
+extern "C" int emd_conv3x3_cout1_f32(const float* x, int ldx, const float* w, float scale, float shift, float* y,
+                                     int B, int H, int W, int Cin, int act, emd_stream_t stream) {
+    EMD_REQUIRE(x && w && y, EMD_E_INVALID, "emd_conv3x3_cout1_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_conv3x3_cout1_f32: bad shape");
+    const int LP = Cin / 4;
+    EMD_REQUIRE(Cin % 4 == 0 && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, EMD_E_UNSUPPORTED,
+                "emd_conv3x3_cout1_f32: Cin/4 must be a power of two <= 64");
+    EMD_REQUIRE(ldx % 4 == 0 && ldx >= Cin && emd::aligned16(x) && emd::aligned16(w), EMD_E_ALIGN,
+                "emd_conv3x3_cout1_f32: alignment");
+    if (B == 0) return EMD_OK;
+    const long npix = (long)B * H * W;
+    const int ppw = 64 / LP;
+    unsigned nb;
+    int rc = grid_for((npix + ppw - 1) / ppw * 64, &nb);
+    if (rc != EMD_OK) return rc;
+    hipLaunchKernelGGL(conv3x3_cout1_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w, scale,
+                       shift, y, H, W, LP, npix, act ? 1 : 0);
+    return emd::check_launch("conv3x3_cout1_kernel");
+}
+
+extern "C" int emd_resize_bilinear_f32(const float* x, int ldx, float* y, int ldy, int B, int Hi, int Wi, int Ho,
+                                       int Wo, int C, emd_stream_t stream) {
+    EMD_REQUIRE(x && y, EMD_E_INVALID, "emd_resize_bilinear_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && Hi >= 1 && Wi >= 1 && Ho >= 1 && Wo >= 1 && C >= 4, EMD_E_INVALID,
+                "emd_resize_bilinear_f32: bad shape");
+    EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && emd::aligned16(x) &&
+                    emd::aligned16(y), EMD_E_ALIGN, "emd_resize_bilinear_f32: alignment");
+    if (B == 0) return EMD_OK;
+    const long nthreads = (long)B * Ho * Wo * (C / 4);
+    unsigned nb;
+    int rc = grid_for(nthreads, &nb);
+    if (rc != EMD_OK) return rc;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, y, ldy,
+                       Hi, Wi, Ho, Wo, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo, nthreads);
+    return emd::check_launch("resize_bilinear_kernel");
+}
+
+extern "C" int emd_affine_relu6_f32(const float* x, int ldx, const float* scale, const float* shift, float* y,
+                                    int ldy, long npix, int C, int act, emd_stream_t stream) {
+    EMD_REQUIRE(x && y && scale && shift, EMD_E_INVALID, "emd_affine_relu6_f32: null pointer");
+    EMD_REQUIRE(npix >= 0 && C >= 4, EMD_E_INVALID, "emd_affine_relu6_f32: bad shape");
+    EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && emd::aligned16(x) &&
+                    emd::aligned16(y) && emd::aligned16(scale) && emd::aligned16(shift), EMD_E_ALIGN,
+                "emd_affine_relu6_f32: alignment");
+    if (npix == 0) return EMD_OK;
+    const long nthreads = npix * (C / 4);
+    unsigned nb;
+    int rc = grid_for(nthreads, &nb);
+    if (rc != EMD_OK) return rc;
+    hipLaunchKernelGGL(affine_relu6_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, scale,
+                       shift, y, ldy, C / 4, nthreads, act ? 1 : 0);
+    return emd::check_launch("affine_relu6_kernel");
+}

@@ -1,0 +1,425 @@
+// Implicit-GEMM convolution on the matrix cores: pointwise 1x1, strided 1x1 and the four output
+// phases of the 3x3 stride-2 transposed convolution, all with a fused per-channel epilogue.
+//
+// replaces (TensorFlow ops called by machine_learning/denoiser.py):
+//   the pointwise half of slim.separable_convolution2d (:113-131) + its normalizer BN (:123) +
+//     batch_then_activ (:134)                                  -> emd_conv1x1_f32
+//   slim.conv2d(kernel_size=1[, stride=2]) + bias + BN + relu6 (:91-97, :159-164, :208-214,
+//     :220-227)                                                -> emd_conv1x1_f32
+//   slim.conv2d_transpose(k=3, stride=2, 'same') + bias + BN + relu6 (:141-148)
+//                                                              -> emd_deconv3x3s2_f32
+//   the residual "+=" that follows them (:264, :279, :294, :309, :322, :246, :360, :372, :384)
+//     and tf.concat (:203, :353, :365: outputs are written straight into channel slices).
+//
+// C[M,N] = epilogue( A[M,K] * W[K,N] ):  M = B*Hg*Wg output positions, K = taps*Cin, N = Cout.
+//   A is never materialised: row m = (b,i,j) reads, for tap t, source pixel (b, i*sa+dy_t, j*sa+dx_t)
+//   of the NHWC fp32 activation tensor (zero outside the image), channels contiguous.
+//   W is pre-packed once on the host (emd_pack_weights_bf16) as two bf16 planes (hi, lo) in
+//   [Npad][taps*Cpad] order, i.e. K-contiguous per output channel, zero padded.
+//
+// Numerics ("split-bf16", PASSES=3): fp32 activations are split in-kernel into bf16 hi + bf16 lo
+// (a = hi + lo + O(2^-17 a)) and  acc += Ahi*Whi + Ahi*Wlo + Alo*Whi  in fp32 on
+// v_mfma_f32_32x32x16_bf16: ~2^-16 relative per product, which is what keeps a ~60-layer network
+// inside the 1e-3 relative-L2 parity bar (plain bf16 inputs, PASSES=1, is ~2^-9 per layer and is
+// offered as the fast mode).
+//
+// Block = 256 threads = 4 waves; block tile BM x BN, K step BK; each wave owns a (BM/WM)x(BN/WN)
+// sub-tile as 32x32 MFMA tiles.  A: global fp32 -> registers (issued one K step ahead) -> split ->
+// LDS bf16 planes; W: global bf16 -> registers -> LDS.  LDS rows are padded by 16 B so that the
+// ds_read_b128 fragment reads (32 rows x 16 B per half-wave) are bank-conflict free.
+// Block index -> tile mapping is XCD-aware: the N-tiles of one M-tile (which re-read the same
+// activation rows) get consecutive indices inside one XCD's share of the grid.
+#include "emd_common.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int kMaxTaps = 4;
+
+struct GemmParams {
+    const float* A;       // source activations (NHWC), pixel stride lda
+    const uint16_t* Whi;  // [Npad][taps*Cpad]
+    const uint16_t* Wlo;
+    float* C;             // destination, pixel stride ldc
+    const float* res;     // optional residual (same pixel indexing as C), pixel stride ldres
+    const float* scale1;  // [N] epilogue: y = acc*scale1 + shift1
+    const float* shift1;
+    const float* scale2;  // optional second affine + relu6 (ASPP extra BN)
+    const float* shift2;
+    long M;               // B*Hg*Wg
+    int N, Cin, Cpad, ntaps;
+    int lda, ldc, ldres;
+    int act;              // 1: relu6 after the first affine
+    // row map: m -> (b,i,j) on Hg x Wg;  source (b, i*sa+dy, j*sa+dx) in Ha x Wa;  dest (b, i*sc+py, j*sc+px) in Hc x Wc
+    int flat;             // 1: source pixel = dest pixel = m (plain pointwise)
+    int Hg, Wg, Ha, Wa, Hc, Wc, sa, sc, py, px;
+    int dy[kMaxTaps], dx[kMaxTaps];
+    int n_mtiles, n_ntiles;
+};
+
+// a = hi + lo (+ O(2^-17)): two packed bf16 words for two floats
+__device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {a0, a1};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);
+    const bf16x2 l = __builtin_convertvector(r, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int PASSES>
+__global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int LDK = BK + 8;               // bf16 elements per LDS row (16-B pad)
+    constexpr int TM = BM / WM / 32;          // 32x32 MFMA tiles per wave along M
+    constexpr int TN = BN / WN / 32;
+    constexpr int A_F4_PER_ROW = BK / 4;      // float4 per A-tile row
+    constexpr int A_ROWS_PER_PASS = 256 / A_F4_PER_ROW;
+    constexpr int A_PASSES = BM / A_ROWS_PER_PASS;
+    constexpr int W_CH_PER_ROW = BK / 8;      // 16-B chunks per W-tile row
+    constexpr int W_ROWS_PER_PASS = 256 / W_CH_PER_ROW;
+    constexpr int W_PASSES = BN / W_ROWS_PER_PASS;
+    constexpr int NPL = PASSES == 3 ? 2 : 1;  // bf16 planes kept in LDS
+
+    __shared__ __attribute__((aligned(16))) uint16_t As[NPL][BM][LDK];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[NPL][BN][LDK];
+    __shared__ long long rowA[BM];  // source pixel index of each tile row for the current tap (-1: zero)
+    __shared__ long long rowP[BM];  // destination pixel index (-1: row beyond M)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+
+    // XCD-aware tile mapping (bijective for any grid size)
+    const int nblk = p.n_mtiles * p.n_ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.n_ntiles, nt = bid % p.n_ntiles;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    // ---- row maps
+    auto map_rows = [&](int tap, bool with_dest) {
+        if (tid < BM) {
+            const long m = m0 + tid;
+            long long src = -1, dst = -1;
+            if (m < p.M) {
+                if (p.flat) {
+                    src = dst = m;
+                } else {
+                    const int j = (int)(m % p.Wg);
+                    const long t = m / p.Wg;
+                    const int i = (int)(t % p.Hg);
+                    const long b = t / p.Hg;
+                    // select without dynamic indexing (keeps the by-value params out of scratch)
+                    const int dy = tap == 0 ? p.dy[0] : tap == 1 ? p.dy[1] : tap == 2 ? p.dy[2] : p.dy[3];
+                    const int dx = tap == 0 ? p.dx[0] : tap == 1 ? p.dx[1] : tap == 2 ? p.dx[2] : p.dx[3];
+                    const int iy = i * p.sa + dy, ix = j * p.sa + dx;
+                    if (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) src = (b * p.Ha + iy) * (long)p.Wa + ix;
+                    dst = (b * p.Hc + (i * p.sc + p.py)) * (long)p.Wc + (j * p.sc + p.px);
+                }
+            }
+            rowA[tid] = src;
+            if (with_dest) rowP[tid] = dst;
+        }
+    };
+
+    // ---- global -> register staging, one K step ahead.  The loop starts at it = -1 (stage tile 0 only)
+    //      so that the load code and the LDS-store code each exist ONCE, in straight-line unrolled form:
+    //      the staging arrays must stay in registers (closures / macro-expanded loops sent them to scratch).
+    float4 areg[A_PASSES];
+    static_assert(W_PASSES == 1 || W_PASSES == 2, "W tile staging");
+    uint4 wh0 = make_uint4(0, 0, 0, 0), wh1 = wh0, wl0 = wh0, wl1 = wh0;  // named, not arrays: see above
+    const int a_col = (tid % A_F4_PER_ROW) * 4;
+    const int a_row = tid / A_F4_PER_ROW;
+    const int w_col = (tid % W_CH_PER_ROW) * 8;
+    const int w_row = tid / W_CH_PER_ROW;
+    const int Ktot = p.ntaps * p.Cpad;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int ksteps = p.Cpad / BK;
+    const int total = p.ntaps * ksteps;
+    map_rows(0, true);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+
+    for (int it = -1; it < total; ++it) {
+        if (it >= 0) {
+            // registers (tile `it`) -> LDS, splitting the activations into bf16 hi/lo on the way
+#pragma unroll
+            for (int q = 0; q < A_PASSES; ++q) {
+                const int r = a_row + q * A_ROWS_PER_PASS;
+                unsigned h0, l0, h1, l1;
+                split2(areg[q].x, areg[q].y, h0, l0);
+                split2(areg[q].z, areg[q].w, h1, l1);
+                *reinterpret_cast<uint2*>(&As[0][r][a_col]) = make_uint2(h0, h1);
+                if (NPL == 2) *reinterpret_cast<uint2*>(&As[NPL - 1][r][a_col]) = make_uint2(l0, l1);
+            }
+            *reinterpret_cast<uint4*>(&Bs[0][w_row][w_col]) = wh0;
+            if (NPL == 2) *reinterpret_cast<uint4*>(&Bs[NPL - 1][w_row][w_col]) = wl0;
+            if (W_PASSES == 2) {
+                *reinterpret_cast<uint4*>(&Bs[0][w_row + W_ROWS_PER_PASS][w_col]) = wh1;
+                if (NPL == 2) *reinterpret_cast<uint4*>(&Bs[NPL - 1][w_row + W_ROWS_PER_PASS][w_col]) = wl1;
+            }
+            __syncthreads();  // tile `it` visible; rowA free to be re-mapped
+        }
+        {
+            // stage tile it+1 (the last iteration re-loads its own tile: keeps this path branch-free)
+            const int nx = it + 1 < total ? it + 1 : it;
+            const int tap = nx / ksteps, c0 = (nx % ksteps) * BK;
+            if (c0 == 0 && !p.flat && nx != it && nx > 0) {  // tap change: new source rows (block-uniform)
+                map_rows(tap, false);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int q = 0; q < A_PASSES; ++q) {
+                const long long src = rowA[a_row + q * A_ROWS_PER_PASS];
+                const int c = c0 + a_col;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (src >= 0 && c < p.Cin) v = *reinterpret_cast<const float4*>(p.A + src * p.lda + c);
+                areg[q] = v;
+            }
+            const long kk = (long)tap * p.Cpad + c0 + w_col;
+            {
+                const long off = (long)(n0 + w_row) * Ktot + kk;
+                wh0 = *reinterpret_cast<const uint4*>(p.Whi + off);
+                if (NPL == 2) wl0 = *reinterpret_cast<const uint4*>(p.Wlo + off);
+                if (W_PASSES == 2) {
+                    const long off1 = off + (long)W_ROWS_PER_PASS * Ktot;
+                    wh1 = *reinterpret_cast<const uint4*>(p.Whi + off1);
+                    if (NPL == 2) wl1 = *reinterpret_cast<const uint4*>(p.Wlo + off1);
+                }
+            }
+        }
+        if (it < 0) continue;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (BM / WM) + i * 32 + fr;
+                ah[i] = *reinterpret_cast<const bf16x8*>(&As[0][r][ks * 16 + fh * 8]);
+                if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(&As[NPL - 1][r][ks * 16 + fh * 8]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (BN / WN) + j * 32 + fr;
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[0][r][ks * 16 + fh * 8]);
+                if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[NPL - 1][r][ks * 16 + fh * 8]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (PASSES == 3) {  // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();  // all fragment reads of tile `it` done before it is overwritten
+    }
+
+    // ---- epilogue: C/D layout of mfma_32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + fr;
+        if (n >= p.N) continue;
+        const float s1 = p.scale1[n], t1 = p.shift1[n];
+        float s2 = 1.f, t2 = 0.f;
+        if (p.scale2) { s2 = p.scale2[n]; t2 = p.shift2[n]; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const long long pix = rowP[r];
+                if (pix < 0) continue;
+                float v = fmaf(acc[i][j][e], s1, t1);
+                if (p.act) v = fminf(fmaxf(v, 0.f), 6.f);
+                if (p.scale2) v = fminf(fmaxf(fmaf(v, s2, t2), 0.f), 6.f);
+                if (p.res) v += p.res[pix * p.ldres + n];
+                p.C[pix * p.ldc + n] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+int launch(const GemmParams& p0, int passes, hipStream_t st) {
+    GemmParams p = p0;
+    p.n_mtiles = (int)((p.M + BM - 1) / BM);
+    p.n_ntiles = (p.N + BN - 1) / BN;
+    const long nblk = (long)p.n_mtiles * p.n_ntiles;
+    if (nblk <= 0 || nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "gemm_conv: grid too large");
+    if (passes == 3)
+        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, WM, WN, 3>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, WM, WN, 1>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    return emd::check_launch("gemm_conv_kernel");
+}
+
+constexpr int kBK = 32;     // K step (also the channel padding unit of the packed weights)
+constexpr int kNPadTo = 128;  // packed weights are padded to a multiple of the widest BN
+
+int dispatch(const GemmParams& p, int passes, hipStream_t st) {
+    if (p.N <= 64) return launch<128, 64, kBK, 4, 1>(p, passes, st);
+    return launch<128, 128, kBK, 2, 2>(p, passes, st);
+}
+
+inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+int common_checks(const char* who, const float* x, const void* whi, const void* wlo, const float* scale1,
+                  const float* shift1, const float* scale2, const float* shift2, const float* res, float* y,
+                  int Cin, int N, int ldx, int ldy, int ldres, int passes) {
+    (void)who;
+    EMD_REQUIRE(x && whi && scale1 && shift1 && y, EMD_E_INVALID, "conv: null pointer");
+    EMD_REQUIRE(passes == 1 || passes == 3, EMD_E_INVALID, "conv: precision must be EMD_PREC_BF16 or EMD_PREC_BF16X3");
+    EMD_REQUIRE(passes == 1 || wlo, EMD_E_INVALID, "conv: the split-bf16 mode needs the lo weight plane");
+    EMD_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), EMD_E_INVALID, "conv: scale2/shift2 must come together");
+    EMD_REQUIRE(Cin >= 4 && N >= 1, EMD_E_INVALID, "conv: bad channel counts");
+    EMD_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0 && ldx >= Cin, EMD_E_ALIGN, "conv: Cin and ldx must be multiples of 4, ldx >= Cin");
+    EMD_REQUIRE(ldy >= N && (!res || ldres >= N), EMD_E_INVALID, "conv: ldy/ldres smaller than Cout");
+    EMD_REQUIRE(emd::aligned16(x) && emd::aligned16(whi) && (!wlo || emd::aligned16(wlo)), EMD_E_ALIGN,
+                "conv: x and the weight planes must be 16-byte aligned");
+    return EMD_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- host packing
+extern "C" size_t emd_packed_weight_elems(int taps, int Cin, int Cout) {
+    if (taps < 1 || Cin < 1 || Cout < 1) return 0;
+    const size_t cpad = (size_t)(Cin + kBK - 1) / kBK * kBK;
+    const size_t npad = (size_t)(Cout + kNPadTo - 1) / kNPadTo * kNPadTo;
+    return npad * taps * cpad;
+}
+
+extern "C" int emd_pack_weights_bf16(const float* w_host, int taps, int Cin, int Cout, int cout_major,
+                                     uint16_t* hi_host, uint16_t* lo_host) {
+    EMD_REQUIRE(w_host && hi_host && lo_host, EMD_E_INVALID, "emd_pack_weights_bf16: null pointer");
+    EMD_REQUIRE(taps >= 1 && taps <= 9 && Cin >= 1 && Cout >= 1, EMD_E_INVALID, "emd_pack_weights_bf16: bad shape");
+    const size_t cpad = (size_t)(Cin + kBK - 1) / kBK * kBK;
+    const size_t npad = (size_t)(Cout + kNPadTo - 1) / kNPadTo * kNPadTo;
+    const size_t ktot = (size_t)taps * cpad;
+    for (size_t i = 0; i < npad * ktot; ++i) hi_host[i] = lo_host[i] = 0;
+    for (int t = 0; t < taps; ++t)
+        for (int c = 0; c < Cin; ++c)
+            for (int n = 0; n < Cout; ++n) {
+                // TF layouts: conv [taps][Cin][Cout]; conv2d_transpose [taps][Cout][Cin]
+                const float w = cout_major ? w_host[((size_t)t * Cout + n) * Cin + c]
+                                           : w_host[((size_t)t * Cin + c) * Cout + n];
+                const uint16_t h = f32_to_bf16_rne(w);
+                const uint16_t l = f32_to_bf16_rne(w - bf16_to_f32(h));
+                const size_t o = (size_t)n * ktot + (size_t)t * cpad + c;
+                hi_host[o] = h;
+                lo_host[o] = l;
+            }
+    return EMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- 1x1 convolution
+extern "C" int emd_conv1x1_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo,
+                               const float* scale1, const float* shift1, const float* scale2,
+                               const float* shift2, const float* res, int ldres, float* y, int ldy, int B,
+                               int H, int W, int Cin, int Cout, int stride, int act, int precision,
+                               emd_stream_t stream) {
+    int rc = common_checks("emd_conv1x1_f32", x, whi, wlo, scale1, shift1, scale2, shift2, res, y, Cin, Cout, ldx,
+                           ldy, ldres, precision);
+    if (rc != EMD_OK) return rc;
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_conv1x1_f32: bad shape");
+    EMD_REQUIRE(stride == 1 || stride == 2, EMD_E_UNSUPPORTED, "emd_conv1x1_f32: stride must be 1 or 2");
+    if (B == 0) return EMD_OK;
+    GemmParams p{};
+    p.A = x; p.Whi = whi; p.Wlo = wlo; p.C = y; p.res = res;
+    p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
+    p.N = Cout; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.ntaps = 1;
+    p.lda = ldx; p.ldc = ldy; p.ldres = ldres; p.act = act ? 1 : 0;
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;  // TF SAME, k=1: pad 0, samples x[0::s]
+    p.M = (long)B * Ho * Wo;
+    p.flat = stride == 1;
+    p.Hg = Ho; p.Wg = Wo; p.Ha = H; p.Wa = W; p.Hc = Ho; p.Wc = Wo; p.sa = stride; p.sc = 1; p.py = p.px = 0;
+    p.dy[0] = p.dx[0] = 0;
+    return dispatch(p, precision, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------- 3x3 stride-2 transposed convolution
+// y[2i+k] += x[i]*w[k] cropped to [0,2N) (gradient of the SAME stride-2 conv, denoiser.py:141-148):
+//   even output index 2i  : taps k=0 (from x[i]) and k=2 (from x[i-1]);  odd 2i+1 : tap k=1 (from x[i]).
+// The four (row-parity, column-parity) phases are four GEMMs over the INPUT grid with 4/2/2/1 taps,
+// each with its own packed weight block (see emd_deconv_phase_taps).
+extern "C" int emd_deconv_phase_taps(int phase, int* ky, int* kx) {
+    // phase = 2*py + px; returns the number of taps and their 3x3 kernel coordinates, in the order
+    // the packed weights of that phase must be laid out
+    if (phase < 0 || phase > 3 || !ky || !kx) return 0;
+    const int py = phase >> 1, px = phase & 1;
+    int kys[2], kxs[2], ny, nx;
+    if (py) { kys[0] = 1; ny = 1; } else { kys[0] = 0; kys[1] = 2; ny = 2; }
+    if (px) { kxs[0] = 1; nx = 1; } else { kxs[0] = 0; kxs[1] = 2; nx = 2; }
+    int n = 0;
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) { ky[n] = kys[a]; kx[n] = kxs[b]; ++n; }
+    return n;
+}
+
+extern "C" int emd_deconv3x3s2_f32(const float* x, int ldx, const uint16_t* const whi[4],
+                                   const uint16_t* const wlo[4], const float* scale1, const float* shift1,
+                                   float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                                   int precision, emd_stream_t stream) {
+    EMD_REQUIRE(whi, EMD_E_INVALID, "emd_deconv3x3s2_f32: null weight table");
+    for (int ph = 0; ph < 4; ++ph) {
+        int rc = common_checks("emd_deconv3x3s2_f32", x, whi[ph], wlo ? wlo[ph] : nullptr, scale1, shift1, nullptr,
+                               nullptr, nullptr, y, Cin, Cout, ldx, ldy, 0, precision);
+        if (rc != EMD_OK) return rc;
+    }
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_deconv3x3s2_f32: bad shape");
+    if (B == 0) return EMD_OK;
+    for (int ph = 0; ph < 4; ++ph) {
+        GemmParams p{};
+        int ky[4], kx[4];
+        p.ntaps = emd_deconv_phase_taps(ph, ky, kx);
+        p.A = x; p.Whi = whi[ph]; p.Wlo = wlo ? wlo[ph] : nullptr; p.C = y; p.res = nullptr;
+        p.scale1 = scale1; p.shift1 = shift1; p.scale2 = p.shift2 = nullptr;
+        p.N = Cout; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK;
+        p.lda = ldx; p.ldc = ldy; p.ldres = 0; p.act = act ? 1 : 0;
+        p.M = (long)B * H * W;
+        p.flat = 0;
+        p.Hg = H; p.Wg = W; p.Ha = H; p.Wa = W; p.Hc = 2 * H; p.Wc = 2 * W; p.sa = 1; p.sc = 2;
+        p.py = ph >> 1; p.px = ph & 1;
+        for (int t = 0; t < p.ntaps; ++t) {  // kernel index 2 reads the previous input sample
+            p.dy[t] = ky[t] == 2 ? -1 : 0;
+            p.dx[t] = kx[t] == 2 ? -1 : 0;
+        }
+        int rc = dispatch(p, precision, static_cast<hipStream_t>(stream));
+        if (rc != EMD_OK) return rc;
+    }
+    return EMD_OK;
+}

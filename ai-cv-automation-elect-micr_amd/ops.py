@@ -1,0 +1,164 @@
+"""Thin torch-tensor wrappers over the graph-D entry points of libemdenoise.so.
+
+An activation is an ``Act``: a view [B,H,W,C] into a torch CUDA buffer whose pixel stride ``ld`` may be
+wider than C (a channel slice of a concat buffer, denoiser.py:203/:353/:365).  Every function here
+only checks shapes and forwards pointers; the arithmetic is in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+PREC_BF16 = 1
+PREC_BF16X3 = 3
+
+
+class Act:
+    """[B,H,W,C] float32 view: channels [c0, c0+C) of ``buf`` [B,H,W,ld]."""
+
+    __slots__ = ("buf", "B", "H", "W", "C", "ld", "c0")
+
+    def __init__(self, buf, C_=None, c0=0):
+        assert buf.dim() == 4 and buf.is_contiguous() and str(buf.dtype) == "torch.float32" and buf.is_cuda
+        self.buf = buf
+        self.B, self.H, self.W, self.ld = buf.shape
+        self.C = self.ld - c0 if C_ is None else C_
+        self.c0 = c0
+        assert 0 <= c0 and c0 + self.C <= self.ld
+
+    @classmethod
+    def empty(cls, B, H, W, Cc, device):
+        import torch
+
+        return cls(torch.empty((B, H, W, Cc), dtype=torch.float32, device=device))
+
+    def slice(self, c0, Cc):
+        return Act(self.buf, Cc, self.c0 + c0)
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.buf.data_ptr() + 4 * self.c0)
+
+    def torch(self):
+        return self.buf[..., self.c0: self.c0 + self.C]
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class PackedWeights:
+    """bf16 hi/lo planes of one conv's weights on the device (emd_pack_weights_bf16 layout)."""
+
+    def __init__(self, w_tf: np.ndarray, cout_major: bool, device):
+        import torch
+
+        lib = _lib.load()
+        w = np.ascontiguousarray(w_tf, dtype=np.float32)
+        if cout_major:
+            taps, cout, cin = w.shape
+        else:
+            taps, cin, cout = w.shape
+        n = lib.emd_packed_weight_elems(taps, cin, cout)
+        hi = np.empty(n, np.uint16)
+        lo = np.empty(n, np.uint16)
+        _lib.check(lib.emd_pack_weights_bf16(w.ctypes.data, taps, cin, cout, 1 if cout_major else 0,
+                                             hi.ctypes.data, lo.ctypes.data), "emd_pack_weights_bf16")
+        self.taps, self.cin, self.cout = taps, cin, cout
+        # uint16 planes travel as int16 torch tensors (same bits)
+        self.hi = torch.from_numpy(hi.view(np.int16)).to(device)
+        self.lo = torch.from_numpy(lo.view(np.int16)).to(device)
+
+
+def conv1x1(x: Act, w: PackedWeights, scale1, shift1, out: Act, stride=1, act=True, scale2=None, shift2=None,
+            res: Act | None = None, precision=PREC_BF16X3, stream=None):
+    lib = _lib.load()
+    Ho, Wo = -(-x.H // stride), -(-x.W // stride)
+    assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, w.cout) and w.cin == x.C and w.taps == 1
+    if res is not None:
+        assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
+    rc = lib.emd_conv1x1_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
+                             res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
+                             out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, stride, 1 if act else 0, precision,
+                             _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_conv1x1_f32")
+    return out
+
+
+def deconv3x3s2(x: Act, w_phases, scale1, shift1, out: Act, act=True, precision=PREC_BF16X3, stream=None):
+    lib = _lib.load()
+    assert len(w_phases) == 4 and (out.B, out.H, out.W) == (x.B, 2 * x.H, 2 * x.W) and out.C == w_phases[0].cout
+    hi = (C.c_void_p * 4)(*[w.hi.data_ptr() for w in w_phases])
+    lo = (C.c_void_p * 4)(*[w.lo.data_ptr() for w in w_phases])
+    rc = lib.emd_deconv3x3s2_f32(x.ptr, x.ld, hi, lo, _p(scale1), _p(shift1), out.ptr, out.ld, x.B, x.H, x.W, x.C,
+                                 out.C, 1 if act else 0, precision, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_deconv3x3s2_f32")
+    return out
+
+
+def deconv_phase_taps(phase):
+    lib = _lib.load()
+    ky = (C.c_int * 4)()
+    kx = (C.c_int * 4)()
+    n = lib.emd_deconv_phase_taps(phase, ky, kx)
+    return [(ky[i], kx[i]) for i in range(n)]
+
+
+def pack_deconv(w_tf: np.ndarray, device):
+    """w_tf [3,3,Cout,Cin] (slim.conv2d_transpose) -> the four per-phase PackedWeights."""
+    out = []
+    for ph in range(4):
+        taps = deconv_phase_taps(ph)
+        sub = np.stack([w_tf[ky, kx] for (ky, kx) in taps])  # [taps,Cout,Cin]
+        out.append(PackedWeights(sub, True, device))
+    return out
+
+
+def dw3x3(x: Act, w_dev, out: Act, stride=1, rate=1, stream=None):
+    lib = _lib.load()
+    assert out.C == x.C and out.B == x.B and (out.H, out.W) == (-(-x.H // stride), -(-x.W // stride))
+    rc = lib.emd_dw3x3_f32(x.ptr, x.ld, _p(w_dev), out.ptr, out.ld, x.B, x.H, x.W, x.C, stride, rate,
+                           _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_dw3x3_f32")
+    return out
+
+
+def cin1(x_img, w9_dev, a_dev, shift_dev, out: Act, stride=1, act=True, stream=None):
+    """x_img: torch CUDA float32 [B,H,W] or [B,H,W,1] contiguous."""
+    lib = _lib.load()
+    B, H, W = x_img.shape[0], x_img.shape[1], x_img.shape[2]
+    assert x_img.is_contiguous() and (out.B, out.H, out.W) == (B, -(-H // stride), -(-W // stride))
+    rc = lib.emd_cin1_f32(_p(x_img), _p(w9_dev), _p(a_dev), _p(shift_dev), out.ptr, out.ld, B, H, W, out.C, stride,
+                          1 if act else 0, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_cin1_f32")
+    return out
+
+
+def conv3x3_cout1(x: Act, w_dev, scale: float, shift: float, out_img, act=True, stream=None):
+    lib = _lib.load()
+    assert out_img.is_contiguous() and out_img.numel() == x.B * x.H * x.W
+    rc = lib.emd_conv3x3_cout1_f32(x.ptr, x.ld, _p(w_dev), C.c_float(scale), C.c_float(shift), _p(out_img), x.B, x.H,
+                                   x.W, x.C, 1 if act else 0, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_conv3x3_cout1_f32")
+    return out_img
+
+
+def resize_bilinear(x: Act, out: Act, stream=None):
+    lib = _lib.load()
+    assert out.C == x.C and out.B == x.B
+    rc = lib.emd_resize_bilinear_f32(x.ptr, x.ld, out.ptr, out.ld, x.B, x.H, x.W, out.H, out.W, x.C,
+                                     _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_resize_bilinear_f32")
+    return out
+
+
+def affine_relu6(x: Act, scale_dev, shift_dev, out: Act, act=True, stream=None):
+    lib = _lib.load()
+    assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, x.C)
+    rc = lib.emd_affine_relu6_f32(x.ptr, x.ld, _p(scale_dev), _p(shift_dev), out.ptr, out.ld,
+                                  C.c_long(x.B * x.H * x.W), x.C, 1 if act else 0, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_affine_relu6_f32")
+    return out

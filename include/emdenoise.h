@@ -72,6 +72,83 @@ size_t emd_kernel_params_count(int width, int depth);
 int emd_kernel_denoise_f32(const float* x, float* y, int B, int H, int W, int width, int depth,
                            const float* params, unsigned flags, emd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Graph D: the depthwise-separable encoder-decoder (machine_learning/denoiser.py:58-398).
+ *
+ * Fused epilogue shared by the matrix-core entry points (per output channel n):
+ *     v = acc * scale1[n] + shift1[n]          conv bias and the inference batch norm(s) folded
+ *     if (act)    v = min(max(v,0),6)          tf.nn.relu6                        (denoiser.py:83)
+ *     if (scale2) v = relu6(v*scale2[n]+shift2[n])   a second batch_then_activ  (:170,:176,:182)
+ *     if (res)    v += res[pixel][n]           the "+=" residual that follows     (:264 ...)
+ * scale*, shift*: device float[Cout]; scale2/shift2/res may be NULL.
+ *
+ * precision: EMD_PREC_BF16X3 (split-bf16, 3 MFMA passes, ~2^-16 relative: the parity mode) or
+ *            EMD_PREC_BF16   (one bf16 MFMA pass, ~2^-9 relative per layer: the fast mode).
+ */
+#define EMD_PREC_BF16 1
+#define EMD_PREC_BF16X3 3
+
+/* Host-side weight packing for the matrix-core kernels (all pointers are HOST pointers).
+ * w_host : taps x Cin x Cout float32 in TensorFlow order, [taps][Cin][Cout] (slim.conv2d /
+ *          pointwise_weights, cout_major = 0) or [taps][Cout][Cin] (slim.conv2d_transpose, cout_major = 1).
+ * hi/lo  : emd_packed_weight_elems(taps,Cin,Cout) bf16 words each: w = hi + lo (+2^-17), stored
+ *          [Cout padded to 128][taps][Cin padded to 32], zero padded. */
+size_t emd_packed_weight_elems(int taps, int Cin, int Cout);
+int emd_pack_weights_bf16(const float* w_host, int taps, int Cin, int Cout, int cout_major,
+                          uint16_t* hi_host, uint16_t* lo_host);
+
+/* 1x1 convolution on the matrix cores, optional stride 2 (TF SAME for k=1: samples x[0::2]).
+ * replaces: the pointwise half of slim.separable_convolution2d + normalizer BN + batch_then_activ
+ *           (denoiser.py:113-134); slim.conv2d(kernel_size=1[,stride=2]) + bias + BN + relu6
+ *           (:91-97 with :359/:371/:383, :159-164, :208-214, :220-227); the residual adds.
+ * x [B,H,W,Cin] pixel stride ldx;  y [B,ceil(H/s),ceil(W/s),Cout] pixel stride ldy;  res like y, ldres.
+ * Cin, ldx multiples of 4; x, whi, wlo 16-byte aligned.  wlo may be NULL with EMD_PREC_BF16. */
+int emd_conv1x1_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo,
+                    const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                    const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin,
+                    int Cout, int stride, int act, int precision, emd_stream_t stream);
+
+/* 3x3 stride-2 transposed convolution, output exactly 2H x 2W, as four output-phase GEMMs.
+ * replaces: slim.conv2d_transpose(kernel_size=3, stride=2, padding='same') + bias + BN + relu6
+ *           (denoiser.py:141-148):  y[2i+k] += x[i]*w[k], cropped at the end.
+ * whi/wlo: HOST arrays of 4 DEVICE pointers, one packed block per phase (phase = 2*row_parity +
+ *          col_parity) holding the taps emd_deconv_phase_taps lists, in that order, cout_major = 1. */
+int emd_deconv_phase_taps(int phase, int* ky, int* kx);
+int emd_deconv3x3s2_f32(const float* x, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4],
+                        const float* scale1, const float* shift1, float* y, int ldy, int B, int H, int W,
+                        int Cin, int Cout, int act, int precision, emd_stream_t stream);
+
+/* Depthwise 3x3, TF SAME padding, stride 1 or 2 (rate 1) or stride 1 with dilation `rate`.
+ * replaces: the depthwise half of slim.separable_convolution2d (denoiser.py:113-131).
+ * x [B,H,W,C] pixel stride ldx; w [3][3][C] (TF [3,3,C,1]); y [B,ceil(H/s),ceil(W/s),C] pixel stride ldy. */
+int emd_dw3x3_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
+                  int stride, int rate, emd_stream_t stream);
+
+/* Layers fed by the 1-channel image: y[pix][n] = act( d[pix]*a[n] + shift[n] ).
+ * w9 != NULL: d = 3x3 SAME depthwise of x with the 9 weights w9 (stride 1)  -- cnn0 (denoiser.py:252),
+ *             a[n] = pointwise_weights[0][n] * folded BN scale;
+ * w9 == NULL: d = x sampled with `stride`                                   -- residual0 (:263),
+ *             a[n] = weights[0][n] * folded BN scale, shift includes the bias.
+ * x [B,H,W]; y [B,ceil(H/s),ceil(W/s),Cout] pixel stride ldy; Cout/4 must divide 64. */
+int emd_cin1_f32(const float* x, const float* w9, const float* a, const float* shift, float* y, int ldy,
+                 int B, int H, int W, int Cout, int stride, int act, emd_stream_t stream);
+
+/* Dense 3x3 SAME convolution to ONE output channel + scalar affine + relu6.
+ * replaces: the final slim.conv2d(num_outputs=1, kernel_size=3) + bias + BN + relu6 (denoiser.py:387).
+ * x [B,H,W,Cin] pixel stride ldx; w [3][3][Cin]; y [B,H,W]; scale/shift: bias and BN folded. */
+int emd_conv3x3_cout1_f32(const float* x, int ldx, const float* w, float scale, float shift, float* y, int B,
+                          int H, int W, int Cin, int act, emd_stream_t stream);
+
+/* tf.image.resize_images(x,[Ho,Wo]): bilinear, align_corners=False, legacy (no half-pixel) sampling.
+ * replaces: denoiser.py:199 (identity size) and :350 (32 -> 128). */
+int emd_resize_bilinear_f32(const float* x, int ldx, float* y, int ldy, int B, int Hi, int Wi, int Ho, int Wo,
+                            int C, emd_stream_t stream);
+
+/* A lone inference batch norm (+ relu6): y = act(x*scale + shift) per channel.
+ * replaces: batch_then_activ on the ASPP image-level branch (denoiser.py:200). */
+int emd_affine_relu6_f32(const float* x, int ldx, const float* scale, const float* shift, float* y, int ldy,
+                         long npix, int C, int act, emd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,227 @@
+"""GPU parity tests, op by op: every graph-D entry point of libemdenoise.so (called through the C ABI
+via emdenoise.ops) against the oracle's TF-op restatement (oracle/tf_ops.py, float64) on the same
+seeded inputs.  Tolerances are relative L2:
+  split-bf16 matrix-core ops (EMD_PREC_BF16X3) ........ 2e-5   (north_star bar for the network: 1e-3)
+  one-pass bf16 matrix-core ops (EMD_PREC_BF16) ....... 6e-3   (fast mode, ~2^-9 per product)
+  fp32 VALU ops (depthwise, resize, ...) .............. 2e-6
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_X3 = 2e-5
+TOL_X1 = 6e-3
+TOL_F32 = 2e-6
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def rnd(shape, seed, scale=1.0, positive=False):
+    r = np.random.default_rng(seed)
+    a = r.standard_normal(shape) * scale
+    if positive:
+        a = np.abs(a)
+    return a.astype(np.float32)
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def to_act(x_np, ld=None, c0=0):
+    """Upload [B,H,W,C]; with ld, place it as channels [c0,c0+C) of a wider NaN-filled buffer."""
+    from emdenoise import ops
+
+    B, H, W, Cc = x_np.shape
+    if ld is None:
+        return ops.Act(torch.from_numpy(x_np).to(dev()))
+    buf = torch.full((B, H, W, ld), float("nan"), dtype=torch.float32, device=dev())
+    buf[..., c0:c0 + Cc] = torch.from_numpy(x_np).to(dev())
+    return ops.Act(buf, Cc, c0)
+
+
+def out_act(B, H, W, Cc, ld=None, c0=0):
+    from emdenoise import ops
+
+    buf = torch.full((B, H, W, ld or Cc), float("nan"), dtype=torch.float32, device=dev())
+    return ops.Act(buf, Cc, c0)
+
+
+def t64(a):
+    return torch.from_numpy(np.asarray(a, np.float64))
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,ci,co,stride", [
+    (2, 16, 16, 64, 64, 1),      # N <= 64 tile
+    (1, 9, 13, 128, 256, 1),     # ragged M
+    (2, 8, 8, 728, 728, 1),      # K, N not multiples of 32 / 128
+    (1, 4, 4, 3640, 256, 1),     # ASPP reduce
+    (2, 16, 16, 128, 128, 2),    # residual projection, stride 2
+    (1, 7, 9, 256, 728, 2),      # stride 2 on odd sizes
+    (1, 32, 32, 384, 128, 1),
+])
+@pytest.mark.parametrize("prec", [3, 1])
+def test_conv1x1(B, H, W, ci, co, stride, prec):
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 1, positive=True)
+    w = rnd((1, 1, ci, co), 2, scale=(2.0 / (ci + co)) ** 0.5)
+    s1, t1 = rnd((co,), 3, 0.3) + 1.0, rnd((co,), 4, 0.5)
+    ref = T.relu6_t(T.conv2d_t(t64(x), t64(w), None, stride=stride) * t64(s1) + t64(t1)).numpy()
+    pw = ops.PackedWeights(w[0], False, dev())
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    out = out_act(B, Ho, Wo, co)
+    ops.conv1x1(to_act(x), pw, torch.from_numpy(s1).to(dev()), torch.from_numpy(t1).to(dev()), out, stride=stride,
+                precision=prec)
+    torch.cuda.synchronize()
+    assert rel_l2(out.torch().cpu().numpy(), ref) < (TOL_X3 if prec == 3 else TOL_X1)
+
+
+def test_conv1x1_epilogue_slices_and_residual():
+    """Second affine+relu6, residual add, input and output as channel slices of wider buffers; bytes
+    outside the output slice must stay untouched."""
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    B, H, W, ci, co = 2, 10, 12, 128, 256
+    x = rnd((B, H, W, ci), 5, positive=True)
+    w = rnd((1, 1, ci, co), 6, scale=0.08)
+    s1, t1, s2, t2 = rnd((co,), 7, 0.2) + 1, rnd((co,), 8, 0.5), rnd((co,), 9, 0.2) + 1, rnd((co,), 10, 0.5)
+    r = rnd((B, H, W, co), 11, positive=True)
+    y = T.relu6_t(T.conv2d_t(t64(x), t64(w)) * t64(s1) + t64(t1))
+    y = T.relu6_t(y * t64(s2) + t64(t2)) + t64(r)
+    pw = ops.PackedWeights(w[0], False, dev())
+    out = out_act(B, H, W, co, ld=co + 128, c0=64)
+    d = lambda a: torch.from_numpy(a).to(dev())
+    ops.conv1x1(to_act(x, ld=ci + 32, c0=16), pw, d(s1), d(t1), out, scale2=d(s2), shift2=d(t2),
+                res=to_act(r, ld=co + 4, c0=4))
+    torch.cuda.synchronize()
+    assert rel_l2(out.torch().cpu().numpy(), y.numpy()) < TOL_X3
+    full = out.buf.cpu().numpy()
+    assert np.isnan(full[..., :64]).all() and np.isnan(full[..., 64 + co:]).all()
+
+
+@pytest.mark.parametrize("B,H,W,ci,co", [(2, 5, 7, 64, 32), (1, 8, 8, 128, 128), (1, 3, 3, 256, 256), (1, 1, 1, 64, 64)])
+@pytest.mark.parametrize("prec", [3, 1])
+def test_deconv3x3s2(B, H, W, ci, co, prec):
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 12, positive=True)
+    w = rnd((3, 3, co, ci), 13, scale=(2.0 / (9 * ci)) ** 0.5)
+    bias = rnd((co,), 14, 0.2)
+    s1, t1 = rnd((co,), 15, 0.2) + 1, rnd((co,), 16, 0.4)
+    ref = T.relu6_t(T.conv2d_transpose_s2_t(t64(x), t64(w), t64(bias)) * t64(s1) + t64(t1)).numpy()
+    packs = ops.pack_deconv(w, dev())
+    shift = (bias.astype(np.float64) * s1 + t1).astype(np.float32)  # bias folded into the shift
+    out = out_act(B, 2 * H, 2 * W, co)
+    ops.deconv3x3s2(to_act(x), packs, torch.from_numpy(s1).to(dev()), torch.from_numpy(shift).to(dev()), out,
+                    precision=prec)
+    torch.cuda.synchronize()
+    got = out.torch().cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_l2(got, ref) < (TOL_X3 if prec == 3 else TOL_X1)
+
+
+@pytest.mark.parametrize("B,H,W,Cc,stride,rate", [
+    (2, 16, 16, 64, 1, 1), (1, 13, 9, 128, 1, 1), (1, 8, 8, 728, 1, 1), (2, 16, 16, 64, 2, 1), (1, 9, 7, 256, 2, 1),
+    (1, 32, 32, 128, 1, 6), (1, 32, 32, 64, 1, 12), (1, 32, 32, 64, 1, 18), (1, 3, 3, 384, 1, 1),
+])
+def test_dw3x3(B, H, W, Cc, stride, rate):
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, Cc), 17)
+    w = rnd((3, 3, Cc, 1), 18, 0.4)
+    ref = T.depthwise_conv2d_t(t64(x), t64(w), stride, rate).numpy()
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    out = out_act(B, Ho, Wo, Cc)
+    ops.dw3x3(to_act(x, ld=Cc + 8, c0=4), torch.from_numpy(np.ascontiguousarray(w[..., 0])).to(dev()), out,
+              stride=stride, rate=rate)
+    torch.cuda.synchronize()
+    assert rel_l2(out.torch().cpu().numpy(), ref) < TOL_F32
+
+
+def test_cin1_both_forms():
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    B, H, W = 2, 17, 24
+    x = rnd((B, H, W, 1), 19, positive=True)
+    # cnn0: depthwise 3x3 on one channel, then 1 -> 64 pointwise, affine, relu6
+    dw = rnd((3, 3, 1, 1), 20, 0.5)
+    pw = rnd((1, 1, 1, 64), 21, 0.7)
+    s, t = rnd((64,), 22, 0.2) + 1, rnd((64,), 23, 0.3)
+    ref = T.relu6_t(T.conv2d_t(T.depthwise_conv2d_t(t64(x), t64(dw)), t64(pw)) * t64(s) + t64(t)).numpy()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    out = out_act(B, H, W, 64)
+    ops.cin1(d(x), d(dw.reshape(9)), d(pw.reshape(64) * s), d(t), out)
+    torch.cuda.synchronize()
+    assert rel_l2(out.torch().cpu().numpy(), ref) < TOL_F32
+    # residual0: 1x1 stride-2 conv 1 -> 128 with bias
+    w = rnd((1, 1, 1, 128), 24, 0.7)
+    bias = rnd((128,), 25, 0.2)
+    s, t = rnd((128,), 26, 0.2) + 1, rnd((128,), 27, 0.3)
+    ref = T.relu6_t(T.conv2d_t(t64(x), t64(w), t64(bias), stride=2) * t64(s) + t64(t)).numpy()
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    out = out_act(B, Ho, Wo, 128, ld=384, c0=256)
+    ops.cin1(d(x), None, d(w.reshape(128) * s), d(bias * s + t), out, stride=2)
+    torch.cuda.synchronize()
+    assert rel_l2(out.torch().cpu().numpy(), ref) < TOL_F32
+
+
+@pytest.mark.parametrize("B,H,W,ci", [(2, 12, 16, 64), (1, 5, 7, 128), (1, 9, 9, 16)])
+def test_conv3x3_cout1(B, H, W, ci):
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 28, positive=True)
+    w = rnd((3, 3, ci, 1), 29, 0.1)
+    bias, s, t = 0.13, 1.7, -0.2
+    ref = T.relu6_t((T.conv2d_t(t64(x), t64(w)) + bias) * s + t).numpy()
+    out = torch.full((B, H, W, 1), float("nan"), dtype=torch.float32, device=dev())
+    ops.conv3x3_cout1(to_act(x), torch.from_numpy(np.ascontiguousarray(w[..., 0])).to(dev()), s, bias * s + t, out)
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu().numpy(), ref) < TOL_F32
+
+
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo,Cc", [(4, 4, 16, 16, 256), (8, 8, 8, 8, 728), (3, 5, 12, 20, 64), (32, 32, 128, 128, 8)])
+def test_resize_bilinear(Hi, Wi, Ho, Wo, Cc):
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((2, Hi, Wi, Cc), 30)
+    ref = T.resize_bilinear_legacy_t(t64(x), Ho, Wo).numpy()
+    out = out_act(2, Ho, Wo, Cc, ld=Cc + 128, c0=0)
+    ops.resize_bilinear(to_act(x), out)
+    torch.cuda.synchronize()
+    assert rel_l2(out.torch().cpu().numpy(), ref) < TOL_F32
+
+
+def test_affine_relu6():
+    from emdenoise import ops
+
+    x = rnd((2, 6, 5, 728), 31, 3.0)
+    s, t = rnd((728,), 32, 0.3) + 1, rnd((728,), 33, 1.0)
+    ref = np.clip(x.astype(np.float64) * s + t, 0, 6)
+    out = out_act(2, 6, 5, 728, ld=3640, c0=2912)
+    ops.affine_relu6(to_act(x), torch.from_numpy(s).to(dev()), torch.from_numpy(t).to(dev()), out)
+    torch.cuda.synchronize()
+    assert rel_l2(out.torch().cpu().numpy(), ref) < TOL_F32
+
+
+def test_error_paths_report_through_last_error():
+    from emdenoise import _lib, ops
+
+    x = to_act(rnd((1, 4, 4, 6), 34))  # C = 6: not a multiple of 4
+    out = out_act(1, 4, 4, 6)
+    with pytest.raises(_lib.EmdError, match="multiples of 4"):
+        ops.dw3x3(x, torch.zeros(9 * 6, device=dev()), out)
