@@ -1,0 +1,503 @@
+"""Graph D host side: the depthwise-separable encoder-decoder denoiser on MI355X.
+
+Mirrors machine_learning/denoiser.py of the reference:
+  * ``architecture()`` (:58-398)  -> ``DenoiserEngine`` (declares the layers in the reference's
+    graph-construction order so that every variable keeps its TensorFlow name, folds the inference
+    batch norms into per-channel affines, packs the weights once, and runs the graph as a sequence of
+    libemdenoise.so launches);
+  * ``class Denoiser`` (:584-682) -> ``Denoiser`` with the same constructor arguments and
+    ``preprocess`` / ``denoise_crop`` / ``denoise`` methods, plus the batched
+    ``denoise(lq_batch[B,512,512,1]) -> hq_batch`` form;
+  * ``scale0to1`` (:684-695).
+Python here is plumbing only (buffers, pointers, launch order); there is no CPU compute path.
+
+``cropsize`` is 512 in the reference (:54) with ``aspp_size = 32 = cropsize/16`` (:45); the engine keeps
+that ratio so the same graph can be run (and checked against the oracle) at smaller crops.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib, ops
+
+# denoiser.py:38-52
+features0, features1, features2, features3, features4 = 64, 128, 256, 728, 728
+aspp_filters = features4
+aspp_output = 256
+aspp_rateSmall, aspp_rateMedium, aspp_rateLarge = 6, 12, 18
+num_extra_blocks = 11
+cropsize = 512
+channels = 1
+BN_EPS = 1e-3  # tf.contrib.layers.batch_norm default
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+SYNTH_SEED = 1234
+
+
+# ------------------------------------------------------------------------------------------------
+# layer declarations in the reference's creation order (=> TensorFlow variable names)
+# ------------------------------------------------------------------------------------------------
+class _Scope:
+    """tf.variable_scope default-name uniquifier inside scope 'nn' (denoiser.py:514)."""
+
+    def __init__(self):
+        self.n = {}
+
+    def __call__(self, base):
+        k = self.n.get(base, 0)
+        self.n[base] = k + 1
+        return f"nn/{base}" if k == 0 else f"nn/{base}_{k}"
+
+
+class Layer:
+    def __init__(self, kind, cin, cout, **kw):
+        self.kind, self.cin, self.cout = kind, cin, cout
+        self.stride = kw.get("stride", 1)
+        self.rate = kw.get("rate", 1)
+        self.k = kw.get("k", 1)
+        self.scope = kw.get("scope")      # conv / separable-conv / conv2d_transpose scope
+        self.bn = kw.get("bn", [])        # batch-norm scopes applied after it, in order
+        self.extra_bn = kw.get("extra_bn")  # a second batch_then_activ (ASPP rate branches)
+
+    def variables(self):
+        v = OrderedDict()
+        if self.kind == "sep":
+            v[self.scope + "/depthwise_weights"] = (3, 3, self.cin, 1)
+            v[self.scope + "/pointwise_weights"] = (1, 1, self.cin, self.cout)
+        elif self.kind == "conv":
+            v[self.scope + "/weights"] = (self.k, self.k, self.cin, self.cout)
+            v[self.scope + "/biases"] = (self.cout,)
+        elif self.kind == "deconv":
+            v[self.scope + "/weights"] = (3, 3, self.cout, self.cin)
+            v[self.scope + "/biases"] = (self.cout,)
+        c = self.cout
+        for s in self.bn + ([self.extra_bn] if self.extra_bn else []):
+            # creation order inside tf.contrib.layers.batch_norm: beta, gamma, moving_mean, moving_variance
+            for leaf in ("beta", "gamma", "moving_mean", "moving_variance"):
+                v[f"{s}/{leaf}"] = (c,)
+        return v
+
+
+def declare_layers():
+    """Every parameterised layer of architecture() (denoiser.py:248-398) keyed by the reference's
+    Python variable name, in creation order."""
+    sc = _Scope()
+    L = OrderedDict()
+
+    def sep(key, cin, cout, stride=1, rate=1, extra=False):
+        scope = sc("SeparableConv2d")
+        inner = scope + "/BatchNorm"          # normalizer_fn runs inside the layer's scope (:123)
+        outer = sc("BatchNorm")               # batch_then_activ (:134)
+        L[key] = Layer("sep", cin, cout, stride=stride, rate=rate, scope=scope, bn=[inner, outer],
+                       extra_bn=sc("BatchNorm") if extra else None)
+
+    def conv(key, cin, cout, k=1, stride=1):
+        scope = sc("Conv")
+        L[key] = Layer("conv", cin, cout, k=k, stride=stride, scope=scope, bn=[sc("BatchNorm")])
+
+    def deconv(key, cin, cout):
+        scope = sc("Conv2d_transpose")
+        L[key] = Layer("deconv", cin, cout, scope=scope, bn=[sc("BatchNorm")])
+
+    f0, f1, f2, f3, f4 = features0, features1, features2, features3, features4
+    sep("cnn0", channels, f0); sep("cnn0_last", f0, f0); sep("cnn0_strided", f0, f1, stride=2)
+    conv("residual0", channels, f1, stride=2)
+    sep("cnn1", f1, f1); sep("cnn1_last", f1, f1); sep("cnn1_strided", f1, f1, stride=2)
+    conv("residual1", f1, f1, stride=2)
+    sep("cnn2", f1, f2); sep("cnn2_last", f2, f2); sep("cnn2_strided", f2, f2, stride=2)
+    conv("residual2", f1, f2, stride=2)
+    sep("cnn3", f2, f3); sep("cnn3_last", f3, f3); sep("cnn3_strided", f3, f3, stride=2)
+    conv("residual3", f2, f3, stride=2)
+    sep("cnn4_a", f3, f4); sep("cnn4_b", f4, f4); sep("cnn4_last", f4, f4)
+    for i in range(num_extra_blocks):
+        for j in range(3):
+            sep(f"middle{i}_{j}", f4, f4)
+    conv("aspp_conv1x1", f4, aspp_filters)
+    sep("aspp_small", f4, aspp_filters, rate=aspp_rateSmall, extra=True)
+    sep("aspp_medium", f4, aspp_filters, rate=aspp_rateMedium, extra=True)
+    sep("aspp_large", f4, aspp_filters, rate=aspp_rateLarge, extra=True)
+    L["aspp_pooling_bn"] = Layer("bn", f4, f4, bn=[sc("BatchNorm")])   # :199-200
+    conv("aspp_reduce", 5 * aspp_filters, aspp_output)
+    sep("deconv2_a", aspp_output + f1, f2); sep("deconv2_b", f2, f2)
+    conv("residual2_d", aspp_output + f1, f2)
+    deconv("deconv2to1", f2, f2)
+    sep("deconv1_a", f2 + f1, f1); sep("deconv1_b", f1, f1)
+    conv("residual1_d", f2 + f1, f1)
+    deconv("deconv1to0", f1, f1)
+    sep("deconv0_a", f1, f0); sep("deconv0_b", f0, f0)
+    conv("residual0_d", f1, f0)
+    conv("deconv_final", f0, 1, k=3)      # :387 -- kernel_size defaults to 3
+    return L
+
+
+def variable_specs():
+    """TF variable name -> shape, in creation order."""
+    out = OrderedDict()
+    for layer in declare_layers().values():
+        out.update(layer.variables())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic weights (no checkpoint ships with the reference: its paths are network shares, :588)
+# ------------------------------------------------------------------------------------------------
+def synthetic_weights(seed: int = SYNTH_SEED, bn: str = "calibrated"):
+    """Seeded weights: Xavier-uniform kernels as the reference initialises them (denoiser.py:125),
+    small random biases and batch-norm gamma/beta; moving statistics either TF's initial values
+    (bn='tf_init': mean 0, variance 1) or the calibrated set shipped in data/ for the default seed
+    (bn='calibrated'), which keeps every layer's pre-activation near zero mean / unit variance so that
+    relu6 is exercised on both sides through all ~60 layers."""
+    rng = np.random.default_rng(seed)
+    w = OrderedDict()
+    for name, shape in variable_specs().items():
+        leaf = name.rsplit("/", 1)[1]
+        if leaf in ("depthwise_weights", "pointwise_weights", "weights"):
+            rf = shape[0] * shape[1]
+            lim = np.sqrt(6.0 / (rf * shape[2] + rf * shape[3]))
+            w[name] = rng.uniform(-lim, lim, shape).astype(np.float32)
+        elif leaf == "biases":
+            w[name] = rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+        elif leaf == "gamma":
+            w[name] = rng.uniform(0.8, 2.0, shape).astype(np.float32)
+        elif leaf == "beta":
+            w[name] = rng.uniform(-0.5, 1.0, shape).astype(np.float32)
+        elif leaf == "moving_mean":
+            w[name] = np.zeros(shape, np.float32)
+        elif leaf == "moving_variance":
+            w[name] = np.ones(shape, np.float32)
+        else:
+            raise AssertionError(name)
+    if bn == "calibrated":
+        path = os.path.join(DATA_DIR, f"synth_bn_seed{seed}.npz")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: calibrated batch-norm statistics exist only for the shipped seed; "
+                                    "use bn='tf_init' for other seeds")
+        z = np.load(path, allow_pickle=False)
+        for name in z.files:
+            assert name in w and w[name].shape == z[name].shape, name
+            w[name] = z[name].astype(np.float32)
+    elif bn != "tf_init":
+        raise ValueError("bn must be 'calibrated' or 'tf_init'")
+    return w
+
+
+def load_weights(checkpoint_loc):
+    """Weights saved as ``<checkpoint_loc>/denoiser_weights.npz`` keyed by TF variable name.  Reading
+    TensorFlow checkpoint bundles directly is a later step."""
+    path = checkpoint_loc if checkpoint_loc.endswith(".npz") else os.path.join(checkpoint_loc, "denoiser_weights.npz")
+    z = np.load(path, allow_pickle=False)
+    specs = variable_specs()
+    w = OrderedDict()
+    for name, shape in specs.items():
+        if name not in z.files:
+            raise KeyError(f"{path}: missing variable {name}")
+        a = z[name]
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {a.shape} != {shape}")
+        w[name] = a.astype(np.float32)
+    return w
+
+
+# ------------------------------------------------------------------------------------------------
+def _bn_affine(w, scope):
+    """Inference batch norm as y = x*g + h (float64)."""
+    g = w[scope + "/gamma"].astype(np.float64) / np.sqrt(w[scope + "/moving_variance"].astype(np.float64) + BN_EPS)
+    h = w[scope + "/beta"].astype(np.float64) - w[scope + "/moving_mean"].astype(np.float64) * g
+    return g, h
+
+
+def _fold(w, layer, bias=None):
+    """bias + the layer's consecutive batch norms -> one affine (scale, shift), float32."""
+    c = layer.cout
+    s = np.ones(c)
+    t = np.zeros(c) if bias is None else bias.astype(np.float64)
+    for scope in layer.bn:
+        g, h = _bn_affine(w, scope)
+        s, t = s * g, t * g + h
+    return s.astype(np.float32), t.astype(np.float32)
+
+
+class DenoiserEngine:
+    """Weights resident on one GPU + the launch sequence of architecture() (denoiser.py:248-398)."""
+
+    def __init__(self, weights, device, precision="bf16x3"):
+        import torch
+
+        _lib.load()
+        self.device = device
+        self.precision = {"bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[precision]
+        self.layers = declare_layers()
+        self.P = {}
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        for key, L in self.layers.items():
+            p = {}
+            if L.kind == "sep":
+                dw = weights[L.scope + "/depthwise_weights"][..., 0]           # [3,3,Cin]
+                pw = weights[L.scope + "/pointwise_weights"][0]                # [1,Cin,Cout]
+                s, t = _fold(weights, L)
+                if L.cin == 1:   # cnn0: depthwise on the 1-channel image, then an outer product
+                    p["w9"] = d(dw.reshape(9))
+                    p["a"] = d(pw.reshape(L.cout).astype(np.float64) * s)
+                    p["shift"] = d(t)
+                else:
+                    p["dw"] = d(dw.reshape(9, L.cin))
+                    p["pw"] = ops.PackedWeights(pw, False, device)
+                    p["scale"], p["shift"] = d(s), d(t)
+                if L.extra_bn:
+                    g, h = _bn_affine(weights, L.extra_bn)
+                    p["scale2"], p["shift2"] = d(g), d(h)
+            elif L.kind == "conv":
+                wt = weights[L.scope + "/weights"]
+                s, t = _fold(weights, L, weights[L.scope + "/biases"])
+                if L.cin == 1:   # residual0
+                    p["a"] = d(wt.reshape(L.cout).astype(np.float64) * s)
+                    p["shift"] = d(t)
+                elif L.cout == 1:  # deconv_final
+                    p["w"] = d(wt[..., 0].reshape(9, L.cin))
+                    p["scale_f"], p["shift_f"] = float(s[0]), float(t[0])
+                else:
+                    p["pw"] = ops.PackedWeights(wt.reshape(L.k * L.k, L.cin, L.cout), False, device)
+                    p["scale"], p["shift"] = d(s), d(t)
+            elif L.kind == "deconv":
+                s, t = _fold(weights, L, weights[L.scope + "/biases"])
+                p["phases"] = ops.pack_deconv(weights[L.scope + "/weights"], device)
+                p["scale"], p["shift"] = d(s), d(t)
+            elif L.kind == "bn":
+                g, h = _bn_affine(weights, L.bn[0])
+                p["scale"], p["shift"] = d(g), d(h)
+            self.P[key] = p
+
+    # ---- building blocks
+    def _sep(self, key, x, out=None, res=None):
+        """strided_conv_block (denoiser.py:110-136): depthwise 3x3 -> 1x1 on the matrix cores with
+        BN x2 (+ the optional extra BN) + relu6 (+ residual) fused into its epilogue."""
+        L, p = self.layers[key], self.P[key]
+        Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
+        tmp = ops.Act.empty(x.B, Ho, Wo, L.cin, self.device)
+        ops.dw3x3(x, p["dw"], tmp, stride=L.stride, rate=L.rate)
+        if out is None:
+            out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
+        ops.conv1x1(tmp, p["pw"], p["scale"], p["shift"], out, scale2=p.get("scale2"), shift2=p.get("shift2"),
+                    res=res, precision=self.precision)
+        return out
+
+    def _conv1x1(self, key, x, out=None, res=None):
+        L, p = self.layers[key], self.P[key]
+        Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
+        if out is None:
+            out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
+        ops.conv1x1(x, p["pw"], p["scale"], p["shift"], out, stride=L.stride, res=res, precision=self.precision)
+        return out
+
+    def _deconv(self, key, x, out):
+        p = self.P[key]
+        return ops.deconv3x3s2(x, p["phases"], p["scale"], p["shift"], out, precision=self.precision)
+
+    # ---- the graph
+    def forward(self, x):
+        """x: torch CUDA float32 [B,S,S,1] contiguous, S a multiple of 16 -> [B,S,S,1].
+        No output clip (denoiser.py:396; the clip is applied by Denoiser.denoise_crop, :649)."""
+        import torch
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[3] == 1
+        B, S = x.shape[0], x.shape[1]
+        assert x.shape[2] == S and S % 16 == 0 and S >= 16, "square crops with side a multiple of 16"
+        dev = self.device
+        E = lambda H, Cc: ops.Act.empty(B, H, H, Cc, dev)
+        P = self.P
+        S2, S4, S8, S16 = S // 2, S // 4, S // 8, S // 16
+        f0, f1, f2, f3 = features0, features1, features2, features3
+
+        # encoder 0 (:252-264).  cnn0_strided lives in the channel slice of concat1 that :365 reads it from.
+        cnn0 = ops.cin1(x, P["cnn0"]["w9"], P["cnn0"]["a"], P["cnn0"]["shift"], E(S, f0))
+        cnn0_last = self._sep("cnn0_last", cnn0)
+        residual0 = ops.cin1(x, None, P["residual0"]["a"], P["residual0"]["shift"], E(S2, f1), stride=2)
+        concat1 = E(S2, f2 + f1)
+        cnn0_strided = self._sep("cnn0_strided", cnn0_last, out=concat1.slice(f2, f1), res=residual0)
+        del cnn0, cnn0_last, residual0
+        # encoder 1 (:267-279); cnn1_strided lives in concat2 (:353)
+        cnn1 = self._sep("cnn1", cnn0_strided)
+        cnn1_last = self._sep("cnn1_last", cnn1)
+        residual1 = self._conv1x1("residual1", cnn0_strided)
+        concat2 = E(S4, aspp_output + f1)
+        cnn1_strided = self._sep("cnn1_strided", cnn1_last, out=concat2.slice(aspp_output, f1), res=residual1)
+        del cnn1, cnn1_last, residual1
+        # encoder 2 (:282-294)
+        cnn2 = self._sep("cnn2", cnn1_strided)
+        cnn2_last = self._sep("cnn2_last", cnn2)
+        residual2 = self._conv1x1("residual2", cnn1_strided)
+        cnn2_strided = self._sep("cnn2_strided", cnn2_last, res=residual2)
+        del cnn2, cnn2_last, residual2
+        # encoder 3 (:297-309)
+        cnn3 = self._sep("cnn3", cnn2_strided)
+        cnn3_last = self._sep("cnn3_last", cnn3)
+        residual3 = self._conv1x1("residual3", cnn2_strided)
+        cnn3_strided = self._sep("cnn3_strided", cnn3_last, res=residual3)
+        del cnn2_strided, cnn3, cnn3_last, residual3
+        # encoder 4 (:312-322) and the middle flow (:324-325)
+        t = self._sep("cnn4_a", cnn3_strided)
+        t = self._sep("cnn4_b", t)
+        cur = self._sep("cnn4_last", t, res=cnn3_strided)
+        del cnn3_strided
+        for i in range(num_extra_blocks):
+            t = self._sep(f"middle{i}_0", cur)
+            t = self._sep(f"middle{i}_1", t)
+            cur = self._sep(f"middle{i}_2", t, res=cur)
+        # ASPP (:152-216): the five branches write straight into their slices of the 3640-channel concat
+        af = aspp_filters
+        cat = E(S16, 5 * af)
+        self._conv1x1("aspp_conv1x1", cur, out=cat.slice(0, af))
+        self._sep("aspp_small", cur, out=cat.slice(af, af))
+        self._sep("aspp_medium", cur, out=cat.slice(2 * af, af))
+        self._sep("aspp_large", cur, out=cat.slice(3 * af, af))
+        # :185-189 the pooled tensor is discarded; :199 "pooling" = resize of the INPUT to [aspp,aspp]
+        # (an identity resize here) followed by BN + relu6 (:200)
+        ops.affine_relu6(cur, P["aspp_pooling_bn"]["scale"], P["aspp_pooling_bn"]["shift"], cat.slice(4 * af, af))
+        aspp = self._conv1x1("aspp_reduce", cat)
+        del cur, cat, t
+        # decoder (:350-384)
+        ops.resize_bilinear(aspp, concat2.slice(0, aspp_output))            # deconv3 (:350)
+        t = self._sep("deconv2_a", concat2)
+        residual2_d = self._conv1x1("residual2_d", concat2)
+        deconv2 = self._sep("deconv2_b", t, res=residual2_d)
+        del aspp, concat2, cnn1_strided, residual2_d, t
+        self._deconv("deconv2to1", deconv2, concat1.slice(0, f2))
+        t = self._sep("deconv1_a", concat1)
+        residual1_d = self._conv1x1("residual1_d", concat1)
+        deconv1 = self._sep("deconv1_b", t, res=residual1_d)
+        del deconv2, concat1, cnn0_strided, residual1_d, t
+        deconv1to0 = self._deconv("deconv1to0", deconv1, E(S, f1))
+        del deconv1
+        t = self._sep("deconv0_a", deconv1to0)
+        residual0_d = self._conv1x1("residual0_d", deconv1to0)
+        deconv0 = self._sep("deconv0_b", t, res=residual0_d)
+        del deconv1to0, residual0_d, t
+        out = torch.empty((B, S, S, 1), dtype=torch.float32, device=dev)
+        pf = P["deconv_final"]
+        ops.conv3x3_cout1(deconv0, pf["w"], pf["scale_f"], pf["shift_f"], out)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+def scale0to1(img):
+    """Rescale image between 0 and 1 (denoiser.py:684-695)."""
+    img = np.asarray(img)
+    lo, hi = np.min(img), np.max(img)
+    if lo == hi:
+        img = np.full(img.shape, 0.5)
+    else:
+        img = (img - lo) / (hi - lo)
+    return img.astype(np.float32)
+
+
+def _resize_bilinear_host(img, size):
+    """cv2.resize(img, size) with its default INTER_LINEAR (half-pixel centres, edge clamp), in numpy:
+    the reference's preprocessing step (denoiser.py:634), host side, identity for 512x512 inputs."""
+    H, W = img.shape
+    oh, ow = size[1], size[0]
+    if (H, W) == (oh, ow):
+        return img.astype(np.float32)
+
+    def axis(n_in, n_out):
+        src = (np.arange(n_out) + 0.5) * (n_in / n_out) - 0.5
+        lo = np.floor(src).astype(np.int64)
+        frac = src - lo
+        return np.clip(lo, 0, n_in - 1), np.clip(lo + 1, 0, n_in - 1), frac
+
+    y0, y1, fy = axis(H, oh)
+    x0, x1, fx = axis(W, ow)
+    img = img.astype(np.float64)
+    top = img[y0][:, x0] * (1 - fx) + img[y0][:, x1] * fx
+    bot = img[y1][:, x0] * (1 - fx) + img[y1][:, x1] * fx
+    return (top * (1 - fy)[:, None] + bot * fy[:, None]).astype(np.float32)
+
+
+class Denoiser(object):
+    """Drop-in for the reference's ``Denoiser`` (machine_learning/denoiser.py:584-682)."""
+
+    def __init__(self, checkpoint_loc=None, visible_cuda=None, precision="bf16x3", weights=None, seed=SYNTH_SEED):
+        import torch
+
+        # reference: os.environ["CUDA_VISIBLE_DEVICES"] = visible_cuda (:591); here: a device index
+        idx = int(str(visible_cuda).split(",")[0]) if visible_cuda not in (None, "") else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        if weights is None:
+            weights = load_weights(checkpoint_loc) if checkpoint_loc else synthetic_weights(seed)
+        self.engine = DenoiserEngine(weights, self.device, precision)
+
+    # ---- :632-643
+    def preprocess(self, img):
+        img = _resize_bilinear_host(np.asarray(img, dtype=np.float32), (cropsize, cropsize))
+        img = scale0to1(img)
+        img[np.isnan(img)] = 0.5
+        img[np.isinf(img)] = 0.5
+        return scale0to1(img).reshape(1, cropsize, cropsize, 1)
+
+    def _forward_np(self, batch):
+        import torch
+
+        x = torch.from_numpy(np.ascontiguousarray(batch, dtype=np.float32)).to(self.device)
+        return self.engine.forward(x).cpu().numpy()
+
+    # ---- :645-651
+    def denoise_crop(self, img, preprocess=True, postprocess=True):
+        x = self.preprocess(img) if preprocess else np.asarray(img, np.float32).reshape(1, cropsize, cropsize, 1)
+        pred = self._forward_np(x)
+        if postprocess:
+            return pred.clip(0.0, 1.0).reshape(cropsize, cropsize)
+        return pred
+
+    def denoise_batch(self, lq_batch, postprocess=False):
+        """lq_batch [B,S,S,1] float32, numpy or torch (host or device) -> hq_batch, same container."""
+        import torch
+
+        is_np = isinstance(lq_batch, np.ndarray)
+        x = torch.from_numpy(np.ascontiguousarray(lq_batch, dtype=np.float32)) if is_np else lq_batch
+        on_dev = x.is_cuda
+        y = self.engine.forward(x.to(self.device, dtype=torch.float32).contiguous())
+        if postprocess:
+            y = y.clamp_(0.0, 1.0)
+        if is_np:
+            return y.cpu().numpy()
+        return y if on_dev else y.cpu()
+
+    # ---- :653-682 (the reference's body is not executable as written: no `self`, float slice indices,
+    #      `=` instead of `+=`); this implements its stated intent, with all tiles in one batch
+    def denoise(self, img, preprocess=True, postprocess=True, overlap=80, max_batch=32):
+        if not isinstance(img, np.ndarray) or img.ndim == 4:
+            return self.denoise_batch(img, postprocess=postprocess)
+        img = np.asarray(img, dtype=np.float32)
+        if preprocess:
+            img = self.preprocess(img).reshape(cropsize, cropsize)
+        H, W = img.shape
+        if H < cropsize or W < cropsize:
+            raise ValueError("denoise(preprocess=False) needs an image of at least 512x512")
+        num0 = (H - cropsize + (cropsize - overlap) - 1) // (cropsize - overlap) + 1 if H > cropsize else 1
+        num1 = (W - cropsize + (cropsize - overlap) - 1) // (cropsize - overlap) + 1 if W > cropsize else 1
+        ys = [int(round(i * (H - cropsize) / max(num0 - 1, 1))) for i in range(num0)]
+        xs = [int(round(j * (W - cropsize) / max(num1 - 1, 1))) for j in range(num1)]
+        tiles = [(y, x) for y in ys for x in xs]
+        denoised = np.zeros((H, W), np.float64)
+        contributions = np.zeros((H, W), np.float64)
+        for k in range(0, len(tiles), max_batch):
+            chunk = tiles[k:k + max_batch]
+            batch = np.stack([img[y:y + cropsize, x:x + cropsize] for (y, x) in chunk])[..., None]
+            pred = self._forward_np(batch)[..., 0]
+            for (y, x), p in zip(chunk, pred):
+                denoised[y:y + cropsize, x:x + cropsize] += p
+                contributions[y:y + cropsize, x:x + cropsize] += 1
+        denoised /= contributions
+        return denoised.clip(0.0, 1.0) if postprocess else denoised
+
+
+def architecture(inputs, ground_truth=None, phase=False, params=None, engine=None):
+    """Signature of the reference's graph builder (denoiser.py:58-61).  ``phase`` must be False
+    (inference); ``params`` may carry {'weights': dict} or an engine is passed directly."""
+    if phase:
+        raise NotImplementedError("training-mode batch norm is the D' path (not in this round)")
+    if engine is None:
+        raise ValueError("pass engine=DenoiserEngine(...)")
+    return engine.forward(inputs)

@@ -48,7 +48,8 @@ class _Graph:
         self.get = get_var
         self.names = _Names("nn")
         self.dtype = dtype
-        self.trace = None  # optional list of (tag, tensor) for per-layer statistics
+        self.trace = None  # optional list of tensors (post-activation) for per-layer statistics
+        self.calibrate = None  # optional dict: batch statistics of every BN input are written here AND used
 
     # ---- denoiser.py:71-84
     def _batch_norm_fn(self, x, scope=None):
@@ -56,8 +57,17 @@ class _Graph:
         C = x.shape[-1]
         beta = self.get(scope + "/beta", (C,))
         gamma = self.get(scope + "/gamma", (C,))
-        mean = self.get(scope + "/moving_mean", (C,))
-        var = self.get(scope + "/moving_variance", (C,))
+        if self.calibrate is not None:
+            # data-dependent initialisation of the moving statistics (used only to SYNTHESISE weights:
+            # tests/golden/make_synth_bn.py); biased variance, like TF's fused batch norm normalisation
+            mean = x.mean(dim=(0, 1, 2))
+            var = x.var(dim=(0, 1, 2), unbiased=False)
+            self.calibrate[scope + "/moving_mean"] = mean.to(torch.float32).numpy().copy()
+            self.calibrate[scope + "/moving_variance"] = var.to(torch.float32).numpy().copy()
+            mean, var = mean.to(torch.float32).to(self.dtype), var.to(torch.float32).to(self.dtype)
+        else:
+            mean = self.get(scope + "/moving_mean", (C,))
+            var = self.get(scope + "/moving_variance", (C,))
         return T.batch_norm_inference_t(x, gamma, beta, mean, var)
 
     def batch_then_activ(self, x):
@@ -191,7 +201,7 @@ def variable_specs(cropsize=32) -> "OrderedDict[str, tuple]":
     return specs
 
 
-def architecture(inputs, weights, cropsize=512, dtype=torch.float32, trace=None):
+def architecture(inputs, weights, cropsize=512, dtype=torch.float32, trace=None, calibrate=None):
     """inputs [B,cropsize,cropsize,1] (numpy or torch) -> torch tensor [B,cropsize,cropsize,1].
     ``weights``: dict TF-name -> numpy array.  No output clip (denoiser.py:396)."""
     cache = {}
@@ -205,6 +215,7 @@ def architecture(inputs, weights, cropsize=512, dtype=torch.float32, trace=None)
 
     g = _Graph(get, dtype)
     g.trace = trace
+    g.calibrate = calibrate
     x = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(inputs))
     with torch.no_grad():
         return g.build(x.to(dtype), cropsize)

@@ -1,0 +1,42 @@
+"""Generates ai-cv-automation-elect-micr_amd/data/synth_bn_seed1234.npz: calibrated batch-norm moving
+statistics for the package's seeded synthetic weights (SURVEY.md 8d "Synthetic weights").
+
+The reference ships no checkpoint (its paths are network shares, machine_learning/denoiser.py:588).
+With TF-initial moving statistics (mean 0, variance 1) and Xavier kernels the activations of the
+~60-layer graph decay to ~1e-7, so relu6 never sees its upper side and a parity check would be vacuous.
+This script runs the ORACLE (float64) once on a fixed synthetic 2-image 128x128 batch in calibration
+mode -- every batch norm takes the batch statistics of its own input as its moving statistics -- and
+stores those vectors.  Output is data (seeded, reproducible), not code.
+
+    python tests/golden/make_synth_bn.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import emdenoise  # noqa: E402
+from emdenoise import denoiser as D  # noqa: E402
+from oracle import denoiser_graph as G  # noqa: E402
+from tests.synth_inputs import synthetic_lq  # noqa: E402
+
+
+def main():
+    seed = D.SYNTH_SEED
+    w = D.synthetic_weights(seed, bn="tf_init")
+    assert list(w.keys()) == list(G.variable_specs().keys()), "product and oracle disagree on the TF variable names"
+    x = synthetic_lq(2, 128, 128, seed=seed)
+    calib = {}
+    y = G.architecture(x, w, cropsize=128, dtype=torch.float64, calibrate=calib)
+    out = os.path.join(ROOT, "ai-cv-automation-elect-micr_amd", "data", f"synth_bn_seed{seed}.npz")
+    np.savez_compressed(out, **calib)
+    print(f"wrote {out}: {len(calib)} vectors, {sum(v.size for v in calib.values())} floats, "
+          f"output mean {float(y.mean()):.4f} std {float(y.std()):.4f}")
+
+
+if __name__ == "__main__":
+    main()
