@@ -236,26 +236,40 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
         __syncthreads();  // all fragment reads of tile `it` done before it is overwritten
     }
 
-    // ---- epilogue: C/D layout of mfma_32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // ---- epilogue: C/D layout of mfma_32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    // Local restrict-qualified copies: the residual loads of a tile are all issued before its first store
+    // (through the struct the compiler must assume res aliases C and serialises load -> store per element).
+    const float* __restrict__ resp = p.res;
+    float* __restrict__ outp = p.C;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WN) + j * 32 + fr;
-        if (n >= p.N) continue;
-        const float s1 = p.scale1[n], t1 = p.shift1[n];
+        const bool nok = n < p.N;
+        const float s1 = nok ? p.scale1[n] : 0.f, t1 = nok ? p.shift1[n] : 0.f;
         float s2 = 1.f, t2 = 0.f;
-        if (p.scale2) { s2 = p.scale2[n]; t2 = p.shift2[n]; }
+        if (p.scale2 && nok) { s2 = p.scale2[n]; t2 = p.shift2[n]; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            long long pix[16];
+            float rv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                const long long pix = rowP[r];
-                if (pix < 0) continue;
+                pix[e] = nok ? rowP[r] : -1;
+                rv[e] = 0.f;
+            }
+            if (resp) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (pix[e] >= 0) rv[e] = resp[pix[e] * p.ldres + n];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (pix[e] < 0) continue;
                 float v = fmaf(acc[i][j][e], s1, t1);
                 if (p.act) v = fminf(fmaxf(v, 0.f), 6.f);
                 if (p.scale2) v = fminf(fmaxf(fmaf(v, s2, t2), 0.f), 6.f);
-                if (p.res) v += p.res[pix * p.ldres + n];
-                p.C[pix * p.ldc + n] = v;
+                outp[pix[e] * p.ldc + n] = v + rv[e];
             }
         }
     }

@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- megapixels/s restored on synthetic 512x512x1 micrograph batches (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload K|D] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload K|D|both] [--batch B]
 
 A "step" is one pass of the hot path over one batch that is already resident in HBM.
 Workloads:
-  K  BASELINE configs[1]: the 3-layer 3x3 kernel denoiser (misc_py/noise-removal-kernels.py,
-     depth 2, width 3) on [32,512,512,1]                                   -- default
-  D  BASELINE configs[2]: the modified-Xception encoder-decoder of machine_learning/denoiser.py
-     on [32,512,512,1]
-For N > 1 the driver launches one rank per GPU (torch.distributed.run); inference shards whole
-images across ranks with no data-path collective (weak scaling: B images PER GPU).
-Rank 0 prints ONE JSON line.
+  K  BASELINE configs[1]: the 3-layer 3x3 kernel denoiser (misc_py/noise-removal-kernels.py, depth 2,
+     width 3) on [32,512,512,1].  This is the configuration the metric line is quoted on.
+  D  BASELINE configs[2]: the modified-Xception encoder-decoder of machine_learning/denoiser.py on
+     [32,512,512,1] (matrix cores in split-bf16 parity mode unless --precision bf16).
+Default ("both"): the JSON line's metric/value/roofline/cpu_baseline are workload K's; workload D's
+figures ride along under "workload_D".  --workload D makes D the primary line.
+For N > 1 the driver launches one rank per GPU (torch.distributed.run); inference shards whole images
+across ranks with no data-path collective (weak scaling: --batch images PER GPU).  Rank 0 prints ONE
+JSON line.
 """
 from __future__ import annotations
 
@@ -28,14 +30,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+CPU_THREADS = min(16, os.cpu_count() or 1)  # a 1-GPU box owns a 16-CPU share; more threads only oversubscribe it
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+D_GMAC_MATRIX_B32_512 = 2218.3  # pointwise 1304.5 + dense 1x1 295.3 - final 4.8 + conv-T 618.5 ... per B=32 batch
 
 
 def synthetic_lq(B, H, W, seed=1234):
-    """Synthetic low-quality crops of the reference's shape and statistics:
-    smooth field -> Poisson counts (scale = 25 + Exp(75), denoiser-multi-gpu.py:783-799) ->
-    min-max to [0,1]; the K path additionally divides by the mean (noise-removal-kernels.py:525-527)."""
+    """Synthetic low-quality crops of the reference's shape and statistics: smooth field ->
+    Poisson counts (scale = 25 + Exp(75), denoiser-multi-gpu.py:783-799) -> min-max to [0,1]."""
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
     base = []
@@ -46,19 +49,17 @@ def synthetic_lq(B, H, W, seed=1234):
             hq += np.float32(rng.uniform(0.2, 1.0)) * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / np.float32(2 * s * s))
         hq = (hq - hq.min()) / max(float(hq.max() - hq.min()), 1e-9)
         lq = rng.poisson(hq * (25.0 + rng.exponential(75.0))).astype(np.float32)
-        lq = (lq - lq.min()) / max(float(lq.max() - lq.min()), 1e-9)
-        base.append(lq)
+        base.append((lq - lq.min()) / max(float(lq.max() - lq.min()), 1e-9))
     out = np.stack([base[i % len(base)] for i in range(B)])[..., None].astype(np.float32)
-    # decorrelate the replicas with a little extra shot noise so no two images are identical
-    out += rng.random(out.shape, dtype=np.float32) * np.float32(1e-3)
-    return out
+    out += rng.random(out.shape, dtype=np.float32) * np.float32(1e-3)  # no two images identical
+    return np.clip(out, 0.0, 1.0)
 
 
 # ------------------------------------------------------------------------------------------------
-# CPU baseline (the oracle, timed; reported next to the GPU number, never the thing shipped)
+# CPU baselines: the ORACLE timed on the host cores (reported next to the GPU number; never shipped)
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline_K(x_host, W, Bm, s, budget_s=12.0):
-    """Times oracle/k_oracle.c (plain-C port of graph K, OpenMP over rows) on the host cores."""
+def cpu_baseline_K(x_host, W, Bm, s, budget_s=10.0):
+    """oracle/k_oracle.c (plain-C port of graph K, OpenMP over rows)."""
     import subprocess
 
     so = os.path.join(ROOT, "oracle", "_build", "libk_oracle.so")
@@ -68,17 +69,16 @@ def cpu_baseline_K(x_host, W, Bm, s, budget_s=12.0):
     lib.k_oracle_f32.restype = ctypes.c_int
     lib.k_oracle_f32.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_int]
     lib.k_oracle_max_threads.restype = ctypes.c_int
-    cores = min(lib.k_oracle_max_threads(), os.cpu_count() or 1)
+    cores = min(lib.k_oracle_max_threads(), CPU_THREADS)
     x = np.ascontiguousarray(x_host[..., 0])
     y = np.empty_like(x)
     B, H, Wd = x.shape
 
     def run():
-        rc = lib.k_oracle_f32(x.ctypes.data, y.ctypes.data, B, H, Wd, W.shape[1], W.shape[0], W.ctypes.data,
-                              Bm.ctypes.data, s.ctypes.data, cores)
-        assert rc == 0
+        assert lib.k_oracle_f32(x.ctypes.data, y.ctypes.data, B, H, Wd, W.shape[1], W.shape[0], W.ctypes.data,
+                                Bm.ctypes.data, s.ctypes.data, cores) == 0
 
-    run()  # warm-up
+    run()
     reps, t0 = 0, time.perf_counter()
     while True:
         run()
@@ -86,21 +86,198 @@ def cpu_baseline_K(x_host, W, Bm, s, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or reps >= 200:
             break
-    mpx = B * H * Wd / 1e6 * reps / el
-    return {"value": round(mpx, 2), "unit": "MPx/s", "cores": cores, "kind": "port",
+    return {"value": round(B * H * Wd / 1e6 * reps / el, 2), "unit": "MPx/s", "cores": cores, "kind": "port",
             "sample": f"{reps} passes over the same [{B},{H},{Wd},1] batch, oracle/k_oracle.c (gcc -O3 -fopenmp), {el:.1f} s"}, y
 
 
+def cpu_baseline_D(x_host, weights):
+    """oracle/denoiser_graph.py (PyTorch-CPU float32 restatement of the TF graph) on ONE 512x512 image,
+    which mirrors the reference's own batch shape (denoiser.py:613)."""
+    import torch
+
+    from oracle import denoiser_graph as G
+
+    cores = CPU_THREADS
+    torch.set_num_threads(cores)
+    x1 = x_host[:1]
+    S = x1.shape[1]
+    t0 = time.perf_counter()
+    y = G.architecture(x1, weights, S, dtype=torch.float32).numpy()
+    el = time.perf_counter() - t0
+    return {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s", "cores": cores, "kind": "port",
+            "sample": f"1 pass over image 0 of the batch ([1,{S},{S},1]), oracle/denoiser_graph.py "
+                      f"(PyTorch-CPU float32, {torch.get_num_threads()} threads), {el:.1f} s"}, y
+
+
 # ------------------------------------------------------------------------------------------------
+class Timer:
+    """Barrier + synchronize on both sides, exactly `steps` steps, max over ranks."""
+
+    def __init__(self, torch, dist, dev):
+        self.torch, self.dist, self.dev = torch, dist, dev
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def run(self, step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.sync()
+        wall = time.perf_counter() - t0
+        if self.dist is not None:
+            tt = self.torch.tensor([wall], dtype=self.torch.float64, device=self.dev)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            wall = float(tt.item())
+        return wall * 1e3 / steps
+
+
+def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
+    B, H, W = a.batch, a.size, a.size
+    steps = a.steps if a.steps is not None else 200
+    warmup = a.warmup if a.warmup is not None else 20
+    x_host = synthetic_lq(B, H, W, seed=1234 + rank)
+    x_host = (x_host / np.maximum(x_host.mean(axis=(1, 2, 3), keepdims=True), 1e-9)).astype(np.float32)  # noise-removal-kernels.py:525-527
+    rng = np.random.default_rng(7)
+    pairs = emdenoise.kernel_denoiser.sym_pairs(3)
+    wsc = [(rng.standard_normal(len(pairs)) * 0.15 + 1.0 / 9).astype(np.float32) for _ in range(2)]
+    bsc = [np.zeros(len(pairs), np.float32), (rng.standard_normal(len(pairs)) * 0.5).astype(np.float32)]
+    params = emdenoise.KernelParams.from_symmetric(wsc, bsc, [1.0, 1.3], 3)
+    pd = torch.from_numpy(params.packed()).to(dev)
+    x = torch.from_numpy(x_host).to(dev)
+    y = torch.empty_like(x)
+
+    def step():
+        emdenoise.kernel_denoise(x, pd, 3, 2, params.symmetric, out=y)
+
+    ms = timer.run(step, steps, warmup)
+    # the dominant (only) kernel, timed live with HIP events on the launch stream: torch's current stream IS
+    # the stream handed to the C ABI.  One event pair around a back-to-back burst cancels the per-event cost.
+    n_burst = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n_burst):
+            step()
+    g.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    launch_us = e0.elapsed_time(e1) * 1e3 / n_burst
+    alg_bytes = 8.0 * B * H * W  # SURVEY.md 8(d): 8 B per pixel (read 4 + write 4)
+    achieved = alg_bytes / (launch_us * 1e-6) / 1e9
+    out = {
+        "value": B * H * W / 1e6 * world / (ms / 1e3), "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "f32",
+        "config": {"workload": f"K: kernel denoiser depth 2 width 3 (noise-removal-kernels.py), [{B},{H},{W},1] fp32 per GPU",
+                   "global_batch": B * world, "image": f"{H}x{W}x1", "sharding": f"{world} x {B} whole images, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "k3_tile<2,8>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "avg_launch_us": round(launch_us, 3),
+                     "how": f"HIP events around a hipGraph of {n_burst} back-to-back launches (includes the ~1.5 us kernel boundary)"},
+    }
+    if want_cpu:
+        cb, y_cpu = cpu_baseline_K(x_host, params.wmaps, params.bmaps, params.s)
+        out["cpu_baseline"] = cb
+        y_gpu = y.cpu().numpy()[..., 0].astype(np.float64)
+        out["rel_l2_vs_oracle"] = float(f"{np.linalg.norm(y_gpu - y_cpu) / np.linalg.norm(y_cpu):.3e}")
+    return out
+
+
+def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
+    from emdenoise import ops
+
+    B, H, W = a.batch, a.size, a.size
+    steps = a.steps if (a.steps is not None and a.workload == "D") else 10
+    warmup = a.warmup if (a.warmup is not None and a.workload == "D") else 2
+    x_host = synthetic_lq(B, H, W, seed=1234 + rank)
+    weights = emdenoise.synthetic_weights()
+    eng = emdenoise.DenoiserEngine(weights, dev, a.precision)
+    x = torch.from_numpy(x_host).to(dev)
+    box = [None]
+
+    def step():
+        box[0] = eng.forward(x)
+
+    ms = timer.run(step, steps, warmup)
+    # per-kernel-family device time of ONE more step, HIP events around every launch of the family
+    fam = {}
+    orig = {}
+
+    def wrap(name):
+        f = getattr(ops, name)
+        orig[name] = f
+
+        def g(*args, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = f(*args, **kw)
+            e1.record()
+            fam.setdefault(name, []).append((e0, e1))
+            return r
+
+        setattr(ops, name, g)
+
+    for name in ("conv1x1", "deconv3x3s2", "dw3x3", "cin1", "conv3x3_cout1", "resize_bilinear", "affine_relu6"):
+        wrap(name)
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        for name, f in orig.items():
+            setattr(ops, name, f)
+    fam_ms = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) for k, v in fam.items()}
+    gemm_ms = fam_ms.get("conv1x1", 0.0) + fam_ms.get("deconv3x3s2", 0.0)
+    scale = (B / 32.0) * (H * W) / (512.0 * 512.0)
+    alg_flops = 2.0 * D_GMAC_MATRIX_B32_512 * 1e9 * scale
+    achieved = alg_flops / (gemm_ms * 1e-3) / 1e12
+    passes = 3 if a.precision == "bf16x3" else 1
+    dw_bytes = 48.1e9 * scale  # SURVEY.md 8(d): 57 depthwise stages, in+out fp32
+    out = {
+        "value": B * H * W / 1e6 * world / (ms / 1e3), "ms_per_step": ms, "steps": steps, "warmup": warmup,
+        "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)" if passes == 3 else "bf16",
+        "config": {"workload": f"D: modified-Xception encoder-decoder (machine_learning/denoiser.py), [{B},{H},{W},1] fp32 per GPU",
+                   "global_batch": B * world, "image": f"{H}x{W}x1", "precision": a.precision,
+                   "sharding": f"{world} x {B} whole images, no collective"},
+        "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel (every 1x1 / transposed-conv launch of one step)",
+                     "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "algorithmic_flops_per_step": alg_flops, "mfma_passes": passes,
+                     "issued_tflops": round(achieved * passes, 1),
+                     "kernel_ms_per_step": round(gemm_ms, 3),
+                     "how": "HIP events around every launch of the family in one extra step"},
+        "depthwise": {"bound": "hbm", "kernel": "dw3x3_s1_roll / dw3x3_generic", "ms_per_step": round(fam_ms.get("dw3x3", 0.0), 3),
+                      "achieved_GBps": round(dw_bytes / (fam_ms.get("dw3x3", 1e9) * 1e-3) / 1e9, 1),
+                      "frac_of_8TBps": round(dw_bytes / (fam_ms.get("dw3x3", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+        "kernel_family_ms": {k: round(v, 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])},
+    }
+    if want_cpu:
+        cb, y_cpu = cpu_baseline_D(x_host, weights)
+        out["cpu_baseline"] = cb
+        y_gpu = box[0][:1].cpu().numpy().astype(np.float64)
+        out["rel_l2_vs_oracle"] = float(f"{np.linalg.norm(y_gpu - y_cpu) / np.linalg.norm(y_cpu):.3e}")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["K", "D"], default="K")
+    ap.add_argument("--workload", choices=["K", "D", "both"], default="both")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3",
+                    help="workload D matrix-core mode: bf16x3 = split-bf16 parity mode (default), bf16 = fast mode")
     a = ap.parse_args()
 
     import torch
@@ -110,7 +287,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
+    if world > 1 and a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
@@ -124,94 +301,47 @@ def main():
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    timer = Timer(torch, dist, dev)
+    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
 
-    B, H, W = a.batch, a.size, a.size
-    x_host = synthetic_lq(B, H, W, seed=1234 + rank)
+    primary_is_D = a.workload == "D"
+    res_K = res_D = None
+    if a.workload in ("K", "both"):
+        res_K = bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
+    if a.workload in ("D", "both"):
+        try:
+            res_D = bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
+        except Exception as e:  # the primary (K) line must survive a failure of the rider
+            if primary_is_D:
+                raise
+            res_D = {"error": f"{type(e).__name__}: {e}"}
 
-    if a.workload == "K":
-        steps = a.steps if a.steps is not None else 200
-        warmup = a.warmup if a.warmup is not None else 20
-        x_host = x_host / np.maximum(x_host.mean(axis=(1, 2, 3), keepdims=True), 1e-9)
-        rng = np.random.default_rng(7)
-        pairs = emdenoise.kernel_denoiser.sym_pairs(3)
-        wsc = [(rng.standard_normal(len(pairs)) * 0.15 + 1.0 / 9).astype(np.float32) for _ in range(2)]
-        bsc = [np.zeros(len(pairs), np.float32), (rng.standard_normal(len(pairs)) * 0.5).astype(np.float32)]
-        params = emdenoise.KernelParams.from_symmetric(wsc, bsc, [1.0, 1.3], 3)
-        pd = torch.from_numpy(params.packed()).to(dev)
-        x = torch.from_numpy(x_host).to(dev)
-        y = torch.empty_like(x)
-
-        def step():
-            emdenoise.kernel_denoise(x, pd, 3, 2, params.symmetric, out=y)
-
-        workload = f"K: kernel denoiser depth 2 width 3 (noise-removal-kernels.py), [{B},{H},{W},1] fp32 per GPU"
-        dtype = "f32"
-        alg_bytes_per_launch = 8.0 * B * H * W  # 8 B/pixel (read 4 + write 4)
-        dominant = "k3_rows<MODE_SYM>"
-        launches_per_step = 1
-    else:
-        raise SystemExit("workload D is not wired into bench.py yet")
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(warmup):
-        step()
-    sync_all()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    for s_ev, e_ev in evs:
-        s_ev.record()
-        step()
-        e_ev.record()
-    sync_all()
-    t1 = time.perf_counter()
-    wall = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
-    ms_per_step = wall * 1e3 / steps
-    # HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on)
-    ev_ms = np.array([s_ev.elapsed_time(e_ev) for s_ev, e_ev in evs])
-    kern_ms = float(np.mean(ev_ms)) / launches_per_step
-    total_ms_events = evs[0][0].elapsed_time(evs[-1][1])
-
-    mpx_per_step = B * H * W / 1e6 * world
-    value = mpx_per_step / (ms_per_step / 1e3)
-    achieved = alg_bytes_per_launch / (kern_ms * 1e-3) / 1e9
-
+    prim = res_D if primary_is_D else res_K
     out = {
         "metric": "megapixels/sec restored (512x512x1 bs=32)",
-        "value": round(value, 1),
+        "value": round(prim["value"], 1),
         "unit": "MPx/s",
         "n_gpus": world,
-        "steps": steps,
-        "warmup": warmup,
-        "ms_per_step": round(ms_per_step, 5),
+        "steps": prim["steps"],
+        "warmup": prim["warmup"],
+        "ms_per_step": round(prim["ms_per_step"], 5),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": dtype,
+        "dtype": prim["dtype"],
         "data": "synthetic",
-        "config": {"workload": workload, "global_batch": B * world, "image": f"{H}x{W}x1",
-                   "sharding": f"{world} x {B} whole images, no collective"},
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                     "avg_launch_us_hip_events": round(kern_ms * 1e3, 3),
-                     "avg_step_us_back_to_back": round(total_ms_events * 1e3 / steps, 3)},
+        "config": prim["config"],
+        "roofline": prim["roofline"],
     }
-    if rank == 0 and not a.no_cpu_baseline:
-        W_, Bm_, s_ = params.wmaps, params.bmaps, params.s
-        cb, y_cpu = cpu_baseline_K(x_host, W_, Bm_, s_)
-        out["cpu_baseline"] = cb
-        y_gpu = y.cpu().numpy()[..., 0]
-        rel = float(np.linalg.norm(y_gpu.astype(np.float64) - y_cpu) / np.linalg.norm(y_cpu))
-        out["rel_l2_vs_oracle"] = float(f"{rel:.3e}")
+    for k in ("cpu_baseline", "rel_l2_vs_oracle", "depthwise", "kernel_family_ms"):
+        if k in prim:
+            out[k] = prim[k]
+    if not primary_is_D and res_D is not None:
+        if "value" in res_D:
+            res_D["value"] = round(res_D["value"], 1)
+            res_D["ms_per_step"] = round(res_D["ms_per_step"], 4)
+            res_D["unit"] = "MPx/s"
+        out["workload_D"] = res_D
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

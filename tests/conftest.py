@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:  # the oracle runs on PyTorch-CPU: more threads than the box's CPU share only oversubscribe it
+        import torch
+
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
