@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libemdenoise.so")
+LIB_PATH = os.environ.get("EMD_LIB_PATH") or os.path.join(PKG_DIR, "libemdenoise.so")  # override: A/B kernel builds
 
 EMD_OK = 0
 EMD_K_SYMMETRIC = 1

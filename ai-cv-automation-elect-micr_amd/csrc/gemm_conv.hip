@@ -23,10 +23,12 @@
 // inside the 1e-3 relative-L2 parity bar (plain bf16 inputs, PASSES=1, is ~2^-9 per layer and is
 // offered as the fast mode).
 //
-// Block = 256 threads = 4 waves; block tile BM x BN, K step BK; each wave owns a (BM/WM)x(BN/WN)
-// sub-tile as 32x32 MFMA tiles.  A: global fp32 -> registers (issued one K step ahead) -> split ->
-// LDS bf16 planes; W: global bf16 -> registers -> LDS.  LDS rows are padded by 16 B so that the
-// ds_read_b128 fragment reads (32 rows x 16 B per half-wave) are bank-conflict free.
+// Block = 256 threads = 4 waves; block tile 128 x BN (BN 128 or 64), K step 64; each wave owns a
+// 64x64 (or 32x64) sub-tile as 32x32 MFMA tiles.  A: global fp32 -> registers (issued one K step
+// ahead) -> split -> LDS bf16 planes; W: global bf16 -> registers -> LDS.  LDS rows are 144 B
+// (128 + 16 pad): the ds_read_b128 fragment reads and the ds_write_b64/b128 staging writes (one full
+// row per lane group) are bank-conflict free.  The epilogue stages the fp32 tile through LDS so that
+// stores and residual loads are 16 B per lane, a whole pixel's channel run per 32 lanes.
 // Block index -> tile mapping is XCD-aware: the N-tiles of one M-tile (which re-read the same
 // activation rows) get consecutive indices inside one XCD's share of the grid.
 #include "emd_common.hpp"
@@ -37,6 +39,9 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;      // native vectors for the staging registers:
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // HIP's float4/uint4 structs end up in scratch
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr int kMaxTaps = 4;
 
@@ -71,31 +76,35 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigne
     lo = __builtin_bit_cast(unsigned, l);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int PASSES>
-__global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
-    static_assert(WM * WN == 4, "4 waves");
-    constexpr int LDK = BK + 8;               // bf16 elements per LDS row (16-B pad)
-    constexpr int TM = BM / WM / 32;          // 32x32 MFMA tiles per wave along M
-    constexpr int TN = BN / WN / 32;
-    constexpr int A_F4_PER_ROW = BK / 4;      // float4 per A-tile row
-    constexpr int A_ROWS_PER_PASS = 256 / A_F4_PER_ROW;
-    constexpr int A_PASSES = BM / A_ROWS_PER_PASS;
-    constexpr int W_CH_PER_ROW = BK / 8;      // 16-B chunks per W-tile row
-    constexpr int W_ROWS_PER_PASS = 256 / W_CH_PER_ROW;
-    constexpr int W_PASSES = BN / W_ROWS_PER_PASS;
-    constexpr int NPL = PASSES == 3 ? 2 : 1;  // bf16 planes kept in LDS
+// Block tile 128 x BN (BN = 128: 2x2 waves of 64x64; BN = 64: 4x1 waves of 32x64), K step 64.
+template <int BN, int PASSES>
+__global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
+    constexpr int BM = 128, BK = 64;
+    constexpr int LDK = BK + 8;                      // bf16 elements per LDS row: 144 B, conflict-free b128 reads
+    constexpr int WM = BN == 128 ? 2 : 4, WN = 4 / WM;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NPL = PASSES == 3 ? 2 : 1;         // bf16 planes kept in LDS
+    constexpr int A_PASSES = BM / 16;                // 16 float4 per 64-float row -> 16 rows per pass
+    constexpr int W_PASSES = BN / 32;                // 8 x 16-B chunks per 64-bf16 row -> 32 rows per pass
+    constexpr int LDS_STAGE = BN + 4;                // fp32 epilogue staging row (floats)
+    constexpr int A_BYTES = NPL * BM * LDK * 2, B_BYTES = NPL * BN * LDK * 2;
+    constexpr int STAGE_BYTES = BM * LDS_STAGE * 4;
+    constexpr int TILE_BYTES = A_BYTES + B_BYTES > STAGE_BYTES ? A_BYTES + B_BYTES : STAGE_BYTES;
 
-    __shared__ __attribute__((aligned(16))) uint16_t As[NPL][BM][LDK];
-    __shared__ __attribute__((aligned(16))) uint16_t Bs[NPL][BN][LDK];
-    __shared__ long long rowA[BM];  // source pixel index of each tile row for the current tap (-1: zero)
-    __shared__ long long rowP[BM];  // destination pixel index (-1: row beyond M)
+    // ONE LDS object, carved by hand (tiles | row maps); the epilogue staging overlays the tiles
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES + 2 * BM * 8];
+    auto As = reinterpret_cast<uint16_t(*)[BM][LDK]>(smem);
+    auto Bs = reinterpret_cast<uint16_t(*)[BN][LDK]>(smem + A_BYTES);
+    float(*stage)[LDS_STAGE] = reinterpret_cast<float(*)[LDS_STAGE]>(smem);
+    long long* rowA = reinterpret_cast<long long*>(smem + TILE_BYTES);  // element offset of the source pixel (-1: zero row)
+    long long* rowP = rowA + BM;                                        // destination pixel index (-1: beyond M)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
 
-    // XCD-aware tile mapping (bijective for any grid size)
+    // XCD-aware tile mapping (bijective for any grid size): the N-tiles of one M-tile are neighbours in one XCD
     const int nblk = p.n_mtiles * p.n_ntiles;
     int bid = blockIdx.x;
     {
@@ -106,7 +115,6 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
 
-    // ---- row maps
     auto map_rows = [&](int tap, bool with_dest) {
         if (tid < BM) {
             const long m = m0 + tid;
@@ -127,22 +135,27 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
                     dst = (b * p.Hc + (i * p.sc + p.py)) * (long)p.Wc + (j * p.sc + p.px);
                 }
             }
-            rowA[tid] = src;
+            rowA[tid] = src < 0 ? -1 : src * p.lda;
             if (with_dest) rowP[tid] = dst;
         }
     };
+    // block-uniform: every row of this tile has a source pixel for every tap (true for all interior tiles of
+    // the flat / strided 1x1 forms); then the loads need no per-row validity select
+    const bool rows_all_valid = p.flat ? (m0 + BM <= p.M) : false;
 
-    // ---- global -> register staging, one K step ahead.  The loop starts at it = -1 (stage tile 0 only)
-    //      so that the load code and the LDS-store code each exist ONCE, in straight-line unrolled form:
-    //      the staging arrays must stay in registers (closures / macro-expanded loops sent them to scratch).
-    float4 areg[A_PASSES];
-    static_assert(W_PASSES == 1 || W_PASSES == 2, "W tile staging");
-    uint4 wh0 = make_uint4(0, 0, 0, 0), wh1 = wh0, wl0 = wh0, wl1 = wh0;  // named, not arrays: see above
-    const int a_col = (tid % A_F4_PER_ROW) * 4;
-    const int a_row = tid / A_F4_PER_ROW;
-    const int w_col = (tid % W_CH_PER_ROW) * 8;
-    const int w_row = tid / W_CH_PER_ROW;
+    // global -> register staging, one K step ahead.  The loop starts at it = -1 (stage tile 0 only) so that
+    // the load code and the LDS-store code each exist once, straight-line and fully unrolled.
+    f32x4 areg[A_PASSES];
+    u32x4 whreg[W_PASSES], wlreg[W_PASSES];
+    const int a_col = (tid & 15) * 4;     // first of this thread's 4 consecutive channels in the K step
+    const int a_row = tid >> 4;           // + 16 per pass
+    const int w_col = (tid & 7) * 8;
+    const int w_row = tid >> 3;           // + 32 per pass
     const int Ktot = p.ntaps * p.Cpad;
+    const uint16_t* __restrict__ whi = p.Whi + (long)(n0 + w_row) * Ktot + w_col;
+    const uint16_t* __restrict__ wlo = NPL == 2 ? p.Wlo + (long)(n0 + w_row) * Ktot + w_col : nullptr;
+    const long w_pass_stride = 32L * Ktot;
+    const float* __restrict__ Ab = p.A + a_col;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -157,53 +170,60 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
     map_rows(0, true);
     __syncthreads();
     const int fr = lane & 31, fh = lane >> 5;
+    // this thread's 8 source-row offsets live in registers for a whole tap: re-reading them from LDS before
+    // every load put 8 serial LDS round trips + 8 divergent branches in front of each K step's loads
+    long long aoff[A_PASSES];
+#pragma unroll
+    for (int q = 0; q < A_PASSES; ++q) aoff[q] = rowA[a_row + q * 16];
 
     for (int it = -1; it < total; ++it) {
         if (it >= 0) {
             // registers (tile `it`) -> LDS, splitting the activations into bf16 hi/lo on the way
 #pragma unroll
             for (int q = 0; q < A_PASSES; ++q) {
-                const int r = a_row + q * A_ROWS_PER_PASS;
+                const int r = a_row + q * 16;
                 unsigned h0, l0, h1, l1;
-                split2(areg[q].x, areg[q].y, h0, l0);
-                split2(areg[q].z, areg[q].w, h1, l1);
-                *reinterpret_cast<uint2*>(&As[0][r][a_col]) = make_uint2(h0, h1);
-                if (NPL == 2) *reinterpret_cast<uint2*>(&As[NPL - 1][r][a_col]) = make_uint2(l0, l1);
+                split2(areg[q][0], areg[q][1], h0, l0);
+                split2(areg[q][2], areg[q][3], h1, l1);
+                *reinterpret_cast<u32x2*>(&As[0][r][a_col]) = u32x2{h0, h1};
+                if (NPL == 2) *reinterpret_cast<u32x2*>(&As[NPL - 1][r][a_col]) = u32x2{l0, l1};
             }
-            *reinterpret_cast<uint4*>(&Bs[0][w_row][w_col]) = wh0;
-            if (NPL == 2) *reinterpret_cast<uint4*>(&Bs[NPL - 1][w_row][w_col]) = wl0;
-            if (W_PASSES == 2) {
-                *reinterpret_cast<uint4*>(&Bs[0][w_row + W_ROWS_PER_PASS][w_col]) = wh1;
-                if (NPL == 2) *reinterpret_cast<uint4*>(&Bs[NPL - 1][w_row + W_ROWS_PER_PASS][w_col]) = wl1;
+#pragma unroll
+            for (int q = 0; q < W_PASSES; ++q) {
+                const int r = w_row + q * 32;
+                *reinterpret_cast<u32x4*>(&Bs[0][r][w_col]) = whreg[q];
+                if (NPL == 2) *reinterpret_cast<u32x4*>(&Bs[NPL - 1][r][w_col]) = wlreg[q];
             }
-            __syncthreads();  // tile `it` visible; rowA free to be re-mapped
+            __syncthreads();  // tile `it` visible
         }
         {
             // stage tile it+1 (the last iteration re-loads its own tile: keeps this path branch-free)
             const int nx = it + 1 < total ? it + 1 : it;
-            const int tap = nx / ksteps, c0 = (nx % ksteps) * BK;
+            const int tap = nx / ksteps, c0 = (nx - tap * ksteps) * BK;
             if (c0 == 0 && !p.flat && nx != it && nx > 0) {  // tap change: new source rows (block-uniform)
                 map_rows(tap, false);
                 __syncthreads();
-            }
 #pragma unroll
-            for (int q = 0; q < A_PASSES; ++q) {
-                const long long src = rowA[a_row + q * A_ROWS_PER_PASS];
-                const int c = c0 + a_col;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (src >= 0 && c < p.Cin) v = *reinterpret_cast<const float4*>(p.A + src * p.lda + c);
-                areg[q] = v;
+                for (int q = 0; q < A_PASSES; ++q) aoff[q] = rowA[a_row + q * 16];
             }
-            const long kk = (long)tap * p.Cpad + c0 + w_col;
-            {
-                const long off = (long)(n0 + w_row) * Ktot + kk;
-                wh0 = *reinterpret_cast<const uint4*>(p.Whi + off);
-                if (NPL == 2) wl0 = *reinterpret_cast<const uint4*>(p.Wlo + off);
-                if (W_PASSES == 2) {
-                    const long off1 = off + (long)W_ROWS_PER_PASS * Ktot;
-                    wh1 = *reinterpret_cast<const uint4*>(p.Whi + off1);
-                    if (NPL == 2) wl1 = *reinterpret_cast<const uint4*>(p.Wlo + off1);
+            if (rows_all_valid && c0 + BK <= p.Cin) {  // block-uniform fast path: plain loads
+#pragma unroll
+                for (int q = 0; q < A_PASSES; ++q) areg[q] = *reinterpret_cast<const f32x4*>(Ab + aoff[q] + c0);
+            } else {
+                const bool kok = c0 + a_col < p.Cin;  // Cin % 4 == 0: a float4 is all inside or all outside
+#pragma unroll
+                for (int q = 0; q < A_PASSES; ++q) {
+                    // branch-free: an invalid row / K-tail chunk reads the tensor's first 16 bytes and is zeroed
+                    const bool ok = aoff[q] >= 0 && kok;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? Ab + aoff[q] + c0 : p.A);
+                    areg[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+            }
+            const long kk = (long)tap * p.Cpad + c0;
+#pragma unroll
+            for (int q = 0; q < W_PASSES; ++q) {
+                whreg[q] = *reinterpret_cast<const u32x4*>(whi + kk + q * w_pass_stride);
+                if (NPL == 2) wlreg[q] = *reinterpret_cast<const u32x4*>(wlo + kk + q * w_pass_stride);
             }
         }
         if (it < 0) continue;
@@ -222,6 +242,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
                 bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[0][r][ks * 16 + fh * 8]);
                 if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[NPL - 1][r][ks * 16 + fh * 8]);
             }
+
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -232,69 +253,80 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
                     }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
+
         }
         __syncthreads();  // all fragment reads of tile `it` done before it is overwritten
     }
 
-    // ---- epilogue: C/D layout of mfma_32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-    // Local restrict-qualified copies: the residual loads of a tile are all issued before its first store
-    // (through the struct the compiler must assume res aliases C and serialises load -> store per element).
-    const float* __restrict__ resp = p.res;
-    float* __restrict__ outp = p.C;
+    // ---- epilogue.  The accumulators (C/D layout of mfma_32x32: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5))
+    // go through an fp32 staging tile in LDS so that global traffic is 16 B per lane along the channel axis:
+    // one 512-B (BN=128) run per output pixel for the stores and for the residual loads.
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 32 + fr;
-        const bool nok = n < p.N;
-        const float s1 = nok ? p.scale1[n] : 0.f, t1 = nok ? p.shift1[n] : 0.f;
-        float s2 = 1.f, t2 = 0.f;
-        if (p.scale2 && nok) { s2 = p.scale2[n]; t2 = p.shift2[n]; }
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            long long pix[16];
-            float rv[16];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                pix[e] = nok ? rowP[r] : -1;
-                rv[e] = 0.f;
+                stage[r][wn * (BN / WN) + j * 32 + fr] = acc[i][j][e];
             }
-            if (resp) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (pix[e] >= 0) rv[e] = resp[pix[e] * p.ldres + n];
+    __syncthreads();
+    constexpr int C4 = BN / 4;            // float4 chunks per staged row
+    constexpr int ROWS_PER_PASS = 256 / C4;
+    const int ec = (tid % C4) * 4, er = tid / C4;
+    const int n = n0 + ec;
+    if (n < p.N) {                        // N % 4 == 0: a chunk is all inside or all outside
+        const float4 s1 = *reinterpret_cast<const float4*>(p.scale1 + n);
+        const float4 t1 = *reinterpret_cast<const float4*>(p.shift1 + n);
+        float4 s2 = make_float4(1.f, 1.f, 1.f, 1.f), t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale2) {
+            s2 = *reinterpret_cast<const float4*>(p.scale2 + n);
+            t2 = *reinterpret_cast<const float4*>(p.shift2 + n);
+        }
+        const float* __restrict__ resp = p.res;
+        float* __restrict__ outp = p.C;
+#pragma unroll 4
+        for (int r = er; r < BM; r += ROWS_PER_PASS) {
+            const long long pix = rowP[r];
+            if (pix < 0) continue;
+            float4 v = *reinterpret_cast<const float4*>(&stage[r][ec]);
+            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (resp) rv = *reinterpret_cast<const float4*>(resp + pix * p.ldres + n);
+            v.x = fmaf(v.x, s1.x, t1.x); v.y = fmaf(v.y, s1.y, t1.y); v.z = fmaf(v.z, s1.z, t1.z); v.w = fmaf(v.w, s1.w, t1.w);
+            if (p.act) {
+                v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+                v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
             }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                if (pix[e] < 0) continue;
-                float v = fmaf(acc[i][j][e], s1, t1);
-                if (p.act) v = fminf(fmaxf(v, 0.f), 6.f);
-                if (p.scale2) v = fminf(fmaxf(fmaf(v, s2, t2), 0.f), 6.f);
-                outp[pix[e] * p.ldc + n] = v + rv[e];
+            if (p.scale2) {
+                v.x = fminf(fmaxf(fmaf(v.x, s2.x, t2.x), 0.f), 6.f); v.y = fminf(fmaxf(fmaf(v.y, s2.y, t2.y), 0.f), 6.f);
+                v.z = fminf(fmaxf(fmaf(v.z, s2.z, t2.z), 0.f), 6.f); v.w = fminf(fmaxf(fmaf(v.w, s2.w, t2.w), 0.f), 6.f);
             }
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            *reinterpret_cast<float4*>(outp + pix * p.ldc + n) = v;
         }
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BN>
 int launch(const GemmParams& p0, int passes, hipStream_t st) {
     GemmParams p = p0;
-    p.n_mtiles = (int)((p.M + BM - 1) / BM);
+    p.n_mtiles = (int)((p.M + 127) / 128);
     p.n_ntiles = (p.N + BN - 1) / BN;
     const long nblk = (long)p.n_mtiles * p.n_ntiles;
     if (nblk <= 0 || nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "gemm_conv: grid too large");
     if (passes == 3)
-        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, WM, WN, 3>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemm_conv_kernel<BN, 3>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     else
-        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, WM, WN, 1>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemm_conv_kernel<BN, 1>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     return emd::check_launch("gemm_conv_kernel");
 }
 
-constexpr int kBK = 32;     // K step (also the channel padding unit of the packed weights)
+constexpr int kBK = 64;       // K step (also the channel padding unit of the packed weights)
 constexpr int kNPadTo = 128;  // packed weights are padded to a multiple of the widest BN
 
 int dispatch(const GemmParams& p, int passes, hipStream_t st) {
-    if (p.N <= 64) return launch<128, 64, kBK, 4, 1>(p, passes, st);
-    return launch<128, 128, kBK, 2, 2>(p, passes, st);
+    if (p.N <= 64) return launch<64>(p, passes, st);
+    return launch<128>(p, passes, st);
 }
 
 inline uint16_t f32_to_bf16_rne(float f) {
@@ -322,6 +354,10 @@ int common_checks(const char* who, const float* x, const void* whi, const void* 
     EMD_REQUIRE(Cin >= 4 && N >= 1, EMD_E_INVALID, "conv: bad channel counts");
     EMD_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0 && ldx >= Cin, EMD_E_ALIGN, "conv: Cin and ldx must be multiples of 4, ldx >= Cin");
     EMD_REQUIRE(ldy >= N && (!res || ldres >= N), EMD_E_INVALID, "conv: ldy/ldres smaller than Cout");
+    EMD_REQUIRE(N % 4 == 0 && ldy % 4 == 0 && emd::aligned16(y) && (!res || (ldres % 4 == 0 && emd::aligned16(res))),
+                EMD_E_ALIGN, "conv: Cout, ldy, ldres must be multiples of 4 and y, res 16-byte aligned");
+    EMD_REQUIRE(emd::aligned16(scale1) && emd::aligned16(shift1) && (!scale2 || (emd::aligned16(scale2) && emd::aligned16(shift2))),
+                EMD_E_ALIGN, "conv: scale/shift vectors must be 16-byte aligned");
     EMD_REQUIRE(emd::aligned16(x) && emd::aligned16(whi) && (!wlo || emd::aligned16(wlo)), EMD_E_ALIGN,
                 "conv: x and the weight planes must be 16-byte aligned");
     return EMD_OK;

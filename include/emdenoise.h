@@ -92,7 +92,7 @@ int emd_kernel_denoise_f32(const float* x, float* y, int B, int H, int W, int wi
  * w_host : taps x Cin x Cout float32 in TensorFlow order, [taps][Cin][Cout] (slim.conv2d /
  *          pointwise_weights, cout_major = 0) or [taps][Cout][Cin] (slim.conv2d_transpose, cout_major = 1).
  * hi/lo  : emd_packed_weight_elems(taps,Cin,Cout) bf16 words each: w = hi + lo (+2^-17), stored
- *          [Cout padded to 128][taps][Cin padded to 32], zero padded. */
+ *          [Cout padded to 128][taps][Cin padded to 64], zero padded. */
 size_t emd_packed_weight_elems(int taps, int Cin, int Cout);
 int emd_pack_weights_bf16(const float* w_host, int taps, int Cin, int Cout, int cout_major,
                           uint16_t* hi_host, uint16_t* lo_host);
@@ -102,7 +102,8 @@ int emd_pack_weights_bf16(const float* w_host, int taps, int Cin, int Cout, int 
  *           (denoiser.py:113-134); slim.conv2d(kernel_size=1[,stride=2]) + bias + BN + relu6
  *           (:91-97 with :359/:371/:383, :159-164, :208-214, :220-227); the residual adds.
  * x [B,H,W,Cin] pixel stride ldx;  y [B,ceil(H/s),ceil(W/s),Cout] pixel stride ldy;  res like y, ldres.
- * Cin, ldx multiples of 4; x, whi, wlo 16-byte aligned.  wlo may be NULL with EMD_PREC_BF16. */
+ * Cin, Cout, ldx, ldy, ldres multiples of 4; x, y, res, whi, wlo, scale*, shift* 16-byte aligned.
+ * wlo may be NULL with EMD_PREC_BF16. */
 int emd_conv1x1_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo,
                     const float* scale1, const float* shift1, const float* scale2, const float* shift2,
                     const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin,
