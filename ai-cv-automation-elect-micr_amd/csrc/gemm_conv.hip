@@ -31,17 +31,11 @@
 // stores and residual loads are 16 B per lane, a whole pixel's channel run per 32 lanes.
 // Block index -> tile mapping is XCD-aware: the N-tiles of one M-tile (which re-read the same
 // activation rows) get consecutive indices inside one XCD's share of the grid.
-#include "emd_common.hpp"
+#include "mfma_common.hpp"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;      // native vectors for the staging registers:
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // HIP's float4/uint4 structs end up in scratch
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+using namespace emd;
 
 constexpr int kMaxTaps = 4;
 
@@ -65,16 +59,6 @@ struct GemmParams {
     int dy[kMaxTaps], dx[kMaxTaps];
     int n_mtiles, n_ntiles;
 };
-
-// a = hi + lo (+ O(2^-17)): two packed bf16 words for two floats
-__device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigned& lo) {
-    const f32x2 v = {a0, a1};
-    const bf16x2 h = __builtin_convertvector(v, bf16x2);
-    const f32x2 r = v - __builtin_convertvector(h, f32x2);
-    const bf16x2 l = __builtin_convertvector(r, bf16x2);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
 
 // Block tile 128 x BN (BN = 128: 2x2 waves of 64x64; BN = 64: 4x1 waves of 32x64), K step 64.
 template <int BN, int PASSES>
@@ -320,9 +304,6 @@ int launch(const GemmParams& p0, int passes, hipStream_t st) {
         hipLaunchKernelGGL((gemm_conv_kernel<BN, 1>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     return emd::check_launch("gemm_conv_kernel");
 }
-
-constexpr int kBK = 64;       // K step (also the channel padding unit of the packed weights)
-constexpr int kNPadTo = 128;  // packed weights are padded to a multiple of the widest BN
 
 int dispatch(const GemmParams& p, int passes, hipStream_t st) {
     if (p.N <= 64) return launch<64>(p, passes, st);

@@ -1,0 +1,279 @@
+// Fused separable convolution: depthwise 3x3 (stride 1, rate 1, TF SAME) -> 1x1 on the matrix cores ->
+// folded batch norms + relu6 (+ second affine + relu6, + residual), in ONE kernel.
+// replaces: slim.separable_convolution2d + _batch_norm_fn + batch_then_activ, i.e. the whole
+//           strided_conv_block of machine_learning/denoiser.py:110-136 (for stride 1), and the "+=" after it.
+//
+// Why: for the layers whose Cout fits one N-tile (<= 128) and that run at 256x256 / 512x512 the unfused
+// pair (emd_dw3x3_f32 + emd_conv1x1_f32) is HBM-bound and moves the depthwise result through HBM twice
+// (write, then read): in + dw + dw + out bytes.  Fused, the depthwise result only ever exists as the bf16
+// hi/lo A-operand planes in LDS: in(+halo) + out bytes.
+//
+// Block = 256 threads = 4 waves; output tile = 8 x 16 pixels (128 GEMM rows) x all Cout (BN = 64 or 128).
+// Per 32-channel chunk of Cin:
+//   1. the (8+2) x (16+2) pixel fp32 input patch of the chunk is staged global -> registers (one chunk
+//      ahead) -> LDS; pixel pitch 40 floats so the depthwise reads below are bank-conflict free;
+//   2. thread (pixel group of 4 along W, 4 channels) reads 3 x 6 patch vectors (18 ds_read_b128 for 16
+//      outputs), accumulates the 9 taps in fp32, splits to bf16 hi/lo and writes the A planes;
+//   3. v_mfma_f32_32x32x16_bf16, split-bf16 (3 passes) as in gemm_conv.hip; W tile staged like there.
+// Epilogue identical to gemm_conv.hip (fp32 LDS staging, 16-byte stores / residual loads).
+#include "mfma_common.hpp"
+
+using namespace emd;
+
+namespace {
+
+struct SepParams {
+    const float* x;       // [B,H,W,Cin] pixel stride ldx
+    const float* dw;      // [9][Cin]
+    const uint16_t* Whi;  // [Npad][Cpad]
+    const uint16_t* Wlo;
+    float* y;             // [B,H,W,N] pixel stride ldy
+    const float* res;
+    const float* scale1;
+    const float* shift1;
+    const float* scale2;
+    const float* shift2;
+    int H, W, Cin, Cpad, N;
+    int ldx, ldy, ldres, act;
+};
+
+template <int BN, int PASSES>
+__global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
+    constexpr int TH = 8, TW = 16, BM = TH * TW, BK = 32;
+    constexpr int PH = TH + 2, PW = TW + 2, NPX = PH * PW;  // 10 x 18 = 180 patch pixels
+    constexpr int PLD = 40;                                 // floats per patch pixel (32 + 8 pad)
+    constexpr int LDK = BK + 8;                             // bf16 per A/B row (80 B)
+    constexpr int WM = BN == 128 ? 2 : 4, WN = 4 / WM;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NPL = PASSES == 3 ? 2 : 1;
+    constexpr int P_PASSES = (NPX * 8 + 255) / 256;          // 1440 float4 -> 6 passes
+    constexpr int W_PASSES = BN / 64;                        // BN rows x 4 chunks of 16 B
+    constexpr int LDS_STAGE = BN + 4;
+    constexpr int PATCH_BYTES = NPX * PLD * 4, A_BYTES = NPL * BM * LDK * 2, B_BYTES = NPL * BN * LDK * 2;
+    constexpr int STAGE_BYTES = BM * LDS_STAGE * 4;
+    constexpr int TILE_BYTES = PATCH_BYTES + A_BYTES + B_BYTES > STAGE_BYTES ? PATCH_BYTES + A_BYTES + B_BYTES : STAGE_BYTES;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES];
+    float* patch = reinterpret_cast<float*>(smem);
+    auto As = reinterpret_cast<uint16_t(*)[BM][LDK]>(smem + PATCH_BYTES);
+    auto Bs = reinterpret_cast<uint16_t(*)[BN][LDK]>(smem + PATCH_BYTES + A_BYTES);
+    float(*stage)[LDS_STAGE] = reinterpret_cast<float(*)[LDS_STAGE]>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const long img = (long)blockIdx.z * p.H * p.W;  // pixel index of this image's (0,0)
+
+    // ---- patch loader role: float4 #idx of the patch = (patch pixel idx/8, channel group idx%8)
+    long long poff[P_PASSES];  // element offset of the source pixel + channel group, or -1 (zero padding / unused)
+#pragma unroll
+    for (int q = 0; q < P_PASSES; ++q) {
+        const int idx = tid + q * 256;
+        long long o = -1;
+        if (idx < NPX * 8) {
+            const int ppx = idx >> 3, py = ppx / PW, px = ppx - py * PW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) o = (img + (long)gy * p.W + gx) * p.ldx + (idx & 7) * 4;
+        }
+        poff[q] = o;
+    }
+    // ---- W loader role
+    const int w_col = (tid & 3) * 8, w_row = tid >> 2;  // + 64 rows per pass
+    const uint16_t* __restrict__ whi = p.Whi + (long)w_row * p.Cpad + w_col;
+    const uint16_t* __restrict__ wlo = NPL == 2 ? p.Wlo + (long)w_row * p.Cpad + w_col : nullptr;
+    // ---- depthwise role: 4 consecutive pixels of tile row ty, 4 channels
+    const int c4 = tid & 7, pg = tid >> 3;
+    const int ty = pg >> 2, tx0 = (pg & 3) * 4;
+    const float* __restrict__ dwp = p.dw + c4 * 4;
+
+    f32x4 preg[P_PASSES];
+    u32x4 wh0 = {0, 0, 0, 0}, wh1 = wh0, wl0 = wh0, wl1 = wh0;
+    f32x4 wk[9];
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nchunks = p.Cin / BK;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    for (int it = -1; it < nchunks; ++it) {
+        if (it >= 0) {
+            // staged registers (chunk `it`) -> LDS
+#pragma unroll
+            for (int q = 0; q < P_PASSES; ++q) {
+                const int idx = tid + q * 256;
+                if (idx < NPX * 8) *reinterpret_cast<f32x4*>(patch + (idx >> 3) * PLD + (idx & 7) * 4) = preg[q];
+            }
+            *reinterpret_cast<u32x4*>(&Bs[0][w_row][w_col]) = wh0;
+            if (NPL == 2) *reinterpret_cast<u32x4*>(&Bs[NPL - 1][w_row][w_col]) = wl0;
+            if (W_PASSES == 2) {
+                *reinterpret_cast<u32x4*>(&Bs[0][w_row + 64][w_col]) = wh1;
+                if (NPL == 2) *reinterpret_cast<u32x4*>(&Bs[NPL - 1][w_row + 64][w_col]) = wl1;
+            }
+            __syncthreads();  // (1) patch + W tile of chunk `it` visible
+            // depthwise 3x3 from the LDS patch -> bf16 hi/lo A planes
+            f32x4 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f32x4 pr[6];
+#pragma unroll
+                for (int d = 0; d < 6; ++d)
+                    pr[d] = *reinterpret_cast<const f32x4*>(patch + ((ty + i) * PW + tx0 + d) * PLD + c4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) o[j] += wk[i * 3 + d] * pr[j + d];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = ty * TW + tx0 + j;
+                unsigned h0, l0, h1, l1;
+                split2(o[j][0], o[j][1], h0, l0);
+                split2(o[j][2], o[j][3], h1, l1);
+                *reinterpret_cast<u32x2*>(&As[0][r][c4 * 4]) = u32x2{h0, h1};
+                if (NPL == 2) *reinterpret_cast<u32x2*>(&As[NPL - 1][r][c4 * 4]) = u32x2{l0, l1};
+            }
+        }
+        {
+            // stage chunk it+1 (the last iteration re-loads its own chunk: branch-free), in flight during the MFMAs
+            const int nx = it + 1 < nchunks ? it + 1 : it;
+            const int c0 = nx * BK;
+#pragma unroll
+            for (int q = 0; q < P_PASSES; ++q) {
+                const bool ok = poff[q] >= 0;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? p.x + poff[q] + c0 : p.x);
+                preg[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            wh0 = *reinterpret_cast<const u32x4*>(whi + c0);
+            if (NPL == 2) wl0 = *reinterpret_cast<const u32x4*>(wlo + c0);
+            if (W_PASSES == 2) {
+                wh1 = *reinterpret_cast<const u32x4*>(whi + 64L * p.Cpad + c0);
+                if (NPL == 2) wl1 = *reinterpret_cast<const u32x4*>(wlo + 64L * p.Cpad + c0);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const f32x4*>(dwp + (long)k * p.Cin + c0);
+        }
+        if (it < 0) continue;
+        __syncthreads();  // (2) A planes of chunk `it` visible
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (BM / WM) + i * 32 + fr;
+                ah[i] = *reinterpret_cast<const bf16x8*>(&As[0][r][ks * 16 + fh * 8]);
+                if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(&As[NPL - 1][r][ks * 16 + fh * 8]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (BN / WN) + j * 32 + fr;
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[0][r][ks * 16 + fh * 8]);
+                if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[NPL - 1][r][ks * 16 + fh * 8]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (PASSES == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();  // (3) fragment reads done before the next chunk overwrites patch / A / B
+    }
+
+    // ---- epilogue (see gemm_conv.hip): accumulators -> fp32 LDS tile -> 16-byte stores along the channel axis
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                stage[r][wn * (BN / WN) + j * 32 + fr] = acc[i][j][e];
+            }
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    constexpr int ROWS_PER_PASS = 256 / C4;
+    const int n = (tid % C4) * 4, er = tid / C4;
+    if (n < p.N) {
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
+        f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale2) {
+            s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
+            t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
+        }
+        const float* __restrict__ resp = p.res;
+        float* __restrict__ outp = p.y;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, six = {6.f, 6.f, 6.f, 6.f};
+#pragma unroll 4
+        for (int r = er; r < BM; r += ROWS_PER_PASS) {
+            const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
+            f32x4 v = *reinterpret_cast<const f32x4*>(&stage[r][n]);
+            f32x4 rv = zero;
+            if (resp) rv = *reinterpret_cast<const f32x4*>(resp + pix * p.ldres + n);
+            v = v * s1 + t1;
+            if (p.act) v = __builtin_elementwise_min(__builtin_elementwise_max(v, zero), six);
+            if (p.scale2) v = __builtin_elementwise_min(__builtin_elementwise_max(v * s2 + t2, zero), six);
+            *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = v + rv;
+        }
+    }
+}
+
+template <int BN>
+int launch(const SepParams& p, int B, int passes, hipStream_t st) {
+    const dim3 grid(p.W / 16, p.H / 8, B);
+    if (passes == 3)
+        hipLaunchKernelGGL((sep_fused_kernel<BN, 3>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((sep_fused_kernel<BN, 1>), grid, dim3(256), 0, st, p);
+    return emd::check_launch("sep_fused_kernel");
+}
+
+}  // namespace
+
+extern "C" int emd_sep3x3_fused_supported(int H, int W, int Cin, int Cout, int stride, int rate) {
+    return stride == 1 && rate == 1 && H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && Cin >= 32 && Cout % 4 == 0 &&
+           Cout >= 4 && Cout <= 128;
+}
+
+extern "C" int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, const uint16_t* whi,
+                                    const uint16_t* wlo, const float* scale1, const float* shift1,
+                                    const float* scale2, const float* shift2, const float* res, int ldres,
+                                    float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                                    int precision, emd_stream_t stream) {
+    EMD_REQUIRE(x && dw && whi && scale1 && shift1 && y, EMD_E_INVALID, "emd_sep3x3_fused_f32: null pointer");
+    EMD_REQUIRE(precision == 1 || precision == 3, EMD_E_INVALID, "emd_sep3x3_fused_f32: bad precision");
+    EMD_REQUIRE(precision == 1 || wlo, EMD_E_INVALID, "emd_sep3x3_fused_f32: the split-bf16 mode needs the lo plane");
+    EMD_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), EMD_E_INVALID, "emd_sep3x3_fused_f32: scale2/shift2 pair");
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_sep3x3_fused_f32: bad shape");
+    EMD_REQUIRE(emd_sep3x3_fused_supported(H, W, Cin, Cout, 1, 1), EMD_E_UNSUPPORTED,
+                "emd_sep3x3_fused_f32: needs H%8==0, W%16==0, Cin%32==0, Cout%4==0, Cout<=128 (use emd_dw3x3_f32 + emd_conv1x1_f32)");
+    EMD_REQUIRE(B <= 65535, EMD_E_UNSUPPORTED, "emd_sep3x3_fused_f32: B > 65535");
+    EMD_REQUIRE(ldx % 4 == 0 && ldx >= Cin && ldy % 4 == 0 && ldy >= Cout && (!res || (ldres % 4 == 0 && ldres >= Cout)),
+                EMD_E_ALIGN, "emd_sep3x3_fused_f32: pixel strides must be multiples of 4 and >= the channel count");
+    EMD_REQUIRE(emd::aligned16(x) && emd::aligned16(dw) && emd::aligned16(whi) && (!wlo || emd::aligned16(wlo)) &&
+                    emd::aligned16(y) && (!res || emd::aligned16(res)) && emd::aligned16(scale1) &&
+                    emd::aligned16(shift1) && (!scale2 || (emd::aligned16(scale2) && emd::aligned16(shift2))),
+                EMD_E_ALIGN, "emd_sep3x3_fused_f32: pointers must be 16-byte aligned");
+    if (B == 0) return EMD_OK;
+    SepParams p{};
+    p.x = x; p.dw = dw; p.Whi = whi; p.Wlo = wlo; p.y = y; p.res = res;
+    p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
+    p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
+    p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act ? 1 : 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return Cout <= 64 ? launch<64>(p, B, precision, st) : launch<128>(p, B, precision, st);
+}

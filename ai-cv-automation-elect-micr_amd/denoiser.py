@@ -223,11 +223,12 @@ def _fold(w, layer, bias=None):
 class DenoiserEngine:
     """Weights resident on one GPU + the launch sequence of architecture() (denoiser.py:248-398)."""
 
-    def __init__(self, weights, device, precision="bf16x3"):
+    def __init__(self, weights, device, precision="bf16x3", fuse_sep=True):
         import torch
 
         _lib.load()
         self.device = device
+        self.fuse_sep = fuse_sep
         self.precision = {"bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[precision]
         self.layers = declare_layers()
         self.P = {}
@@ -276,6 +277,12 @@ class DenoiserEngine:
         BN x2 (+ the optional extra BN) + relu6 (+ residual) fused into its epilogue."""
         L, p = self.layers[key], self.P[key]
         Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
+        if self.fuse_sep and ops.sep_fused_supported(x, L.cout, L.stride, L.rate):
+            # one launch, the depthwise result stays in LDS (the HBM-bound single-N-tile layers)
+            if out is None:
+                out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
+            return ops.sep_fused(x, p["dw"], p["pw"], p["scale"], p["shift"], out, scale2=p.get("scale2"),
+                                 shift2=p.get("shift2"), res=res, precision=self.precision)
         tmp = ops.Act.empty(x.B, Ho, Wo, L.cin, self.device)
         ops.dw3x3(x, p["dw"], tmp, stride=L.stride, rate=L.rate)
         if out is None:

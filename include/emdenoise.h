@@ -119,6 +119,18 @@ int emd_deconv3x3s2_f32(const float* x, int ldx, const uint16_t* const whi[4], c
                         const float* scale1, const float* shift1, float* y, int ldy, int B, int H, int W,
                         int Cin, int Cout, int act, int precision, emd_stream_t stream);
 
+/* The whole strided_conv_block (denoiser.py:110-136) for stride 1 in ONE kernel: depthwise 3x3 (SAME) ->
+ * pointwise 1x1 on the matrix cores -> fused epilogue (above).  The depthwise result never reaches HBM.
+ * replaces: slim.separable_convolution2d + normalizer BN + batch_then_activ (+ the residual "+=").
+ * Supported when emd_sep3x3_fused_supported() returns 1: stride 1, rate 1, H%8==0, W%16==0, Cin%32==0,
+ * Cout%4==0, Cout<=128 (one N tile); otherwise call emd_dw3x3_f32 + emd_conv1x1_f32.
+ * x [B,H,W,Cin] ldx; dw [3][3][Cin]; whi/wlo packed pointwise weights (taps=1); y [B,H,W,Cout] ldy. */
+int emd_sep3x3_fused_supported(int H, int W, int Cin, int Cout, int stride, int rate);
+int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                         const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                         const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin,
+                         int Cout, int act, int precision, emd_stream_t stream);
+
 /* Depthwise 3x3, TF SAME padding, stride 1 or 2 (rate 1) or stride 1 with dilation `rate`.
  * replaces: the depthwise half of slim.separable_convolution2d (denoiser.py:113-131).
  * x [B,H,W,C] pixel stride ldx; w [3][3][C] (TF [3,3,C,1]); y [B,ceil(H/s),ceil(W/s),C] pixel stride ldy. */

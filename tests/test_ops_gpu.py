@@ -225,3 +225,52 @@ def test_error_paths_report_through_last_error():
     out = out_act(1, 4, 4, 6)
     with pytest.raises(_lib.EmdError, match="multiples of 4"):
         ops.dw3x3(x, torch.zeros(9 * 6, device=dev()), out)
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,res,extra", [
+    (2, 16, 32, 64, 64, False, False),      # BN = 64 tile
+    (1, 8, 16, 128, 128, True, False),      # single tile: every patch border is zero padding
+    (2, 24, 48, 384, 128, False, True),     # concat-slice input, second affine
+    (1, 32, 32, 32, 8, True, True),
+])
+@pytest.mark.parametrize("prec", [3, 1])
+def test_sep_fused(B, H, W, ci, co, res, extra, prec):
+    """emd_sep3x3_fused_f32 == depthwise 3x3 (SAME) -> pointwise -> affine -> relu6 [-> affine -> relu6] [+ res]."""
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 40, positive=True)
+    dw = rnd((3, 3, ci, 1), 41, 0.35)
+    pw = rnd((1, 1, ci, co), 42, scale=(2.0 / (ci + co)) ** 0.5)
+    s1, t1 = rnd((co,), 43, 0.2) + 1, rnd((co,), 44, 0.5)
+    s2, t2 = rnd((co,), 45, 0.2) + 1, rnd((co,), 46, 0.5)
+    r = rnd((B, H, W, co), 47, positive=True)
+    y = T.relu6_t(T.conv2d_t(T.depthwise_conv2d_t(t64(x), t64(dw)), t64(pw)) * t64(s1) + t64(t1))
+    if extra:
+        y = T.relu6_t(y * t64(s2) + t64(t2))
+    if res:
+        y = y + t64(r)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    xa = to_act(x, ld=ci + 64, c0=32)
+    assert ops.sep_fused_supported(xa, co, 1, 1)
+    out = out_act(B, H, W, co, ld=co + 8, c0=4)
+    ops.sep_fused(xa, d(dw[..., 0]), ops.PackedWeights(pw[0], False, dev()), d(s1), d(t1), out,
+                  scale2=d(s2) if extra else None, shift2=d(t2) if extra else None,
+                  res=to_act(r, ld=co + 12, c0=8) if res else None, precision=prec)
+    torch.cuda.synchronize()
+    got = out.torch().cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_l2(got, y.numpy()) < (TOL_X3 if prec == 3 else TOL_X1)
+    full = out.buf.cpu().numpy()
+    assert np.isnan(full[..., :4]).all() and np.isnan(full[..., 4 + co:]).all()   # nothing written outside the slice
+
+
+def test_sep_fused_falls_back_cleanly():
+    from emdenoise import _lib, ops
+
+    x = to_act(rnd((1, 12, 16, 64), 48))       # H % 8 != 0
+    assert not ops.sep_fused_supported(x, 64, 1, 1)
+    assert not ops.sep_fused_supported(to_act(rnd((1, 8, 16, 64), 49)), 256, 1, 1)   # more than one N tile
+    with pytest.raises(_lib.EmdError, match="emd_dw3x3_f32"):
+        ops.sep_fused(x, torch.zeros(9 * 64, device=dev()), ops.PackedWeights(rnd((1, 64, 64), 50), False, dev()),
+                      torch.ones(64, device=dev()), torch.zeros(64, device=dev()), out_act(1, 12, 16, 64))

@@ -6,7 +6,7 @@ import emdenoise
 from tests.synth_inputs import synthetic_lq
 B = int(os.environ.get("DP_B", "32")); S = int(os.environ.get("DP_S", "512")); prec = os.environ.get("DP_PREC", "bf16x3")
 n = int(os.environ.get("DP_N", "3"))
-eng = emdenoise.DenoiserEngine(emdenoise.synthetic_weights(), torch.device("cuda", 0), prec)
+eng = emdenoise.DenoiserEngine(emdenoise.synthetic_weights(), torch.device("cuda", 0), prec, fuse_sep=os.environ.get("DP_FUSE", "1") == "1")
 x = torch.from_numpy(np.concatenate([synthetic_lq(2, S, S, seed=1)] * (B // 2 + 1))[:B]).cuda()
 y = eng.forward(x); torch.cuda.synchronize()
 t0 = time.perf_counter()
