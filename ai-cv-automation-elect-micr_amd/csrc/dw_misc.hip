@@ -197,6 +197,60 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restr
     }
 }
 
+// Rolling form of the above (W % (64/LP) == 0): a lane owns (pixel column, 4 channels) and walks down TH
+// output rows keeping the vector partial sums of the three live input rows, so an input row is read once
+// per strip (3 shifted 16-B loads per lane) instead of 9 loads per output; the cross-lane reduction over the
+// LP channel groups happens once per output pixel.
+template <int TH>
+__global__ __launch_bounds__(256) void conv3x3_cout1_roll(const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ w, float scale, float shift,
+                                                          float* __restrict__ y, int H, int W, int LP, int nstrip,
+                                                          long nthreads, int act) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nthreads) return;  // nthreads is a multiple of 64: whole waves leave together
+    const int c4 = (int)(tid % LP);
+    long t = tid / LP;
+    const int ox = (int)(t % W);
+    t /= W;
+    const int strip = (int)(t % nstrip);
+    const long b = t / nstrip;
+    const int C = LP * 4;
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(w + k * C + c4 * 4);
+    const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
+    float* yb = y + (b * H) * (long)W;
+    const int oy0 = strip * TH;
+    const bool hasl = ox > 0, hasr = ox + 1 < W;
+    float4 s0 = f4zero(), s1 = f4zero();
+#pragma unroll
+    for (int tt = 0; tt < TH + 2; ++tt) {
+        const int iy = oy0 - 1 + tt;
+        float4 h0 = f4zero(), h1 = f4zero(), h2 = f4zero();
+        if (iy >= 0 && iy < H) {
+            const float* row = xb + ((long)iy * W + ox) * ldx;
+            const float4 c = *reinterpret_cast<const float4*>(row);
+            const float4 l = hasl ? *reinterpret_cast<const float4*>(row - ldx) : f4zero();
+            const float4 r = hasr ? *reinterpret_cast<const float4*>(row + ldx) : f4zero();
+            h0 = fma4(wk[0], l, fma4(wk[1], c, fma4(wk[2], r, h0)));
+            h1 = fma4(wk[3], l, fma4(wk[4], c, fma4(wk[5], r, h1)));
+            h2 = fma4(wk[6], l, fma4(wk[7], c, fma4(wk[8], r, h2)));
+        }
+        if (tt >= 2) {
+            const int oy = oy0 + tt - 2;
+            const float4 a = add4(s0, h2);
+            float s = (a.x + a.y) + (a.z + a.w);
+            for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m);
+            if (c4 == 0 && oy < H) {
+                const float v = fmaf(s, scale, shift);
+                yb[(long)oy * W + ox] = act ? relu6f(v) : v;
+            }
+        }
+        s0 = add4(s1, h1);
+        s1 = h0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // tf.image.resize_images: bilinear, align_corners=False, legacy sampling src = dst * (in/out).
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ x, int ldx,
@@ -332,6 +386,16 @@ extern "C" int emd_conv3x3_cout1_f32(const float* x, int ldx, const float* w, fl
     const long npix = (long)B * H * W;
     const int ppw = 64 / LP;
     unsigned nb;
+    if (W % ppw == 0) {  // a wave never straddles an image row: rolling kernel (3 loads per output, not 9)
+        constexpr int TH = 8;
+        const int nstrip = (H + TH - 1) / TH;
+        const long nthreads = (long)B * nstrip * W * LP;
+        int rc = grid_for(nthreads, &nb);
+        if (rc != EMD_OK) return rc;
+        hipLaunchKernelGGL(conv3x3_cout1_roll<TH>, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w,
+                           scale, shift, y, H, W, LP, nstrip, nthreads, act ? 1 : 0);
+        return emd::check_launch("conv3x3_cout1_roll");
+    }
     int rc = grid_for((npix + ppw - 1) / ppw * 64, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL(conv3x3_cout1_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w, scale,

@@ -211,8 +211,12 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
             }
         }
         if (it < 0) continue;
+        // 16-wide K sub-steps that hold real channels in this tile (the last tile of Cin = 728 has 24 of 64:
+        // the all-padding sub-steps are skipped, block-uniformly)
+        const int kvalid = p.Cin - (it % ksteps) * BK;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+            if (ks * 16 >= kvalid) break;
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {

@@ -118,6 +118,24 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                 if (NPL == 2) *reinterpret_cast<u32x4*>(&Bs[NPL - 1][w_row + 64][w_col]) = wl1;
             }
             __syncthreads();  // (1) patch + W tile of chunk `it` visible
+        }
+        // stage chunk it+1 (the last iteration re-loads its own chunk: branch-free).  Issued BEFORE the
+        // depthwise work below so the loads have the depthwise + MFMA phases (not just the MFMAs) to land.
+        const int nx = it + 1 < nchunks ? it + 1 : it;
+        const int c0n = nx * BK;
+#pragma unroll
+        for (int q = 0; q < P_PASSES; ++q) {
+            const bool ok = poff[q] >= 0;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? p.x + poff[q] + c0n : p.x);
+            preg[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        wh0 = *reinterpret_cast<const u32x4*>(whi + c0n);
+        if (NPL == 2) wl0 = *reinterpret_cast<const u32x4*>(wlo + c0n);
+        if (W_PASSES == 2) {
+            wh1 = *reinterpret_cast<const u32x4*>(whi + 64L * p.Cpad + c0n);
+            if (NPL == 2) wl1 = *reinterpret_cast<const u32x4*>(wlo + 64L * p.Cpad + c0n);
+        }
+        if (it >= 0) {
             // depthwise 3x3 from the LDS patch -> bf16 hi/lo A planes
             f32x4 o[4];
 #pragma unroll
@@ -143,25 +161,9 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                 if (NPL == 2) *reinterpret_cast<u32x2*>(&As[NPL - 1][r][c4 * 4]) = u32x2{l0, l1};
             }
         }
-        {
-            // stage chunk it+1 (the last iteration re-loads its own chunk: branch-free), in flight during the MFMAs
-            const int nx = it + 1 < nchunks ? it + 1 : it;
-            const int c0 = nx * BK;
+        // the next chunk's depthwise weights (their registers are free only now)
 #pragma unroll
-            for (int q = 0; q < P_PASSES; ++q) {
-                const bool ok = poff[q] >= 0;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? p.x + poff[q] + c0 : p.x);
-                preg[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            wh0 = *reinterpret_cast<const u32x4*>(whi + c0);
-            if (NPL == 2) wl0 = *reinterpret_cast<const u32x4*>(wlo + c0);
-            if (W_PASSES == 2) {
-                wh1 = *reinterpret_cast<const u32x4*>(whi + 64L * p.Cpad + c0);
-                if (NPL == 2) wl1 = *reinterpret_cast<const u32x4*>(wlo + 64L * p.Cpad + c0);
-            }
-#pragma unroll
-            for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const f32x4*>(dwp + (long)k * p.Cin + c0);
-        }
+        for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const f32x4*>(dwp + (long)k * p.Cin + c0n);
         if (it < 0) continue;
         __syncthreads();  // (2) A planes of chunk `it` visible
 #pragma unroll

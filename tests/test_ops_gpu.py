@@ -178,7 +178,7 @@ def test_cin1_both_forms():
     assert rel_l2(out.torch().cpu().numpy(), ref) < TOL_F32
 
 
-@pytest.mark.parametrize("B,H,W,ci", [(2, 12, 16, 64), (1, 5, 7, 128), (1, 9, 9, 16)])
+@pytest.mark.parametrize("B,H,W,ci", [(2, 12, 16, 64), (1, 5, 7, 128), (1, 9, 9, 16), (1, 13, 8, 64), (2, 3, 64, 256)])
 def test_conv3x3_cout1(B, H, W, ci):
     from emdenoise import ops
     from oracle import tf_ops as T
