@@ -33,6 +33,13 @@ SIGNATURES = {
     "emd_sep3x3_fused_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
                                        _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # x ldx whi wlo scale1 shift1 scale2 shift2 res ldres y ldy B H W Cin Cout stride rate act precision stream
+    "emd_conv3x3_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p,
+                                  _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # x ldx y ldy B H W C stream
+    "emd_avgpool2x2_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p]),
     "emd_deconv_phase_taps": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     # x ldx whi[4] wlo[4] scale1 shift1 y ldy B H W Cin Cout act precision stream
     "emd_deconv3x3s2_f32": (C.c_int, [_c_float_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _c_float_p,

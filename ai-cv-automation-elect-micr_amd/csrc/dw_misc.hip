@@ -18,6 +18,8 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+// act code of the Cout=1 kernels: 0 none, 1 relu6, 2 relu6 followed by tf.clip_by_value(0,1) = clamp to [0,1]
+__device__ __forceinline__ float act_out(float v, int act) { return act == 0 ? v : fminf(fmaxf(v, 0.f), act == 2 ? 1.f : 6.f); }
 
 // ------------------------------------------------------------------------------------------------
 // Depthwise 3x3, stride 1, rate 1: each thread owns (image b, column ox, channel group c4) and rolls
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restr
     for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m);
     if (c4 == 0 && pix < npix) {
         float v = fmaf(s, scale, shift);
-        y[pix] = act ? relu6f(v) : v;
+        y[pix] = act_out(v, act);
     }
 }
 
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_roll(const float* __restric
             for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m);
             if (c4 == 0 && oy < H) {
                 const float v = fmaf(s, scale, shift);
-                yb[(long)oy * W + ox] = act ? relu6f(v) : v;
+                yb[(long)oy * W + ox] = act_out(v, act);
             }
         }
         s0 = add4(s1, h1);
@@ -297,6 +299,35 @@ __global__ __launch_bounds__(256) void affine_relu6_kernel(const float* __restri
     float4 o = make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
     if (act) o = make_float4(relu6f(o.x), relu6f(o.y), relu6f(o.z), relu6f(o.w));
     *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = o;
+}
+
+// tf.nn.pool(window (2,2), "AVG", "SAME", strides (2,2)): mean over the window's in-image samples.
+__global__ __launch_bounds__(256) void avgpool2x2_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                         int ldy, int H, int W, int Ho, int Wo, int C4, long nthreads) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nthreads) return;
+    const int c4 = (int)(tid % C4);
+    long t = tid / C4;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const long b = t / Ho;
+    const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
+    float4 acc = f4zero();
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int iy = 2 * oy + i, ix = 2 * ox + j;  // SAME with k=2,s=2: pad 0 before (only "after" on odd sizes)
+            if (iy < H && ix < W) {
+                acc = add4(acc, *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx));
+                ++cnt;
+            }
+        }
+    const float inv = 1.0f / (float)cnt;
+    *reinterpret_cast<float4*>(y + ((b * Ho + oy) * (long)Wo + ox) * ldy + c4 * 4) =
+        make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
 inline int same_pad_before(int n, int k, int s, int r, int* out) {
@@ -393,13 +424,13 @@ extern "C" int emd_conv3x3_cout1_f32(const float* x, int ldx, const float* w, fl
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
         hipLaunchKernelGGL(conv3x3_cout1_roll<TH>, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w,
-                           scale, shift, y, H, W, LP, nstrip, nthreads, act ? 1 : 0);
+                           scale, shift, y, H, W, LP, nstrip, nthreads, act);
         return emd::check_launch("conv3x3_cout1_roll");
     }
     int rc = grid_for((npix + ppw - 1) / ppw * 64, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL(conv3x3_cout1_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w, scale,
-                       shift, y, H, W, LP, npix, act ? 1 : 0);
+                       shift, y, H, W, LP, npix, act);
     return emd::check_launch("conv3x3_cout1_kernel");
 }
 
@@ -435,4 +466,21 @@ extern "C" int emd_affine_relu6_f32(const float* x, int ldx, const float* scale,
     hipLaunchKernelGGL(affine_relu6_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, scale,
                        shift, y, ldy, C / 4, nthreads, act ? 1 : 0);
     return emd::check_launch("affine_relu6_kernel");
+}
+
+extern "C" int emd_avgpool2x2_f32(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C,
+                                  emd_stream_t stream) {
+    EMD_REQUIRE(x && y, EMD_E_INVALID, "emd_avgpool2x2_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1 && C >= 4, EMD_E_INVALID, "emd_avgpool2x2_f32: bad shape");
+    EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && emd::aligned16(x) &&
+                    emd::aligned16(y), EMD_E_ALIGN, "emd_avgpool2x2_f32: alignment");
+    if (B == 0) return EMD_OK;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long nthreads = (long)B * Ho * Wo * (C / 4);
+    unsigned nb;
+    int rc = grid_for(nthreads, &nb);
+    if (rc != EMD_OK) return rc;
+    hipLaunchKernelGGL(avgpool2x2_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, y, ldy, H,
+                       W, Ho, Wo, C / 4, nthreads);
+    return emd::check_launch("avgpool2x2_kernel");
 }

@@ -37,8 +37,6 @@ namespace {
 
 using namespace emd;
 
-constexpr int kMaxTaps = 4;
-
 struct GemmParams {
     const float* A;       // source activations (NHWC), pixel stride lda
     const uint16_t* Whi;  // [Npad][taps*Cpad]
@@ -56,7 +54,7 @@ struct GemmParams {
     // row map: m -> (b,i,j) on Hg x Wg;  source (b, i*sa+dy, j*sa+dx) in Ha x Wa;  dest (b, i*sc+py, j*sc+px) in Hc x Wc
     int flat;             // 1: source pixel = dest pixel = m (plain pointwise)
     int Hg, Wg, Ha, Wa, Hc, Wc, sa, sc, py, px;
-    int dy[kMaxTaps], dx[kMaxTaps];
+    unsigned long long dyp, dxp;  // per-tap source offsets, 7 bits each, biased by 64 (no dynamic kernarg indexing)
     int n_mtiles, n_ntiles;
 };
 
@@ -111,9 +109,8 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
                     const long t = m / p.Wg;
                     const int i = (int)(t % p.Hg);
                     const long b = t / p.Hg;
-                    // select without dynamic indexing (keeps the by-value params out of scratch)
-                    const int dy = tap == 0 ? p.dy[0] : tap == 1 ? p.dy[1] : tap == 2 ? p.dy[2] : p.dy[3];
-                    const int dx = tap == 0 ? p.dx[0] : tap == 1 ? p.dx[1] : tap == 2 ? p.dx[2] : p.dx[3];
+                    const int dy = (int)((p.dyp >> (7 * tap)) & 127) - 64;
+                    const int dx = (int)((p.dxp >> (7 * tap)) & 127) - 64;
                     const int iy = i * p.sa + dy, ix = j * p.sa + dx;
                     if (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) src = (b * p.Ha + iy) * (long)p.Wa + ix;
                     dst = (b * p.Hc + (i * p.sc + p.py)) * (long)p.Wc + (j * p.sc + p.px);
@@ -328,6 +325,15 @@ inline float bf16_to_f32(uint16_t h) {
     return f;
 }
 
+void set_taps(GemmParams& p, int n, const int* dy, const int* dx) {
+    p.ntaps = n;
+    p.dyp = p.dxp = 0;
+    for (int t = 0; t < n; ++t) {
+        p.dyp |= (unsigned long long)((dy ? dy[t] : 0) + 64) << (7 * t);
+        p.dxp |= (unsigned long long)((dx ? dx[t] : 0) + 64) << (7 * t);
+    }
+}
+
 int common_checks(const char* who, const float* x, const void* whi, const void* wlo, const float* scale1,
                   const float* shift1, const float* scale2, const float* shift2, const float* res, float* y,
                   int Cin, int N, int ldx, int ldy, int ldres, int passes) {
@@ -402,7 +408,7 @@ extern "C" int emd_conv1x1_f32(const float* x, int ldx, const uint16_t* whi, con
     p.M = (long)B * Ho * Wo;
     p.flat = stride == 1;
     p.Hg = Ho; p.Wg = Wo; p.Ha = H; p.Wa = W; p.Hc = Ho; p.Wc = Wo; p.sa = stride; p.sc = 1; p.py = p.px = 0;
-    p.dy[0] = p.dx[0] = 0;
+    set_taps(p, 1, nullptr, nullptr);
     return dispatch(p, precision, static_cast<hipStream_t>(stream));
 }
 
@@ -449,12 +455,55 @@ extern "C" int emd_deconv3x3s2_f32(const float* x, int ldx, const uint16_t* cons
         p.flat = 0;
         p.Hg = H; p.Wg = W; p.Ha = H; p.Wa = W; p.Hc = 2 * H; p.Wc = 2 * W; p.sa = 1; p.sc = 2;
         p.py = ph >> 1; p.px = ph & 1;
+        int dy[4], dx[4];
         for (int t = 0; t < p.ntaps; ++t) {  // kernel index 2 reads the previous input sample
-            p.dy[t] = ky[t] == 2 ? -1 : 0;
-            p.dx[t] = kx[t] == 2 ? -1 : 0;
+            dy[t] = ky[t] == 2 ? -1 : 0;
+            dx[t] = kx[t] == 2 ? -1 : 0;
         }
+        set_taps(p, p.ntaps, dy, dx);
         int rc = dispatch(p, precision, static_cast<hipStream_t>(stream));
         if (rc != EMD_OK) return rc;
     }
     return EMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- dense 3x3 convolution
+// tf.layers.conv2d / slim.conv2d with kernel_size 3, TF SAME padding, stride 1 or 2, dilation `rate`
+// (stride 1 only) as a 9-tap implicit GEMM: tap (ky,kx) reads source pixel (i*s + ky*rate - pad_top,
+// j*s + kx*rate - pad_left), zero outside.  Weights: emd_pack_weights_bf16(taps = 9, [ky][kx][Cin][Cout]).
+extern "C" int emd_conv3x3_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo,
+                               const float* scale1, const float* shift1, const float* scale2,
+                               const float* shift2, const float* res, int ldres, float* y, int ldy, int B,
+                               int H, int W, int Cin, int Cout, int stride, int rate, int act, int precision,
+                               emd_stream_t stream) {
+    int rc = common_checks("emd_conv3x3_f32", x, whi, wlo, scale1, shift1, scale2, shift2, res, y, Cin, Cout, ldx,
+                           ldy, ldres, precision);
+    if (rc != EMD_OK) return rc;
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_conv3x3_f32: bad shape");
+    EMD_REQUIRE(stride == 1 || stride == 2, EMD_E_UNSUPPORTED, "emd_conv3x3_f32: stride must be 1 or 2");
+    EMD_REQUIRE(rate >= 1 && rate <= 31 && (rate == 1 || stride == 1), EMD_E_UNSUPPORTED,
+                "emd_conv3x3_f32: rate must be 1..31, and 1 when stride is 2");
+    if (B == 0) return EMD_OK;
+    GemmParams p{};
+    p.A = x; p.Whi = whi; p.Wlo = wlo; p.C = y; p.res = res;
+    p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
+    p.N = Cout; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK;
+    p.lda = ldx; p.ldc = ldy; p.ldres = ldres; p.act = act ? 1 : 0;
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    const int eff = 2 * rate + 1;
+    int pth = (Ho - 1) * stride + eff - H, ptw = (Wo - 1) * stride + eff - W;  // TF SAME: total padding
+    if (pth < 0) pth = 0;
+    if (ptw < 0) ptw = 0;
+    const int pt = pth / 2, pl = ptw / 2;
+    p.M = (long)B * Ho * Wo;
+    p.flat = 0;
+    p.Hg = Ho; p.Wg = Wo; p.Ha = H; p.Wa = W; p.Hc = Ho; p.Wc = Wo; p.sa = stride; p.sc = 1; p.py = p.px = 0;
+    int dy[9], dx[9];
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+            dy[ky * 3 + kx] = ky * rate - pt;
+            dx[ky * 3 + kx] = kx * rate - pl;
+        }
+    set_taps(p, 9, dy, dx);
+    return dispatch(p, precision, static_cast<hipStream_t>(stream));
 }

@@ -61,6 +61,15 @@ class Layer:
         self.scope = kw.get("scope")      # conv / separable-conv / conv2d_transpose scope
         self.bn = kw.get("bn", [])        # batch-norm scopes applied after it, in order
         self.extra_bn = kw.get("extra_bn")  # a second batch_then_activ (ASPP rate branches)
+        self.style = kw.get("style", "slim")  # "slim": weights/biases; "layers" (tf.layers): kernel/bias
+
+    @property
+    def wname(self):
+        return "weights" if self.style == "slim" else "kernel"
+
+    @property
+    def bname(self):
+        return "biases" if self.style == "slim" else "bias"
 
     def variables(self):
         v = OrderedDict()
@@ -68,11 +77,11 @@ class Layer:
             v[self.scope + "/depthwise_weights"] = (3, 3, self.cin, 1)
             v[self.scope + "/pointwise_weights"] = (1, 1, self.cin, self.cout)
         elif self.kind == "conv":
-            v[self.scope + "/weights"] = (self.k, self.k, self.cin, self.cout)
-            v[self.scope + "/biases"] = (self.cout,)
+            v[self.scope + "/" + self.wname] = (self.k, self.k, self.cin, self.cout)
+            v[self.scope + "/" + self.bname] = (self.cout,)
         elif self.kind == "deconv":
-            v[self.scope + "/weights"] = (3, 3, self.cout, self.cin)
-            v[self.scope + "/biases"] = (self.cout,)
+            v[self.scope + "/" + self.wname] = (3, 3, self.cout, self.cin)
+            v[self.scope + "/" + self.bname] = (self.cout,)
         c = self.cout
         for s in self.bn + ([self.extra_bn] if self.extra_bn else []):
             # creation order inside tf.contrib.layers.batch_norm: beta, gamma, moving_mean, moving_variance
@@ -81,9 +90,15 @@ class Layer:
         return v
 
 
-def declare_layers():
-    """Every parameterised layer of architecture() (denoiser.py:248-398) keyed by the reference's
-    Python variable name, in creation order."""
+def declare_layers(variant="D"):
+    """Every parameterised layer of architecture() keyed by the reference's Python variable name, in creation
+    order.  variant "D": machine_learning/denoiser.py:248-398 (slim.conv2d / slim.conv2d_transpose);
+    variant "Dprime": the training twin misc_py/denoiser-multi-gpu.py:200-540 run with phase=False
+    (tf.layers.conv2d / conv2d_transpose => scopes conv2d_k / conv2d_transpose_k with kernel/bias, named ASPP
+    convs, dense dilated 3x3 ASPP branches, a real image-level branch)."""
+    if variant not in ("D", "Dprime"):
+        raise ValueError("variant must be 'D' or 'Dprime'")
+    twin = variant == "Dprime"
     sc = _Scope()
     L = OrderedDict()
 
@@ -94,13 +109,14 @@ def declare_layers():
         L[key] = Layer("sep", cin, cout, stride=stride, rate=rate, scope=scope, bn=[inner, outer],
                        extra_bn=sc("BatchNorm") if extra else None)
 
-    def conv(key, cin, cout, k=1, stride=1):
-        scope = sc("Conv")
-        L[key] = Layer("conv", cin, cout, k=k, stride=stride, scope=scope, bn=[sc("BatchNorm")])
+    def conv(key, cin, cout, k=1, stride=1, rate=1, name=None, bn=True):
+        scope = ("nn/" + name if name else sc("conv2d")) if twin else sc("Conv")
+        L[key] = Layer("conv", cin, cout, k=k, stride=stride, rate=rate, scope=scope,
+                       bn=[sc("BatchNorm")] if bn else [], style="layers" if twin else "slim")
 
     def deconv(key, cin, cout):
-        scope = sc("Conv2d_transpose")
-        L[key] = Layer("deconv", cin, cout, scope=scope, bn=[sc("BatchNorm")])
+        scope = sc("conv2d_transpose") if twin else sc("Conv2d_transpose")
+        L[key] = Layer("deconv", cin, cout, scope=scope, bn=[sc("BatchNorm")], style="layers" if twin else "slim")
 
     f0, f1, f2, f3, f4 = features0, features1, features2, features3, features4
     sep("cnn0", channels, f0); sep("cnn0_last", f0, f0); sep("cnn0_strided", f0, f1, stride=2)
@@ -115,12 +131,21 @@ def declare_layers():
     for i in range(num_extra_blocks):
         for j in range(3):
             sep(f"middle{i}_{j}", f4, f4)
-    conv("aspp_conv1x1", f4, aspp_filters)
-    sep("aspp_small", f4, aspp_filters, rate=aspp_rateSmall, extra=True)
-    sep("aspp_medium", f4, aspp_filters, rate=aspp_rateMedium, extra=True)
-    sep("aspp_large", f4, aspp_filters, rate=aspp_rateLarge, extra=True)
-    L["aspp_pooling_bn"] = Layer("bn", f4, f4, bn=[sc("BatchNorm")])   # :199-200
-    conv("aspp_reduce", 5 * aspp_filters, aspp_output)
+    if not twin:
+        conv("aspp_conv1x1", f4, aspp_filters)
+        sep("aspp_small", f4, aspp_filters, rate=aspp_rateSmall, extra=True)
+        sep("aspp_medium", f4, aspp_filters, rate=aspp_rateMedium, extra=True)
+        sep("aspp_large", f4, aspp_filters, rate=aspp_rateLarge, extra=True)
+        L["aspp_pooling_bn"] = Layer("bn", f4, f4, bn=[sc("BatchNorm")])   # :199-200
+        conv("aspp_reduce", 5 * aspp_filters, aspp_output)
+    else:  # denoiser-multi-gpu.py:291-361
+        conv("aspp_conv1x1", f4, aspp_filters, name="1x1")
+        conv("aspp_small", f4, aspp_filters, k=3, rate=aspp_rateSmall, name="lowRate")
+        conv("aspp_medium", f4, aspp_filters, k=3, rate=aspp_rateMedium, name="mediumRate")
+        conv("aspp_large", f4, aspp_filters, k=3, rate=aspp_rateLarge, name="highRate")
+        conv("aspp_image_conv", f4, aspp_filters, name="imageLevel", bn=False)   # conv -> resize -> BN -> relu6
+        L["aspp_pooling_bn"] = Layer("bn", aspp_filters, aspp_filters, bn=[sc("BatchNorm")])
+        conv("aspp_reduce", 5 * aspp_filters, aspp_output, name="pellet")
     sep("deconv2_a", aspp_output + f1, f2); sep("deconv2_b", f2, f2)
     conv("residual2_d", aspp_output + f1, f2)
     deconv("deconv2to1", f2, f2)
@@ -133,10 +158,10 @@ def declare_layers():
     return L
 
 
-def variable_specs():
+def variable_specs(variant="D"):
     """TF variable name -> shape, in creation order."""
     out = OrderedDict()
-    for layer in declare_layers().values():
+    for layer in declare_layers(variant).values():
         out.update(layer.variables())
     return out
 
@@ -144,7 +169,7 @@ def variable_specs():
 # ------------------------------------------------------------------------------------------------
 # synthetic weights (no checkpoint ships with the reference: its paths are network shares, :588)
 # ------------------------------------------------------------------------------------------------
-def synthetic_weights(seed: int = SYNTH_SEED, bn: str = "calibrated"):
+def synthetic_weights(seed: int = SYNTH_SEED, bn: str = "calibrated", variant: str = "D"):
     """Seeded weights: Xavier-uniform kernels as the reference initialises them (denoiser.py:125),
     small random biases and batch-norm gamma/beta; moving statistics either TF's initial values
     (bn='tf_init': mean 0, variance 1) or the calibrated set shipped in data/ for the default seed
@@ -152,13 +177,13 @@ def synthetic_weights(seed: int = SYNTH_SEED, bn: str = "calibrated"):
     relu6 is exercised on both sides through all ~60 layers."""
     rng = np.random.default_rng(seed)
     w = OrderedDict()
-    for name, shape in variable_specs().items():
+    for name, shape in variable_specs(variant).items():
         leaf = name.rsplit("/", 1)[1]
-        if leaf in ("depthwise_weights", "pointwise_weights", "weights"):
+        if leaf in ("depthwise_weights", "pointwise_weights", "weights", "kernel"):
             rf = shape[0] * shape[1]
             lim = np.sqrt(6.0 / (rf * shape[2] + rf * shape[3]))
             w[name] = rng.uniform(-lim, lim, shape).astype(np.float32)
-        elif leaf == "biases":
+        elif leaf in ("biases", "bias"):
             w[name] = rng.uniform(-0.1, 0.1, shape).astype(np.float32)
         elif leaf == "gamma":
             w[name] = rng.uniform(0.8, 2.0, shape).astype(np.float32)
@@ -171,7 +196,7 @@ def synthetic_weights(seed: int = SYNTH_SEED, bn: str = "calibrated"):
         else:
             raise AssertionError(name)
     if bn == "calibrated":
-        path = os.path.join(DATA_DIR, f"synth_bn_seed{seed}.npz")
+        path = os.path.join(DATA_DIR, f"synth_bn_seed{seed}.npz" if variant == "D" else f"synth_bn_{variant}_seed{seed}.npz")
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path}: calibrated batch-norm statistics exist only for the shipped seed; "
                                     "use bn='tf_init' for other seeds")
@@ -184,12 +209,12 @@ def synthetic_weights(seed: int = SYNTH_SEED, bn: str = "calibrated"):
     return w
 
 
-def load_weights(checkpoint_loc):
+def load_weights(checkpoint_loc, variant="D"):
     """Weights saved as ``<checkpoint_loc>/denoiser_weights.npz`` keyed by TF variable name.  Reading
     TensorFlow checkpoint bundles directly is a later step."""
     path = checkpoint_loc if checkpoint_loc.endswith(".npz") else os.path.join(checkpoint_loc, "denoiser_weights.npz")
     z = np.load(path, allow_pickle=False)
-    specs = variable_specs()
+    specs = variable_specs(variant)
     w = OrderedDict()
     for name, shape in specs.items():
         if name not in z.files:
@@ -223,14 +248,15 @@ def _fold(w, layer, bias=None):
 class DenoiserEngine:
     """Weights resident on one GPU + the launch sequence of architecture() (denoiser.py:248-398)."""
 
-    def __init__(self, weights, device, precision="bf16x3", fuse_sep=True):
+    def __init__(self, weights, device, precision="bf16x3", fuse_sep=True, variant="D"):
         import torch
 
         _lib.load()
         self.device = device
         self.fuse_sep = fuse_sep
+        self.variant = variant
         self.precision = {"bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[precision]
-        self.layers = declare_layers()
+        self.layers = declare_layers(variant)
         self.P = {}
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
         for key, L in self.layers.items():
@@ -251,8 +277,8 @@ class DenoiserEngine:
                     g, h = _bn_affine(weights, L.extra_bn)
                     p["scale2"], p["shift2"] = d(g), d(h)
             elif L.kind == "conv":
-                wt = weights[L.scope + "/weights"]
-                s, t = _fold(weights, L, weights[L.scope + "/biases"])
+                wt = weights[L.scope + "/" + L.wname]
+                s, t = _fold(weights, L, weights[L.scope + "/" + L.bname])
                 if L.cin == 1:   # residual0
                     p["a"] = d(wt.reshape(L.cout).astype(np.float64) * s)
                     p["shift"] = d(t)
@@ -263,8 +289,8 @@ class DenoiserEngine:
                     p["pw"] = ops.PackedWeights(wt.reshape(L.k * L.k, L.cin, L.cout), False, device)
                     p["scale"], p["shift"] = d(s), d(t)
             elif L.kind == "deconv":
-                s, t = _fold(weights, L, weights[L.scope + "/biases"])
-                p["phases"] = ops.pack_deconv(weights[L.scope + "/weights"], device)
+                s, t = _fold(weights, L, weights[L.scope + "/" + L.bname])
+                p["phases"] = ops.pack_deconv(weights[L.scope + "/" + L.wname], device)
                 p["scale"], p["shift"] = d(s), d(t)
             elif L.kind == "bn":
                 g, h = _bn_affine(weights, L.bn[0])
@@ -296,8 +322,16 @@ class DenoiserEngine:
         Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
         if out is None:
             out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
-        ops.conv1x1(x, p["pw"], p["scale"], p["shift"], out, stride=L.stride, res=res, precision=self.precision)
+        ops.conv1x1(x, p["pw"], p["scale"], p["shift"], out, stride=L.stride, act=bool(L.bn), res=res,
+                    precision=self.precision)
         return out
+
+    def _conv3x3(self, key, x, out=None):
+        """Dense (dilated) 3x3 conv + bias + BN + relu6: the twin's ASPP rate branches (denoiser-multi-gpu.py:306-328)."""
+        L, p = self.layers[key], self.P[key]
+        if out is None:
+            out = ops.Act.empty(x.B, x.H, x.W, L.cout, self.device)
+        return ops.conv3x3(x, p["pw"], p["scale"], p["shift"], out, stride=L.stride, rate=L.rate, precision=self.precision)
 
     def _deconv(self, key, x, out):
         p = self.P[key]
@@ -357,12 +391,24 @@ class DenoiserEngine:
         af = aspp_filters
         cat = E(S16, 5 * af)
         self._conv1x1("aspp_conv1x1", cur, out=cat.slice(0, af))
-        self._sep("aspp_small", cur, out=cat.slice(af, af))
-        self._sep("aspp_medium", cur, out=cat.slice(2 * af, af))
-        self._sep("aspp_large", cur, out=cat.slice(3 * af, af))
-        # :185-189 the pooled tensor is discarded; :199 "pooling" = resize of the INPUT to [aspp,aspp]
-        # (an identity resize here) followed by BN + relu6 (:200)
-        ops.affine_relu6(cur, P["aspp_pooling_bn"]["scale"], P["aspp_pooling_bn"]["shift"], cat.slice(4 * af, af))
+        if self.variant == "D":
+            self._sep("aspp_small", cur, out=cat.slice(af, af))
+            self._sep("aspp_medium", cur, out=cat.slice(2 * af, af))
+            self._sep("aspp_large", cur, out=cat.slice(3 * af, af))
+            # :185-189 the pooled tensor is discarded; :199 "pooling" = resize of the INPUT to [aspp,aspp]
+            # (an identity resize here) followed by BN + relu6 (:200)
+            ops.affine_relu6(cur, P["aspp_pooling_bn"]["scale"], P["aspp_pooling_bn"]["shift"], cat.slice(4 * af, af))
+        else:
+            # the training twin (denoiser-multi-gpu.py:306-345): dense dilated 3x3 branches, and a real image-level
+            # branch: avg-pool 2x2 -> 1x1 conv + bias -> bilinear back to [aspp,aspp] -> BN -> relu6
+            self._conv3x3("aspp_small", cur, out=cat.slice(af, af))
+            self._conv3x3("aspp_medium", cur, out=cat.slice(2 * af, af))
+            self._conv3x3("aspp_large", cur, out=cat.slice(3 * af, af))
+            pooled = ops.avgpool2x2(cur, ops.Act.empty(B, -(-S16 // 2), -(-S16 // 2), af, dev))
+            img_lvl = self._conv1x1("aspp_image_conv", pooled)
+            up = ops.resize_bilinear(img_lvl, E(S16, af))
+            ops.affine_relu6(up, P["aspp_pooling_bn"]["scale"], P["aspp_pooling_bn"]["shift"], cat.slice(4 * af, af))
+            del pooled, img_lvl, up
         aspp = self._conv1x1("aspp_reduce", cat)
         del cur, cat, t
         # decoder (:350-384)
@@ -384,7 +430,8 @@ class DenoiserEngine:
         del deconv1to0, residual0_d, t
         out = torch.empty((B, S, S, 1), dtype=torch.float32, device=dev)
         pf = P["deconv_final"]
-        ops.conv3x3_cout1(deconv0, pf["w"], pf["scale_f"], pf["shift_f"], out)
+        # the twin clips in-graph (denoiser-multi-gpu.py:534-538); D does not (denoiser.py:396)
+        ops.conv3x3_cout1(deconv0, pf["w"], pf["scale_f"], pf["shift_f"], out, act=2 if self.variant == "Dprime" else 1)
         return out
 
 

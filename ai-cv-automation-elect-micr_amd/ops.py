@@ -88,6 +88,28 @@ def conv1x1(x: Act, w: PackedWeights, scale1, shift1, out: Act, stride=1, act=Tr
     return out
 
 
+def conv3x3(x: Act, w: PackedWeights, scale1, shift1, out: Act, stride=1, rate=1, act=True, res: Act | None = None,
+            precision=PREC_BF16X3, stream=None):
+    """Dense 3x3 conv (9-tap implicit GEMM), TF SAME, optional dilation."""
+    lib = _lib.load()
+    Ho, Wo = -(-x.H // stride), -(-x.W // stride)
+    assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, w.cout) and w.cin == x.C and w.taps == 9
+    rc = lib.emd_conv3x3_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), C.c_void_p(0), C.c_void_p(0),
+                             res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
+                             out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, stride, rate, 1 if act else 0, precision,
+                             _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_conv3x3_f32")
+    return out
+
+
+def avgpool2x2(x: Act, out: Act, stream=None):
+    lib = _lib.load()
+    assert (out.B, out.H, out.W, out.C) == (x.B, -(-x.H // 2), -(-x.W // 2), x.C)
+    rc = lib.emd_avgpool2x2_f32(x.ptr, x.ld, out.ptr, out.ld, x.B, x.H, x.W, x.C, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_avgpool2x2_f32")
+    return out
+
+
 def sep_fused_supported(x: Act, cout: int, stride: int, rate: int) -> bool:
     return bool(_lib.load().emd_sep3x3_fused_supported(x.H, x.W, x.C, cout, stride, rate))
 
@@ -157,10 +179,11 @@ def cin1(x_img, w9_dev, a_dev, shift_dev, out: Act, stride=1, act=True, stream=N
 
 
 def conv3x3_cout1(x: Act, w_dev, scale: float, shift: float, out_img, act=True, stream=None):
+    """act: False/0 none, True/1 relu6, 2 relu6 then clip to [0,1]."""
     lib = _lib.load()
     assert out_img.is_contiguous() and out_img.numel() == x.B * x.H * x.W
     rc = lib.emd_conv3x3_cout1_f32(x.ptr, x.ld, _p(w_dev), C.c_float(scale), C.c_float(shift), _p(out_img), x.B, x.H,
-                                   x.W, x.C, 1 if act else 0, _lib.stream_ptr(stream))
+                                   x.W, x.C, int(act), _lib.stream_ptr(stream))
     _lib.check(rc, "emd_conv3x3_cout1_f32")
     return out_img
 

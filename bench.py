@@ -36,6 +36,17 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 D_GMAC_MATRIX_B32_512 = 2218.3  # pointwise 1304.5 + dense 1x1 295.3 - final 4.8 + conv-T 618.5 ... per B=32 batch
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC run (tools/collect_traffic.sh: FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 correction applied).  bench.py cannot profile itself, so `traffic`
+    is the figure of that run for the same kernels and shapes; None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        return json.load(open(path))["kernels"]
+    except Exception:
+        return None
+
+
 def synthetic_lq(B, H, W, seed=1234):
     """Synthetic low-quality crops of the reference's shape and statistics: smooth field ->
     Poisson counts (scale = 25 + Exp(75), denoiser-multi-gpu.py:783-799) -> min-max to [0,1]."""
@@ -174,12 +185,17 @@ def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     launch_us = e0.elapsed_time(e1) * 1e3 / n_burst
     alg_bytes = 8.0 * B * H * W  # 8 B per pixel (read 4 + write 4)
     achieved = alg_bytes / (launch_us * 1e-6) / 1e9
+    tr = pmc_traffic()
+    traffic = None
+    if tr and "K:k3_tile<2, 8>" in tr and (B, H, W) == (32, 512, 512):
+        traffic = round(tr["K:k3_tile<2, 8>"]["hbm_bytes_per_launch_corrected"])
     out = {
         "value": B * H * W / 1e6 * world / (ms / 1e3), "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "f32",
         "config": {"workload": f"K: kernel denoiser depth 2 width 3 (noise-removal-kernels.py), [{B},{H},{W},1] fp32 per GPU",
                    "global_batch": B * world, "image": f"{H}x{W}x1", "sharding": f"{world} x {B} whole images, no collective"},
         "roofline": {"bound": "hbm", "kernel": "k3_tile<2,8>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2x FETCH correction)",
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_us": round(launch_us, 3),
                      "how": f"HIP events around a hipGraph of {n_burst} back-to-back launches (includes the ~1.5 us kernel boundary)"},
@@ -241,6 +257,11 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     achieved = alg_flops / (gemm_ms * 1e-3) / 1e12
     passes = 3 if a.precision == "bf16x3" else 1
     dw_bytes = 48.1e9 * scale  # 57 depthwise stages, in+out fp32
+    tr = pmc_traffic()
+    traffic = None
+    if tr and (B, H, W) == (32, 512, 512):  # HBM bytes of all gemm_conv launches of one step
+        traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_sampled"] / 4.0
+                            for k, v in tr.items() if k.startswith("D:gemm_conv_kernel")))
     out = {
         "value": B * H * W / 1e6 * world / (ms / 1e3), "ms_per_step": ms, "steps": steps, "warmup": warmup,
         "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)" if passes == 3 else "bf16",
@@ -249,7 +270,8 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
                    "sharding": f"{world} x {B} whole images, no collective"},
         "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel (every 1x1 / transposed-conv launch of one step)",
                      "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "traffic_note": "HBM bytes per step over the family (PMC run of 4 forwards, profiles/r01_pmc_traffic.json)",
                      "algorithmic_flops_per_step": alg_flops, "mfma_passes": passes,
                      "issued_tflops": round(achieved * passes, 1),
                      "kernel_ms_per_step": round(gemm_ms, 3),

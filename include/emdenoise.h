@@ -109,6 +109,21 @@ int emd_conv1x1_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t
                     const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin,
                     int Cout, int stride, int act, int precision, emd_stream_t stream);
 
+/* Dense 3x3 convolution on the matrix cores (9-tap implicit GEMM), TF SAME, stride 1 or 2, or stride 1 with
+ * dilation `rate` <= 31.
+ * replaces: tf.layers.conv2d(kernel_size=3[, dilation_rate=r]) + bias + BN + relu6 -- the ASPP rate branches
+ *           of the training twin (misc_py/denoiser-multi-gpu.py:306-328).
+ * whi/wlo: emd_pack_weights_bf16(taps = 9, w_host = [ky][kx][Cin][Cout]).  Alignment rules as emd_conv1x1_f32. */
+int emd_conv3x3_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                    const float* shift1, const float* scale2, const float* shift2, const float* res, int ldres,
+                    float* y, int ldy, int B, int H, int W, int Cin, int Cout, int stride, int rate, int act,
+                    int precision, emd_stream_t stream);
+
+/* tf.nn.pool(window_shape=(2,2), "AVG", "SAME", strides=(2,2)): y [B,ceil(H/2),ceil(W/2),C].
+ * replaces: the image-level branch of the training twin's ASPP (misc_py/denoiser-multi-gpu.py:331-335). */
+int emd_avgpool2x2_f32(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C,
+                       emd_stream_t stream);
+
 /* 3x3 stride-2 transposed convolution, output exactly 2H x 2W, as four output-phase GEMMs.
  * replaces: slim.conv2d_transpose(kernel_size=3, stride=2, padding='same') + bias + BN + relu6
  *           (denoiser.py:141-148):  y[2i+k] += x[i]*w[k], cropped at the end.
@@ -148,7 +163,8 @@ int emd_cin1_f32(const float* x, const float* w9, const float* a, const float* s
 
 /* Dense 3x3 SAME convolution to ONE output channel + scalar affine + relu6.
  * replaces: the final slim.conv2d(num_outputs=1, kernel_size=3) + bias + BN + relu6 (denoiser.py:387).
- * x [B,H,W,Cin] pixel stride ldx; w [3][3][Cin]; y [B,H,W]; scale/shift: bias and BN folded. */
+ * x [B,H,W,Cin] pixel stride ldx; w [3][3][Cin]; y [B,H,W]; scale/shift: bias and BN folded.
+ * act: 0 none, 1 relu6, 2 relu6 then tf.clip_by_value(.,0,1) (misc_py/denoiser-multi-gpu.py:534-538). */
 int emd_conv3x3_cout1_f32(const float* x, int ldx, const float* w, float scale, float shift, float* y, int B,
                           int H, int W, int Cin, int act, emd_stream_t stream);
 

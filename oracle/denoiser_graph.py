@@ -44,7 +44,14 @@ class _Names:
 
 
 class _Graph:
-    def __init__(self, get_var, dtype):
+    """variant "D": machine_learning/denoiser.py:58-398.  variant "Dprime": its training twin,
+    misc_py/denoiser-multi-gpu.py:200-540, run with phase=False (inference batch norm): tf.layers convs
+    (scopes conv2d_k / conv2d_transpose_k, variables kernel/bias; named ASPP convs), dense dilated 3x3 ASPP
+    branches (:306-328), a real image-level branch (:331-345) and an in-graph clip to [0,1] (:534-538)."""
+
+    def __init__(self, get_var, dtype, variant="D"):
+        assert variant in ("D", "Dprime")
+        self.twin = variant == "Dprime"
         self.get = get_var
         self.names = _Names("nn")
         self.dtype = dtype
@@ -77,11 +84,20 @@ class _Graph:
         return y
 
     # ---- denoiser.py:86-99
+    def _conv(self, x, filters, kernel_size, stride=1, rate=1, name=None):
+        """slim.conv2d (D, :91-96) / tf.layers.conv2d (twin, denoiser-multi-gpu.py:231-235): conv + bias."""
+        if self.twin:
+            scope = self.names.prefix + "/" + name if name else self.names.unique("conv2d")
+            wn, bn = "/kernel", "/bias"
+        else:
+            scope = self.names.unique("Conv")
+            wn, bn = "/weights", "/biases"
+        w = self.get(scope + wn, (kernel_size, kernel_size, x.shape[-1], filters))
+        b = self.get(scope + bn, (filters,))
+        return T.conv2d_t(x, w, b, stride=stride, rate=rate)
+
     def conv_block_not_sep(self, x, filters, kernel_size=3, stride=1):
-        scope = self.names.unique("Conv")
-        w = self.get(scope + "/weights", (kernel_size, kernel_size, x.shape[-1], filters))
-        b = self.get(scope + "/biases", (filters,))
-        return self.batch_then_activ(T.conv2d_t(x, w, b, stride=stride))
+        return self.batch_then_activ(self._conv(x, filters, kernel_size, stride))
 
     # ---- denoiser.py:110-136 (slim.separable_convolution2d: stride and rate act on the
     #      depthwise stage; no bias because normalizer_fn is set; normalizer BN then outer BN+relu6)
@@ -100,13 +116,28 @@ class _Graph:
 
     # ---- denoiser.py:138-150
     def deconv_block(self, x, filters):
-        scope = self.names.unique("Conv2d_transpose")
-        w = self.get(scope + "/weights", (3, 3, filters, x.shape[-1]))
-        b = self.get(scope + "/biases", (filters,))
+        scope = self.names.unique("conv2d_transpose" if self.twin else "Conv2d_transpose")
+        w = self.get(scope + ("/kernel" if self.twin else "/weights"), (3, 3, filters, x.shape[-1]))
+        b = self.get(scope + ("/bias" if self.twin else "/biases"), (filters,))
         return self.batch_then_activ(T.conv2d_transpose_s2_t(x, w, b))
 
     # ---- denoiser.py:152-216
+    def aspp_block_twin(self, x, aspp_size):
+        """denoiser-multi-gpu.py:291-361."""
+        conv1x1 = self.batch_then_activ(self._conv(x, aspp_filters, 1, name="1x1"))
+        small = self.batch_then_activ(self._conv(x, aspp_filters, 3, rate=aspp_rateSmall, name="lowRate"))
+        medium = self.batch_then_activ(self._conv(x, aspp_filters, 3, rate=aspp_rateMedium, name="mediumRate"))
+        large = self.batch_then_activ(self._conv(x, aspp_filters, 3, rate=aspp_rateLarge, name="highRate"))
+        pooling = T.avg_pool2x2_same_t(x)
+        pooling = self._conv(pooling, aspp_filters, 1, name="imageLevel")
+        pooling = T.resize_bilinear_legacy_t(pooling, aspp_size, aspp_size)
+        pooling = self.batch_then_activ(pooling)
+        cat = torch.cat([conv1x1, small, medium, large, pooling], dim=3)
+        return self.batch_then_activ(self._conv(cat, aspp_output, 1, name="pellet"))
+
     def aspp_block(self, x, aspp_size):
+        if self.twin:
+            return self.aspp_block_twin(x, aspp_size)
         conv1x1 = self.conv_block_not_sep(x, aspp_filters, 1)
         small = self.batch_then_activ(self.strided_conv_block(x, aspp_filters, 1, aspp_rateSmall))
         medium = self.batch_then_activ(self.strided_conv_block(x, aspp_filters, 1, aspp_rateMedium))
@@ -184,10 +215,13 @@ class _Graph:
         deconv0 = deconv0 + self.conv_block_not_sep(deconv1to0, features0, 1)
 
         # :387 "1x1" in the comment, but kernel_size defaults to 3
-        return self.conv_block_not_sep(deconv0, 1)
+        out = self.conv_block_not_sep(deconv0, 1)
+        if self.twin:  # denoiser-multi-gpu.py:534-538
+            out = torch.clamp(out, 0.0, 1.0)
+        return out
 
 
-def variable_specs(cropsize=32) -> "OrderedDict[str, tuple]":
+def variable_specs(cropsize=32, variant="D") -> "OrderedDict[str, tuple]":
     """Names and shapes of every variable, in creation order."""
     specs = OrderedDict()
 
@@ -195,13 +229,13 @@ def variable_specs(cropsize=32) -> "OrderedDict[str, tuple]":
         specs[name] = tuple(int(s) for s in shape)
         return torch.zeros(shape, dtype=torch.float32)
 
-    g = _Graph(rec, torch.float32)
+    g = _Graph(rec, torch.float32, variant)
     with torch.no_grad():
         g.build(torch.zeros(1, cropsize, cropsize, 1), cropsize)
     return specs
 
 
-def architecture(inputs, weights, cropsize=512, dtype=torch.float32, trace=None, calibrate=None):
+def architecture(inputs, weights, cropsize=512, dtype=torch.float32, trace=None, calibrate=None, variant="D"):
     """inputs [B,cropsize,cropsize,1] (numpy or torch) -> torch tensor [B,cropsize,cropsize,1].
     ``weights``: dict TF-name -> numpy array.  No output clip (denoiser.py:396)."""
     cache = {}
@@ -213,7 +247,7 @@ def architecture(inputs, weights, cropsize=512, dtype=torch.float32, trace=None,
             cache[name] = torch.from_numpy(np.ascontiguousarray(w)).to(dtype)
         return cache[name]
 
-    g = _Graph(get, dtype)
+    g = _Graph(get, dtype, variant)
     g.trace = trace
     g.calibrate = calibrate
     x = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(inputs))

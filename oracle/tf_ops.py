@@ -127,6 +127,15 @@ def resize_bilinear_legacy_t(x, oh, ow):
     return top + (bot - top) * yl
 
 
+def avg_pool2x2_same_t(x):
+    """tf.nn.pool(window (2,2), 'AVG', 'SAME', strides (2,2)) (denoiser-multi-gpu.py:331-335): mean over the
+    in-image samples of each window (padding does not count)."""
+    xn = _nchw(x)
+    H, W = xn.shape[2], xn.shape[3]
+    return _nhwc(F.avg_pool2d(xn, 2, 2, padding=0, ceil_mode=True, count_include_pad=False) if (H % 2 or W % 2)
+                 else F.avg_pool2d(xn, 2, 2))
+
+
 def reflect_pad_t(x, p):
     """tf.pad(mode='REFLECT') on H and W (noise-removal-kernels.py:99-105): mirror without
     repeating the border sample."""
@@ -216,6 +225,16 @@ def resize_bilinear_legacy_np(x, oh, ow):
             top = x[:, y0, x0] + (x[:, y0, x1] - x[:, y0, x0]) * lx
             bot = x[:, y1, x0] + (x[:, y1, x1] - x[:, y1, x0]) * lx
             y[:, i, j] = top + (bot - top) * ly
+    return y
+
+
+def avg_pool2x2_same_np(x):
+    B, H, W, C = x.shape
+    oh, ow = -(-H // 2), -(-W // 2)
+    y = np.zeros((B, oh, ow, C), dtype=x.dtype)
+    for i in range(oh):
+        for j in range(ow):
+            y[:, i, j] = x[:, 2 * i: min(2 * i + 2, H), 2 * j: min(2 * j + 2, W)].mean(axis=(1, 2))
     return y
 
 

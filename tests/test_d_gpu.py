@@ -114,3 +114,20 @@ def test_denoiser_class_surface(weights):
     assert full.shape == (600, 700) and np.isfinite(full).all()
     tl = den.denoise_crop(big[:512, :512], preprocess=False, postprocess=True)
     np.testing.assert_allclose(full[:80, :80], tl[:80, :80], atol=1e-5)   # region covered by one tile only
+
+
+@pytest.mark.parametrize("B,S", [(2, 64), (1, 32)])
+def test_training_twin_forward_matches_oracle(B, S):
+    """Graph D' = misc_py/denoiser-multi-gpu.py:200-540 with phase=False: dense dilated ASPP convs on the 9-tap
+    implicit GEMM, avg-pool image-level branch, in-graph clip."""
+    import emdenoise
+    from oracle import denoiser_graph as G
+
+    w = emdenoise.synthetic_weights(variant="Dprime")
+    eng = emdenoise.DenoiserEngine(w, torch.device("cuda", 0), "bf16x3", variant="Dprime")
+    x = synthetic_lq(B, S, S, seed=300 + S)
+    ref = G.architecture(x, w, S, dtype=torch.float64, variant="Dprime").numpy()
+    got = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    r = rel_l2(got, ref)
+    print(f"D' graph B={B} S={S}: rel L2 {r:.2e}")
+    assert r < 3e-4 and got.min() >= 0.0 and got.max() <= 1.0

@@ -274,3 +274,40 @@ def test_sep_fused_falls_back_cleanly():
     with pytest.raises(_lib.EmdError, match="emd_dw3x3_f32"):
         ops.sep_fused(x, torch.zeros(9 * 64, device=dev()), ops.PackedWeights(rnd((1, 64, 64), 50), False, dev()),
                       torch.ones(64, device=dev()), torch.zeros(64, device=dev()), out_act(1, 12, 16, 64))
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,stride,rate", [
+    (1, 12, 12, 64, 64, 1, 1), (2, 32, 32, 128, 256, 1, 6), (1, 32, 32, 728, 728, 1, 18), (1, 9, 11, 32, 64, 2, 1),
+    (1, 16, 16, 64, 128, 2, 1), (1, 8, 8, 256, 64, 1, 12),
+])
+def test_conv3x3_dense(B, H, W, ci, co, stride, rate):
+    """9-tap implicit GEMM: tf.layers.conv2d(kernel_size=3, dilation_rate, 'same') + bias + affine + relu6."""
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 60, positive=True)
+    w = rnd((3, 3, ci, co), 61, scale=(2.0 / (9 * ci)) ** 0.5)
+    bias = rnd((co,), 62, 0.2)
+    s1, t1 = rnd((co,), 63, 0.2) + 1, rnd((co,), 64, 0.4)
+    ref = T.relu6_t(T.conv2d_t(t64(x), t64(w), t64(bias), stride=stride, rate=rate) * t64(s1) + t64(t1)).numpy()
+    pw = ops.PackedWeights(w.reshape(9, ci, co), False, dev())
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    out = out_act(B, Ho, Wo, co, ld=co + 4, c0=4)
+    shift = (bias.astype(np.float64) * s1 + t1).astype(np.float32)
+    ops.conv3x3(to_act(x), pw, torch.from_numpy(s1).to(dev()), torch.from_numpy(shift).to(dev()), out, stride=stride,
+                rate=rate)
+    torch.cuda.synchronize()
+    assert rel_l2(out.torch().cpu().numpy(), ref) < TOL_X3
+
+
+@pytest.mark.parametrize("H,W,Cc", [(32, 32, 728), (5, 7, 64), (2, 2, 8)])
+def test_avgpool2x2(H, W, Cc):
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((2, H, W, Cc), 65)
+    ref = T.avg_pool2x2_same_t(t64(x)).numpy()
+    out = out_act(2, -(-H // 2), -(-W // 2), Cc)
+    ops.avgpool2x2(to_act(x, ld=Cc + 4, c0=0), out)
+    torch.cuda.synchronize()
+    assert rel_l2(out.torch().cpu().numpy(), ref) < TOL_F32

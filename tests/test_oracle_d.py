@@ -70,3 +70,20 @@ def test_host_resize_is_identity_at_512_and_bilinear_otherwise():
     ramp = np.tile(np.arange(4, dtype=np.float32), (4, 1))
     up = D._resize_bilinear_host(ramp, (8, 8))
     np.testing.assert_allclose(up[0], [0, 0.25, 0.75, 1.25, 1.75, 2.25, 2.75, 3.0], atol=1e-6)  # half-pixel centres
+
+
+def test_training_twin_names_and_sizes():
+    """misc_py/denoiser-multi-gpu.py:200-540 (phase=False): tf.layers scopes, named ASPP convs, 38.50 M conv
+    parameters."""
+    a, b = D.variable_specs("Dprime"), G.variable_specs(variant="Dprime")
+    assert list(a.items()) == list(b.items())
+    nconv = sum(int(np.prod(s)) for n, s in a.items() if n.rsplit("/", 1)[1] in ("kernel", "depthwise_weights", "pointwise_weights"))
+    assert nconv == 38_497_049
+    assert a["nn/lowRate/kernel"] == (3, 3, 728, 728) and a["nn/pellet/kernel"] == (1, 1, 3640, 256)
+    assert a["nn/conv2d/kernel"] == (1, 1, 1, 128)              # residual0 is the first unnamed tf.layers conv
+    assert a["nn/conv2d_transpose_1/kernel"] == (3, 3, 128, 128)
+    assert "nn/imageLevel/bias" in a and "nn/Conv/weights" not in a
+    w = emdenoise.synthetic_weights(variant="Dprime")
+    x = synthetic_lq(1, 32, 32, seed=5)
+    y = G.architecture(x, w, 32, variant="Dprime").numpy()
+    assert y.min() >= 0.0 and y.max() <= 1.0                     # in-graph clip (:534-538)

@@ -148,3 +148,27 @@ def test_depthwise_stride2_samples_from_index_zero():
     w[0, 0, 0, 0] = 1.0   # top-left tap
     y = T.depthwise_conv2d_t(t(x), t(w), stride=2).numpy()
     assert y[0, 0, 0, 0] == 1.0  # window of output (0,0) starts at input (0,0)
+
+
+@pytest.mark.parametrize("H,W,rate,stride", [(12, 12, 6, 1), (8, 10, 18, 1), (9, 9, 2, 1), (8, 8, 1, 2)])
+def test_dense_dilated_conv_torch_vs_numpy(H, W, rate, stride):
+    """tf.layers.conv2d(kernel_size=3, dilation_rate=r, 'same') -- the training twin's ASPP branches
+    (misc_py/denoiser-multi-gpu.py:306-328)."""
+    x = rnd((2, H, W, 3), 40)
+    w = rnd((3, 3, 3, 4), 41)
+    b = rnd((4,), 42)
+    a = T.conv2d_t(t(x), t(w), t(b), stride=stride, rate=rate).numpy()
+    n = T.conv2d_np(x, w, b, stride=stride, rate=rate)
+    np.testing.assert_allclose(a, n, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("H,W", [(4, 4), (6, 8), (5, 7), (1, 1)])
+def test_avg_pool_same(H, W):
+    x = rnd((2, H, W, 3), 43)
+    a = T.avg_pool2x2_same_t(t(x)).numpy()
+    n = T.avg_pool2x2_same_np(x)
+    assert a.shape == (2, -(-H // 2), -(-W // 2), 3)
+    np.testing.assert_allclose(a, n, rtol=1e-13, atol=1e-13)
+    # known answer: the window that hangs over the edge averages only the samples inside the image
+    if H == 5:
+        np.testing.assert_allclose(a[:, 2, 0], x[:, 4, 0:2].mean(axis=1))

@@ -1,0 +1,33 @@
+# Collects HBM traffic of the dominant kernels with rocprofv3 PMC counters, FETCH_SIZE and WRITE_SIZE in
+# SEPARATE passes (they do not fit one pass on gfx950), and writes profiles/r01_pmc_traffic.json.
+# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of wide coalesced
+# streaming reads -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  Both counters are in KiB.
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
+rm -rf $OUT; mkdir -p $OUT
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $OUT/K_$c -- python3 $GRAFT_REPO_ROOT/bench.py --workload K --no-cpu-baseline --steps 20 --warmup 2 > /dev/null 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/D_$c -- python3 $GRAFT_REPO_ROOT/tools/dprofile.py > /dev/null 2>&1
+done
+python3 - <<PY
+import csv, glob, json, collections
+out = {}
+for wl in ("K", "D"):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for f in glob.glob("$OUT/%s_%s/*/*counter_collection.csv" % (wl, c)):
+            for r in csv.DictReader(open(f)):
+                nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                if "rocclr" in nm: continue
+                if wl == "K" and int(r["Grid_Size"]) < 500000: continue
+                per[nm][c].append(float(r["Counter_Value"]))
+    for nm, d in per.items():
+        n = max(len(v) for v in d.values())
+        f_kib = sum(d.get("FETCH_SIZE", [0])) / max(len(d.get("FETCH_SIZE", [1])), 1)
+        w_kib = sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [1])), 1)
+        out[wl + ":" + nm] = {"launches_sampled": n, "FETCH_SIZE_KiB_avg": f_kib, "WRITE_SIZE_KiB_avg": w_kib,
+                              "hbm_bytes_per_launch_corrected": (2.0 * f_kib + w_kib) * 1024.0}
+json.dump({"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B read requests as 64 B)", "kernels": out}, open("$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic.json", "w"), indent=1)
+for k, v in out.items(): print(f"{k:60s} n={v['launches_sampled']:4d} fetch {v['FETCH_SIZE_KiB_avg']/1024:10.1f} MiB(raw) write {v['WRITE_SIZE_KiB_avg']/1024:10.1f} MiB -> corrected {v['hbm_bytes_per_launch_corrected']/1e6:10.1f} MB/launch")
+PY
+rm -rf $OUT
