@@ -19,6 +19,7 @@ _c_float_p = C.c_void_p  # device pointers travel as integers
 SIGNATURES = {
     "emd_version": (C.c_int, []),
     "emd_last_error": (C.c_char_p, []),
+    "emd_crc32c": (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "emd_kernel_params_count": (C.c_size_t, [C.c_int, C.c_int]),
     "emd_kernel_denoise_f32": (C.c_int, [_c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          _c_float_p, C.c_uint, C.c_void_p]),

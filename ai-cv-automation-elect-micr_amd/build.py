@@ -47,7 +47,7 @@ def _newer(src_files, target) -> bool:
 
 
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
 def headers():
@@ -63,14 +63,15 @@ def build_lib(force: bool = False, jobs: int = 4, verbose: bool = True, extra_fl
     todo = []
     objs = []
     for src in sources():
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
         objs.append(obj)
         if force or _newer([src] + hdrs, obj):
             todo.append((src, obj))
 
     def compile_one(so):
         src, obj = so
-        cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-c", src, "-o", obj]
+        flags = HIPCC_FLAGS if src.endswith(".hip") else ["-O3", "-std=c++17", "-fPIC", "-msse4.2", "-Wall", "-I" + INCLUDE]
+        cmd = [hipcc, *flags, *extra_flags, "-c", src, "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

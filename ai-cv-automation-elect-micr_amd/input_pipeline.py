@@ -126,3 +126,143 @@ def input_fn(stack, batch_size: int, num_shards: int, seed: int = 0, epochs: int
             lq = np.stack([p[0] for p in pairs])[..., None]
             hq = np.stack([p[1] for p in pairs])[..., None]
             yield shard_round_robin(lq, num_shards), shard_round_robin(hq, num_shards)
+
+
+# ---- TFRecord files (misc_py/TFRecord_creator.py:57-85) -----------------------------------------------------
+# One tf.train.Example per image with a single bytes feature 'image' = the raw float32 pixels.  TensorFlow is
+# not needed to read them: the container and the protobuf wire format are public.  (Format restated from the
+# TFRecord / protobuf specifications; no TensorFlow-written file ships with the reference to pin it against.)
+def _masked_crc(data) -> int:
+    from . import _lib
+
+    buf = np.frombuffer(data, dtype=np.uint8)
+    crc = _lib.load().emd_crc32c(buf.ctypes.data if len(buf) else None, len(buf), 0)
+    return ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _varint(buf, pos):
+    out = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        out |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return out, pos
+        shift += 7
+
+
+def _fields(buf):
+    """Yield (field number, wire type, value) of one protobuf message; LEN values are memoryviews."""
+    pos, n = 0, len(buf)
+    while pos < n:
+        key, pos = _varint(buf, pos)
+        fno, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            v = buf[pos:pos + ln]
+            pos += ln
+        elif wt == 5:
+            v = bytes(buf[pos:pos + 4])
+            pos += 4
+        elif wt == 1:
+            v = bytes(buf[pos:pos + 8])
+            pos += 8
+        else:
+            raise ValueError(f"unsupported protobuf wire type {wt}")
+        yield fno, wt, v
+
+
+def parse_example(record) -> dict:
+    """tf.train.Example -> {feature name: list of bytes objects} (bytes_list features only)."""
+    out = {}
+    for fno, _, feats in _fields(memoryview(record)):
+        if fno != 1:
+            continue
+        for f2, _, entry in _fields(feats):          # Features.feature: map<string, Feature>
+            if f2 != 1:
+                continue
+            key, value = None, None
+            for f3, _, v in _fields(entry):
+                if f3 == 1:
+                    key = bytes(v).decode()
+                elif f3 == 2:
+                    value = v
+            vals = []
+            if value is not None:
+                for f4, _, lst in _fields(value):        # Feature.bytes_list = 1
+                    if f4 == 1:
+                        vals.extend(bytes(b) for f5, _, b in _fields(lst) if f5 == 1)
+            out[key] = vals
+    return out
+
+
+def read_tfrecord(path, verify=True):
+    """Yield the raw record payloads of a TFRecord file (memory-mapped, CRCs checked when verify)."""
+    import mmap
+    import struct
+
+    with open(path, "rb") as fh:
+        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        try:
+            pos, n = 0, len(mm)
+            while pos < n:
+                if pos + 12 > n:
+                    raise ValueError(f"{path}: truncated record header at byte {pos}")
+                (length,) = struct.unpack_from("<Q", mm, pos)
+                (lcrc,) = struct.unpack_from("<I", mm, pos + 8)
+                if verify and _masked_crc(mm[pos:pos + 8]) != lcrc:
+                    raise ValueError(f"{path}: corrupt length field at byte {pos}")
+                start, end = pos + 12, pos + 12 + length
+                if end + 4 > n:
+                    raise ValueError(f"{path}: truncated record at byte {pos}")
+                data = mm[start:end]
+                (dcrc,) = struct.unpack_from("<I", mm, end)
+                if verify and _masked_crc(data) != dcrc:
+                    raise ValueError(f"{path}: corrupt record at byte {pos}")
+                yield data
+                pos = end + 4
+        finally:
+            mm.close()
+
+
+def tfrecord_images(path, shape=None, verify=True):
+    """Yield float32 images from the 'image' feature (TFRecord_creator.py:75); `shape` = (H, W) if known,
+    else square images are assumed (the reference stores 2048 x 2048)."""
+    for rec in read_tfrecord(path, verify):
+        raw = parse_example(rec)["image"][0]
+        a = np.frombuffer(raw, dtype=np.float32)
+        if shape is None:
+            side = int(round(len(a) ** 0.5))
+            if side * side != len(a):
+                raise ValueError("non-square image: pass shape=(H, W)")
+            shp = (side, side)
+        else:
+            shp = tuple(shape)
+        yield a.reshape(shp)
+
+
+def write_tfrecord(path, images):
+    """Write float32 images exactly as TFRecord_creator.py:57-85 does (one Example, bytes feature 'image')."""
+    import struct
+
+    def ln(b):  # protobuf varint
+        out = bytearray()
+        while True:
+            out.append((b & 0x7F) | (0x80 if b > 0x7F else 0))
+            b >>= 7
+            if not b:
+                return bytes(out)
+
+    def field(no, payload):
+        return ln((no << 3) | 2) + ln(len(payload)) + payload
+
+    with open(path, "wb") as fh:
+        for img in images:
+            raw = np.ascontiguousarray(img, dtype=np.float32).tobytes()
+            feature = field(1, field(1, raw))                       # Feature{bytes_list{value}}
+            entry = field(1, b"image") + field(2, feature)          # map entry
+            example = field(1, field(1, entry))                     # Example{features{feature}}
+            head = struct.pack("<Q", len(example))
+            fh.write(head + struct.pack("<I", _masked_crc(head)) + example + struct.pack("<I", _masked_crc(example)))

@@ -178,6 +178,12 @@ int emd_resize_bilinear_f32(const float* x, int ldx, float* y, int ldy, int B, i
 int emd_affine_relu6_f32(const float* x, int ldx, const float* scale, const float* shift, float* y, int ldy,
                          long npix, int C, int act, emd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Host utility (no GPU): CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start).
+ * Used by the TFRecord reader (emdenoise.input_pipeline) for the container that
+ * misc_py/TFRecord_creator.py:57-85 writes with tf.python_io.TFRecordWriter. */
+uint32_t emd_crc32c(const void* data_host, size_t n, uint32_t crc);
+
 #ifdef __cplusplus
 }
 #endif
