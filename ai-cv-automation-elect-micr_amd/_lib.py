@@ -54,7 +54,15 @@ SIGNATURES = {
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     # x ldx w scale shift y B H W Cin act stream
     "emd_conv3x3_cout1_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_float, C.c_float, _c_float_p, C.c_int,
-                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    # x ldx scale shift res ldres y ldy npix C act stream
+    "emd_affine_act_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p,
+                                     C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "emd_bn_stats_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int]),
+    "emd_bn_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_long, C.c_int, _c_float_p, _c_float_p, C.c_void_p,
+                                   C.c_void_p]),
+    "emd_bn_fold_f32": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, C.c_float, _c_float_p, _c_float_p,
+                                  C.c_int, C.c_void_p]),
     # x ldx y ldy B Hi Wi Ho Wo C stream
     "emd_resize_bilinear_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_void_p]),

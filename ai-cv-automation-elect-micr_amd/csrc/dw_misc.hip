@@ -20,6 +20,12 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 // act code of the Cout=1 kernels: 0 none, 1 relu6, 2 relu6 followed by tf.clip_by_value(0,1) = clamp to [0,1]
 __device__ __forceinline__ float act_out(float v, int act) { return act == 0 ? v : fminf(fmaxf(v, 0.f), act == 2 ? 1.f : 6.f); }
+// the Cout=1 kernels' output stage: optional "+pre_bias, relu" first (tf.layers.conv2d(activation=relu) before the
+// batch norm, misc_py/modified_Xception.py:215-229), then the scalar affine and the act code above
+__device__ __forceinline__ float cout1_out(float s, float pre_bias, int pre_relu, float scale, float shift, int act) {
+    if (pre_relu) s = fmaxf(s + pre_bias, 0.f);
+    return act_out(fmaf(s, scale, shift), act);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Depthwise 3x3, stride 1, rate 1: each thread owns (image b, column ox, channel group c4) and rolls
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void cin1_kernel(const float* __restrict__ x, 
 __global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ w, float scale,
                                                             float shift, float* __restrict__ y, int H, int W,
-                                                            int LP, long npix, int act) {
+                                                            int LP, long npix, int act, float pre_bias, int pre_relu) {
     const int lane = threadIdx.x & 63;
     const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int ppw = 64 / LP;
@@ -194,8 +200,7 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restr
     float s = (acc.x + acc.y) + (acc.z + acc.w);
     for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m);
     if (c4 == 0 && pix < npix) {
-        float v = fmaf(s, scale, shift);
-        y[pix] = act_out(v, act);
+        y[pix] = cout1_out(s, pre_bias, pre_relu, scale, shift, act);
     }
 }
 
@@ -207,7 +212,7 @@ template <int TH>
 __global__ __launch_bounds__(256) void conv3x3_cout1_roll(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ w, float scale, float shift,
                                                           float* __restrict__ y, int H, int W, int LP, int nstrip,
-                                                          long nthreads, int act) {
+                                                          long nthreads, int act, float pre_bias, int pre_relu) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;  // nthreads is a multiple of 64: whole waves leave together
     const int c4 = (int)(tid % LP);
@@ -244,8 +249,7 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_roll(const float* __restric
             float s = (a.x + a.y) + (a.z + a.w);
             for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m);
             if (c4 == 0 && oy < H) {
-                const float v = fmaf(s, scale, shift);
-                yb[(long)oy * W + ox] = act_out(v, act);
+                yb[(long)oy * W + ox] = cout1_out(s, pre_bias, pre_relu, scale, shift, act);
             }
         }
         s0 = add4(s1, h1);
@@ -285,10 +289,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     *reinterpret_cast<float4*>(y + ((b * Ho + oy) * (long)Wo + ox) * ldy + c4 * 4) = o;
 }
 
-__global__ __launch_bounds__(256) void affine_relu6_kernel(const float* __restrict__ x, int ldx,
-                                                           const float* __restrict__ sc,
-                                                           const float* __restrict__ sh, float* __restrict__ y,
-                                                           int ldy, int C4, long nthreads, int act) {
+// y = act(x*scale + shift) [+ res]; x and y may be the same buffer (elementwise, same index).
+__global__ __launch_bounds__(256) void affine_relu6_kernel(const float* x, int ldx, const float* __restrict__ sc,
+                                                           const float* __restrict__ sh, const float* res, int ldres,
+                                                           float* y, int ldy, int C4, long nthreads, int act) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;
     const int c4 = (int)(tid % C4);
@@ -297,8 +301,68 @@ __global__ __launch_bounds__(256) void affine_relu6_kernel(const float* __restri
     const float4 s = *reinterpret_cast<const float4*>(sc + c4 * 4);
     const float4 t = *reinterpret_cast<const float4*>(sh + c4 * 4);
     float4 o = make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
-    if (act) o = make_float4(relu6f(o.x), relu6f(o.y), relu6f(o.z), relu6f(o.w));
+    if (act) {
+        const float hi = act == 2 ? __builtin_inff() : 6.f;
+        o = make_float4(fminf(fmaxf(o.x, 0.f), hi), fminf(fmaxf(o.y, 0.f), hi), fminf(fmaxf(o.z, 0.f), hi),
+                        fminf(fmaxf(o.w, 0.f), hi));
+    }
+    if (res) o = add4(o, *reinterpret_cast<const float4*>(res + pix * ldres + c4 * 4));
     *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batch statistics of a [npix, C] tensor (tf.contrib.layers.batch_norm with is_training=True, as the
+// separable convs of misc_py/modified_Xception.py:302-323 call it even at inference): per-channel mean and
+// BIASED variance over N,H,W.  Pass 1: each block sums a slab of rows for 64 channels in double; pass 2
+// combines the slabs.  Double keeps E[x^2]-E[x]^2 safe from cancellation.
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int ldx, long npix, int C,
+                                                        long rows_per_slab, double* __restrict__ part) {
+    __shared__ double sm[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rsub = threadIdx.x >> 6;  // 4 row phases
+    const long r0 = (long)blockIdx.y * rows_per_slab;
+    const long r1 = min(r0 + rows_per_slab, npix);
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (long r = r0 + rsub; r < r1; r += 4) {
+            const double v = (double)x[r * ldx + c];
+            s += v;
+            q += v * v;
+        }
+    sm[0][rsub][threadIdx.x & 63] = s;
+    sm[1][rsub][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (rsub == 0 && c < C) {
+        const int l = threadIdx.x;
+        part[((long)blockIdx.y * 2 + 0) * C + c] = sm[0][0][l] + sm[0][1][l] + sm[0][2][l] + sm[0][3][l];
+        part[((long)blockIdx.y * 2 + 1) * C + c] = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final(const double* __restrict__ part, int nslab, int C, long npix,
+                                                      float* __restrict__ mean, float* __restrict__ var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nslab; ++k) {
+        s += part[((long)k * 2 + 0) * C + c];
+        q += part[((long)k * 2 + 1) * C + c];
+    }
+    const double m = s / (double)npix;
+    double v = q / (double)npix - m * m;
+    mean[c] = (float)m;
+    var[c] = (float)(v > 0.0 ? v : 0.0);
+}
+
+// scale = gamma / sqrt(var + eps) (gamma may be NULL = 1), shift = beta - mean*scale: a batch norm as one affine
+__global__ void bn_fold_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                               float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float g = (gamma ? gamma[c] : 1.0f) / sqrtf(var[c] + eps);
+    scale[c] = g;
+    shift[c] = (beta ? beta[c] : 0.0f) - mean[c] * g;
 }
 
 // tf.nn.pool(window (2,2), "AVG", "SAME", strides (2,2)): mean over the window's in-image samples.
@@ -405,7 +469,8 @@ extern "C" int emd_cin1_f32(const float* x, const float* w9, const float* a, con
 }
 
 extern "C" int emd_conv3x3_cout1_f32(const float* x, int ldx, const float* w, float scale, float shift, float* y,
-                                     int B, int H, int W, int Cin, int act, emd_stream_t stream) {
+                                     int B, int H, int W, int Cin, int act, float pre_bias, int pre_relu,
+                                     emd_stream_t stream) {
     EMD_REQUIRE(x && w && y, EMD_E_INVALID, "emd_conv3x3_cout1_f32: null pointer");
     EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_conv3x3_cout1_f32: bad shape");
     const int LP = Cin / 4;
@@ -424,13 +489,13 @@ extern "C" int emd_conv3x3_cout1_f32(const float* x, int ldx, const float* w, fl
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
         hipLaunchKernelGGL(conv3x3_cout1_roll<TH>, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w,
-                           scale, shift, y, H, W, LP, nstrip, nthreads, act);
+                           scale, shift, y, H, W, LP, nstrip, nthreads, act, pre_bias, pre_relu);
         return emd::check_launch("conv3x3_cout1_roll");
     }
     int rc = grid_for((npix + ppw - 1) / ppw * 64, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL(conv3x3_cout1_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w, scale,
-                       shift, y, H, W, LP, npix, act);
+                       shift, y, H, W, LP, npix, act, pre_bias, pre_relu);
     return emd::check_launch("conv3x3_cout1_kernel");
 }
 
@@ -451,21 +516,58 @@ extern "C" int emd_resize_bilinear_f32(const float* x, int ldx, float* y, int ld
     return emd::check_launch("resize_bilinear_kernel");
 }
 
-extern "C" int emd_affine_relu6_f32(const float* x, int ldx, const float* scale, const float* shift, float* y,
-                                    int ldy, long npix, int C, int act, emd_stream_t stream) {
-    EMD_REQUIRE(x && y && scale && shift, EMD_E_INVALID, "emd_affine_relu6_f32: null pointer");
-    EMD_REQUIRE(npix >= 0 && C >= 4, EMD_E_INVALID, "emd_affine_relu6_f32: bad shape");
+extern "C" int emd_affine_act_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res,
+                                  int ldres, float* y, int ldy, long npix, int C, int act, emd_stream_t stream) {
+    EMD_REQUIRE(x && y && scale && shift, EMD_E_INVALID, "emd_affine_act_f32: null pointer");
+    EMD_REQUIRE(npix >= 0 && C >= 4 && act >= 0 && act <= 2, EMD_E_INVALID, "emd_affine_act_f32: bad argument");
     EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && emd::aligned16(x) &&
-                    emd::aligned16(y) && emd::aligned16(scale) && emd::aligned16(shift), EMD_E_ALIGN,
-                "emd_affine_relu6_f32: alignment");
+                    emd::aligned16(y) && emd::aligned16(scale) && emd::aligned16(shift) &&
+                    (!res || (ldres % 4 == 0 && ldres >= C && emd::aligned16(res))), EMD_E_ALIGN,
+                "emd_affine_act_f32: alignment");
     if (npix == 0) return EMD_OK;
     const long nthreads = npix * (C / 4);
     unsigned nb;
     int rc = grid_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL(affine_relu6_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, scale,
-                       shift, y, ldy, C / 4, nthreads, act ? 1 : 0);
+                       shift, res, ldres, y, ldy, C / 4, nthreads, act);
     return emd::check_launch("affine_relu6_kernel");
+}
+
+extern "C" int emd_affine_relu6_f32(const float* x, int ldx, const float* scale, const float* shift, float* y,
+                                    int ldy, long npix, int C, int act, emd_stream_t stream) {
+    return emd_affine_act_f32(x, ldx, scale, shift, nullptr, 0, y, ldy, npix, C, act ? 1 : 0, stream);
+}
+
+extern "C" size_t emd_bn_stats_workspace_bytes(long npix, int C) {
+    if (npix <= 0 || C <= 0) return 0;
+    long nslab = (npix + 4095) / 4096;
+    if (nslab > 1024) nslab = 1024;
+    return (size_t)nslab * 2 * C * sizeof(double);
+}
+
+extern "C" int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float* mean, float* var, void* workspace,
+                                emd_stream_t stream) {
+    EMD_REQUIRE(x && mean && var && workspace, EMD_E_INVALID, "emd_bn_stats_f32: null pointer");
+    EMD_REQUIRE(npix >= 1 && C >= 1 && ldx >= C, EMD_E_INVALID, "emd_bn_stats_f32: bad shape");
+    EMD_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EMD_E_ALIGN, "emd_bn_stats_f32: workspace alignment");
+    long nslab = (npix + 4095) / 4096;
+    if (nslab > 1024) nslab = 1024;
+    const long rows_per_slab = (npix + nslab - 1) / nslab;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_stats_partial, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, npix, C,
+                       rows_per_slab, static_cast<double*>(workspace));
+    hipLaunchKernelGGL(bn_stats_final, dim3((C + 255) / 256), dim3(256), 0, st, static_cast<const double*>(workspace),
+                       (int)nslab, C, npix, mean, var);
+    return emd::check_launch("bn_stats");
+}
+
+extern "C" int emd_bn_fold_f32(const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                               float* scale, float* shift, int C, emd_stream_t stream) {
+    EMD_REQUIRE(mean && var && scale && shift && C >= 1, EMD_E_INVALID, "emd_bn_fold_f32: bad argument");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), mean, var,
+                       gamma, beta, eps, scale, shift, C);
+    return emd::check_launch("bn_fold_kernel");
 }
 
 extern "C" int emd_avgpool2x2_f32(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C,

@@ -50,7 +50,7 @@ struct GemmParams {
     long M;               // B*Hg*Wg
     int N, Cin, Cpad, ntaps;
     int lda, ldc, ldres;
-    int act;              // 1: relu6 after the first affine
+    int act;              // EMD_ACT_*: 0 none, 1 relu6, 2 relu -- after the first affine (and after the second)
     // row map: m -> (b,i,j) on Hg x Wg;  source (b, i*sa+dy, j*sa+dx) in Ha x Wa;  dest (b, i*sc+py, j*sc+px) in Hc x Wc
     int flat;             // 1: source pixel = dest pixel = m (plain pointwise)
     int Hg, Wg, Ha, Wa, Hc, Wc, sa, sc, py, px;
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
         }
         const float* __restrict__ resp = p.res;
         float* __restrict__ outp = p.C;
+        const float hi = p.act == 2 ? __builtin_inff() : 6.f;
 #pragma unroll 4
         for (int r = er; r < BM; r += ROWS_PER_PASS) {
             const long long pix = rowP[r];
@@ -278,13 +279,13 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
             float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (resp) rv = *reinterpret_cast<const float4*>(resp + pix * p.ldres + n);
             v.x = fmaf(v.x, s1.x, t1.x); v.y = fmaf(v.y, s1.y, t1.y); v.z = fmaf(v.z, s1.z, t1.z); v.w = fmaf(v.w, s1.w, t1.w);
-            if (p.act) {
-                v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
-                v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+            if (p.act) {  // hi = 6 (relu6) or +inf (relu)
+                v.x = fminf(fmaxf(v.x, 0.f), hi); v.y = fminf(fmaxf(v.y, 0.f), hi);
+                v.z = fminf(fmaxf(v.z, 0.f), hi); v.w = fminf(fmaxf(v.w, 0.f), hi);
             }
             if (p.scale2) {
-                v.x = fminf(fmaxf(fmaf(v.x, s2.x, t2.x), 0.f), 6.f); v.y = fminf(fmaxf(fmaf(v.y, s2.y, t2.y), 0.f), 6.f);
-                v.z = fminf(fmaxf(fmaf(v.z, s2.z, t2.z), 0.f), 6.f); v.w = fminf(fmaxf(fmaf(v.w, s2.w, t2.w), 0.f), 6.f);
+                v.x = fminf(fmaxf(fmaf(v.x, s2.x, t2.x), 0.f), hi); v.y = fminf(fmaxf(fmaf(v.y, s2.y, t2.y), 0.f), hi);
+                v.z = fminf(fmaxf(fmaf(v.z, s2.z, t2.z), 0.f), hi); v.w = fminf(fmaxf(fmaf(v.w, s2.w, t2.w), 0.f), hi);
             }
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             *reinterpret_cast<float4*>(outp + pix * p.ldc + n) = v;
@@ -403,7 +404,7 @@ extern "C" int emd_conv1x1_f32(const float* x, int ldx, const uint16_t* whi, con
     p.A = x; p.Whi = whi; p.Wlo = wlo; p.C = y; p.res = res;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.N = Cout; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.ntaps = 1;
-    p.lda = ldx; p.ldc = ldy; p.ldres = ldres; p.act = act ? 1 : 0;
+    p.lda = ldx; p.ldc = ldy; p.ldres = ldres; p.act = act;
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;  // TF SAME, k=1: pad 0, samples x[0::s]
     p.M = (long)B * Ho * Wo;
     p.flat = stride == 1;
@@ -450,7 +451,7 @@ extern "C" int emd_deconv3x3s2_f32(const float* x, int ldx, const uint16_t* cons
         p.A = x; p.Whi = whi[ph]; p.Wlo = wlo ? wlo[ph] : nullptr; p.C = y; p.res = nullptr;
         p.scale1 = scale1; p.shift1 = shift1; p.scale2 = p.shift2 = nullptr;
         p.N = Cout; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK;
-        p.lda = ldx; p.ldc = ldy; p.ldres = 0; p.act = act ? 1 : 0;
+        p.lda = ldx; p.ldc = ldy; p.ldres = 0; p.act = act;
         p.M = (long)B * H * W;
         p.flat = 0;
         p.Hg = H; p.Wg = W; p.Ha = H; p.Wa = W; p.Hc = 2 * H; p.Wc = 2 * W; p.sa = 1; p.sc = 2;
@@ -488,7 +489,7 @@ extern "C" int emd_conv3x3_f32(const float* x, int ldx, const uint16_t* whi, con
     p.A = x; p.Whi = whi; p.Wlo = wlo; p.C = y; p.res = res;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.N = Cout; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK;
-    p.lda = ldx; p.ldc = ldy; p.ldres = ldres; p.act = act ? 1 : 0;
+    p.lda = ldx; p.ldc = ldy; p.ldres = ldres; p.act = act;
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const int eff = 2 * rate + 1;
     int pth = (Ho - 1) * stride + eff - H, ptw = (Wo - 1) * stride + eff - W;  // TF SAME: total padding

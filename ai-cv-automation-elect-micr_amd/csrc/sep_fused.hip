@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
         }
         const float* __restrict__ resp = p.res;
         float* __restrict__ outp = p.y;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, six = {6.f, 6.f, 6.f, 6.f};
+        const float hi = p.act == 2 ? __builtin_inff() : 6.f;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, six = {hi, hi, hi, hi};
 #pragma unroll 4
         for (int r = er; r < BM; r += ROWS_PER_PASS) {
             const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
@@ -275,7 +276,7 @@ extern "C" int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, co
     p.x = x; p.dw = dw; p.Whi = whi; p.Wlo = wlo; p.y = y; p.res = res;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
-    p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act ? 1 : 0;
+    p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return Cout <= 64 ? launch<64>(p, B, precision, st) : launch<128>(p, B, precision, st);
 }

@@ -14,6 +14,12 @@ from . import _lib
 
 PREC_BF16 = 1
 PREC_BF16X3 = 3
+ACT_NONE, ACT_RELU6, ACT_RELU = 0, 1, 2
+
+
+def _act(a):
+    """bool -> relu6 / none (graph D); int EMD_ACT_* passes through."""
+    return int(a) if not isinstance(a, bool) else (ACT_RELU6 if a else ACT_NONE)
 
 
 class Act:
@@ -82,21 +88,21 @@ def conv1x1(x: Act, w: PackedWeights, scale1, shift1, out: Act, stride=1, act=Tr
         assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
     rc = lib.emd_conv1x1_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
                              res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
-                             out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, stride, 1 if act else 0, precision,
+                             out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, stride, _act(act), precision,
                              _lib.stream_ptr(stream))
     _lib.check(rc, "emd_conv1x1_f32")
     return out
 
 
 def conv3x3(x: Act, w: PackedWeights, scale1, shift1, out: Act, stride=1, rate=1, act=True, res: Act | None = None,
-            precision=PREC_BF16X3, stream=None):
+            precision=PREC_BF16X3, stream=None, scale2=None, shift2=None):
     """Dense 3x3 conv (9-tap implicit GEMM), TF SAME, optional dilation."""
     lib = _lib.load()
     Ho, Wo = -(-x.H // stride), -(-x.W // stride)
     assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, w.cout) and w.cin == x.C and w.taps == 9
-    rc = lib.emd_conv3x3_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), C.c_void_p(0), C.c_void_p(0),
+    rc = lib.emd_conv3x3_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
                              res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
-                             out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, stride, rate, 1 if act else 0, precision,
+                             out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, stride, rate, _act(act), precision,
                              _lib.stream_ptr(stream))
     _lib.check(rc, "emd_conv3x3_f32")
     return out
@@ -124,7 +130,7 @@ def sep_fused(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, act=Tr
     rc = lib.emd_sep3x3_fused_f32(x.ptr, x.ld, _p(dw_dev), _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2),
                                   _p(shift2), res.ptr if res is not None else C.c_void_p(0),
                                   res.ld if res is not None else 0, out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout,
-                                  1 if act else 0, precision, _lib.stream_ptr(stream))
+                                  _act(act), precision, _lib.stream_ptr(stream))
     _lib.check(rc, "emd_sep3x3_fused_f32")
     return out
 
@@ -135,7 +141,7 @@ def deconv3x3s2(x: Act, w_phases, scale1, shift1, out: Act, act=True, precision=
     hi = (C.c_void_p * 4)(*[w.hi.data_ptr() for w in w_phases])
     lo = (C.c_void_p * 4)(*[w.lo.data_ptr() for w in w_phases])
     rc = lib.emd_deconv3x3s2_f32(x.ptr, x.ld, hi, lo, _p(scale1), _p(shift1), out.ptr, out.ld, x.B, x.H, x.W, x.C,
-                                 out.C, 1 if act else 0, precision, _lib.stream_ptr(stream))
+                                 out.C, _act(act), precision, _lib.stream_ptr(stream))
     _lib.check(rc, "emd_deconv3x3s2_f32")
     return out
 
@@ -178,12 +184,13 @@ def cin1(x_img, w9_dev, a_dev, shift_dev, out: Act, stride=1, act=True, stream=N
     return out
 
 
-def conv3x3_cout1(x: Act, w_dev, scale: float, shift: float, out_img, act=True, stream=None):
-    """act: False/0 none, True/1 relu6, 2 relu6 then clip to [0,1]."""
+def conv3x3_cout1(x: Act, w_dev, scale: float, shift: float, out_img, act=True, pre_bias=0.0, pre_relu=False,
+                  stream=None):
+    """act: False/0 none, True/1 relu6, 2 relu6 then clip to [0,1]; pre_relu: relu(conv + pre_bias) before the affine."""
     lib = _lib.load()
     assert out_img.is_contiguous() and out_img.numel() == x.B * x.H * x.W
     rc = lib.emd_conv3x3_cout1_f32(x.ptr, x.ld, _p(w_dev), C.c_float(scale), C.c_float(shift), _p(out_img), x.B, x.H,
-                                   x.W, x.C, int(act), _lib.stream_ptr(stream))
+                                   x.W, x.C, int(act), C.c_float(pre_bias), 1 if pre_relu else 0, _lib.stream_ptr(stream))
     _lib.check(rc, "emd_conv3x3_cout1_f32")
     return out_img
 
@@ -204,3 +211,40 @@ def affine_relu6(x: Act, scale_dev, shift_dev, out: Act, act=True, stream=None):
                                   C.c_long(x.B * x.H * x.W), x.C, 1 if act else 0, _lib.stream_ptr(stream))
     _lib.check(rc, "emd_affine_relu6_f32")
     return out
+
+
+def affine_act(x: Act, scale_dev, shift_dev, out: Act, act=ACT_RELU, res: Act | None = None, stream=None):
+    """out = act(x*scale + shift) [+ res]; out may be x."""
+    lib = _lib.load()
+    assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, x.C)
+    rc = lib.emd_affine_act_f32(x.ptr, x.ld, _p(scale_dev), _p(shift_dev), res.ptr if res is not None else C.c_void_p(0),
+                                res.ld if res is not None else 0, out.ptr, out.ld, C.c_long(x.B * x.H * x.W), x.C,
+                                _act(act), _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_affine_act_f32")
+    return out
+
+
+def bn_batch_stats(x: Act, stream=None):
+    """Per-channel batch mean and biased variance of x over (B,H,W): two float32 CUDA vectors."""
+    import torch
+
+    lib = _lib.load()
+    npix = x.B * x.H * x.W
+    mean = torch.empty(x.C, dtype=torch.float32, device=x.buf.device)
+    var = torch.empty_like(mean)
+    ws = torch.empty(lib.emd_bn_stats_workspace_bytes(npix, x.C) // 8, dtype=torch.float64, device=x.buf.device)
+    _lib.check(lib.emd_bn_stats_f32(x.ptr, x.ld, C.c_long(npix), x.C, _p(mean), _p(var), _p(ws),
+                                    _lib.stream_ptr(stream)), "emd_bn_stats_f32")
+    return mean, var
+
+
+def bn_fold(mean, var, gamma, beta, eps=1e-3, stream=None):
+    """(mean, var, gamma|None, beta|None) -> (scale, shift) device vectors of the equivalent affine."""
+    import torch
+
+    lib = _lib.load()
+    scale = torch.empty_like(mean)
+    shift = torch.empty_like(mean)
+    _lib.check(lib.emd_bn_fold_f32(_p(mean), _p(var), _p(gamma), _p(beta), C.c_float(eps), _p(scale), _p(shift),
+                                   mean.numel(), _lib.stream_ptr(stream)), "emd_bn_fold_f32")
+    return scale, shift

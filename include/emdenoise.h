@@ -88,6 +88,11 @@ int emd_kernel_denoise_f32(const float* x, float* y, int B, int H, int W, int wi
 #define EMD_PREC_BF16 1
 #define EMD_PREC_BF16X3 3
 
+/* activation codes of the `act` arguments (applied after the first affine, and after the second if present) */
+#define EMD_ACT_NONE 0
+#define EMD_ACT_RELU6 1 /* tf.nn.relu6: machine_learning/denoiser.py:83 */
+#define EMD_ACT_RELU 2  /* tf.nn.relu:  misc_py/modified_Xception.py:209, :222, :312 */
+
 /* Host-side weight packing for the matrix-core kernels (all pointers are HOST pointers).
  * w_host : taps x Cin x Cout float32 in TensorFlow order, [taps][Cin][Cout] (slim.conv2d /
  *          pointwise_weights, cout_major = 0) or [taps][Cout][Cin] (slim.conv2d_transpose, cout_major = 1).
@@ -164,9 +169,11 @@ int emd_cin1_f32(const float* x, const float* w9, const float* a, const float* s
 /* Dense 3x3 SAME convolution to ONE output channel + scalar affine + relu6.
  * replaces: the final slim.conv2d(num_outputs=1, kernel_size=3) + bias + BN + relu6 (denoiser.py:387).
  * x [B,H,W,Cin] pixel stride ldx; w [3][3][Cin]; y [B,H,W]; scale/shift: bias and BN folded.
- * act: 0 none, 1 relu6, 2 relu6 then tf.clip_by_value(.,0,1) (misc_py/denoiser-multi-gpu.py:534-538). */
+ * act: 0 none, 1 relu6, 2 relu6 then tf.clip_by_value(.,0,1) (misc_py/denoiser-multi-gpu.py:534-538).
+ * pre_relu != 0: the convolution is followed by "+pre_bias, relu" BEFORE the affine, i.e.
+ *   tf.layers.conv2d(activation=relu) -> BN -> relu (conv_block, misc_py/modified_Xception.py:215-229, :621). */
 int emd_conv3x3_cout1_f32(const float* x, int ldx, const float* w, float scale, float shift, float* y, int B,
-                          int H, int W, int Cin, int act, emd_stream_t stream);
+                          int H, int W, int Cin, int act, float pre_bias, int pre_relu, emd_stream_t stream);
 
 /* tf.image.resize_images(x,[Ho,Wo]): bilinear, align_corners=False, legacy (no half-pixel) sampling.
  * replaces: denoiser.py:199 (identity size) and :350 (32 -> 128). */
@@ -177,6 +184,22 @@ int emd_resize_bilinear_f32(const float* x, int ldx, float* y, int ldy, int B, i
  * replaces: batch_then_activ on the ASPP image-level branch (denoiser.py:200). */
 int emd_affine_relu6_f32(const float* x, int ldx, const float* scale, const float* shift, float* y, int ldy,
                          long npix, int C, int act, emd_stream_t stream);
+
+/* y = act(x*scale + shift) [+ res], act = EMD_ACT_*; y may be x (in place).  The normalise+activate step that
+ * follows a batch-statistics batch norm, and the "+ residual" after it (misc_py/modified_Xception.py:397, :533). */
+int emd_affine_act_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
+                       float* y, int ldy, long npix, int C, int act, emd_stream_t stream);
+
+/* Batch statistics for tf.contrib.layers.batch_norm called with its defaults (is_training=True) -- what the
+ * separable convs of misc_py/modified_Xception.py:302-323 do even at inference: per-channel mean and BIASED
+ * variance of x [npix, C] (pixel stride ldx), accumulated in double.  workspace: device buffer of
+ * emd_bn_stats_workspace_bytes(npix, C) bytes, 8-byte aligned.  emd_bn_fold_f32 turns (mean, var, gamma|NULL,
+ * beta|NULL, eps) into the (scale, shift) of one affine, on the device (no host round trip). */
+size_t emd_bn_stats_workspace_bytes(long npix, int C);
+int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float* mean, float* var, void* workspace,
+                     emd_stream_t stream);
+int emd_bn_fold_f32(const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                    float* scale, float* shift, int C, emd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Host utility (no GPU): CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start).

@@ -1,0 +1,194 @@
+"""Graph X oracle: the Xception autoencoder (oracle; test infrastructure only).
+
+Restates ``architecture()`` of misc_py/modified_Xception.py:194-654 (inference, phase=False) with the TF
+op semantics of oracle/tf_ops.py on PyTorch-CPU tensors.  PARITY UNPINNED (oracle/__init__.py).
+
+Things the reference does that are reproduced on purpose:
+  * the separable convs pass ``normalizer_fn=tf.contrib.layers.batch_norm`` bare (:312-314), so that batch
+    norm runs with the contrib defaults ``is_training=True, scale=False``: BATCH statistics (biased variance,
+    eps 1e-3) and a beta but no gamma -- even at inference; ``activation_fn=tf.nn.relu`` follows it;
+  * ``batch_then_activ`` (:203-213) uses is_training=phase => moving statistics at inference, then relu;
+  * ``conv_block`` (:215-229) is conv+bias -> relu -> batch norm -> relu;
+  * in the ASPP block the image-level branch is computed and then DISCARDED: ``pooling`` is overwritten by
+    ``batch_then_activ(conv3x3_rateLarge)`` (:285); the 'imageLevel' conv variables still exist;
+  * ``deconv_block`` (:325-354) is dead code; the output is clipped to [0,1] (:639-641).
+Variables live under ``tf.variable_scope('pellet')`` (:794).  ``cropsize`` is 1024 in the file (:116); any
+multiple of 64 works.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import tf_ops as T
+
+# modified_Xception.py:38-70
+filters00, filters01, filters1, filters2, filters4 = 32, 64, 128, 256, 728
+filters5, filters6, filters7 = 1024, 1536, 2048
+numMiddleXception = 16
+aspp_filters, aspp_output = 256, 32
+aspp_rateSmall, aspp_rateMedium, aspp_rateLarge = 3, 6, 9
+decode_channels = [728, 728, 512, 384, 256, 192, 128, 64]  # decode_channels0, 2..8
+BN_EPS = 1e-3
+
+
+class _Names:
+    def __init__(self, prefix):
+        self.prefix, self.counts = prefix, {}
+
+    def unique(self, base):
+        n = self.counts.get(base, 0)
+        self.counts[base] = n + 1
+        return f"{self.prefix}/{base}" if n == 0 else f"{self.prefix}/{base}_{n}"
+
+
+class _X:
+    def __init__(self, get, dtype):
+        self.get, self.dtype, self.names = get, dtype, _Names("pellet")
+        self.calibrate = None
+        self.trace = None  # optional list: every layer output is appended (debugging / per-layer parity)
+
+    # :203-213
+    def batch_then_activ(self, x):
+        scope = self.names.unique("BatchNorm")
+        C = x.shape[-1]
+        beta, gamma = self.get(scope + "/beta", (C,)), self.get(scope + "/gamma", (C,))
+        if self.calibrate is not None:
+            mean, var = x.mean(dim=(0, 1, 2)), x.var(dim=(0, 1, 2), unbiased=False)
+            self.calibrate[scope + "/moving_mean"] = mean.to(torch.float32).numpy().copy()
+            self.calibrate[scope + "/moving_variance"] = var.to(torch.float32).numpy().copy()
+            mean, var = mean.to(torch.float32).to(self.dtype), var.to(torch.float32).to(self.dtype)
+        else:
+            mean, var = self.get(scope + "/moving_mean", (C,)), self.get(scope + "/moving_variance", (C,))
+        y = torch.relu(T.batch_norm_inference_t(x, gamma, beta, mean, var))
+        if self.trace is not None:
+            self.trace.append(y)
+        return y
+
+    def conv(self, x, filters, k, stride=1, rate=1, name=None):
+        scope = self.names.prefix + "/" + name if name else self.names.unique("conv2d")
+        w = self.get(scope + "/kernel", (k, k, x.shape[-1], filters))
+        b = self.get(scope + "/bias", (filters,))
+        return T.conv2d_t(x, w, b, stride=stride, rate=rate)
+
+    # :215-229
+    def conv_block(self, x, filters):
+        return self.batch_then_activ(torch.relu(self.conv(x, filters, 3)))
+
+    # :302-323
+    def sep(self, x, filters, stride=1):
+        scope = self.names.unique("SeparableConv2d")
+        cin = x.shape[-1]
+        dw = self.get(scope + "/depthwise_weights", (3, 3, cin, 1))
+        pw = self.get(scope + "/pointwise_weights", (1, 1, cin, filters))
+        y = T.conv2d_t(T.depthwise_conv2d_t(x, dw, stride=stride), pw)
+        beta = self.get(scope + "/BatchNorm/beta", (filters,))
+        self.get(scope + "/BatchNorm/moving_mean", (filters,))       # created, not used by the forward pass
+        self.get(scope + "/BatchNorm/moving_variance", (filters,))
+        mean, var = y.mean(dim=(0, 1, 2)), y.var(dim=(0, 1, 2), unbiased=False)
+        y = torch.relu((y - mean) / torch.sqrt(var + BN_EPS) + beta)
+        if self.trace is not None:
+            self.trace.append(y)
+        return y
+
+    def deconv(self, x, filters):
+        scope = self.names.unique("conv2d_transpose")
+        w = self.get(scope + "/kernel", (3, 3, filters, x.shape[-1]))
+        b = self.get(scope + "/bias", (filters,))
+        return self.batch_then_activ(T.conv2d_transpose_s2_t(x, w, b))
+
+    # :356-473
+    def entry_flow(self, x):
+        e = self.batch_then_activ(self.conv(x, filters00, 3, stride=2))
+        e = self.batch_then_activ(self.conv(e, filters01, 3))
+        for f in (filters1, filters2, filters4):
+            res = self.batch_then_activ(self.conv(e, f, 1, stride=2))
+            m = self.sep(e, f)
+            m = self.sep(m, f)
+            m = self.sep(m, f, stride=2)
+            e = m + res
+        return e
+
+    # :475-491
+    def middle_block(self, x):
+        m = self.sep(x, filters4)
+        m = self.sep(m, filters4)
+        m = self.sep(m, filters4)
+        return m + x
+
+    # :493-535
+    def exit_flow(self, x):
+        res = self.batch_then_activ(self.conv(x, filters5, 1, stride=2))
+        m = self.sep(x, filters4)
+        m = self.sep(m, filters5)
+        m = self.sep(m, filters5, stride=2)
+        m = m + res
+        m = self.sep(m, filters6)
+        m = self.sep(m, filters6, stride=2)
+        return self.sep(m, filters7)
+
+    # :231-299
+    def aspp_block(self, x):
+        c1 = self.batch_then_activ(self.conv(x, aspp_filters, 1, name="1x1"))
+        small = self.batch_then_activ(self.conv(x, aspp_filters, 3, rate=aspp_rateSmall, name="lowRate"))
+        medium = self.batch_then_activ(self.conv(x, aspp_filters, 3, rate=aspp_rateMedium, name="mediumRate"))
+        large = self.batch_then_activ(self.conv(x, aspp_filters, 3, rate=aspp_rateLarge, name="highRate"))
+        self.conv(T.avg_pool2x2_same_t(x), aspp_filters, 1, name="imageLevel")   # :268-284 computed, then discarded
+        pooling = self.batch_then_activ(large)                                     # :285
+        cat = torch.cat([c1, small, medium, large, pooling], dim=3)
+        return self.batch_then_activ(self.conv(cat, aspp_output, 1))
+
+    # :538-621
+    def decoder(self, x):
+        d = self.batch_then_activ(self.conv(x, decode_channels[0], 1))
+        for _ in range(3):
+            d = self.conv_block(d, decode_channels[1])
+        for ch, nblocks in zip(decode_channels[2:], (3, 3, 3, 2, 2, 2)):
+            # the transposed conv keeps the PREVIOUS stage's channel count (:551-555, :563-567, ...)
+            d = self.deconv(d, d.shape[-1])
+            for _ in range(nblocks):
+                d = self.conv_block(d, ch)
+        return self.conv_block(d, 1)
+
+    def build(self, inputs, cropsize):
+        x = inputs.reshape(-1, cropsize, cropsize, 1)
+        m = self.entry_flow(x)
+        for _ in range(numMiddleXception):
+            m = self.middle_block(m)
+        m = self.exit_flow(m)
+        out = self.decoder(self.aspp_block(m))
+        return torch.clamp(out, 0.0, 1.0)
+
+
+def variable_specs(cropsize=64) -> "OrderedDict[str, tuple]":
+    specs = OrderedDict()
+
+    def rec(name, shape):
+        specs[name] = tuple(int(s) for s in shape)
+        return torch.zeros(shape, dtype=torch.float32)
+
+    with torch.no_grad():
+        _X(rec, torch.float32).build(torch.zeros(1, cropsize, cropsize, 1), cropsize)
+    return specs
+
+
+def architecture(inputs, weights, cropsize=512, dtype=torch.float32, calibrate=None, trace=None):
+    """inputs [B,S,S,1] -> torch [B,S,S,1] in [0,1].  Batch statistics are those of THIS batch (the reference
+    computes them per tower, misc_py/modified_Xception.py:786-800)."""
+    cache = {}
+
+    def get(name, shape):
+        if name not in cache:
+            w = weights[name]
+            assert tuple(w.shape) == tuple(shape), (name, w.shape, shape)
+            cache[name] = torch.from_numpy(np.ascontiguousarray(w)).to(dtype)
+        return cache[name]
+
+    g = _X(get, dtype)
+    g.calibrate = calibrate
+    g.trace = trace
+    x = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(inputs))
+    with torch.no_grad():
+        return g.build(x.to(dtype), cropsize)

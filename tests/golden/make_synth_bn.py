@@ -39,9 +39,27 @@ def one(variant):
           f"output mean {float(y.mean()):.4f} std {float(y.std()):.4f}")
 
 
+def one_x():
+    from emdenoise import xception as X
+    from oracle import xception_graph as XG
+
+    seed = D.SYNTH_SEED
+    w = X.synthetic_weights(seed, bn="tf_init")
+    assert list(w.keys()) == list(XG.variable_specs().keys()), "product and oracle disagree on the TF variable names"
+    # 512x512: the deepest maps are 8x8, so every norm is calibrated on >= 128 samples per channel (at 128x128
+    # they would be 2x2 and the plain-relu decoder of X explodes on any other input)
+    x = synthetic_lq(2, 512, 512, seed=seed)
+    calib = {}
+    y = XG.architecture(x, w, cropsize=512, dtype=torch.float64, calibrate=calib)
+    out = os.path.join(ROOT, "ai-cv-automation-elect-micr_amd", "data", f"synth_bn_X_seed{seed}.npz")
+    np.savez_compressed(out, **calib)
+    print(f"wrote {out}: {len(calib)} vectors, {sum(v.size for v in calib.values())} floats, "
+          f"output mean {float(y.mean()):.4f} std {float(y.std()):.4f} min {float(y.min()):.3f} max {float(y.max()):.3f}")
+
+
 def main():
-    for variant in (sys.argv[1:] or ["D", "Dprime"]):
-        one(variant)
+    for variant in (sys.argv[1:] or ["D", "Dprime", "X"]):
+        one_x() if variant == "X" else one(variant)
 
 
 if __name__ == "__main__":
