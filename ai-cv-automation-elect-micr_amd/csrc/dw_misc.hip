@@ -430,12 +430,17 @@ extern "C" int emd_dw3x3_f32(const float* x, int ldx, const float* w, float* y, 
     const int C4 = C / 4;
     unsigned nb;
     if (stride == 1 && rate == 1) {
-        constexpr int TH = 8;
+        // strip height: 16 rows (input re-read factor 18/16) measured 1-4 % faster than 8 on the 256^2/512^2 layers;
+        // short images keep 8 so that small maps still spread over the chip
+        const int TH = H >= 64 ? 16 : 8;
         const int nstrip = (H + TH - 1) / TH;
         const long nthreads = (long)B * nstrip * W * C4;
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
-        hipLaunchKernelGGL(dw3x3_s1_roll<TH>, dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip);
+        if (TH == 16)
+            hipLaunchKernelGGL(dw3x3_s1_roll<16>, dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip);
+        else
+            hipLaunchKernelGGL(dw3x3_s1_roll<8>, dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip);
         return emd::check_launch("dw3x3_s1_roll");
     }
     const long nthreads = (long)B * Ho * Wo * C4;

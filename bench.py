@@ -227,6 +227,7 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     # per-kernel-family device time of ONE more step, HIP events around every launch of the family
     fam = {}
     orig = {}
+    dw_bytes_box = [0.0]
 
     def wrap(name):
         f = getattr(ops, name)
@@ -238,11 +239,15 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
             r = f(*args, **kw)
             e1.record()
             fam.setdefault(name, []).append((e0, e1))
+            if name == "dw3x3":  # algorithmic bytes of THIS launch: fp32 in + out
+                xin, out = args[0], args[2]
+                dw_bytes_box[0] += 4.0 * xin.C * (xin.B * xin.H * xin.W + out.B * out.H * out.W)
             return r
 
         setattr(ops, name, g)
 
-    for name in ("conv1x1", "deconv3x3s2", "dw3x3", "cin1", "conv3x3_cout1", "resize_bilinear", "affine_relu6"):
+    for name in ("conv1x1", "conv3x3", "deconv3x3s2", "sep_fused", "dw3x3", "cin1", "conv3x3_cout1", "resize_bilinear",
+                 "affine_relu6", "affine_act", "bn_batch_stats", "avgpool2x2"):
         wrap(name)
     try:
         step()
@@ -251,12 +256,14 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
         for name, f in orig.items():
             setattr(ops, name, f)
     fam_ms = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) for k, v in fam.items()}
-    gemm_ms = fam_ms.get("conv1x1", 0.0) + fam_ms.get("deconv3x3s2", 0.0)
+    # matrix-core time: the implicit-GEMM launches plus the fused separable convs (whose pointwise halves carry
+    # part of the algorithmic flops)
+    gemm_ms = sum(fam_ms.get(k, 0.0) for k in ("conv1x1", "conv3x3", "deconv3x3s2", "sep_fused"))
     scale = (B / 32.0) * (H * W) / (512.0 * 512.0)
     alg_flops = 2.0 * D_GMAC_MATRIX_B32_512 * 1e9 * scale
     achieved = alg_flops / (gemm_ms * 1e-3) / 1e12
     passes = 3 if a.precision == "bf16x3" else 1
-    dw_bytes = 48.1e9 * scale  # 57 depthwise stages, in+out fp32
+    dw_bytes = dw_bytes_box[0]  # only the STANDALONE depthwise launches (the fused layers never write the depthwise result)
     tr = pmc_traffic()
     traffic = None
     if tr and (B, H, W) == (32, 512, 512):  # HBM bytes of all gemm_conv launches of one step
@@ -268,7 +275,7 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
         "config": {"workload": f"D: modified-Xception encoder-decoder (machine_learning/denoiser.py), [{B},{H},{W},1] fp32 per GPU",
                    "global_batch": B * world, "image": f"{H}x{W}x1", "precision": a.precision,
                    "sharding": f"{world} x {B} whole images, no collective"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel (every 1x1 / transposed-conv launch of one step)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel + sep_fused_kernel (every matrix-core launch of one step)",
                      "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_note": "HBM bytes per step over the family (PMC run of 4 forwards, profiles/r01_pmc_traffic.json)",
@@ -276,7 +283,8 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
                      "issued_tflops": round(achieved * passes, 1),
                      "kernel_ms_per_step": round(gemm_ms, 3),
                      "how": "HIP events around every launch of the family in one extra step"},
-        "depthwise": {"bound": "hbm", "kernel": "dw3x3_s1_roll / dw3x3_generic", "ms_per_step": round(fam_ms.get("dw3x3", 0.0), 3),
+        "depthwise": {"bound": "hbm", "kernel": "dw3x3_s1_roll / dw3x3_generic (standalone launches only)",
+                      "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(fam_ms.get("dw3x3", 0.0), 3),
                       "achieved_GBps": round(dw_bytes / (fam_ms.get("dw3x3", 1e9) * 1e-3) / 1e9, 1),
                       "frac_of_8TBps": round(dw_bytes / (fam_ms.get("dw3x3", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         "kernel_family_ms": {k: round(v, 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])},
