@@ -9,8 +9,9 @@ Workloads:
      width 3) on [32,512,512,1].  This is the configuration the metric line is quoted on.
   D  BASELINE configs[2]: the modified-Xception encoder-decoder of machine_learning/denoiser.py on
      [32,512,512,1] (matrix cores in split-bf16 parity mode unless --precision bf16).
-Default ("both"): the JSON line's metric/value/roofline/cpu_baseline are workload K's; workload D's
-figures ride along under "workload_D".  --workload D makes D the primary line.
+  X  the other graph BASELINE configs[2] can mean: misc_py/modified_Xception.py at 512x512.
+Default ("all"): the JSON line's metric/value/roofline/cpu_baseline are workload K's; workload D's and X's
+figures ride along under "workload_D" / "workload_X".  --workload D makes D the primary line.
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); inference shards whole images
 across ranks with no data-path collective (weak scaling: --batch images PER GPU).  Rank 0 prints ONE
 JSON line.
@@ -95,7 +96,7 @@ def cpu_baseline_K(x_host, W, Bm, s, budget_s=10.0):
         run()
         reps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 200:
+        if el >= budget_s or reps >= 2000:
             break
     return {"value": round(B * H * Wd / 1e6 * reps / el, 2), "unit": "MPx/s", "cores": cores, "kind": "port",
             "sample": f"{reps} passes over the same [{B},{H},{Wd},1] batch, oracle/k_oracle.c (gcc -O3 -fopenmp), {el:.1f} s"}, y
@@ -110,13 +111,16 @@ def cpu_baseline_D(x_host, weights):
 
     cores = CPU_THREADS
     torch.set_num_threads(cores)
-    x1 = x_host[:1]
-    S = x1.shape[1]
+    S = x_host.shape[1]
     t0 = time.perf_counter()
-    y = G.architecture(x1, weights, S, dtype=torch.float32).numpy()
+    y = G.architecture(x_host[:1], weights, S, dtype=torch.float32).numpy()   # also the parity reference for image 0
+    t1 = time.perf_counter() - t0
+    n = int(max(1, min(len(x_host), round(12.0 / max(t1, 1e-3)))))             # ~12 s of CPU work
+    t0 = time.perf_counter()
+    G.architecture(x_host[:n], weights, S, dtype=torch.float32)
     el = time.perf_counter() - t0
-    return {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s", "cores": cores, "kind": "port",
-            "sample": f"1 pass over image 0 of the batch ([1,{S},{S},1]), oracle/denoiser_graph.py "
+    return {"value": round(n * S * S / 1e6 / el, 4), "unit": "MPx/s", "cores": cores, "kind": "port",
+            "sample": f"1 pass over the first {n} images of the batch ([{n},{S},{S},1]), oracle/denoiser_graph.py "
                       f"(PyTorch-CPU float32, {torch.get_num_threads()} threads), {el:.1f} s"}, y
 
 
@@ -297,12 +301,52 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     return out
 
 
+def bench_X(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
+    """BASELINE configs[2], second graph of that name: misc_py/modified_Xception.py at 512x512."""
+    from emdenoise import xception as X
+
+    B, H, W = a.batch, a.size, a.size
+    steps, warmup = 3, 1
+    x_host = synthetic_lq(B, H, W, seed=1234 + rank)
+    weights = X.synthetic_weights()
+    eng = X.XceptionEngine(weights, dev, a.precision)
+    x = torch.from_numpy(x_host).to(dev)
+    box = [None]
+
+    def step():
+        box[0] = eng.forward(x)
+
+    ms = timer.run(step, steps, warmup)
+    scale = (B / 32.0) * (H * W) / (512.0 * 512.0)
+    out = {"value": round(B * H * W / 1e6 * world / (ms / 1e3), 1), "unit": "MPx/s", "ms_per_step": round(ms, 3),
+           "steps": steps, "warmup": warmup,
+           "config": {"workload": f"X: Xception autoencoder (misc_py/modified_Xception.py), [{B},{H},{W},1] fp32 per GPU",
+                      "precision": a.precision, "algorithmic_tflop_per_step": round(9.01 * scale, 3)},
+           "tflops_algorithmic": round(9.01 * scale / (ms / 1e3), 1)}
+    if want_cpu:
+        from oracle import xception_graph as XG
+
+        torch.set_num_threads(CPU_THREADS)
+        t0 = time.perf_counter()
+        XG.architecture(x_host[:1], weights, H, dtype=torch.float32)
+        t1 = time.perf_counter() - t0
+        n = int(max(1, min(B, round(12.0 / max(t1, 1e-3)))))
+        t0 = time.perf_counter()
+        XG.architecture(x_host[:n], weights, H, dtype=torch.float32)
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(n * H * W / 1e6 / el, 4), "unit": "MPx/s", "cores": CPU_THREADS, "kind": "port",
+                               "sample": f"1 pass over the first {n} images ([{n},{H},{W},1]), oracle/xception_graph.py "
+                                         f"(PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["K", "D", "both"], default="both")
+    ap.add_argument("--workload", choices=["K", "D", "X", "both", "all"], default="all",
+                    help="K and D: see the module docstring; X: misc_py/modified_Xception.py; all (default) = K primary, D and X alongside")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -336,9 +380,15 @@ def main():
 
     primary_is_D = a.workload == "D"
     res_K = res_D = None
-    if a.workload in ("K", "both"):
+    res_X = None
+    if a.workload in ("K", "both", "all"):
         res_K = bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
-    if a.workload in ("D", "both"):
+    if a.workload in ("X", "all"):
+        try:
+            res_X = bench_X(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
+        except Exception as e:
+            res_X = {"error": f"{type(e).__name__}: {e}"}
+    if a.workload in ("D", "both", "all"):
         try:
             res_D = bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
         except Exception as e:  # the primary (K) line must survive a failure of the rider
@@ -347,6 +397,13 @@ def main():
             res_D = {"error": f"{type(e).__name__}: {e}"}
 
     prim = res_D if primary_is_D else res_K
+    if prim is None:  # --workload X alone
+        prim = dict(res_X)
+        prim.setdefault("dtype", "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)")
+        prim.setdefault("roofline", {"bound": "mfma", "kernel": "gemm_conv_kernel", "achieved": prim.get("tflops_algorithmic"),
+                                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round((prim.get("tflops_algorithmic") or 0.0) / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None})
+        res_X = None
     out = {
         "metric": "megapixels/sec restored (512x512x1 bs=32)",
         "value": round(prim["value"], 1),
@@ -372,6 +429,8 @@ def main():
             res_D["ms_per_step"] = round(res_D["ms_per_step"], 4)
             res_D["unit"] = "MPx/s"
         out["workload_D"] = res_D
+    if res_X is not None:
+        out["workload_X"] = res_X
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
