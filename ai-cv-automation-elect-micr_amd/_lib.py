@@ -69,6 +69,51 @@ SIGNATURES = {
     # x ldx scale shift y ldy npix C act stream
     "emd_affine_relu6_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_long,
                                        C.c_int, C.c_int, C.c_void_p]),
+    # ---- training path
+    # a lda dy ldd dw B Hg Wg Ha Wa K N ntaps tap_dy tap_dx sa stream
+    "emd_conv_wgrad_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p] + [C.c_int] * 8 +
+                           [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p]),
+    # w src_taps ntaps tap_sel Cin Cout cout_major hi lo stream
+    "emd_pack_weights_dev": (C.c_int, [_c_float_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    # dy ldd whi wlo scale1 shift1 res ldres dx ldx B H W Cout Cin precision stream
+    "emd_conv1x1_s2_bwd_data_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
+                                              _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "emd_chan_reduce_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int]),
+    # mean var gamma1 beta1 gamma2 beta2 bias eps npix C scale shift rstd1 rstd2 mm1 mv1 mm2 mv2 decay stream
+    "emd_bn_train_fold_f32": (C.c_int, [_c_float_p] * 7 + [C.c_float, C.c_long, C.c_int] + [_c_float_p] * 8 +
+                              [C.c_double, C.c_void_p]),
+    # dy ldd x ldx mean rstd mscale mshift mask npix C s1 s2 accumulate_s1 workspace stream
+    "emd_bn_bwd_reduce_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p,
+                                        _c_float_p, C.c_int, C.c_long, C.c_int, _c_float_p, _c_float_p, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
+    # s1 t gamma1 gamma2 rstd1 rstd2 eps npix C K m1 m2 dgamma1 dgamma2 dbeta2 stream
+    "emd_bn_bwd_prep_f32": (C.c_int, [_c_float_p] * 6 + [C.c_float, C.c_long, C.c_int] + [_c_float_p] * 6 + [C.c_void_p]),
+    # dy ldd x ldx K m1 mean m2 mscale mshift mask dx ldo npix C stream
+    "emd_bn_bwd_apply_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int] + [_c_float_p] * 6 +
+                             [C.c_int, _c_float_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
+    # x ldx dy ldd dw B H W C stride rate stream
+    "emd_dw3x3_wgrad_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p] + [C.c_int] * 6 + [C.c_void_p]),
+    # dy ldd w dx ldx B H W C stride rate stream
+    "emd_dw3x3_bwd_data_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 6 + [C.c_void_p]),
+    # x ldx dy dw B H W Cin stream
+    "emd_conv3x3_cout1_wgrad_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p] + [C.c_int] * 4 + [C.c_void_p]),
+    # dy w dx ldx B H W Cin stream
+    "emd_conv3x3_cout1_bwd_data_f32": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 4 + [C.c_void_p]),
+    # dy ldd dx ldx B Hi Wi Ho Wo C stream
+    "emd_resize_bilinear_bwd_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int] + [C.c_int] * 6 + [C.c_void_p]),
+    # dy ldd dx ldx B H W C stream
+    "emd_avgpool2x2_bwd_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int] + [C.c_int] * 4 + [C.c_void_p]),
+    # x ldx y ldy npix C alpha stream
+    "emd_axpy_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, C.c_long, C.c_int, C.c_float, C.c_void_p]),
+    "emd_denoise_loss_workspace_bytes": (C.c_size_t, []),
+    # out truth n grad_scale result3 dout workspace stream
+    "emd_denoise_loss_f32": (C.c_int, [_c_float_p, _c_float_p, C.c_long, C.c_float, _c_float_p, _c_float_p, C.c_void_p,
+                                       C.c_void_p]),
+    # param grad accum n lr momentum grad_scale stream
+    "emd_nesterov_step_f32": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_long, C.c_float, C.c_float, C.c_float,
+                                        C.c_void_p]),
 }
 
 _lib = None

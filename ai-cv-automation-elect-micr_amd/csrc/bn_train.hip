@@ -1,0 +1,249 @@
+// Training-mode batch normalisation of graph D' (misc_py/denoiser-multi-gpu.py:210-223: tf.contrib.layers.batch_norm
+// with is_training=phase, fused=True, decay 0.999 (the contrib default), eps 1e-3) -- forward fold and backward.
+//
+// A layer is  r = conv(x)  ->  [BN1 inside the separable conv]  ->  BN2 (batch_then_activ)  ->  relu6 [-> clip].
+// With batch statistics both norms are per-channel affines of r, and the statistics of BN2's input follow from
+// those of r analytically (mean2 = beta1, var2 = gamma1^2 * q, q = var1/(var1+eps)), so one statistics pass over r
+// serves the whole chain, forward and backward:
+//   forward :  z = r*scale + shift,            scale = g1*g2*rstd1*rstd2 (double BN) | g*rstd1 (single BN)
+//   backward:  g = dy * mask(z);  s1 = sum g;  t = sum g*rhat,  rhat = (r-mean1)*rstd1
+//              dr = K * ( g - s1/N - rhat * (t/N) * c ),   K = scale,
+//              c = 1 (single BN) | a^2 + eps*rstd2^2, a = g1*rstd2 (double BN)
+//              dbeta2 = s1, dgamma2 = a*t, dgamma1 = g2*rstd2^3*eps*t, dbeta1 = 0      (double BN)
+//              dbeta  = s1, dgamma  = t                                                 (single BN)
+// (a bias added before a training-mode batch norm cancels: its gradient is zero and it only shifts the moving mean).
+#include "emd_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float grad_mask(float dy, float z, int mask) {
+    if (mask == 1) return (z > 0.f && z < 6.f) ? dy : 0.f;   // tf.nn.relu6 (Relu6Grad: 0 < z < 6)
+    if (mask == 2) return (z > 0.f && z <= 1.f) ? dy : 0.f;  // relu6 then tf.clip_by_value(., 0, 1) (passes on [0,1])
+    return dy;
+}
+
+inline long slabs(long npix) {
+    long n = (npix + 4095) / 4096;
+    return n > 1024 ? 1024 : n;
+}
+
+// s1[c] = sum_pix g,  s2[c] = sum_pix g * (x-mean[c])*rstd[c];  g = dy * mask(x*mscale[c] + mshift[c]).
+// Two passes, double accumulation (as the forward statistics in dw_misc.hip).
+__global__ __launch_bounds__(256) void chan_reduce_partial(const float* __restrict__ dy, int ldd,
+                                                           const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ mscale, const float* __restrict__ mshift,
+                                                           int mask, long npix, int C, long rows_per_slab,
+                                                           double* __restrict__ part) {
+    __shared__ double sm[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rsub = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * rows_per_slab;
+    const long r1 = min(r0 + rows_per_slab, npix);
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const float mu = x ? mean[c] : 0.f, rs = x ? rstd[c] : 0.f;
+        const float ms = mask ? mscale[c] : 0.f, mh = mask ? mshift[c] : 0.f;
+        for (long r = r0 + rsub; r < r1; r += 4) {
+            const float xv = x ? x[r * ldx + c] : 0.f;
+            const float g = grad_mask(dy[r * ldd + c], fmaf(xv, ms, mh), mask);
+            s += (double)g;
+            q += (double)g * (double)((xv - mu) * rs);
+        }
+    }
+    sm[0][rsub][threadIdx.x & 63] = s;
+    sm[1][rsub][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (rsub == 0 && c < C) {
+        const int l = threadIdx.x;
+        part[((long)blockIdx.y * 2 + 0) * C + c] = sm[0][0][l] + sm[0][1][l] + sm[0][2][l] + sm[0][3][l];
+        part[((long)blockIdx.y * 2 + 1) * C + c] = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
+    }
+}
+
+__global__ __launch_bounds__(256) void chan_reduce_final(const double* __restrict__ part, int nslab, int C,
+                                                         float* __restrict__ s1, float* __restrict__ s2, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nslab; ++k) {
+        s += part[((long)k * 2 + 0) * C + c];
+        q += part[((long)k * 2 + 1) * C + c];
+    }
+    s1[c] = (accumulate ? s1[c] : 0.f) + (float)s;
+    if (s2) s2[c] = (float)q;
+}
+
+// dx = K * ( g - m1 - (x-mean)*m2 ),  g = dy * mask(x*mscale + mshift); dx may alias dy (elementwise).
+template <int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int ldd, const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ K, const float* __restrict__ m1,
+                                                           const float* __restrict__ mean, const float* __restrict__ m2,
+                                                           const float* __restrict__ mscale, const float* __restrict__ mshift,
+                                                           int mask, float* dx, int ldo, long npix, int CV) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= npix * CV) return;
+    const int c = (int)(tid % CV) * V;
+    const long r = tid / CV;
+    float dd[V], xx[V], o[V];
+    if constexpr (V == 4) {
+        const float4 d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        dd[0] = d.x; dd[1] = d.y; dd[2] = d.z; dd[3] = d.w;
+        xx[0] = xv.x; xx[1] = xv.y; xx[2] = xv.z; xx[3] = xv.w;
+    } else {
+        dd[0] = dy[r * ldd + c];
+        xx[0] = x[r * ldx + c];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const float g = grad_mask(dd[k], fmaf(xx[k], mask ? mscale[c + k] : 0.f, mask ? mshift[c + k] : 0.f), mask);
+        o[k] = K[c + k] * (g - m1[c + k] - (xx[k] - mean[c + k]) * m2[c + k]);
+    }
+    if constexpr (V == 4)
+        *reinterpret_cast<float4*>(dx + r * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+        dx[r * ldo + c] = o[0];
+}
+
+// Forward fold for training: batch statistics -> the affine of the whole BN chain, what backward needs, and the
+// moving-average updates in assign_moving_average's own form, variable -= (variable - value) * float32(1 - decay)
+// (decay 0.999; the moving variance takes the unbiased batch variance, as TF's fused batch norm reports it).
+__global__ __launch_bounds__(256) void bn_train_fold_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                                            const float* __restrict__ gamma1, const float* __restrict__ beta1,
+                                                            const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                            const float* __restrict__ bias, float eps, float n, int C,
+                                                            float* __restrict__ scale, float* __restrict__ shift,
+                                                            float* __restrict__ rstd1, float* __restrict__ rstd2,
+                                                            float* mm1, float* mv1, float* mm2, float* mv2, float omd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mu = mean[c], v = var[c];
+    const float r1 = rsqrtf(v + eps);
+    const float bessel = n > 1.f ? n / (n - 1.f) : 1.f;
+    rstd1[c] = r1;
+    if (gamma1) {  // BN1 (gamma1, beta1) then BN2 (gamma2, beta2)
+        const float g1 = gamma1[c];
+        const float var2 = g1 * g1 * v * r1 * r1;
+        const float r2 = rsqrtf(var2 + eps);
+        rstd2[c] = r2;
+        const float sc = g1 * gamma2[c] * r1 * r2;
+        scale[c] = sc;
+        shift[c] = beta2[c] - mu * sc;
+        if (mm1) {
+            mm1[c] -= (mm1[c] - mu) * omd;
+            mv1[c] -= (mv1[c] - v * bessel) * omd;
+            mm2[c] -= (mm2[c] - beta1[c]) * omd;
+            mv2[c] -= (mv2[c] - var2 * bessel) * omd;
+        }
+    } else {       // a single BN (gamma2, beta2) after conv + bias
+        const float sc = gamma2[c] * r1;
+        scale[c] = sc;
+        shift[c] = beta2[c] - mu * sc;
+        if (mm2) {
+            mm2[c] -= (mm2[c] - (mu + (bias ? bias[c] : 0.f))) * omd;
+            mv2[c] -= (mv2[c] - v * bessel) * omd;
+        }
+    }
+}
+
+// Per-channel step between the backward reduction and the elementwise apply; parameter gradients ACCUMULATE
+// (several towers / micro-batches add into one gradient set, misc_py/denoiser-multi-gpu.py:1040).
+__global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const float* __restrict__ s1, const float* __restrict__ t,
+                                                          const float* __restrict__ gamma1, const float* __restrict__ gamma2,
+                                                          const float* __restrict__ rstd1, const float* __restrict__ rstd2,
+                                                          float eps, float inv_n, int C, float* __restrict__ K,
+                                                          float* __restrict__ m1, float* __restrict__ m2,
+                                                          float* dgamma1, float* dgamma2, float* dbeta2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float r1 = rstd1[c], tv = t[c], sv = s1[c];
+    m1[c] = sv * inv_n;
+    dbeta2[c] += sv;
+    if (gamma1) {
+        const float g1 = gamma1[c], g2 = gamma2[c], r2 = rstd2[c];
+        const float a = g1 * r2;
+        const float e2 = eps * r2 * r2;
+        K[c] = g1 * g2 * r1 * r2;
+        m2[c] = r1 * tv * inv_n * (a * a + e2);
+        dgamma2[c] += a * tv;
+        dgamma1[c] += g2 * r2 * e2 * tv;
+    } else {
+        K[c] = gamma2[c] * r1;
+        m2[c] = r1 * tv * inv_n;
+        dgamma2[c] += tv;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t emd_chan_reduce_workspace_bytes(long npix, int C) {
+    if (npix <= 0 || C <= 0) return 0;
+    return (size_t)slabs(npix) * 2 * C * sizeof(double);
+}
+
+extern "C" int emd_bn_bwd_reduce_f32(const float* dy, int ldd, const float* x, int ldx, const float* mean,
+                                     const float* rstd, const float* mscale, const float* mshift, int mask, long npix,
+                                     int C, float* s1, float* s2, int accumulate_s1, void* workspace, emd_stream_t stream) {
+    EMD_REQUIRE(dy && s1 && workspace, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: null pointer");
+    EMD_REQUIRE(npix >= 1 && C >= 1 && mask >= 0 && mask <= 2, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: bad argument");
+    EMD_REQUIRE(!x || (mean && rstd && s2), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: x needs mean, rstd and s2");
+    EMD_REQUIRE(!mask || (x && mscale && mshift), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: a mask needs x, mscale, mshift");
+    const long ns = slabs(npix);
+    const long rps = (npix + ns - 1) / ns;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(chan_reduce_partial, dim3((C + 63) / 64, (unsigned)ns), dim3(256), 0, st, dy, ldd, x, ldx, mean,
+                       rstd, mscale, mshift, mask, npix, C, rps, static_cast<double*>(workspace));
+    hipLaunchKernelGGL(chan_reduce_final, dim3((C + 255) / 256), dim3(256), 0, st, static_cast<const double*>(workspace),
+                       (int)ns, C, s1, x ? s2 : nullptr, accumulate_s1);
+    return emd::check_launch("chan_reduce");
+}
+
+extern "C" int emd_bn_bwd_apply_f32(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,
+                                    const float* mean, const float* m2, const float* mscale, const float* mshift,
+                                    int mask, float* dx, int ldo, long npix, int C, emd_stream_t stream) {
+    EMD_REQUIRE(dy && x && K && m1 && mean && m2 && dx, EMD_E_INVALID, "emd_bn_bwd_apply_f32: null pointer");
+    EMD_REQUIRE(npix >= 1 && C >= 1 && mask >= 0 && mask <= 2 && (!mask || (mscale && mshift)), EMD_E_INVALID,
+                "emd_bn_bwd_apply_f32: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (C % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && emd::aligned16(dy) && emd::aligned16(x) &&
+        emd::aligned16(dx)) {
+        const long n = npix * (C / 4);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, ldd, x, ldx, K,
+                           m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C / 4);
+    } else {
+        const long n = npix * C;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, ldd, x, ldx, K,
+                           m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C);
+    }
+    return emd::check_launch("bn_bwd_apply_kernel");
+}
+
+extern "C" int emd_bn_train_fold_f32(const float* mean, const float* var, const float* gamma1, const float* beta1,
+                                     const float* gamma2, const float* beta2, const float* bias, float eps, long npix,
+                                     int C, float* scale, float* shift, float* rstd1, float* rstd2, float* mm1, float* mv1,
+                                     float* mm2, float* mv2, double decay, emd_stream_t stream) {
+    EMD_REQUIRE(mean && var && gamma2 && beta2 && scale && shift && rstd1, EMD_E_INVALID, "emd_bn_train_fold_f32: null pointer");
+    EMD_REQUIRE((gamma1 == nullptr) == (beta1 == nullptr) && (!gamma1 || rstd2), EMD_E_INVALID,
+                "emd_bn_train_fold_f32: the double batch norm needs gamma1, beta1 and rstd2");
+    EMD_REQUIRE(!mm2 || mv2, EMD_E_INVALID, "emd_bn_train_fold_f32: moving mean and variance come together");
+    EMD_REQUIRE(!gamma1 || ((mm1 == nullptr) == (mm2 == nullptr) && (!mm1 || mv1)), EMD_E_INVALID,
+                "emd_bn_train_fold_f32: the double batch norm updates both sets of moving statistics or none");
+    EMD_REQUIRE(npix >= 1 && C >= 1, EMD_E_INVALID, "emd_bn_train_fold_f32: bad shape");
+    hipLaunchKernelGGL(bn_train_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), mean,
+                       var, gamma1, beta1, gamma2, beta2, bias, eps, (float)npix, C, scale, shift, rstd1, rstd2, mm1, mv1,
+                       mm2, mv2, (float)(1.0 - decay));
+    return emd::check_launch("bn_train_fold_kernel");
+}
+
+extern "C" int emd_bn_bwd_prep_f32(const float* s1, const float* t, const float* gamma1, const float* gamma2,
+                                   const float* rstd1, const float* rstd2, float eps, long npix, int C, float* K,
+                                   float* m1, float* m2, float* dgamma1, float* dgamma2, float* dbeta2,
+                                   emd_stream_t stream) {
+    EMD_REQUIRE(s1 && t && gamma2 && rstd1 && K && m1 && m2 && dgamma2 && dbeta2, EMD_E_INVALID, "emd_bn_bwd_prep_f32: null pointer");
+    EMD_REQUIRE(!gamma1 || (rstd2 && dgamma1), EMD_E_INVALID, "emd_bn_bwd_prep_f32: the double batch norm needs rstd2 and dgamma1");
+    EMD_REQUIRE(npix >= 1 && C >= 1, EMD_E_INVALID, "emd_bn_bwd_prep_f32: bad shape");
+    hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), s1, t,
+                       gamma1, gamma2, rstd1, rstd2, eps, 1.0f / (float)npix, C, K, m1, m2, dgamma1, dgamma2, dbeta2);
+    return emd::check_launch("bn_bwd_prep_kernel");
+}

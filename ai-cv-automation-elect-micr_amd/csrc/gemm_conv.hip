@@ -413,6 +413,31 @@ extern "C" int emd_conv1x1_f32(const float* x, int ldx, const uint16_t* whi, con
     return dispatch(p, precision, static_cast<hipStream_t>(stream));
 }
 
+// Data gradient of the stride-2 1x1 convolution: dx[b, 2i, 2j, :] (+)= dy[b, i, j, :] * W^T, the other pixels of dx
+// are not touched (the caller zero-fills dx, or passes res == dx to add into a gradient that already exists).
+// whi/wlo: W packed transposed (emd_pack_weights_dev with Cin/Cout swapped and cout_major = 1).
+extern "C" int emd_conv1x1_s2_bwd_data_f32(const float* dy, int ldd, const uint16_t* whi, const uint16_t* wlo,
+                                           const float* scale1, const float* shift1, const float* res, int ldres,
+                                           float* dx, int ldx, int B, int H, int W, int Cout, int Cin, int precision,
+                                           emd_stream_t stream) {
+    int rc = common_checks("emd_conv1x1_s2_bwd_data_f32", dy, whi, wlo, scale1, shift1, nullptr, nullptr, res, dx, Cout, Cin,
+                           ldd, ldx, ldres, precision);
+    if (rc != EMD_OK) return rc;
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_conv1x1_s2_bwd_data_f32: bad shape");
+    if (B == 0) return EMD_OK;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    GemmParams p{};
+    p.A = dy; p.Whi = whi; p.Wlo = wlo; p.C = dx; p.res = res;
+    p.scale1 = scale1; p.shift1 = shift1; p.scale2 = p.shift2 = nullptr;
+    p.N = Cin; p.Cin = Cout; p.Cpad = (Cout + kBK - 1) / kBK * kBK; p.ntaps = 1;
+    p.lda = ldd; p.ldc = ldx; p.ldres = ldres; p.act = 0;
+    p.M = (long)B * Ho * Wo;
+    p.flat = 0;
+    p.Hg = Ho; p.Wg = Wo; p.Ha = Ho; p.Wa = Wo; p.Hc = H; p.Wc = W; p.sa = 1; p.sc = 2; p.py = p.px = 0;
+    set_taps(p, 1, nullptr, nullptr);
+    return dispatch(p, precision, static_cast<hipStream_t>(stream));
+}
+
 // ---------------------------------------------------------------------------------------------- 3x3 stride-2 transposed convolution
 // y[2i+k] += x[i]*w[k] cropped to [0,2N) (gradient of the SAME stride-2 conv, denoiser.py:141-148):
 //   even output index 2i  : taps k=0 (from x[i]) and k=2 (from x[i-1]);  odd 2i+1 : tap k=1 (from x[i]).

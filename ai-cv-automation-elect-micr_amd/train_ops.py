@@ -1,0 +1,204 @@
+"""Torch-tensor wrappers over the training-path entry points of libemdenoise.so (include/emdenoise.h, second
+half): weight gradients, transposed-weight packing on the device, training-mode batch norm, the backward of the
+HBM-bound layers, the loss and the Nesterov step of misc_py/denoiser-multi-gpu.py:752-782 / :1011-1077.
+Shape checks and pointer plumbing only; all arithmetic is in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _lib
+from .ops import PREC_BF16X3, Act, _p
+
+MASK_NONE, MASK_RELU6, MASK_RELU6_CLIP = 0, 1, 2
+BN_EPS = 1e-3
+BN_DECAY = 0.999  # tf.contrib.layers.batch_norm default
+
+
+def _ints(v):
+    return (C.c_int * len(v))(*[int(a) for a in v])
+
+
+def same_pad_before(n, stride, rate):
+    o = -(-n // stride)
+    return max((o - 1) * stride + 2 * rate + 1 - n, 0) // 2
+
+
+class DevPackedWeights:
+    """bf16 hi/lo planes (emd_pack_weights_bf16 layout) refreshed on the device from an fp32 weight tensor.
+    Quacks like ops.PackedWeights (taps, cin, cout, hi, lo) for the forward entry points."""
+
+    def __init__(self, taps, cin, cout, device):
+        import torch
+
+        n = _lib.load().emd_packed_weight_elems(taps, cin, cout)
+        self.taps, self.cin, self.cout = taps, cin, cout
+        self.hi = torch.empty(n, dtype=torch.int16, device=device)
+        self.lo = torch.empty(n, dtype=torch.int16, device=device)
+
+    def pack(self, w_dev, src_taps, cout_major, tap_sel=None, stream=None):
+        """w_dev: fp32 device tensor [src_taps][cin][cout] (cout_major False) or [src_taps][cout][cin] (True), where
+        cin/cout are THIS pack's GEMM K and N."""
+        assert w_dev.is_contiguous() and w_dev.numel() == src_taps * self.cin * self.cout
+        sel = _ints(tap_sel) if tap_sel is not None else None
+        rc = _lib.load().emd_pack_weights_dev(_p(w_dev), src_taps, self.taps, sel, self.cin, self.cout,
+                                              1 if cout_major else 0, _p(self.hi), _p(self.lo), _lib.stream_ptr(stream))
+        _lib.check(rc, "emd_pack_weights_dev")
+        return self
+
+
+def conv_wgrad(a: Act, dy: Act, dw_dev, taps_dy=None, taps_dx=None, sa=1, stream=None):
+    """dw_dev [ntaps][a.C][dy.C] += sum over dy's grid of a[src_t] (x) dy."""
+    ntaps = 1 if taps_dy is None else len(taps_dy)
+    assert dw_dev.is_contiguous() and dw_dev.numel() == ntaps * a.C * dy.C and a.B == dy.B
+    rc = _lib.load().emd_conv_wgrad_f32(a.ptr, a.ld, dy.ptr, dy.ld, _p(dw_dev), dy.B, dy.H, dy.W, a.H, a.W, a.C, dy.C,
+                                        ntaps, _ints(taps_dy) if taps_dy is not None else None,
+                                        _ints(taps_dx) if taps_dx is not None else None, sa, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_conv_wgrad_f32")
+
+
+def conv_taps(H, W, stride, rate):
+    """(tap_dy, tap_dx) of a 3x3 TF-SAME conv on an HxW input."""
+    pt, pl = same_pad_before(H, stride, rate), same_pad_before(W, stride, rate)
+    return [ky * rate - pt for ky in range(3) for _ in range(3)], [kx * rate - pl for _ in range(3) for kx in range(3)]
+
+
+def conv1x1_s2_bwd_data(dy: Act, w: DevPackedWeights, ones, zeros, dx: Act, accumulate, precision=PREC_BF16X3, stream=None):
+    """dx[b,2i,2j,:] (+)= dy[b,i,j,:] W^T; w packed transposed (K = Cout, N = Cin)."""
+    assert (dy.H, dy.W) == (-(-dx.H // 2), -(-dx.W // 2)) and w.cin == dy.C and w.cout == dx.C and w.taps == 1
+    rc = _lib.load().emd_conv1x1_s2_bwd_data_f32(dy.ptr, dy.ld, _p(w.hi), _p(w.lo), _p(ones), _p(zeros),
+                                                 dx.ptr if accumulate else C.c_void_p(0), dx.ld if accumulate else 0,
+                                                 dx.ptr, dx.ld, dx.B, dx.H, dx.W, dy.C, dx.C, precision,
+                                                 _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_conv1x1_s2_bwd_data_f32")
+
+
+def _reduce_ws(npix, Cc, device):
+    import torch
+
+    return torch.empty(max(_lib.load().emd_chan_reduce_workspace_bytes(npix, Cc) // 8, 1), dtype=torch.float64, device=device)
+
+
+def bn_train_fold(mean, var, gamma2, beta2, npix, gamma1=None, beta1=None, bias=None, moving=None, eps=BN_EPS,
+                  decay=BN_DECAY, stream=None):
+    """-> dict(scale, shift, rstd1, rstd2|None).  moving: None, (mm2, mv2) for a single BN, or (mm1, mv1, mm2, mv2)."""
+    import torch
+
+    Cc = mean.numel()
+    scale, shift, rstd1 = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    rstd2 = torch.empty_like(mean) if gamma1 is not None else None
+    mm1 = mv1 = mm2 = mv2 = None
+    if moving is not None:
+        if gamma1 is not None:
+            mm1, mv1, mm2, mv2 = moving
+        else:
+            mm2, mv2 = moving
+    rc = _lib.load().emd_bn_train_fold_f32(_p(mean), _p(var), _p(gamma1), _p(beta1), _p(gamma2), _p(beta2), _p(bias),
+                                           C.c_float(eps), C.c_long(npix), Cc, _p(scale), _p(shift), _p(rstd1), _p(rstd2),
+                                           _p(mm1), _p(mv1), _p(mm2), _p(mv2), C.c_double(decay), _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_bn_train_fold_f32")
+    return {"scale": scale, "shift": shift, "rstd1": rstd1, "rstd2": rstd2, "mean": mean}
+
+
+def chan_reduce(dy: Act, s1, x: Act | None = None, mean=None, rstd=None, s2=None, mscale=None, mshift=None,
+                mask=MASK_NONE, accumulate_s1=False, stream=None):
+    npix = dy.B * dy.H * dy.W
+    ws = _reduce_ws(npix, dy.C, dy.buf.device)
+    rc = _lib.load().emd_bn_bwd_reduce_f32(dy.ptr, dy.ld, x.ptr if x is not None else C.c_void_p(0),
+                                           x.ld if x is not None else 0, _p(mean), _p(rstd), _p(mscale), _p(mshift), mask,
+                                           C.c_long(npix), dy.C, _p(s1), _p(s2), 1 if accumulate_s1 else 0, _p(ws),
+                                           _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_bn_bwd_reduce_f32")
+
+
+def bn_backward(dy: Act, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MASK_RELU6, gamma1=None, dgamma1=None,
+                eps=BN_EPS, stream=None):
+    """Backward of  r -> [BN1] -> BN2 -> mask  given the forward's `fold` dict: dr (may be dy) = d loss / d r; the
+    batch-norm parameter gradients are added into dgamma1 / dgamma2 / dbeta2."""
+    import torch
+
+    lib = _lib.load()
+    npix = dy.B * dy.H * dy.W
+    Cc = dy.C
+    assert (r.B, r.H, r.W, r.C) == (dy.B, dy.H, dy.W, Cc) and (dr.B, dr.H, dr.W, dr.C) == (dy.B, dy.H, dy.W, Cc)
+    dev = dy.buf.device
+    s1, t = torch.empty(Cc, dtype=torch.float32, device=dev), torch.empty(Cc, dtype=torch.float32, device=dev)
+    ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
+    chan_reduce(dy, s1, r, fold["mean"], fold["rstd1"], t, ms, mh, mask, stream=stream)
+    K, m1, m2 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
+    _lib.check(lib.emd_bn_bwd_prep_f32(_p(s1), _p(t), _p(gamma1), _p(gamma2), _p(fold["rstd1"]), _p(fold["rstd2"]),
+                                       C.c_float(eps), C.c_long(npix), Cc, _p(K), _p(m1), _p(m2), _p(dgamma1), _p(dgamma2),
+                                       _p(dbeta2), _lib.stream_ptr(stream)), "emd_bn_bwd_prep_f32")
+    _lib.check(lib.emd_bn_bwd_apply_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(K), _p(m1), _p(fold["mean"]), _p(m2), _p(ms), _p(mh),
+                                        mask, dr.ptr, dr.ld, C.c_long(npix), Cc, _lib.stream_ptr(stream)),
+               "emd_bn_bwd_apply_f32")
+    return dr
+
+
+def dw3x3_wgrad(x: Act, dy: Act, dw_dev, stride=1, rate=1, stream=None):
+    assert dw_dev.is_contiguous() and dw_dev.numel() == 9 * x.C and dy.C == x.C
+    assert (dy.B, dy.H, dy.W) == (x.B, -(-x.H // stride), -(-x.W // stride))
+    _lib.check(_lib.load().emd_dw3x3_wgrad_f32(x.ptr, x.ld, dy.ptr, dy.ld, _p(dw_dev), x.B, x.H, x.W, x.C, stride, rate,
+                                               _lib.stream_ptr(stream)), "emd_dw3x3_wgrad_f32")
+
+
+def dw3x3_bwd_data(dy: Act, w_dev, dx: Act, stride=1, rate=1, stream=None):
+    assert dy.C == dx.C and (dy.B, dy.H, dy.W) == (dx.B, -(-dx.H // stride), -(-dx.W // stride))
+    _lib.check(_lib.load().emd_dw3x3_bwd_data_f32(dy.ptr, dy.ld, _p(w_dev), dx.ptr, dx.ld, dx.B, dx.H, dx.W, dx.C, stride,
+                                                  rate, _lib.stream_ptr(stream)), "emd_dw3x3_bwd_data_f32")
+    return dx
+
+
+def conv3x3_cout1_wgrad(x: Act, dy_img, dw_dev, stream=None):
+    assert dy_img.is_contiguous() and dy_img.numel() == x.B * x.H * x.W and dw_dev.numel() == 9 * x.C
+    _lib.check(_lib.load().emd_conv3x3_cout1_wgrad_f32(x.ptr, x.ld, _p(dy_img), _p(dw_dev), x.B, x.H, x.W, x.C,
+                                                       _lib.stream_ptr(stream)), "emd_conv3x3_cout1_wgrad_f32")
+
+
+def conv3x3_cout1_bwd_data(dy_img, w_dev, dx: Act, stream=None):
+    assert dy_img.is_contiguous() and dy_img.numel() == dx.B * dx.H * dx.W and w_dev.numel() == 9 * dx.C
+    _lib.check(_lib.load().emd_conv3x3_cout1_bwd_data_f32(_p(dy_img), _p(w_dev), dx.ptr, dx.ld, dx.B, dx.H, dx.W, dx.C,
+                                                          _lib.stream_ptr(stream)), "emd_conv3x3_cout1_bwd_data_f32")
+    return dx
+
+
+def resize_bilinear_bwd(dy: Act, dx: Act, stream=None):
+    assert dy.C == dx.C and dy.B == dx.B
+    _lib.check(_lib.load().emd_resize_bilinear_bwd_f32(dy.ptr, dy.ld, dx.ptr, dx.ld, dx.B, dx.H, dx.W, dy.H, dy.W, dx.C,
+                                                       _lib.stream_ptr(stream)), "emd_resize_bilinear_bwd_f32")
+    return dx
+
+
+def avgpool2x2_bwd(dy: Act, dx: Act, stream=None):
+    assert dy.C == dx.C and (dy.B, dy.H, dy.W) == (dx.B, -(-dx.H // 2), -(-dx.W // 2))
+    _lib.check(_lib.load().emd_avgpool2x2_bwd_f32(dy.ptr, dy.ld, dx.ptr, dx.ld, dx.B, dx.H, dx.W, dx.C,
+                                                  _lib.stream_ptr(stream)), "emd_avgpool2x2_bwd_f32")
+    return dx
+
+
+def axpy(x: Act, y: Act, alpha=1.0, stream=None):
+    assert (x.B, x.H, x.W, x.C) == (y.B, y.H, y.W, y.C)
+    _lib.check(_lib.load().emd_axpy_f32(x.ptr, x.ld, y.ptr, y.ld, C.c_long(x.B * x.H * x.W), x.C, C.c_float(alpha),
+                                        _lib.stream_ptr(stream)), "emd_axpy_f32")
+    return y
+
+
+def denoise_loss(out, truth, dout=None, grad_scale=1.0, stream=None):
+    """-> device tensor [3] = (mse, loss, dloss/dout factor); fills dout (same shape as out) if given."""
+    import torch
+
+    lib = _lib.load()
+    assert out.is_contiguous() and truth.is_contiguous() and out.numel() == truth.numel()
+    res = torch.empty(3, dtype=torch.float32, device=out.device)
+    ws = torch.empty(lib.emd_denoise_loss_workspace_bytes() // 8, dtype=torch.float64, device=out.device)
+    _lib.check(lib.emd_denoise_loss_f32(_p(out), _p(truth), C.c_long(out.numel()), C.c_float(grad_scale), _p(res), _p(dout),
+                                        _p(ws), _lib.stream_ptr(stream)), "emd_denoise_loss_f32")
+    return res
+
+
+def nesterov_step(param, grad, accum, lr, momentum=0.9, grad_scale=1.0, stream=None):
+    assert param.is_contiguous() and grad.is_contiguous() and accum.is_contiguous()
+    assert param.numel() == grad.numel() == accum.numel()
+    _lib.check(_lib.load().emd_nesterov_step_f32(_p(param), _p(grad), _p(accum), C.c_long(param.numel()), C.c_float(lr),
+                                                 C.c_float(momentum), C.c_float(grad_scale), _lib.stream_ptr(stream)),
+               "emd_nesterov_step_f32")

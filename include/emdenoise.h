@@ -201,6 +201,96 @@ int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float* mean, flo
 int emd_bn_fold_f32(const float* mean, const float* var, const float* gamma, const float* beta, float eps,
                     float* scale, float* shift, int C, emd_stream_t stream);
 
+/* ================================================================================================
+ * Training path of graph D' (misc_py/denoiser-multi-gpu.py): tf.gradients of the tower loss (:752-782) and the
+ * Nesterov train op (:1011-1077).  Data gradients of the 1x1 / 3x3 / transposed convolutions are the forward
+ * entry points above run with weights packed transposed (emd_pack_weights_dev); the rest follows.
+ * Convention: PARAMETER gradients are ADDED into their destination (towers / micro-batches accumulate one
+ * gradient set, :1040; zero it once per step), activation gradients are written.
+ * ================================================================================================ */
+
+/* Weight gradient of any convolution above: dw[t][k][n] += sum_m a[src_t(m)][k] * dy[m][n].
+ * replaces: the Conv2DBackpropFilter nodes tf.gradients (:779) creates for tf.layers.conv2d / the pointwise half of
+ * slim.separable_convolution2d (:225-276) / tf.layers.conv2d_transpose (:278-289).
+ * m runs over the [B,Hg,Wg] grid of dy (pixel stride ldd, N channels); a is [B,Ha,Wa,K] (pixel stride lda) read at
+ * (i*sa + tap_dy[t], j*sa + tap_dx[t]), zero outside.  conv (stride s, rate r, SAME pad pt): a = layer input,
+ * sa = s, tap = k*r - pt, dw in TF layout [taps][Cin][Cout].  Transposed conv: a = the gradient w.r.t. its OUTPUT,
+ * dy := its INPUT, sa = 2, tap = k, dw in TF layout [taps][Cout][Cin].  K, N multiples of 4. */
+int emd_conv_wgrad_f32(const float* a, int lda, const float* dy, int ldd, float* dw, int B, int Hg, int Wg, int Ha, int Wa,
+                       int K, int N, int ntaps, const int* tap_dy, const int* tap_dx, int sa, emd_stream_t stream);
+
+/* emd_pack_weights_bf16 for weights that live on the DEVICE (re-packed after every optimizer step).
+ * w [src_taps][Cin][Cout] (cout_major 0) or [src_taps][Cout][Cin] (cout_major 1); packed tap t is source tap
+ * tap_sel[t] (NULL: identity, needs ntaps == src_taps) -- reversed order for the data gradient of a 3x3 conv,
+ * emd_deconv_phase_taps subsets for the transposed conv.  hi/lo: emd_packed_weight_elems(ntaps,Cin,Cout) elements. */
+int emd_pack_weights_dev(const float* w, int src_taps, int ntaps, const int* tap_sel, int Cin, int Cout, int cout_major,
+                         uint16_t* hi, uint16_t* lo, emd_stream_t stream);
+
+/* Data gradient of the stride-2 1x1 conv (residual branches, :225-238 with strides=2):
+ * dx[b,2i,2j,:] = dy[b,i,j,:] * W^T (+ res at the same pixels); other pixels of dx are left as they are.
+ * dy [B,ceil(H/2),ceil(W/2),Cout]; dx [B,H,W,Cin]; whi/wlo packed with (Cin:=Cout, Cout:=Cin, cout_major 1). */
+int emd_conv1x1_s2_bwd_data_f32(const float* dy, int ldd, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                                const float* shift1, const float* res, int ldres, float* dx, int ldx, int B, int H, int W,
+                                int Cout, int Cin, int precision, emd_stream_t stream);
+
+/* Training-mode batch norm chain  r -> [BN1] -> BN2 -> relu6 [-> clip]  (:210-223; contrib batch_norm, fused,
+ * decay 0.999, eps 1e-3), see csrc/bn_train.hip for the algebra.
+ * emd_bn_train_fold_f32: batch (mean,var) of r (emd_bn_stats_f32) -> forward affine (scale, shift), rstd1 (and
+ *   rstd2 for the double norm: gamma1/beta1 non-NULL), and, if mm2 != NULL, the moving-average updates
+ *   (mm1/mv1: BN1's, double norm only; bias: the conv bias that precedes a single BN, may be NULL).
+ * emd_bn_bwd_reduce_f32: s1[c] = sum g, s2[c] = sum g*(x-mean)*rstd, g = dy*mask(x*mscale+mshift);
+ *   mask 0 none, 1 relu6 (0<z<6), 2 relu6 then clip [0,1] (0<z<=1).  x == NULL: s1 only (a bias gradient).
+ *   accumulate_s1 != 0: s1 += (bias gradients).  workspace: emd_chan_reduce_workspace_bytes(npix, C) bytes.
+ * emd_bn_bwd_prep_f32: (s1, t=s2) -> K, m1, m2 for the apply step; dgamma1, dgamma2, dbeta2 += .
+ * emd_bn_bwd_apply_f32: dx = K*(g - m1 - (x-mean)*m2); dx may be dy.  C = 1 is allowed (the final layer). */
+size_t emd_chan_reduce_workspace_bytes(long npix, int C);
+int emd_bn_train_fold_f32(const float* mean, const float* var, const float* gamma1, const float* beta1, const float* gamma2,
+                          const float* beta2, const float* bias, float eps, long npix, int C, float* scale, float* shift,
+                          float* rstd1, float* rstd2, float* mm1, float* mv1, float* mm2, float* mv2, double decay,
+                          emd_stream_t stream);
+int emd_bn_bwd_reduce_f32(const float* dy, int ldd, const float* x, int ldx, const float* mean, const float* rstd,
+                          const float* mscale, const float* mshift, int mask, long npix, int C, float* s1, float* s2,
+                          int accumulate_s1, void* workspace, emd_stream_t stream);
+int emd_bn_bwd_prep_f32(const float* s1, const float* t, const float* gamma1, const float* gamma2, const float* rstd1,
+                        const float* rstd2, float eps, long npix, int C, float* K, float* m1, float* m2, float* dgamma1,
+                        float* dgamma2, float* dbeta2, emd_stream_t stream);
+int emd_bn_bwd_apply_f32(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,
+                         const float* mean, const float* m2, const float* mscale, const float* mshift, int mask, float* dx,
+                         int ldo, long npix, int C, emd_stream_t stream);
+
+/* Depthwise 3x3 backward (the depthwise half of slim.separable_convolution2d, :253-273); shapes as emd_dw3x3_f32
+ * (x, dx [B,H,W,C]; dy [B,ceil(H/s),ceil(W/s),C]); dw [3][3][C] +=. */
+int emd_dw3x3_wgrad_f32(const float* x, int ldx, const float* dy, int ldd, float* dw, int B, int H, int W, int C, int stride,
+                        int rate, emd_stream_t stream);
+int emd_dw3x3_bwd_data_f32(const float* dy, int ldd, const float* w, float* dx, int ldx, int B, int H, int W, int C,
+                           int stride, int rate, emd_stream_t stream);
+
+/* Backward of the final 3x3 conv to one channel (:528-532): dy [B,H,W]; dw [3][3][Cin] +=; dx [B,H,W,Cin]. */
+int emd_conv3x3_cout1_wgrad_f32(const float* x, int ldx, const float* dy, float* dw, int B, int H, int W, int Cin,
+                                emd_stream_t stream);
+int emd_conv3x3_cout1_bwd_data_f32(const float* dy, const float* w, float* dx, int ldx, int B, int H, int W, int Cin,
+                                   emd_stream_t stream);
+
+/* Gradients of emd_resize_bilinear_f32 (dx [B,Hi,Wi,C] from dy [B,Ho,Wo,C]) and emd_avgpool2x2_f32. */
+int emd_resize_bilinear_bwd_f32(const float* dy, int ldd, float* dx, int ldx, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                emd_stream_t stream);
+int emd_avgpool2x2_bwd_f32(const float* dy, int ldd, float* dx, int ldx, int B, int H, int W, int C, emd_stream_t stream);
+
+/* y += alpha*x over [npix, C] (gradient fan-in where a tensor feeds several layers). */
+int emd_axpy_f32(const float* x, int ldx, float* y, int ldy, long npix, int C, float alpha, emd_stream_t stream);
+
+/* _tower_fn's loss (:768-775): mse = mean((out-truth)^2); loss = 1000*mse if mse < 1e-3 else sqrt(1000*mse)
+ * (weight_decay = 0, :117).  result3 (device) = {mse, loss, f}; dout (may be NULL) = grad_scale * dloss/dout.
+ * workspace: emd_denoise_loss_workspace_bytes() bytes.  No host synchronisation. */
+size_t emd_denoise_loss_workspace_bytes(void);
+int emd_denoise_loss_f32(const float* out, const float* truth, long n, float grad_scale, float* result3, float* dout,
+                         void* workspace, emd_stream_t stream);
+
+/* tf.train.MomentumOptimizer(lr, momentum, use_nesterov=True) (:1064-1066) on a flat parameter vector:
+ * g = grad*grad_scale (1/number of gradient sets, :1040); accum = momentum*accum + g; param -= lr*(g + momentum*accum). */
+int emd_nesterov_step_f32(float* param, const float* grad, float* accum, long n, float lr, float momentum, float grad_scale,
+                          emd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Host utility (no GPU): CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start).
  * Used by the TFRecord reader (emdenoise.input_pipeline) for the container that

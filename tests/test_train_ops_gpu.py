@@ -1,0 +1,342 @@
+"""GPU parity tests for the training-path kernels (D', misc_py/denoiser-multi-gpu.py:752-782, :1011-1077), op by op:
+each backward entry point of libemdenoise.so (through the C ABI via emdenoise.train_ops) against PyTorch-CPU
+autograd (float64) of the oracle's restatement of the forward op (oracle/tf_ops.py) on the same seeded inputs.
+Tolerances (relative L2):
+  fp32 VALU kernels with fp32 block sums + float atomics (weight gradients) ... 2e-5
+  fp32 elementwise / gather kernels ............................................. 2e-6
+  split-bf16 matrix-core data gradients ......................................... 2e-5
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_ops_gpu import dev, out_act, rel_l2, rnd, t64, to_act
+
+pytestmark = pytest.mark.gpu
+
+TOL_WGRAD = 2e-5
+TOL_F32 = 2e-6
+TOL_X3 = 2e-5
+
+
+def d32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+
+
+def leaf(a):
+    return t64(a).requires_grad_(True)
+
+
+# ------------------------------------------------------------------------------------------------ conv weight gradients
+@pytest.mark.parametrize("B,H,W,ci,co,k,stride,rate", [
+    (2, 16, 16, 64, 64, 1, 1, 1),
+    (1, 9, 13, 128, 256, 1, 1, 1),      # ragged M
+    (2, 8, 8, 728, 728, 1, 1, 1),       # K, N tails
+    (1, 7, 9, 256, 728, 1, 2, 1),       # strided residual projection, odd sizes
+    (2, 16, 16, 4, 64, 1, 1, 1),        # the zero-padded 1-channel image (cnn0 / residual0)
+    (1, 12, 12, 64, 128, 3, 1, 1),
+    (1, 16, 16, 128, 64, 3, 1, 6),      # dilated ASPP branch
+    (2, 10, 6, 64, 64, 3, 2, 1),
+    (2, 64, 64, 64, 128, 1, 1, 1),      # several M splits
+])
+def test_conv_wgrad(B, H, W, ci, co, k, stride, rate):
+    from emdenoise import train_ops as TO
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 1)
+    w = leaf(rnd((k, k, ci, co), 2, 0.1))
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    dy = rnd((B, Ho, Wo, co), 3)
+    y = T.conv2d_t(t64(x), w, None, stride=stride, rate=rate)
+    (ref,) = torch.autograd.grad(y, w, t64(dy))
+    dw = torch.zeros((k * k, ci, co), dtype=torch.float32, device=dev())
+    if k == 1:
+        TO.conv_wgrad(to_act(x, ld=ci + 8, c0=4), to_act(dy), dw, [0], [0], sa=stride)
+    else:
+        tdy, tdx = TO.conv_taps(H, W, stride, rate)
+        TO.conv_wgrad(to_act(x), to_act(dy, ld=co + 4, c0=0), dw, tdy, tdx, sa=stride)
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().numpy().reshape(k, k, ci, co), ref.numpy()) < TOL_WGRAD
+
+
+def test_conv_wgrad_accumulates():
+    from emdenoise import train_ops as TO
+
+    x, dy = rnd((1, 8, 8, 64), 4), rnd((1, 8, 8, 64), 5)
+    dw = torch.zeros((1, 64, 64), dtype=torch.float32, device=dev())
+    TO.conv_wgrad(to_act(x), to_act(dy), dw)
+    once = dw.cpu().numpy().copy()
+    TO.conv_wgrad(to_act(x), to_act(dy), dw)
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().numpy(), 2 * once) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,ci,co", [(2, 5, 7, 64, 64), (1, 8, 8, 256, 128)])
+def test_deconv_wgrad_and_dgrad(B, H, W, ci, co):
+    """conv2d_transpose [3,3,Cout,Cin]: dW through emd_conv_wgrad_f32 (a := dL/dy, sa = 2), dx through the forward
+    stride-2 conv with the same kernel read as [kh,kw,in=Cout,out=Cin]."""
+    from emdenoise import ops, train_ops as TO
+    from oracle import tf_ops as T
+
+    x = leaf(rnd((B, H, W, ci), 6))
+    w = leaf(rnd((3, 3, co, ci), 7, 0.1))
+    dy = rnd((B, 2 * H, 2 * W, co), 8)
+    y = T.conv2d_transpose_s2_t(x, w, None)
+    gx, gw = torch.autograd.grad(y, (x, w), t64(dy))
+    dw = torch.zeros((9, co, ci), dtype=torch.float32, device=dev())
+    tdy, tdx = TO.conv_taps(2 * H, 2 * W, 2, 1)
+    TO.conv_wgrad(to_act(dy), to_act(x.detach().numpy().astype(np.float32)), dw, tdy, tdx, sa=2)
+    wdev = d32(w.detach().numpy().reshape(9, co, ci))
+    pk = TO.DevPackedWeights(9, co, ci, dev()).pack(wdev, 9, cout_major=False)
+    dx = out_act(B, H, W, ci)
+    ones, zeros = torch.ones(ci, device=dev()), torch.zeros(ci, device=dev())
+    ops.conv3x3(to_act(dy), pk, ones, zeros, dx, stride=2, act=False)
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().numpy().reshape(3, 3, co, ci), gw.numpy()) < TOL_WGRAD
+    assert rel_l2(dx.torch().cpu().numpy(), gx.numpy()) < TOL_X3
+
+
+# ------------------------------------------------------------------------------------------------ device packing + data gradients
+def test_pack_weights_dev_matches_host_pack():
+    from emdenoise import ops, train_ops as TO
+
+    w = rnd((9, 100, 72), 9)
+    host = ops.PackedWeights(w, False, dev())
+    devp = TO.DevPackedWeights(9, 100, 72, dev()).pack(d32(w), 9, cout_major=False)
+    torch.cuda.synchronize()
+    assert torch.equal(host.hi, devp.hi) and torch.equal(host.lo, devp.lo)
+    wt = np.ascontiguousarray(w.transpose(0, 2, 1))
+    host = ops.PackedWeights(wt, True, dev())
+    devp = TO.DevPackedWeights(9, 100, 72, dev()).pack(d32(wt), 9, cout_major=True)
+    torch.cuda.synchronize()
+    assert torch.equal(host.hi, devp.hi) and torch.equal(host.lo, devp.lo)
+    # the tap subsets of the transposed conv
+    wd = rnd((3, 3, 40, 24), 10)
+    for ph, hp in enumerate(ops.pack_deconv(wd, dev())):
+        sel = [ky * 3 + kx for (ky, kx) in ops.deconv_phase_taps(ph)]
+        dp = TO.DevPackedWeights(len(sel), 24, 40, dev()).pack(d32(wd.reshape(9, 40, 24)), 9, cout_major=True, tap_sel=sel)
+        torch.cuda.synchronize()
+        assert torch.equal(hp.hi, dp.hi) and torch.equal(hp.lo, dp.lo)
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,k,stride,rate", [
+    (2, 16, 16, 64, 128, 1, 1, 1), (1, 8, 8, 728, 728, 1, 1, 1), (1, 16, 16, 128, 64, 3, 1, 6), (1, 9, 11, 64, 64, 3, 1, 1),
+    (2, 16, 16, 128, 256, 1, 2, 1), (1, 7, 9, 256, 728, 1, 2, 1),
+])
+def test_conv_data_gradient(B, H, W, ci, co, k, stride, rate):
+    """dx of the 1x1 / 3x3 convs = the forward implicit GEMM on dL/dy with W packed transposed (+ taps reversed)."""
+    from emdenoise import ops, train_ops as TO
+    from oracle import tf_ops as T
+
+    x = leaf(rnd((B, H, W, ci), 11))
+    w = rnd((k, k, ci, co), 12, 0.1)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    dy = rnd((B, Ho, Wo, co), 13)
+    y = T.conv2d_t(x, t64(w), None, stride=stride, rate=rate)
+    (ref,) = torch.autograd.grad(y, x, t64(dy))
+    taps = k * k
+    # GEMM K = co, N = ci: the TF array [taps][ci][co] read "cout_major" with the roles swapped
+    pk = TO.DevPackedWeights(taps, co, ci, dev()).pack(d32(w.reshape(taps, ci, co)), taps, cout_major=True,
+                                                      tap_sel=list(range(taps))[::-1])
+    ones, zeros = torch.ones(ci, device=dev()), torch.zeros(ci, device=dev())
+    if stride == 1:
+        dx = out_act(B, H, W, ci)
+        (ops.conv1x1 if k == 1 else ops.conv3x3)(to_act(dy), pk, ones, zeros, dx, act=False, **({"rate": rate} if k == 3 else {}))
+        got = dx.torch().cpu().numpy()
+    else:
+        base = rnd((B, H, W, ci), 14)
+        dx = to_act(base.copy())
+        TO.conv1x1_s2_bwd_data(to_act(dy), pk, ones, zeros, dx, accumulate=True)
+        got = dx.torch().cpu().numpy() - base
+    torch.cuda.synchronize()
+    assert rel_l2(got, ref.numpy()) < TOL_X3
+
+
+# ------------------------------------------------------------------------------------------------ depthwise
+@pytest.mark.parametrize("B,H,W,Cc,stride", [(2, 16, 16, 64, 1), (1, 13, 9, 128, 1), (1, 8, 8, 728, 1), (2, 16, 16, 64, 2),
+                                             (1, 9, 7, 256, 2), (2, 12, 12, 4, 1), (2, 64, 64, 64, 1)])
+def test_dw3x3_backward(B, H, W, Cc, stride):
+    from emdenoise import ops, train_ops as TO
+    from oracle import tf_ops as T
+
+    x, w = leaf(rnd((B, H, W, Cc), 15)), leaf(rnd((3, 3, Cc, 1), 16, 0.4))
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    dy = rnd((B, Ho, Wo, Cc), 17)
+    gx, gw = torch.autograd.grad(T.depthwise_conv2d_t(x, w, stride, 1), (x, w), t64(dy))
+    xa, dya = to_act(x.detach().numpy().astype(np.float32), ld=Cc + 8, c0=4), to_act(dy)
+    dw = torch.zeros((9, Cc), dtype=torch.float32, device=dev())
+    TO.dw3x3_wgrad(xa, dya, dw, stride=stride)
+    wdev = d32(w.detach().numpy().reshape(9, Cc))
+    dx = TO.dw3x3_bwd_data(dya, wdev, out_act(B, H, W, Cc), stride=stride)
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().numpy().reshape(3, 3, Cc, 1), gw.numpy()) < TOL_WGRAD
+    assert rel_l2(dx.torch().cpu().numpy(), gx.numpy()) < TOL_F32
+    if stride == 1 and Cc >= 8:  # the fast path the engine uses: the forward kernel with the taps reversed
+        dx2 = ops.dw3x3(dya, wdev.flip(0).contiguous(), out_act(B, H, W, Cc))
+        torch.cuda.synchronize()
+        assert rel_l2(dx2.torch().cpu().numpy(), gx.numpy()) < TOL_F32
+
+
+@pytest.mark.parametrize("B,H,W,ci", [(2, 12, 16, 64), (1, 5, 7, 128), (2, 64, 64, 64)])
+def test_conv3x3_cout1_backward(B, H, W, ci):
+    from emdenoise import train_ops as TO
+    from oracle import tf_ops as T
+
+    x, w = leaf(rnd((B, H, W, ci), 18)), leaf(rnd((3, 3, ci, 1), 19, 0.1))
+    dy = rnd((B, H, W, 1), 20)
+    # (sum over channels of the depthwise conv == the conv to one channel; torch's CPU conv backward rejects Cout = 1 here)
+    gx, gw = torch.autograd.grad(T.depthwise_conv2d_t(x, w).sum(-1, keepdim=True), (x, w), t64(dy))
+    dw = torch.zeros((9, ci), dtype=torch.float32, device=dev())
+    TO.conv3x3_cout1_wgrad(to_act(x.detach().numpy().astype(np.float32)), d32(dy), dw)
+    dx = TO.conv3x3_cout1_bwd_data(d32(dy), d32(w.detach().numpy().reshape(9, ci)), out_act(B, H, W, ci))
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().numpy().reshape(3, 3, ci, 1), gw.numpy()) < TOL_WGRAD
+    assert rel_l2(dx.torch().cpu().numpy(), gx.numpy()) < TOL_F32
+
+
+# ------------------------------------------------------------------------------------------------ resampling
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo,Cc", [(4, 4, 16, 16, 256), (8, 8, 8, 8, 64), (3, 5, 12, 20, 64), (2, 2, 4, 4, 728),
+                                            (1, 1, 2, 2, 64), (5, 5, 9, 9, 8)])
+def test_resize_bilinear_backward(Hi, Wi, Ho, Wo, Cc):
+    from emdenoise import train_ops as TO
+    from oracle import tf_ops as T
+
+    x = leaf(rnd((2, Hi, Wi, Cc), 21))
+    dy = rnd((2, Ho, Wo, Cc), 22)
+    (ref,) = torch.autograd.grad(T.resize_bilinear_legacy_t(x, Ho, Wo), x, t64(dy))
+    dx = TO.resize_bilinear_bwd(to_act(dy, ld=Cc + 4, c0=4), out_act(2, Hi, Wi, Cc))
+    torch.cuda.synchronize()
+    assert rel_l2(dx.torch().cpu().numpy(), ref.numpy()) < TOL_F32
+
+
+@pytest.mark.parametrize("H,W,Cc", [(8, 8, 64), (7, 5, 128), (2, 2, 728), (1, 1, 64)])
+def test_avgpool2x2_backward(H, W, Cc):
+    from emdenoise import train_ops as TO
+    from oracle import tf_ops as T
+
+    x = leaf(rnd((2, H, W, Cc), 23))
+    dy = rnd((2, -(-H // 2), -(-W // 2), Cc), 24)
+    (ref,) = torch.autograd.grad(T.avg_pool2x2_same_t(x), x, t64(dy))
+    dx = TO.avgpool2x2_bwd(to_act(dy), out_act(2, H, W, Cc))
+    torch.cuda.synchronize()
+    assert rel_l2(dx.torch().cpu().numpy(), ref.numpy()) < TOL_F32
+
+
+def test_axpy():
+    from emdenoise import train_ops as TO
+
+    x, y = rnd((2, 5, 7, 64), 25), rnd((2, 5, 7, 64), 26)
+    ya = to_act(y, ld=96, c0=32)
+    TO.axpy(to_act(x), ya, alpha=0.5)
+    torch.cuda.synchronize()
+    assert rel_l2(ya.torch().cpu().numpy(), y + 0.5 * x) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------------ batch norm (training mode)
+def _bn_train_t(r, gamma, beta, eps=1e-3):
+    mean, var = r.mean(dim=(0, 1, 2)), r.var(dim=(0, 1, 2), unbiased=False)
+    return (r - mean) / torch.sqrt(var + eps) * gamma + beta
+
+
+@pytest.mark.parametrize("double", [True, False])
+@pytest.mark.parametrize("B,H,W,Cc,mask", [(2, 8, 8, 64, 1), (1, 16, 16, 728, 1), (2, 32, 32, 1, 2), (3, 5, 7, 128, 0)])
+def test_bn_train_forward_and_backward(double, B, H, W, Cc, mask):
+    """r -> [BN1] -> BN2 -> relu6 [-> clip]: forward affine, moving-average updates and the backward, against
+    autograd through two explicit batch-statistic normalisations (the outer one computes ITS statistics from the
+    inner one's output numerically, as TensorFlow does)."""
+    from emdenoise import ops, train_ops as TO
+
+    if double and Cc == 1:
+        pytest.skip("the 1-channel layer has a single batch norm")
+    r = leaf(rnd((B, H, W, Cc), 27, 1.5) + 0.7)
+    g1, b1 = leaf(rnd((Cc,), 28, 0.3) + 1.0), leaf(rnd((Cc,), 29, 0.3))
+    g2, b2 = leaf(rnd((Cc,), 30, 0.3) + 1.2), leaf(rnd((Cc,), 31, 0.5) + (0.4 if mask == 2 else 1.0))
+    dy = rnd((B, H, W, Cc), 32)
+    z1 = _bn_train_t(r, g1, b1) if double else r
+    z = _bn_train_t(z1, g2, b2)
+    y = torch.clamp(z, 0.0, 6.0) if mask else z
+    if mask == 2:
+        y = torch.clamp(y, 0.0, 1.0)
+    grads = torch.autograd.grad(y, (r, g1, b1, g2, b2) if double else (r, g2, b2), t64(dy), allow_unused=True)
+
+    f32 = lambda t: d32(t.detach().numpy())
+    ra = to_act(r.detach().numpy().astype(np.float32))
+    mean, var = ops.bn_batch_stats(ra)
+    npix = B * H * W
+    mm = [torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev()), torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())]
+    fold = TO.bn_train_fold(mean, var, f32(g2), f32(b2), npix, gamma1=f32(g1) if double else None,
+                            beta1=f32(b1) if double else None, moving=mm if double else mm[2:])
+    # forward
+    if Cc % 4 == 0:
+        ya = ops.affine_act(ra, fold["scale"], fold["shift"], out_act(B, H, W, Cc), act=ops.ACT_RELU6 if mask else ops.ACT_NONE)
+        torch.cuda.synchronize()
+        assert rel_l2(ya.torch().cpu().numpy(), y.detach().numpy()) < 3e-6
+    # moving statistics: decay 0.999 from (0, 1), unbiased batch variance
+    bessel = npix / (npix - 1)
+    rd = r.detach()
+    if double:
+        v1 = rd.var(dim=(0, 1, 2), unbiased=False)
+        assert rel_l2(mm[0].cpu().numpy(), 0.001 * rd.mean(dim=(0, 1, 2)).numpy()) < 1e-5
+        assert rel_l2(mm[1].cpu().numpy(), 0.999 + 0.001 * bessel * v1.numpy()) < 1e-6
+        z1d = z1.detach()
+        assert rel_l2(mm[2].cpu().numpy(), 0.001 * z1d.mean(dim=(0, 1, 2)).numpy()) < 1e-5
+        assert rel_l2(mm[3].cpu().numpy(), 0.999 + 0.001 * bessel * z1d.var(dim=(0, 1, 2), unbiased=False).numpy()) < 1e-6
+    else:
+        assert rel_l2(mm[2].cpu().numpy(), 0.001 * rd.mean(dim=(0, 1, 2)).numpy()) < 1e-5
+        assert rel_l2(mm[3].cpu().numpy(), 0.999 + 0.001 * bessel * rd.var(dim=(0, 1, 2), unbiased=False).numpy()) < 1e-6
+    # backward
+    dg1, dg2, db2 = (torch.zeros(Cc, device=dev()) for _ in range(3))
+    dya = to_act(dy)
+    dr = TO.bn_backward(dya, ra, fold, f32(g2), dg2, db2, dya, mask=mask, gamma1=f32(g1) if double else None,
+                        dgamma1=dg1 if double else None)
+    torch.cuda.synchronize()
+    if double:
+        gr, gg1, gb1, gg2, gb2 = grads
+        scale = float(gg2.abs().max())
+        assert np.abs(dg1.cpu().numpy() - gg1.numpy()).max() < 2e-5 * scale    # d gamma1 ~ eps-suppressed
+        assert gb1 is None or float(gb1.abs().max()) < 1e-9 * scale            # d beta1 = 0 analytically
+    else:
+        gr, gg2, gb2 = grads
+    assert rel_l2(dr.torch().cpu().numpy(), gr.numpy()) < 1e-5
+    assert rel_l2(dg2.cpu().numpy(), gg2.numpy()) < 1e-5
+    assert rel_l2(db2.cpu().numpy(), gb2.numpy()) < 1e-5
+
+
+def test_bias_gradient_reduction():
+    from emdenoise import train_ops as TO
+
+    dy = rnd((2, 9, 9, 728), 33)
+    s1 = torch.full((728,), 1.0, device=dev())
+    TO.chan_reduce(to_act(dy), s1, accumulate_s1=True)
+    torch.cuda.synchronize()
+    assert rel_l2(s1.cpu().numpy(), 1.0 + dy.astype(np.float64).sum(axis=(0, 1, 2))) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ loss and optimizer
+@pytest.mark.parametrize("noise", [0.01, 0.2])   # both branches of the capped loss
+def test_denoise_loss(noise):
+    from emdenoise import train_ops as TO
+
+    truth = rnd((2, 64, 64, 1), 34, 0.2, positive=True)
+    out = leaf(truth + rnd((2, 64, 64, 1), 35, noise))
+    mse = ((out - t64(truth)) ** 2).mean()
+    loss = 1000.0 * mse if float(mse.detach()) < 0.001 else torch.sqrt(1000.0 * mse)
+    (ref,) = torch.autograd.grad(loss, out)
+    dout = torch.empty((2, 64, 64, 1), dtype=torch.float32, device=dev())
+    res = TO.denoise_loss(d32(out.detach().numpy()), d32(truth), dout).cpu().numpy()
+    assert abs(res[0] - float(mse)) < 1e-6 * float(mse) + 1e-12 and abs(res[1] - float(loss)) < 2e-6 * float(loss)
+    assert rel_l2(dout.cpu().numpy(), ref.numpy()) < 2e-6
+    assert (float(mse) < 0.001) == (noise == 0.01)
+
+
+def test_nesterov_step_matches_apply_momentum():
+    from emdenoise import train_ops as TO
+
+    p, g, a = rnd((1000,), 36).astype(np.float64), rnd((1000,), 37).astype(np.float64), rnd((1000,), 38).astype(np.float64)
+    lr, mom, gs = 0.001, 0.9, 0.1
+    pd, gd, ad = d32(p), d32(g), d32(a)
+    TO.nesterov_step(pd, gd, ad, lr, mom, gs)
+    a2 = mom * a + g * gs                 # ApplyMomentum, use_nesterov=true
+    p2 = p - (g * gs * lr + a2 * mom * lr)
+    torch.cuda.synchronize()
+    assert rel_l2(ad.cpu().numpy(), a2) < 1e-6 and rel_l2(pd.cpu().numpy(), p2) < 1e-6
