@@ -14,7 +14,7 @@ from . import _lib
 
 PREC_BF16 = 1
 PREC_BF16X3 = 3
-ACT_NONE, ACT_RELU6, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_RELU6, ACT_RELU, ACT_RELU6_CLIP01 = 0, 1, 2, 3
 
 
 def _act(a):

@@ -1,0 +1,512 @@
+"""Graph D' training on MI355X: the data-parallel trainer of misc_py/denoiser-multi-gpu.py.
+
+Mirrors, for one process per GPU:
+  * ``_tower_fn`` (:752-782)  -> ``DenoiserTrainer.tower(lq, truth)``: architecture(phase=True) -- every batch norm
+    on BATCH statistics -- the capped-MSE loss, and tf.gradients as a hand-written reverse pass over saved
+    activations (no autograd engine: each layer's backward is a fixed sequence of libemdenoise.so launches);
+  * ``_train_op`` (:1011-1077) + the loop (:1169-1206) -> ``train_step``: gradient sets from all towers / micro
+    batches are summed in ONE flat fp32 buffer (parameter gradients accumulate in place), all-reduced over RCCL,
+    averaged (`add_n * 1/len`, :1040) and applied by tf.train.MomentumOptimizer(use_nesterov=True) (:1064-1066);
+    batch-norm moving statistics are updated by the first tower only (:701-707).
+The reference moves 10 gradient sets of 154 MB through host memory per step (:1177-1196); here parameters,
+gradients and momentum are three flat device vectors and the only exchange is one all-reduce of the gradient vector.
+
+A tower normalises over the images it is given: ``tower_batch=1`` is the reference's behaviour (one image per
+tower, :763), larger tower batches are ordinary batch-statistics training.
+Python here is plumbing (buffers, views, launch order); there is no CPU compute path.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib, ops
+from . import train_ops as TO
+from .denoiser import (aspp_filters, aspp_output, aspp_rateLarge, aspp_rateMedium, aspp_rateSmall, declare_layers,
+                       features0, features1, features2, features3, features4, num_extra_blocks, variable_specs)
+
+INITIAL_LEARNING_RATE = 0.001   # denoiser-multi-gpu.py:118
+MOMENTUM = 0.9                  # :1065
+
+
+def _is_moving(name):
+    return name.endswith(("/moving_mean", "/moving_variance"))
+
+
+class DenoiserTrainer:
+    """Parameters, gradients and momentum of graph D' resident on one GPU + the forward/backward launch sequence."""
+
+    def __init__(self, weights, device, precision="bf16x3", learning_rate=INITIAL_LEARNING_RATE, momentum=MOMENTUM):
+        import torch
+
+        _lib.load()
+        self.device = device
+        self.precision = {"bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[precision]
+        self.lr, self.momentum = learning_rate, momentum
+        self.layers = declare_layers("Dprime")
+        specs = variable_specs("Dprime")
+        self.trainable = OrderedDict((n, s) for n, s in specs.items() if not _is_moving(n))
+        self.moving_names = OrderedDict((n, s) for n, s in specs.items() if _is_moving(n))
+
+        def flat(names, fill=None):
+            # every view starts on a 16-byte boundary (the kernels read weights as float4)
+            offs, n = {}, 0
+            for name, shape in names.items():
+                offs[name] = n
+                n += -(-int(np.prod(shape)) // 4) * 4
+            buf = torch.zeros(n, dtype=torch.float32, device=device)
+            views = OrderedDict((name, buf[offs[name]: offs[name] + int(np.prod(shape))].view(shape)) for name, shape in names.items())
+            if fill is not None:
+                host = np.zeros(n, np.float32)
+                for name, shape in names.items():
+                    host[offs[name]: offs[name] + int(np.prod(shape))] = np.asarray(fill[name], np.float32).reshape(-1)
+                buf.copy_(torch.from_numpy(host))
+            return buf, views
+
+        self.params, self.v = flat(self.trainable, weights)
+        self.grads, self.g = flat(self.trainable)
+        self.accum, _ = flat(self.trainable)
+        self.moving, self.m = flat(self.moving_names, weights)
+        cmax = 5 * aspp_filters
+        self.ones = torch.ones(cmax, dtype=torch.float32, device=device)
+        self.zeros = torch.zeros(cmax, dtype=torch.float32, device=device)
+        # the 1-channel image is processed as 4 channels (3 of zeros): padded copies of the three Cin = 1 weights
+        # and of their gradients (row / channel 0 is the real one)
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
+        self.pad_w = {"cnn0_dw": z(9, 4), "cnn0_pw": z(1, 4, features0), "residual0": z(1, 4, features1)}
+        self.pad_g = {k: torch.zeros_like(t) for k, t in self.pad_w.items()}
+        # packed bf16 weights, forward and transposed (data gradient) orientation
+        self.pk_f, self.pk_b = {}, {}
+        for key, L in self.layers.items():
+            cin = max(L.cin, 4)
+            if L.kind == "sep":
+                self.pk_f[key] = TO.DevPackedWeights(1, cin, L.cout, device)
+                if L.cin > 1:
+                    self.pk_b[key] = TO.DevPackedWeights(1, L.cout, cin, device)
+            elif L.kind == "conv" and L.cout > 1:
+                t = L.k * L.k
+                self.pk_f[key] = TO.DevPackedWeights(t, cin, L.cout, device)
+                if L.cin > 1:
+                    self.pk_b[key] = TO.DevPackedWeights(t, L.cout, cin, device)
+            elif L.kind == "deconv":
+                self.pk_f[key] = [TO.DevPackedWeights(len(ops.deconv_phase_taps(ph)), L.cin, L.cout, device) for ph in range(4)]
+                self.pk_b[key] = TO.DevPackedWeights(9, L.cout, L.cin, device)
+        self.dw_flip = {}
+        self.repack()
+        self.last = None
+
+    # ---- parameters ------------------------------------------------------------------------------------
+    def _w(self, key):
+        """fp32 weight tensor of a layer as [taps][Cin][Cout] (conv / pointwise) or [9][Cout][Cin] (transposed conv)."""
+        L = self.layers[key]
+        if L.kind == "sep":
+            return self.pad_w["cnn0_pw"] if L.cin == 1 else self.v[L.scope + "/pointwise_weights"].view(1, L.cin, L.cout)
+        if L.kind == "conv":
+            return self.pad_w[key] if L.cin == 1 else self.v[L.scope + "/" + L.wname].view(L.k * L.k, L.cin, L.cout)
+        return self.v[L.scope + "/" + L.wname].view(9, L.cout, L.cin)
+
+    def _dw(self, key):
+        L = self.layers[key]
+        return self.pad_w["cnn0_dw"] if L.cin == 1 else self.v[L.scope + "/depthwise_weights"].view(9, L.cin)
+
+    def repack(self):
+        """fp32 parameters -> padded Cin = 1 copies, bf16 hi/lo planes (both orientations), flipped depthwise taps.
+        Runs after every optimizer step; everything stays on the device."""
+        L0, R0 = self.layers["cnn0"], self.layers["residual0"]
+        self.pad_w["cnn0_dw"][:, 0].copy_(self.v[L0.scope + "/depthwise_weights"].view(9))
+        self.pad_w["cnn0_pw"][0, 0].copy_(self.v[L0.scope + "/pointwise_weights"].view(L0.cout))
+        self.pad_w["residual0"][0, 0].copy_(self.v[R0.scope + "/" + R0.wname].view(R0.cout))
+        for key, L in self.layers.items():
+            if L.kind == "sep" or (L.kind == "conv" and L.cout > 1):
+                w = self._w(key)
+                taps = w.shape[0]
+                self.pk_f[key].pack(w, taps, cout_major=False)
+                if key in self.pk_b:  # K = Cout, N = Cin: the same array read "cout_major"; taps reversed
+                    self.pk_b[key].pack(w, taps, cout_major=True, tap_sel=list(range(taps))[::-1])
+            elif L.kind == "deconv":
+                w = self._w(key)
+                for ph in range(4):
+                    sel = [ky * 3 + kx for (ky, kx) in ops.deconv_phase_taps(ph)]
+                    self.pk_f[key][ph].pack(w, 9, cout_major=True, tap_sel=sel)
+                self.pk_b[key].pack(w, 9, cout_major=False)
+            if L.kind == "sep" and L.stride == 1 and L.cin > 1:
+                self.dw_flip[key] = self._dw(key).flip(0).contiguous()
+
+    def state_dict(self):
+        """TF variable name -> numpy array (parameters and moving statistics)."""
+        out = OrderedDict()
+        for name in variable_specs("Dprime"):
+            out[name] = (self.m if _is_moving(name) else self.v)[name].detach().cpu().numpy().copy()
+        return out
+
+    def gradients(self):
+        """TF variable name -> numpy gradient accumulated since zero_grad() (sum over towers)."""
+        self._unpad_grads()
+        return OrderedDict((n, t.detach().cpu().numpy().copy()) for n, t in self.g.items())
+
+    def zero_grad(self):
+        self.grads.zero_()
+        for t in self.pad_g.values():
+            t.zero_()
+
+    def _unpad_grads(self):
+        L0, R0 = self.layers["cnn0"], self.layers["residual0"]
+        self.g[L0.scope + "/depthwise_weights"].view(9).copy_(self.pad_g["cnn0_dw"][:, 0])
+        self.g[L0.scope + "/pointwise_weights"].view(L0.cout).copy_(self.pad_g["cnn0_pw"][0, 0])
+        self.g[R0.scope + "/" + R0.wname].view(R0.cout).copy_(self.pad_g["residual0"][0, 0])
+
+    def _gw(self, key):
+        L = self.layers[key]
+        if L.kind == "sep":
+            return self.pad_g["cnn0_pw"] if L.cin == 1 else self.g[L.scope + "/pointwise_weights"].view(1, L.cin, L.cout)
+        if L.kind == "conv":
+            return self.pad_g[key] if L.cin == 1 else self.g[L.scope + "/" + L.wname].view(L.k * L.k, L.cin, L.cout)
+        return self.g[L.scope + "/" + L.wname].view(9, L.cout, L.cin)
+
+    def _gdw(self, key):
+        L = self.layers[key]
+        return self.pad_g["cnn0_dw"] if L.cin == 1 else self.g[L.scope + "/depthwise_weights"].view(9, L.cin)
+
+    # ---- forward building blocks (training mode); each returns (y, ctx) -----------------------------------
+    def _E(self, B, H, W, Cc):
+        return ops.Act.empty(B, H, W, Cc, self.device)
+
+    def _bn(self, key, r, bias_name=None):
+        """Batch statistics of r -> fold dict of the layer's BN chain (+ moving-average updates on the first tower)."""
+        L = self.layers[key]
+        mean, var = ops.bn_batch_stats(r)
+        npix = r.B * r.H * r.W
+        upd = self._update_moving
+        if len(L.bn) == 2:
+            b1, b2 = L.bn
+            mv = (self.m[b1 + "/moving_mean"], self.m[b1 + "/moving_variance"], self.m[b2 + "/moving_mean"],
+                  self.m[b2 + "/moving_variance"]) if upd else None
+            return TO.bn_train_fold(mean, var, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], npix, gamma1=self.v[b1 + "/gamma"],
+                                    beta1=self.v[b1 + "/beta"], moving=mv)
+        (b2,) = L.bn
+        mv = (self.m[b2 + "/moving_mean"], self.m[b2 + "/moving_variance"]) if upd else None
+        return TO.bn_train_fold(mean, var, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], npix,
+                                bias=self.v[bias_name] if bias_name else None, moving=mv)
+
+    def _sep_fwd(self, key, x, out=None, res=None):
+        L = self.layers[key]
+        Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
+        d = ops.dw3x3(x, self._dw(key), self._E(x.B, Ho, Wo, x.C), stride=L.stride, rate=L.rate)
+        r = ops.conv1x1(d, self.pk_f[key], self.ones, self.zeros, self._E(x.B, Ho, Wo, L.cout), act=False,
+                        precision=self.precision)
+        fold = self._bn(key, r)
+        if out is None:
+            out = self._E(x.B, Ho, Wo, L.cout)
+        ops.affine_act(r, fold["scale"], fold["shift"], out, act=ops.ACT_RELU6, res=res)
+        return out, {"x": x, "d": d, "r": r, "fold": fold}
+
+    def _conv_fwd(self, key, x, out=None, act=True):
+        """conv + bias -> BN -> relu6 (bias folds into the batch mean), or conv + bias alone (the image-level conv)."""
+        L = self.layers[key]
+        Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
+        bias = self.v[L.scope + "/" + L.bname]
+        has_bn = bool(L.bn)
+        tgt = self._E(x.B, Ho, Wo, L.cout) if (has_bn or out is None) else out
+        shift = self.zeros if has_bn else bias
+        if L.k == 1:
+            ops.conv1x1(x, self.pk_f[key], self.ones, shift, tgt, stride=L.stride, act=False, precision=self.precision)
+        else:
+            ops.conv3x3(x, self.pk_f[key], self.ones, shift, tgt, stride=L.stride, rate=L.rate, act=False,
+                        precision=self.precision)
+        if not has_bn:
+            return tgt, {"x": x}
+        fold = self._bn(key, tgt, L.scope + "/" + L.bname)
+        if out is None:
+            out = self._E(x.B, Ho, Wo, L.cout)
+        ops.affine_act(tgt, fold["scale"], fold["shift"], out, act=ops.ACT_RELU6 if act else ops.ACT_NONE)
+        return out, {"x": x, "r": tgt, "fold": fold}
+
+    def _deconv_fwd(self, key, x, out):
+        L = self.layers[key]
+        r = ops.deconv3x3s2(x, self.pk_f[key], self.ones, self.zeros, self._E(x.B, 2 * x.H, 2 * x.W, L.cout), act=False,
+                            precision=self.precision)
+        fold = self._bn(key, r, L.scope + "/" + L.bname)
+        ops.affine_act(r, fold["scale"], fold["shift"], out, act=ops.ACT_RELU6)
+        return out, {"x": x, "r": r, "fold": fold}
+
+    # ---- backward building blocks ---------------------------------------------------------------------------
+    def _put(self, gslot, x, write, gemm_accumulate=None):
+        """Deliver a gradient for tensor x.  gslot: dict id -> Act of gradients that already exist.  write(dst):
+        overwrite dst with the gradient; gemm_accumulate(dst): add it into dst (if the producer can)."""
+        k = id(x.buf), x.c0, x.C
+        if k not in gslot:
+            parent = self._gparent.get((id(x.buf)))
+            dst = parent.slice(x.c0, x.C) if parent is not None else self._E(x.B, x.H, x.W, x.C)
+            write(dst)
+            gslot[k] = dst
+        elif gemm_accumulate is not None:
+            gemm_accumulate(gslot[k])
+        else:
+            tmp = self._E(x.B, x.H, x.W, x.C)
+            write(tmp)
+            TO.axpy(tmp, gslot[k])
+        return gslot[k]
+
+    def _bn_bwd(self, key, dy, ctx, mask=TO.MASK_RELU6):
+        """dy -> d loss / d r, written over r (no longer needed); BN parameter gradients accumulate."""
+        L = self.layers[key]
+        r = ctx["r"]
+        if len(L.bn) == 2:
+            b1, b2 = L.bn
+            return TO.bn_backward(dy, r, ctx["fold"], self.v[b2 + "/gamma"], self.g[b2 + "/gamma"], self.g[b2 + "/beta"], r,
+                                  mask=mask, gamma1=self.v[b1 + "/gamma"], dgamma1=self.g[b1 + "/gamma"])
+        (b2,) = L.bn
+        return TO.bn_backward(dy, r, ctx["fold"], self.v[b2 + "/gamma"], self.g[b2 + "/gamma"], self.g[b2 + "/beta"], r, mask=mask)
+
+    def _sep_bwd(self, key, dy, ctx, gslot, need_dx=True):
+        L = self.layers[key]
+        x, d = ctx["x"], ctx["d"]
+        dr = self._bn_bwd(key, dy, ctx)
+        TO.conv_wgrad(d, dr, self._gw(key))
+        dd = ops.conv1x1(dr, self.pk_b[key], self.ones, self.zeros, d, act=False, precision=self.precision) if key in self.pk_b \
+            else self._cin1_dd(dr, d)
+        TO.dw3x3_wgrad(x, dd, self._gdw(key), stride=L.stride, rate=L.rate)
+        if not need_dx:
+            return
+        if L.stride == 1:
+            self._put(gslot, x, lambda dst: ops.dw3x3(dd, self.dw_flip[key], dst))
+        else:
+            self._put(gslot, x, lambda dst: TO.dw3x3_bwd_data(dd, self._dw(key), dst, stride=L.stride))
+
+    def _cin1_dd(self, dr, d):
+        """cnn0: d loss / d (depthwise output) over the 4 padded channels = dr . pw4^T (K = 64, N = 4)."""
+        if "cnn0_b" not in self.pk_b:
+            self.pk_b["cnn0_b"] = TO.DevPackedWeights(1, features0, 4, self.device)
+        self.pk_b["cnn0_b"].pack(self.pad_w["cnn0_pw"], 1, cout_major=True)
+        return ops.conv1x1(dr, self.pk_b["cnn0_b"], self.ones, self.zeros, d, act=False, precision=self.precision)
+
+    def _conv_bwd(self, key, dy, ctx, gslot, need_dx=True):
+        L = self.layers[key]
+        x = ctx["x"]
+        if L.bn:
+            dr = self._bn_bwd(key, dy, ctx)     # the bias before a training-mode batch norm has zero gradient
+        else:
+            dr = dy
+            TO.chan_reduce(dy, self.g[L.scope + "/" + L.bname], accumulate_s1=True)
+        if L.k == 1:
+            TO.conv_wgrad(x, dr, self._gw(key), [0], [0], sa=L.stride)
+        else:
+            tdy, tdx = TO.conv_taps(x.H, x.W, L.stride, L.rate)
+            TO.conv_wgrad(x, dr, self._gw(key), tdy, tdx, sa=L.stride)
+        if not need_dx:
+            return
+        pk = self.pk_b[key]
+        P = self.precision
+        if L.stride == 2:
+            def first(dst):
+                dst.torch().zero_()
+                TO.conv1x1_s2_bwd_data(dr, pk, self.ones, self.zeros, dst, accumulate=False, precision=P)
+            self._put(gslot, x, first, lambda dst: TO.conv1x1_s2_bwd_data(dr, pk, self.ones, self.zeros, dst, accumulate=True, precision=P))
+        elif L.k == 1:
+            self._put(gslot, x, lambda dst: ops.conv1x1(dr, pk, self.ones, self.zeros, dst, act=False, precision=P),
+                      lambda dst: ops.conv1x1(dr, pk, self.ones, self.zeros, dst, act=False, res=dst, precision=P))
+        else:
+            self._put(gslot, x, lambda dst: ops.conv3x3(dr, pk, self.ones, self.zeros, dst, rate=L.rate, act=False, precision=P),
+                      lambda dst: ops.conv3x3(dr, pk, self.ones, self.zeros, dst, rate=L.rate, act=False, res=dst, precision=P))
+
+    def _deconv_bwd(self, key, dy, ctx, gslot):
+        L = self.layers[key]
+        x = ctx["x"]
+        dr = self._bn_bwd(key, dy, ctx)
+        tdy, tdx = TO.conv_taps(dr.H, dr.W, 2, 1)
+        TO.conv_wgrad(dr, x, self._gw(key), tdy, tdx, sa=2)
+        pk = self.pk_b[key]
+        self._put(gslot, x, lambda dst: ops.conv3x3(dr, pk, self.ones, self.zeros, dst, stride=2, act=False, precision=self.precision),
+                  lambda dst: ops.conv3x3(dr, pk, self.ones, self.zeros, dst, stride=2, act=False, res=dst, precision=self.precision))
+
+    # ---- one tower ---------------------------------------------------------------------------------------------
+    def tower(self, lq, truth, update_moving=True, grad_scale=1.0):
+        """Forward (phase=True) + loss + backward for the images of one tower; parameter gradients are ADDED into
+        self.grads.  lq, truth: CUDA float32 [B,S,S,1] contiguous, S a multiple of 32.  Returns (out, result3) with
+        result3 a device tensor (mse, loss, dloss/dout factor) -- no host synchronisation."""
+        import torch
+
+        assert lq.is_cuda and lq.dtype == torch.float32 and lq.is_contiguous() and lq.dim() == 4 and lq.shape[3] == 1
+        assert truth.shape == lq.shape and truth.is_contiguous() and truth.dtype == torch.float32
+        B, S = lq.shape[0], lq.shape[1]
+        assert lq.shape[2] == S and S % 32 == 0, "square crops with side a multiple of 32"
+        self._update_moving = update_moving
+        E = lambda H, Cc: self._E(B, H, H, Cc)
+        S2, S4, S8, S16 = S // 2, S // 4, S // 8, S // 16
+        f0, f1, f2, f3, f4, af = features0, features1, features2, features3, features4, aspp_filters
+        C = {}   # layer key -> saved context
+
+        # ---------------- forward
+        x4 = torch.zeros((B, S, S, 4), dtype=torch.float32, device=self.device)
+        x4[..., 0:1].copy_(lq)
+        x = ops.Act(x4)
+        cnn0, C["cnn0"] = self._sep_fwd("cnn0", x)
+        cnn0_last, C["cnn0_last"] = self._sep_fwd("cnn0_last", cnn0)
+        residual0, C["residual0"] = self._conv_fwd("residual0", x)
+        concat1 = E(S2, f2 + f1)
+        cnn0_strided, C["cnn0_strided"] = self._sep_fwd("cnn0_strided", cnn0_last, out=concat1.slice(f2, f1), res=residual0)
+        cnn1, C["cnn1"] = self._sep_fwd("cnn1", cnn0_strided)
+        cnn1_last, C["cnn1_last"] = self._sep_fwd("cnn1_last", cnn1)
+        residual1, C["residual1"] = self._conv_fwd("residual1", cnn0_strided)
+        concat2 = E(S4, aspp_output + f1)
+        cnn1_strided, C["cnn1_strided"] = self._sep_fwd("cnn1_strided", cnn1_last, out=concat2.slice(aspp_output, f1), res=residual1)
+        cnn2, C["cnn2"] = self._sep_fwd("cnn2", cnn1_strided)
+        cnn2_last, C["cnn2_last"] = self._sep_fwd("cnn2_last", cnn2)
+        residual2, C["residual2"] = self._conv_fwd("residual2", cnn1_strided)
+        cnn2_strided, C["cnn2_strided"] = self._sep_fwd("cnn2_strided", cnn2_last, res=residual2)
+        cnn3, C["cnn3"] = self._sep_fwd("cnn3", cnn2_strided)
+        cnn3_last, C["cnn3_last"] = self._sep_fwd("cnn3_last", cnn3)
+        residual3, C["residual3"] = self._conv_fwd("residual3", cnn2_strided)
+        cnn3_strided, C["cnn3_strided"] = self._sep_fwd("cnn3_strided", cnn3_last, res=residual3)
+        t, C["cnn4_a"] = self._sep_fwd("cnn4_a", cnn3_strided)
+        t, C["cnn4_b"] = self._sep_fwd("cnn4_b", t)
+        cur, C["cnn4_last"] = self._sep_fwd("cnn4_last", t, res=cnn3_strided)
+        for i in range(num_extra_blocks):
+            t, C[f"middle{i}_0"] = self._sep_fwd(f"middle{i}_0", cur)
+            t, C[f"middle{i}_1"] = self._sep_fwd(f"middle{i}_1", t)
+            cur, C[f"middle{i}_2"] = self._sep_fwd(f"middle{i}_2", t, res=cur)
+        cat = E(S16, 5 * af)
+        _, C["aspp_conv1x1"] = self._conv_fwd("aspp_conv1x1", cur, out=cat.slice(0, af))
+        _, C["aspp_small"] = self._conv_fwd("aspp_small", cur, out=cat.slice(af, af))
+        _, C["aspp_medium"] = self._conv_fwd("aspp_medium", cur, out=cat.slice(2 * af, af))
+        _, C["aspp_large"] = self._conv_fwd("aspp_large", cur, out=cat.slice(3 * af, af))
+        pooled = ops.avgpool2x2(cur, self._E(B, S16 // 2, S16 // 2, af))
+        img_lvl, C["aspp_image_conv"] = self._conv_fwd("aspp_image_conv", pooled)
+        up = ops.resize_bilinear(img_lvl, E(S16, af))
+        Lp = self.layers["aspp_pooling_bn"]
+        fold_p = self._bn("aspp_pooling_bn", up)
+        ops.affine_act(up, fold_p["scale"], fold_p["shift"], cat.slice(4 * af, af), act=ops.ACT_RELU6)
+        C["aspp_pooling_bn"] = {"r": up, "fold": fold_p}
+        aspp, C["aspp_reduce"] = self._conv_fwd("aspp_reduce", cat)
+        ops.resize_bilinear(aspp, concat2.slice(0, aspp_output))
+        t, C["deconv2_a"] = self._sep_fwd("deconv2_a", concat2)
+        residual2_d, C["residual2_d"] = self._conv_fwd("residual2_d", concat2)
+        deconv2, C["deconv2_b"] = self._sep_fwd("deconv2_b", t, res=residual2_d)
+        _, C["deconv2to1"] = self._deconv_fwd("deconv2to1", deconv2, concat1.slice(0, f2))
+        t, C["deconv1_a"] = self._sep_fwd("deconv1_a", concat1)
+        residual1_d, C["residual1_d"] = self._conv_fwd("residual1_d", concat1)
+        deconv1, C["deconv1_b"] = self._sep_fwd("deconv1_b", t, res=residual1_d)
+        deconv1to0, C["deconv1to0"] = self._deconv_fwd("deconv1to0", deconv1, E(S, f1))
+        t, C["deconv0_a"] = self._sep_fwd("deconv0_a", deconv1to0)
+        residual0_d, C["residual0_d"] = self._conv_fwd("residual0_d", deconv1to0)
+        deconv0, C["deconv0_b"] = self._sep_fwd("deconv0_b", t, res=residual0_d)
+        # final 3x3 conv to one channel (+ bias) -> BN -> relu6 -> clip [0,1]  (:528-538)
+        Lf = self.layers["deconv_final"]
+        wf = self.v[Lf.scope + "/" + Lf.wname].view(9, f0)
+        rf = torch.empty((B, S, S, 1), dtype=torch.float32, device=self.device)
+        ops.conv3x3_cout1(deconv0, wf, 1.0, 0.0, rf, act=0)
+        rfa = ops.Act(rf)
+        fold_f = self._bn("deconv_final", rfa, Lf.scope + "/" + Lf.bname)
+        out = torch.empty_like(rf)
+        # one channel: run the per-channel affine over a [.., 4] view with the scalar replicated
+        sc4, sh4 = fold_f["scale"].expand(4).contiguous(), fold_f["shift"].expand(4).contiguous()
+        ops.affine_act(ops.Act(rf.view(B, S, S // 4, 4)), sc4, sh4, ops.Act(out.view(B, S, S // 4, 4)), act=ops.ACT_RELU6_CLIP01)
+
+        # ---------------- loss (:768-775)
+        dout = torch.empty_like(out)
+        result = TO.denoise_loss(out, truth, dout, grad_scale=grad_scale)
+
+        # ---------------- backward: reverse order; gslot holds the gradients that exist so far
+        G = {}
+        gconcat1, gconcat2, gcat = E(S2, f2 + f1), E(S4, aspp_output + f1), E(S16, 5 * af)
+        self._gparent = {id(concat1.buf): gconcat1, id(concat2.buf): gconcat2, id(cat.buf): gcat}
+        grad = lambda a: G[(id(a.buf), a.c0, a.C)]
+
+        drf = TO.bn_backward(ops.Act(dout), rfa, fold_f, self.v[Lf.bn[0] + "/gamma"], self.g[Lf.bn[0] + "/gamma"],
+                             self.g[Lf.bn[0] + "/beta"], rfa, mask=TO.MASK_RELU6_CLIP)
+        TO.conv3x3_cout1_wgrad(deconv0, drf.buf, self.g[Lf.scope + "/" + Lf.wname].view(9, f0))
+        self._put(G, deconv0, lambda dst: TO.conv3x3_cout1_bwd_data(drf.buf, wf, dst))
+        # decoder 0: deconv0 = sep_b(sep_a(deconv1to0)) + residual0_d(deconv1to0)
+        g = grad(deconv0)
+        self._conv_bwd("residual0_d", g, C["residual0_d"], G)
+        self._sep_bwd("deconv0_b", g, C["deconv0_b"], G)
+        self._sep_bwd("deconv0_a", grad(C["deconv0_b"]["x"]), C["deconv0_a"], G)
+        self._deconv_bwd("deconv1to0", grad(deconv1to0), C["deconv1to0"], G)
+        # decoder 1
+        g = grad(deconv1)
+        self._conv_bwd("residual1_d", g, C["residual1_d"], G)
+        self._sep_bwd("deconv1_b", g, C["deconv1_b"], G)
+        self._sep_bwd("deconv1_a", grad(C["deconv1_b"]["x"]), C["deconv1_a"], G)
+        self._deconv_bwd("deconv2to1", gconcat1.slice(0, f2), C["deconv2to1"], G)
+        # decoder 2
+        g = grad(deconv2)
+        self._conv_bwd("residual2_d", g, C["residual2_d"], G)
+        self._sep_bwd("deconv2_b", g, C["deconv2_b"], G)
+        self._sep_bwd("deconv2_a", grad(C["deconv2_b"]["x"]), C["deconv2_a"], G)
+        self._put(G, aspp, lambda dst: TO.resize_bilinear_bwd(gconcat2.slice(0, aspp_output), dst))
+        # ASPP
+        self._conv_bwd("aspp_reduce", grad(aspp), C["aspp_reduce"], G)          # writes gcat (all five slices)
+        Lp = self.layers["aspp_pooling_bn"]
+        dup = TO.bn_backward(gcat.slice(4 * af, af), up, fold_p, self.v[Lp.bn[0] + "/gamma"], self.g[Lp.bn[0] + "/gamma"],
+                             self.g[Lp.bn[0] + "/beta"], up, mask=TO.MASK_RELU6)
+        self._put(G, img_lvl, lambda dst: TO.resize_bilinear_bwd(dup, dst))
+        self._conv_bwd("aspp_image_conv", grad(img_lvl), C["aspp_image_conv"], G)
+        self._put(G, cur, lambda dst: TO.avgpool2x2_bwd(grad(pooled), dst))
+        self._conv_bwd("aspp_large", gcat.slice(3 * af, af), C["aspp_large"], G)
+        self._conv_bwd("aspp_medium", gcat.slice(2 * af, af), C["aspp_medium"], G)
+        self._conv_bwd("aspp_small", gcat.slice(af, af), C["aspp_small"], G)
+        self._conv_bwd("aspp_conv1x1", gcat.slice(0, af), C["aspp_conv1x1"], G)
+        # middle flow and encoder 4: y = sep2(sep1(sep0(x))) + x.  The gradient of y becomes the gradient of x once
+        # sep2's backward has read it (the identity branch), and sep0's data gradient is then added into it.
+        def residual_block(keys, y):
+            gy = grad(y)
+            self._sep_bwd(keys[2], gy, C[keys[2]], G)
+            self._sep_bwd(keys[1], grad(C[keys[2]]["x"]), C[keys[1]], G)
+            xin = C[keys[0]]["x"]
+            G[(id(xin.buf), xin.c0, xin.C)] = gy
+            self._sep_bwd(keys[0], grad(C[keys[1]]["x"]), C[keys[0]], G)
+
+        y = cur
+        for i in reversed(range(num_extra_blocks)):
+            residual_block([f"middle{i}_{j}" for j in range(3)], y)
+            y = C[f"middle{i}_0"]["x"]
+        residual_block(["cnn4_a", "cnn4_b", "cnn4_last"], y)
+        # encoders 3..0: y = sep_strided(sep_last(sep(x))) + residual_conv(x)
+        def encoder(keys, res_key, y, need_dx=True):
+            gy = grad(y)
+            self._conv_bwd(res_key, gy, C[res_key], G, need_dx=need_dx)
+            self._sep_bwd(keys[2], gy, C[keys[2]], G)
+            self._sep_bwd(keys[1], grad(C[keys[2]]["x"]), C[keys[1]], G)
+            self._sep_bwd(keys[0], grad(C[keys[1]]["x"]), C[keys[0]], G, need_dx=need_dx)
+
+        # cnn1_strided / cnn0_strided live in concat2 / concat1: their gradients started in the decoder (the slices of
+        # gconcat2 / gconcat1 written above); the encoder-side consumers below add into them
+        G[(id(cnn1_strided.buf), cnn1_strided.c0, cnn1_strided.C)] = gconcat2.slice(aspp_output, f1)
+        G[(id(cnn0_strided.buf), cnn0_strided.c0, cnn0_strided.C)] = gconcat1.slice(f2, f1)
+        encoder(["cnn3", "cnn3_last", "cnn3_strided"], "residual3", cnn3_strided)
+        encoder(["cnn2", "cnn2_last", "cnn2_strided"], "residual2", cnn2_strided)
+        encoder(["cnn1", "cnn1_last", "cnn1_strided"], "residual1", cnn1_strided)
+        encoder(["cnn0", "cnn0_last", "cnn0_strided"], "residual0", cnn0_strided, need_dx=False)
+        self._gparent = {}
+        self.last = {"out": out, "result": result}
+        return out, result
+
+    # ---- one training step -----------------------------------------------------------------------------------------
+    def train_step(self, lq, truth, tower_batch=1, learning_rate=None, group=None):
+        """One optimizer step on this rank's images (misc_py/denoiser-multi-gpu.py:1169-1206): every ``tower_batch``
+        images form a tower (gradient set); all sets of all ranks are averaged (:1040) and applied with Nesterov
+        momentum (:1064-1066).  Returns the device tensor [n_towers_local, 3] of (mse, loss, factor)."""
+        import torch
+        import torch.distributed as dist
+
+        B = lq.shape[0]
+        assert B % tower_batch == 0
+        n_local = B // tower_batch
+        self.zero_grad()
+        results = []
+        for k in range(n_local):
+            sl = slice(k * tower_batch, (k + 1) * tower_batch)
+            _, res = self.tower(lq[sl].contiguous(), truth[sl].contiguous(), update_moving=(k == 0))
+            results.append(res)
+        self._unpad_grads()
+        world = 1
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(group)
+            if world > 1:
+                dist.all_reduce(self.grads, group=group)      # RCCL sum over xGMI: the step's only exchange
+                dist.broadcast(self.moving, src=0, group=group)  # moving statistics follow tower 0 (:701-707)
+        TO.nesterov_step(self.params, self.grads, self.accum, self.lr if learning_rate is None else learning_rate,
+                         self.momentum, grad_scale=1.0 / (n_local * world))
+        self.repack()
+        return torch.stack(results)

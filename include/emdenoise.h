@@ -92,6 +92,7 @@ int emd_kernel_denoise_f32(const float* x, float* y, int B, int H, int W, int wi
 #define EMD_ACT_NONE 0
 #define EMD_ACT_RELU6 1 /* tf.nn.relu6: machine_learning/denoiser.py:83 */
 #define EMD_ACT_RELU 2  /* tf.nn.relu:  misc_py/modified_Xception.py:209, :222, :312 */
+#define EMD_ACT_RELU6_CLIP01 3 /* relu6 then tf.clip_by_value(.,0,1), misc_py/denoiser-multi-gpu.py:534-538 (emd_affine_act_f32 only) */
 
 /* Host-side weight packing for the matrix-core kernels (all pointers are HOST pointers).
  * w_host : taps x Cin x Cout float32 in TensorFlow order, [taps][Cin][Cout] (slim.conv2d /

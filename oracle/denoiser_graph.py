@@ -28,6 +28,7 @@ aspp_output = 256
 aspp_rateSmall, aspp_rateMedium, aspp_rateLarge = 6, 12, 18
 num_extra_blocks = 11
 channels = 1
+BN_DECAY = 0.999  # tf.contrib.layers.batch_norm default
 
 
 class _Names:
@@ -57,6 +58,8 @@ class _Graph:
         self.dtype = dtype
         self.trace = None  # optional list of tensors (post-activation) for per-layer statistics
         self.calibrate = None  # optional dict: batch statistics of every BN input are written here AND used
+        self.training = False  # phase=True (denoiser-multi-gpu.py:214): batch statistics, differentiable
+        self.moving_updates = None  # training: dict scope/moving_* -> updated value (decay 0.999, unbiased variance)
 
     # ---- denoiser.py:71-84
     def _batch_norm_fn(self, x, scope=None):
@@ -64,6 +67,18 @@ class _Graph:
         C = x.shape[-1]
         beta = self.get(scope + "/beta", (C,))
         gamma = self.get(scope + "/gamma", (C,))
+        if self.training:
+            # tf.contrib.layers.batch_norm(is_training=True, fused=True): normalise with the batch mean and BIASED
+            # variance; the moving statistics move by (1-decay) towards the batch mean / UNBIASED variance
+            mean = x.mean(dim=(0, 1, 2))
+            var = x.var(dim=(0, 1, 2), unbiased=False)
+            if self.moving_updates is not None:
+                n = x.shape[0] * x.shape[1] * x.shape[2]
+                mm = self.get(scope + "/moving_mean", (C,)).detach()
+                mv = self.get(scope + "/moving_variance", (C,)).detach()
+                self.moving_updates[scope + "/moving_mean"] = mm - (mm - mean.detach()) * (1.0 - BN_DECAY)
+                self.moving_updates[scope + "/moving_variance"] = mv - (mv - var.detach() * (n / max(n - 1, 1))) * (1.0 - BN_DECAY)
+            return (x - mean) / torch.sqrt(var + T.BN_EPS) * gamma + beta
         if self.calibrate is not None:
             # data-dependent initialisation of the moving statistics (used only to SYNTHESISE weights:
             # tests/golden/make_synth_bn.py); biased variance, like TF's fused batch norm normalisation
@@ -253,3 +268,51 @@ def architecture(inputs, weights, cropsize=512, dtype=torch.float32, trace=None,
     x = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(inputs))
     with torch.no_grad():
         return g.build(x.to(dtype), cropsize)
+
+
+def tower_gradients(inputs, truth, weights, cropsize, dtype=torch.float64, variant="Dprime", trace=None):
+    """One tower of the training twin (misc_py/denoiser-multi-gpu.py:752-782): architecture(phase=True) on
+    ``inputs``, mse = mean((out-truth)^2), loss = 1000*mse if mse < 1e-3 else sqrt(1000*mse) (+ weight_decay * sum of
+    l2 losses with weight_decay = 0, :117), tf.gradients(loss, trainable variables) via PyTorch autograd.
+    -> dict(out, mse, loss, grads {name: numpy}, moving {name: numpy updated moving statistics}).
+    Use float64: PyTorch's float32 CPU convolution backward was seen to crash (heap corruption) on the GPU box's host."""
+    leaves = {}
+
+    def get(name, shape):
+        if name not in leaves:
+            w = weights[name]
+            assert tuple(w.shape) == tuple(shape), (name, w.shape, shape)
+            t = torch.from_numpy(np.ascontiguousarray(w)).to(dtype)
+            if not name.endswith(("/moving_mean", "/moving_variance")):
+                t.requires_grad_(True)
+            leaves[name] = t
+        return leaves[name]
+
+    g = _Graph(get, dtype, variant)
+    g.training = True
+    g.moving_updates = {}
+    g.trace = trace  # optional list: every relu6 output (detached by the caller if kept)
+    x = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(inputs))
+    t = truth if isinstance(truth, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(truth))
+    out = g.build(x.to(dtype), cropsize)
+    mse = ((out - t.to(dtype).reshape(out.shape)) ** 2).mean()
+    loss = 1000.0 * mse if float(mse.detach()) < 0.001 else torch.sqrt(1000.0 * mse)
+    names = [n for n, v in leaves.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    return {
+        "out": out.detach(), "mse": float(mse.detach()), "loss": float(loss.detach()),
+        "grads": {n: (gr.numpy() if gr is not None else np.zeros(tuple(leaves[n].shape))) for n, gr in zip(names, grads)},
+        "moving": {n: v.numpy() for n, v in g.moving_updates.items()},
+    }
+
+
+def nesterov_step(params, grads, accums, lr, momentum=0.9):
+    """tf.train.MomentumOptimizer(lr, momentum, use_nesterov=True).apply_gradients (denoiser-multi-gpu.py:1064-1071),
+    i.e. ApplyMomentum: accum = momentum*accum + g; var -= lr*g + lr*momentum*accum.  Dicts of numpy arrays; returns
+    (new params, new accums)."""
+    new_p, new_a = {}, {}
+    for n, g in grads.items():
+        a = momentum * accums[n] + g
+        new_a[n] = a
+        new_p[n] = params[n] - (g * lr + a * momentum * lr)
+    return new_p, new_a

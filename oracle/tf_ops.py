@@ -63,7 +63,7 @@ def depthwise_conv2d_t(x, w, stride=1, rate=1):
     _, pt, pb = same_pads(H, kh, stride, rate)
     _, pl, pr = same_pads(W, kw, stride, rate)
     xn = F.pad(_nchw(x), (pl, pr, pt, pb))
-    wt = w.permute(2, 3, 0, 1)  # [C,1,kh,kw]
+    wt = w.permute(2, 3, 0, 1).contiguous()  # [C,1,kh,kw]
     y = F.conv2d(xn, wt, None, stride=stride, dilation=rate, groups=C)
     return _nhwc(y)
 
@@ -76,7 +76,7 @@ def conv2d_t(x, w, bias=None, stride=1, rate=1):
     _, pt, pb = same_pads(H, kh, stride, rate)
     _, pl, pr = same_pads(W, kw, stride, rate)
     xn = F.pad(_nchw(x), (pl, pr, pt, pb))
-    wt = w.permute(3, 2, 0, 1)  # [Cout,Cin,kh,kw]
+    wt = w.permute(3, 2, 0, 1).contiguous()  # [Cout,Cin,kh,kw] (contiguous: torch's CPU conv backward requires it)
     y = F.conv2d(xn, wt, bias, stride=stride, dilation=rate)
     return _nhwc(y)
 
@@ -89,7 +89,7 @@ def conv2d_transpose_s2_t(x, w, bias=None):
     [0,2N): the full (2N+1)-long transposed convolution cropped at the END.
     x [B,H,W,Cin]; w [3,3,Cout,Cin]; output [B,2H,2W,Cout]."""
     B, H, W, C = x.shape
-    wt = w.permute(3, 2, 0, 1)  # conv_transpose2d wants [Cin,Cout,kh,kw]
+    wt = w.permute(3, 2, 0, 1).contiguous()  # conv_transpose2d wants [Cin,Cout,kh,kw]
     y = F.conv_transpose2d(_nchw(x), wt, bias, stride=2, padding=0)
     return _nhwc(y[:, :, : 2 * H, : 2 * W])
 
