@@ -22,11 +22,6 @@ __device__ __forceinline__ float grad_mask(float dy, float z, int mask) {
     return dy;
 }
 
-inline long slabs(long npix) {
-    long n = (npix + 4095) / 4096;
-    return n > 1024 ? 1024 : n;
-}
-
 // s1[c] = sum_pix g,  s2[c] = sum_pix g * (x-mean[c])*rstd[c];  g = dy * mask(x*mscale[c] + mshift[c]).
 // Two passes, double accumulation (as the forward statistics in dw_misc.hip).
 __global__ __launch_bounds__(256) void chan_reduce_partial(const float* __restrict__ dy, int ldd,
@@ -61,15 +56,76 @@ __global__ __launch_bounds__(256) void chan_reduce_partial(const float* __restri
     }
 }
 
+// The same for C % 4 == 0: 16 channel quads x 16 row lanes per workgroup, 16-byte loads.
+__global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __restrict__ dy, int ldd,
+                                                              const float* __restrict__ x, int ldx,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ mscale, const float* __restrict__ mshift,
+                                                              int mask, long npix, int C, long rows_per_slab,
+                                                              double* __restrict__ part) {
+    __shared__ double sm[2][16][64 + 1];
+    const int cl = (threadIdx.x & 15) * 4;
+    const int c = blockIdx.x * 64 + cl;
+    const int rl = threadIdx.x >> 4;
+    const long r0 = (long)blockIdx.y * rows_per_slab;
+    const long r1 = min(r0 + rows_per_slab, npix);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c < C) {
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, ms[4] = {0.f, 0.f, 0.f, 0.f}, mh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (x) { mu[k] = mean[c + k]; rs[k] = rstd[c + k]; }
+            if (mask) { ms[k] = mscale[c + k]; mh[k] = mshift[c + k]; }
+        }
+#pragma unroll 4
+        for (long r = r0 + rl; r < r1; r += 16) {
+            const float4 d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x) xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g = grad_mask(dd[k], fmaf(xx[k], ms[k], mh[k]), mask);
+                s[k] += (double)g;
+                q[k] += (double)g * (double)((xx[k] - mu[k]) * rs[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sm[0][rl][cl + k] = s[k];
+        sm[1][rl][cl + k] = q[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, l = threadIdx.x & 63;
+        const int cc = blockIdx.x * 64 + l;
+        if (cc < C) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += sm[which][k][l];
+            part[((long)blockIdx.y * 2 + which) * C + cc] = t;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void chan_reduce_final(const double* __restrict__ part, int nslab, int C,
                                                          float* __restrict__ s1, float* __restrict__ s2, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sm[2][4][64];
+    const int l = threadIdx.x & 63, k0 = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < nslab; ++k) {
-        s += part[((long)k * 2 + 0) * C + c];
-        q += part[((long)k * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int k = k0; k < nslab; k += 4) {
+            s += part[((long)k * 2 + 0) * C + c];
+            q += part[((long)k * 2 + 1) * C + c];
+        }
+    sm[0][k0][l] = s;
+    sm[1][k0][l] = q;
+    __syncthreads();
+    if (k0 != 0 || c >= C) return;
+    s = sm[0][0][l] + sm[0][1][l] + sm[0][2][l] + sm[0][3][l];
+    q = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
     s1[c] = (accumulate ? s1[c] : 0.f) + (float)s;
     if (s2) s2[c] = (float)q;
 }
@@ -179,7 +235,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const float* __restric
 
 extern "C" size_t emd_chan_reduce_workspace_bytes(long npix, int C) {
     if (npix <= 0 || C <= 0) return 0;
-    return (size_t)slabs(npix) * 2 * C * sizeof(double);
+    return (size_t)emd::reduce_slabs(npix) * 2 * C * sizeof(double);
 }
 
 extern "C" int emd_bn_bwd_reduce_f32(const float* dy, int ldd, const float* x, int ldx, const float* mean,
@@ -189,13 +245,17 @@ extern "C" int emd_bn_bwd_reduce_f32(const float* dy, int ldd, const float* x, i
     EMD_REQUIRE(npix >= 1 && C >= 1 && mask >= 0 && mask <= 2, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: bad argument");
     EMD_REQUIRE(!x || (mean && rstd && s2), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: x needs mean, rstd and s2");
     EMD_REQUIRE(!mask || (x && mscale && mshift), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: a mask needs x, mscale, mshift");
-    const long ns = slabs(npix);
-    const long rps = (npix + ns - 1) / ns;
+    const long ns = emd::reduce_slabs(npix), rps = emd::reduce_rows_per_slab(npix);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(chan_reduce_partial, dim3((C + 63) / 64, (unsigned)ns), dim3(256), 0, st, dy, ldd, x, ldx, mean,
-                       rstd, mscale, mshift, mask, npix, C, rps, static_cast<double*>(workspace));
-    hipLaunchKernelGGL(chan_reduce_final, dim3((C + 255) / 256), dim3(256), 0, st, static_cast<const double*>(workspace),
-                       (int)ns, C, s1, x ? s2 : nullptr, accumulate_s1);
+    double* ws = static_cast<double*>(workspace);
+    if (C % 4 == 0 && ldd % 4 == 0 && (!x || ldx % 4 == 0) && emd::aligned16(dy) && (!x || emd::aligned16(x)))
+        hipLaunchKernelGGL(chan_reduce_partial_v4, dim3((C + 63) / 64, (unsigned)ns), dim3(256), 0, st, dy, ldd, x, ldx, mean,
+                           rstd, mscale, mshift, mask, npix, C, rps, ws);
+    else
+        hipLaunchKernelGGL(chan_reduce_partial, dim3((C + 63) / 64, (unsigned)ns), dim3(256), 0, st, dy, ldd, x, ldx, mean,
+                           rstd, mscale, mshift, mask, npix, C, rps, ws);
+    hipLaunchKernelGGL(chan_reduce_final, dim3((C + 63) / 64), dim3(256), 0, st, static_cast<const double*>(ws), (int)ns, C, s1,
+                       x ? s2 : nullptr, accumulate_s1);
     return emd::check_launch("chan_reduce");
 }
 

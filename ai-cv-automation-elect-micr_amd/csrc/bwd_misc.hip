@@ -260,8 +260,8 @@ int launch_wgrad(const float* x, int ldx, const float* dy, int ldd, float* dw, i
                  int rate, hipStream_t st) {
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const long npix = (long)B * Ho * Wo;
-    long nslab = (npix + 2047) / 2048;
-    if (nslab > 4096) nslab = 4096;
+    long nslab = (npix + 255) / 256;  // >= 16 pixels per pixel lane; few enough slabs to keep the atomics cheap
+    if (nslab > 512) nslab = 512;
     const long pps = (npix + nslab - 1) / nslab;
     hipLaunchKernelGGL(dw_wgrad_kernel<SCALAR>, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, dy, ldd, dw,
                        H, W, Ho, Wo, C, stride, rate, same_pad_before(H, stride, rate), same_pad_before(W, stride, rate), npix,

@@ -339,15 +339,61 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     }
 }
 
+// The same for C % 4 == 0: 16 channel quads x 16 row lanes per workgroup, 16-byte loads, 4 rows in flight per thread.
+__global__ __launch_bounds__(256) void bn_stats_partial_v4(const float* __restrict__ x, int ldx, long npix, int C,
+                                                           long rows_per_slab, double* __restrict__ part) {
+    __shared__ double sm[2][16][64 + 1];
+    const int cl = (threadIdx.x & 15) * 4;
+    const int c = blockIdx.x * 64 + cl;
+    const int rl = threadIdx.x >> 4;
+    const long r0 = (long)blockIdx.y * rows_per_slab;
+    const long r1 = min(r0 + rows_per_slab, npix);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c < C) {
+        const float* xp = x + c;
+#pragma unroll 4
+        for (long r = r0 + rl; r < r1; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + r * ldx);
+            const double d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
+            s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
+            q[0] += d0 * d0; q[1] += d1 * d1; q[2] += d2 * d2; q[3] += d3 * d3;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sm[0][rl][cl + k] = s[k];
+        sm[1][rl][cl + k] = q[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, l = threadIdx.x & 63;
+        const int cc = blockIdx.x * 64 + l;
+        if (cc < C) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += sm[which][k][l];
+            part[((long)blockIdx.y * 2 + which) * C + cc] = t;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_stats_final(const double* __restrict__ part, int nslab, int C, long npix,
                                                       float* __restrict__ mean, float* __restrict__ var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sm[2][4][64];
+    const int l = threadIdx.x & 63, k0 = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < nslab; ++k) {
-        s += part[((long)k * 2 + 0) * C + c];
-        q += part[((long)k * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int k = k0; k < nslab; k += 4) {
+            s += part[((long)k * 2 + 0) * C + c];
+            q += part[((long)k * 2 + 1) * C + c];
+        }
+    sm[0][k0][l] = s;
+    sm[1][k0][l] = q;
+    __syncthreads();
+    if (k0 != 0 || c >= C) return;
+    s = sm[0][0][l] + sm[0][1][l] + sm[0][2][l] + sm[0][3][l];
+    q = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
     const double m = s / (double)npix;
     double v = q / (double)npix - m * m;
     mean[c] = (float)m;
@@ -546,9 +592,7 @@ extern "C" int emd_affine_relu6_f32(const float* x, int ldx, const float* scale,
 
 extern "C" size_t emd_bn_stats_workspace_bytes(long npix, int C) {
     if (npix <= 0 || C <= 0) return 0;
-    long nslab = (npix + 4095) / 4096;
-    if (nslab > 1024) nslab = 1024;
-    return (size_t)nslab * 2 * C * sizeof(double);
+    return (size_t)emd::reduce_slabs(npix) * 2 * C * sizeof(double);
 }
 
 extern "C" int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float* mean, float* var, void* workspace,
@@ -556,14 +600,17 @@ extern "C" int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float
     EMD_REQUIRE(x && mean && var && workspace, EMD_E_INVALID, "emd_bn_stats_f32: null pointer");
     EMD_REQUIRE(npix >= 1 && C >= 1 && ldx >= C, EMD_E_INVALID, "emd_bn_stats_f32: bad shape");
     EMD_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EMD_E_ALIGN, "emd_bn_stats_f32: workspace alignment");
-    long nslab = (npix + 4095) / 4096;
-    if (nslab > 1024) nslab = 1024;
-    const long rows_per_slab = (npix + nslab - 1) / nslab;
+    const long nslab = emd::reduce_slabs(npix), rows_per_slab = emd::reduce_rows_per_slab(npix);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(bn_stats_partial, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, npix, C,
-                       rows_per_slab, static_cast<double*>(workspace));
-    hipLaunchKernelGGL(bn_stats_final, dim3((C + 255) / 256), dim3(256), 0, st, static_cast<const double*>(workspace),
-                       (int)nslab, C, npix, mean, var);
+    double* ws = static_cast<double*>(workspace);
+    if (C % 4 == 0 && ldx % 4 == 0 && emd::aligned16(x))
+        hipLaunchKernelGGL(bn_stats_partial_v4, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, npix, C,
+                           rows_per_slab, ws);
+    else
+        hipLaunchKernelGGL(bn_stats_partial, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, npix, C,
+                           rows_per_slab, ws);
+    hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
+                       npix, mean, var);
     return emd::check_launch("bn_stats");
 }
 

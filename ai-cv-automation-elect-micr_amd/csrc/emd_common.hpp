@@ -33,6 +33,18 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 constexpr int kWave = 64;  // CDNA4 wavefront
 
+// Per-channel reductions over [npix, C] (batch statistics, batch-norm backward sums) run as "slabs" of rows, one
+// workgroup per (64 channels, slab), combined by a second small kernel.  At most 512 slabs, at least 64 rows each:
+// small maps (a 32x32 tower) still spread over tens of workgroups, large ones give every thread a few hundred rows.
+inline long reduce_rows_per_slab(long npix) {
+    long r = (npix + 511) / 512;
+    return r < 64 ? 64 : r;
+}
+inline long reduce_slabs(long npix) {
+    const long r = reduce_rows_per_slab(npix);
+    return (npix + r - 1) / r;
+}
+
 }  // namespace emd
 
 #define EMD_REQUIRE(cond, code, msg)          \

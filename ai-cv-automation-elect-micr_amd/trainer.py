@@ -34,6 +34,22 @@ def _is_moving(name):
     return name.endswith(("/moving_mean", "/moving_variance"))
 
 
+def sync_gradients(grads, moving, group=None):
+    """The step's only exchange (replaces the host-side gradient shuffle of denoiser-multi-gpu.py:1177-1196): SUM the
+    flat gradient vector over all ranks (RCCL all-reduce over xGMI; gloo in the CPU tests) and let the moving
+    statistics follow rank 0's first tower (:701-707).  Returns the world size (1 if torch.distributed is not
+    initialised); the caller divides by the total number of gradient sets (:1040)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(grads, group=group)
+        dist.broadcast(moving, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return world
+
+
 class DenoiserTrainer:
     """Parameters, gradients and momentum of graph D' resident on one GPU + the forward/backward launch sequence."""
 
@@ -488,7 +504,6 @@ class DenoiserTrainer:
         images form a tower (gradient set); all sets of all ranks are averaged (:1040) and applied with Nesterov
         momentum (:1064-1066).  Returns the device tensor [n_towers_local, 3] of (mse, loss, factor)."""
         import torch
-        import torch.distributed as dist
 
         B = lq.shape[0]
         assert B % tower_batch == 0
@@ -500,12 +515,7 @@ class DenoiserTrainer:
             _, res = self.tower(lq[sl].contiguous(), truth[sl].contiguous(), update_moving=(k == 0))
             results.append(res)
         self._unpad_grads()
-        world = 1
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(group)
-            if world > 1:
-                dist.all_reduce(self.grads, group=group)      # RCCL sum over xGMI: the step's only exchange
-                dist.broadcast(self.moving, src=0, group=group)  # moving statistics follow tower 0 (:701-707)
+        world = sync_gradients(self.grads, self.moving, group)
         TO.nesterov_step(self.params, self.grads, self.accum, self.lr if learning_rate is None else learning_rate,
                          self.momentum, grad_scale=1.0 / (n_local * world))
         self.repack()

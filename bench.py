@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- megapixels/s restored on synthetic 512x512x1 micrograph batches (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload K|D|both] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload K|D|X|T|both|all] [--batch B]
 
 A "step" is one pass of the hot path over one batch that is already resident in HBM.
 Workloads:
@@ -10,6 +10,10 @@ Workloads:
   D  BASELINE configs[2]: the modified-Xception encoder-decoder of machine_learning/denoiser.py on
      [32,512,512,1] (matrix cores in split-bf16 parity mode unless --precision bf16).
   X  the other graph BASELINE configs[2] can mean: misc_py/modified_Xception.py at 512x512.
+  T  BASELINE configs[3]: graph D' TRAINING (misc_py/denoiser-multi-gpu.py): --train-batch LQ/HQ pairs per GPU per
+     step (default 8 = bs 64 over 8 GPUs), towers of --tower-batch images (default 1, the reference), one RCCL
+     all-reduce of the flat gradient vector per step, Nesterov step.  Rides along as "workload_T"; --workload T
+     makes it the primary line (metric "megapixels/sec trained").
 Default ("all"): the JSON line's metric/value/roofline/cpu_baseline are workload K's; workload D's and X's
 figures ride along under "workload_D" / "workload_X".  --workload D makes D the primary line.
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); inference shards whole images
@@ -340,15 +344,65 @@ def bench_X(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     return out
 
 
+def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
+    """BASELINE configs[3]: graph D' TRAINING (misc_py/denoiser-multi-gpu.py): data-parallel steps of `--train-batch`
+    512x512 LQ/HQ pairs per GPU (bs=64 over 8 GPUs => 8 per GPU), towers of `--tower-batch` images (1 = the
+    reference, :763), gradients averaged over all towers and ranks (one RCCL all-reduce of the flat gradient vector),
+    Nesterov momentum step, weights re-packed on the device."""
+    from emdenoise import denoiser as D, trainer as TR
+
+    B, S, tb = a.train_batch, a.size, a.tower_batch
+    steps = a.steps if (a.steps is not None and a.workload == "T") else 3
+    warmup = a.warmup if (a.warmup is not None and a.workload == "T") else 1
+    rng = np.random.default_rng(4321 + rank)
+    hq = synthetic_lq(B, S, S, seed=99 + rank)          # smooth synthetic micrographs as the clean images
+    lq = np.clip(hq + rng.normal(0.0, 0.1, hq.shape).astype(np.float32), 0.0, 1.0)
+    weights = D.synthetic_weights(variant="Dprime")
+    tr = TR.DenoiserTrainer(weights, dev, a.precision)
+    x, t = torch.from_numpy(lq).to(dev), torch.from_numpy(hq).to(dev)
+    box = [None]
+
+    def step():
+        box[0] = tr.train_step(x, t, tower_batch=tb)
+
+    ms = timer.run(step, steps, warmup)
+    tflop = 3 * 5.38 / 32.0 * B * (S * S) / (512.0 * 512.0)   # forward + data gradient + weight gradient
+    out = {"value": round(B * S * S / 1e6 * world / (ms / 1e3), 2), "unit": "MPx/s trained", "ms_per_step": round(ms, 3),
+           "steps": steps, "warmup": warmup, "dtype": "bf16x3 GEMMs (split-bf16 MFMA inputs, fp32 accumulate), fp32 elsewhere",
+           "config": {"workload": f"T: graph D' training step (misc_py/denoiser-multi-gpu.py), [{B},{S},{S},1] fp32 LQ/HQ pairs per GPU, "
+                                  f"towers of {tb}, Nesterov momentum 0.9, lr 1e-3",
+                      "global_batch": B * world, "tower_batch": tb, "precision": a.precision, "parallelism": f"dp{world}",
+                      "algorithmic_tflop_per_step_per_gpu": round(tflop, 3)},
+           "tflops_algorithmic": round(tflop / (ms / 1e3), 1),
+           "loss_first_tower": float(box[0][0, 1].item())}
+    out["roofline"] = {"bound": "mfma", "kernel": "whole step (gemm_conv + conv_wgrad dominate)", "achieved": out["tflops_algorithmic"],
+                       "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(out["tflops_algorithmic"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
+    if want_cpu:
+        from oracle import denoiser_graph as G
+
+        torch.set_num_threads(CPU_THREADS)
+        t0 = time.perf_counter()
+        G.tower_gradients(lq[:1], hq[:1], weights, S, dtype=torch.float64)
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s trained", "cores": CPU_THREADS, "kind": "port",
+                               "sample": f"forward + backward of ONE tower of 1 image ([1,{S},{S},1]), oracle/denoiser_graph.py "
+                                         f"tower_gradients (PyTorch-CPU autograd, float64, {CPU_THREADS} threads), {el:.1f} s; "
+                                         "optimizer step not included"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["K", "D", "X", "both", "all"], default="all",
+    ap.add_argument("--workload", choices=["K", "D", "X", "T", "both", "all"], default="all",
                     help="K and D: see the module docstring; X: misc_py/modified_Xception.py; all (default) = K primary, D and X alongside")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--train-batch", type=int, default=8, help="workload T: LQ/HQ pairs per GPU per step (bs=64 over 8 GPUs)")
+    ap.add_argument("--tower-batch", type=int, default=1, help="workload T: images per tower (batch-norm statistics are per tower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3",
                     help="workload D matrix-core mode: bf16x3 = split-bf16 parity mode (default), bf16 = fast mode")
@@ -396,7 +450,18 @@ def main():
                 raise
             res_D = {"error": f"{type(e).__name__}: {e}"}
 
+    res_T = None
+    if a.workload in ("T", "all"):
+        try:
+            res_T = bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist)
+        except Exception as e:
+            if a.workload == "T":
+                raise
+            res_T = {"error": f"{type(e).__name__}: {e}"}
+
     prim = res_D if primary_is_D else res_K
+    if prim is None and a.workload == "T":
+        prim, res_T = res_T, None
     if prim is None:  # --workload X alone
         prim = dict(res_X)
         prim.setdefault("dtype", "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)")
@@ -405,9 +470,9 @@ def main():
                                      "frac": round((prim.get("tflops_algorithmic") or 0.0) / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None})
         res_X = None
     out = {
-        "metric": "megapixels/sec restored (512x512x1 bs=32)",
+        "metric": "megapixels/sec trained (512x512x1 LQ/HQ pairs)" if a.workload == "T" else "megapixels/sec restored (512x512x1 bs=32)",
         "value": round(prim["value"], 1),
-        "unit": "MPx/s",
+        "unit": prim.get("unit", "MPx/s"),
         "n_gpus": world,
         "steps": prim["steps"],
         "warmup": prim["warmup"],
@@ -420,7 +485,7 @@ def main():
         "config": prim["config"],
         "roofline": prim["roofline"],
     }
-    for k in ("cpu_baseline", "rel_l2_vs_oracle", "depthwise", "kernel_family_ms"):
+    for k in ("cpu_baseline", "rel_l2_vs_oracle", "depthwise", "kernel_family_ms", "tflops_algorithmic", "loss_first_tower"):
         if k in prim:
             out[k] = prim[k]
     if not primary_is_D and res_D is not None:
@@ -431,6 +496,8 @@ def main():
         out["workload_D"] = res_D
     if res_X is not None:
         out["workload_X"] = res_X
+    if res_T is not None:
+        out["workload_T"] = res_T
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -98,3 +98,51 @@ def test_world_size_2_over_gloo():
     batch = np.arange(20, dtype=np.float32).reshape(5, 2, 2, 1)
     assert np.isclose(sum(s_ for _, _, s_ in idx), 2.0 * batch.sum())    # every image processed exactly once
     assert step == 2.0
+
+
+def _train_sync_worker(rank, world, port, q):
+    """The collective step of DenoiserTrainer.train_step on CPU tensors over gloo: gradient vectors are summed over
+    ranks, moving statistics follow rank 0, and averaging over all gradient sets reproduces the single-process mean."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emdenoise import trainer as TR
+
+    n_local = 3                                        # towers per rank
+    sets = [torch.arange(10, dtype=torch.float32) * (1 + rank * n_local + k) for k in range(n_local)]
+    grads = torch.stack(sets).sum(0)                   # towers accumulate into one flat vector
+    moving = torch.full((4,), float(rank + 1))
+    w = TR.sync_gradients(grads, moving)
+    mean = grads / (n_local * w)
+    out = [None] * world
+    dist.all_gather_object(out, (w, mean.tolist(), moving.tolist()))
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_gradient_exchange_over_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = (np.arange(10) * np.mean(np.arange(1, 7))).tolist()   # mean over the 6 gradient sets of both ranks
+    for w, mean, moving in out:
+        assert w == 2 and np.allclose(mean, expect) and moving == [1.0] * 4
+
+
+def test_sync_gradients_without_process_group_is_identity():
+    from emdenoise import trainer as TR
+
+    g, m = torch.ones(5), torch.zeros(3)
+    assert TR.sync_gradients(g, m) == 1 and g.tolist() == [1.0] * 5

@@ -1,7 +1,7 @@
 """Per-variable gradient comparison: DenoiserTrainer.tower (GPU) vs the oracle's autograd (CPU float64)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import emdenoise
 from emdenoise import denoiser as D, trainer as TR
 from oracle import denoiser_graph as G

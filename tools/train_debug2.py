@@ -1,7 +1,7 @@
 """Teacher-forced per-step comparison: oracle gradients evaluated at the trainer's own parameters."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import emdenoise
 from emdenoise import trainer as TR
 from oracle import denoiser_graph as G
