@@ -126,40 +126,55 @@ __global__ __launch_bounds__(256) void chan_reduce_final(const double* __restric
     if (k0 != 0 || c >= C) return;
     s = sm[0][0][l] + sm[0][1][l] + sm[0][2][l] + sm[0][3][l];
     q = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
-    s1[c] = (accumulate ? s1[c] : 0.f) + (float)s;
+    if (accumulate) atomicAdd(s1 + c, (float)s);  // bias gradients: towers on different streams add concurrently
+    else s1[c] = (float)s;
     if (s2) s2[c] = (float)q;
 }
 
 // dx = K * ( g - m1 - (x-mean)*m2 ),  g = dy * mask(x*mscale + mshift); dx may alias dy (elementwise).
+// V = 4: a thread keeps the six per-channel vectors of its channel quad in registers and walks ROWS rows with them.
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int ldd, const float* __restrict__ x, int ldx,
                                                            const float* __restrict__ K, const float* __restrict__ m1,
                                                            const float* __restrict__ mean, const float* __restrict__ m2,
                                                            const float* __restrict__ mscale, const float* __restrict__ mshift,
                                                            int mask, float* dx, int ldo, long npix, int CV) {
+    constexpr int ROWS = V == 4 ? 8 : 1;
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (tid >= npix * CV) return;
+    const long ngroups = (npix + ROWS - 1) / ROWS;
+    if (tid >= ngroups * CV) return;
     const int c = (int)(tid % CV) * V;
-    const long r = tid / CV;
-    float dd[V], xx[V], o[V];
-    if constexpr (V == 4) {
-        const float4 d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
-        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
-        dd[0] = d.x; dd[1] = d.y; dd[2] = d.z; dd[3] = d.w;
-        xx[0] = xv.x; xx[1] = xv.y; xx[2] = xv.z; xx[3] = xv.w;
-    } else {
-        dd[0] = dy[r * ldd + c];
-        xx[0] = x[r * ldx + c];
-    }
+    const long r0 = (tid / CV) * ROWS;
+    float kk[V], mm1[V], mu[V], mm2[V], ms[V], mh[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-        const float g = grad_mask(dd[k], fmaf(xx[k], mask ? mscale[c + k] : 0.f, mask ? mshift[c + k] : 0.f), mask);
-        o[k] = K[c + k] * (g - m1[c + k] - (xx[k] - mean[c + k]) * m2[c + k]);
+        kk[k] = K[c + k]; mm1[k] = m1[c + k]; mu[k] = mean[c + k]; mm2[k] = m2[c + k];
+        ms[k] = mask ? mscale[c + k] : 0.f; mh[k] = mask ? mshift[c + k] : 0.f;
     }
-    if constexpr (V == 4)
-        *reinterpret_cast<float4*>(dx + r * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
-    else
-        dx[r * ldo + c] = o[0];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const long r = r0 + i;
+        if (r >= npix) break;
+        float dd[V], xx[V], o[V];
+        if constexpr (V == 4) {
+            const float4 d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            dd[0] = d.x; dd[1] = d.y; dd[2] = d.z; dd[3] = d.w;
+            xx[0] = xv.x; xx[1] = xv.y; xx[2] = xv.z; xx[3] = xv.w;
+        } else {
+            dd[0] = dy[r * ldd + c];
+            xx[0] = x[r * ldx + c];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float g = grad_mask(dd[k], fmaf(xx[k], ms[k], mh[k]), mask);
+            o[k] = kk[k] * (g - mm1[k] - (xx[k] - mu[k]) * mm2[k]);
+        }
+        if constexpr (V == 4)
+            *reinterpret_cast<float4*>(dx + r * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+        else
+            dx[r * ldo + c] = o[0];
+    }
 }
 
 // Forward fold for training: batch statistics -> the affine of the whole BN chain, what backward needs, and the
@@ -215,19 +230,19 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const float* __restric
     if (c >= C) return;
     const float r1 = rstd1[c], tv = t[c], sv = s1[c];
     m1[c] = sv * inv_n;
-    dbeta2[c] += sv;
+    atomicAdd(dbeta2 + c, sv);  // parameter gradients: towers on different streams add concurrently
     if (gamma1) {
         const float g1 = gamma1[c], g2 = gamma2[c], r2 = rstd2[c];
         const float a = g1 * r2;
         const float e2 = eps * r2 * r2;
         K[c] = g1 * g2 * r1 * r2;
         m2[c] = r1 * tv * inv_n * (a * a + e2);
-        dgamma2[c] += a * tv;
-        dgamma1[c] += g2 * r2 * e2 * tv;
+        atomicAdd(dgamma2 + c, a * tv);
+        atomicAdd(dgamma1 + c, g2 * r2 * e2 * tv);
     } else {
         K[c] = gamma2[c] * r1;
         m2[c] = r1 * tv * inv_n;
-        dgamma2[c] += tv;
+        atomicAdd(dgamma2 + c, tv);
     }
 }
 
@@ -268,7 +283,7 @@ extern "C" int emd_bn_bwd_apply_f32(const float* dy, int ldd, const float* x, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (C % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && emd::aligned16(dy) && emd::aligned16(x) &&
         emd::aligned16(dx)) {
-        const long n = npix * (C / 4);
+        const long n = ((npix + 7) / 8) * (C / 4);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, ldd, x, ldx, K,
                            m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C / 4);
     } else {

@@ -260,7 +260,7 @@ int launch_wgrad(const float* x, int ldx, const float* dy, int ldd, float* dw, i
                  int rate, hipStream_t st) {
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const long npix = (long)B * Ho * Wo;
-    long nslab = (npix + 255) / 256;  // >= 16 pixels per pixel lane; few enough slabs to keep the atomics cheap
+    long nslab = (npix + 63) / 64;  // >= 4 pixels per pixel lane; few enough slabs to keep the atomics cheap
     if (nslab > 512) nslab = 512;
     const long pps = (npix + nslab - 1) / nslab;
     hipLaunchKernelGGL(dw_wgrad_kernel<SCALAR>, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, dy, ldd, dw,

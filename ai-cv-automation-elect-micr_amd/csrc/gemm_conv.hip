@@ -309,6 +309,10 @@ int launch(const GemmParams& p0, int passes, hipStream_t st) {
 
 int dispatch(const GemmParams& p, int passes, hipStream_t st) {
     if (p.N <= 64) return launch<64>(p, passes, st);
+    // a grid that cannot even give every CU one 128x128 tile (a single 32x32 training tower: 8 x 6 tiles) runs as
+    // 128x64 tiles: twice the workgroups, each latency-bound pass over K shorter
+    const long tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (tiles128 < 192) return launch<64>(p, passes, st);
     return launch<128>(p, passes, st);
 }
 

@@ -5,7 +5,7 @@
 //   emd_pack_weights_dev      fp32 weights on the device -> bf16 hi/lo planes, either orientation, any tap subset
 // (bn_train.hip: training-mode batch norm forward fold / backward; bwd_misc.hip: depthwise, resize, pooling,
 // 1-channel conv backward, the loss and the optimizer step.)
-// Numerics: fp32 VALU, fp32 accumulation per block, float atomics across blocks.
+// Numerics: split-bf16 MFMA (~2^-16 relative) or fp32 VALU per block, fp32 accumulation, float atomics across blocks.
 #include "mfma_common.hpp"
 
 using namespace emd;
@@ -92,6 +92,163 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same weight gradient on the matrix cores (the default path; the VALU kernel above remains for K or N < 32,
+// where a 128x128 tile would be nearly empty).  dW[k][n] = sum_m A[m][k] * dY[m][n]: the CONTRACTION runs over
+// pixels, which is the strided direction of both NHWC operands, while an MFMA fragment wants 8 consecutive
+// contraction elements per lane.  So every 64-pixel chunk of A (128 channels) and dY (128 channels) is split into
+// bf16 hi/lo and TRANSPOSED on its way into LDS (planes [channel][pixel], one ds_write_b64 = 4 pixels of one
+// channel), after which the k-loop is the forward GEMM's: ds_read_b128 fragments, three
+// mfma_f32_32x32x16_bf16 per fragment pair (lo*hi + hi*lo + hi*hi), fp32 accumulators.  Block = 4 waves, each a
+// 64x64 sub-tile; the next chunk's 16 global loads per thread are in flight during the MFMA phase.  The M range is
+// split over blockIdx.z and combined with float atomics, as above.
+template <int UA, int UD>  // tile = 64*UA channels of A x 64*UD channels of dY
+__global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(const WgradParams p) {
+    constexpr int TK = 64 * UA, TN = 64 * UD, MC = 64;
+    constexpr int LDM = MC + 8;  // bf16 elements per LDS row (144 B): conflict-free ds_read_b128 fragments
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[TK][LDM], Al[TK][LDM], Dh[TN][LDM], Dl[TN][LDM];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wk = wv >> 1, wn = wv & 1;   // 2 x 2 waves, each (32*UA) x (32*UD)
+    const int fr = lane & 31, fh = lane >> 5;
+    // XCD-aware block order: workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  All (k,n)
+    // tiles of one (tap, M-slice) read the same A and dY rows, so they are given ids that land on ONE XCD and are
+    // dispatched together: the slice is fetched into that L2 once instead of once per tile.
+    const int ntile = gridDim.x * gridDim.y, nblk = ntile * gridDim.z;
+    int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile = bid % ntile, zz = bid / ntile;
+    const int k0 = (tile % gridDim.x) * TK, n0 = (tile / gridDim.x) * TN;
+    const int tap = zz / p.msplit, split = zz % p.msplit;
+    const int M = (int)p.M;  // the host guarantees M < 2^31: pixel indices are 32-bit, byte offsets 64-bit
+    const int mper = ((M + p.msplit - 1) / p.msplit + MC - 1) / MC * MC;
+    const int mbeg = split * mper, mend = mbeg + mper < M ? mbeg + mper : M;
+    const int dyo = (int)((p.dyp >> (7 * tap)) & 127) - 64, dxo = (int)((p.dxp >> (7 * tap)) & 127) - 64;
+    // loader: 4 consecutive pixels (pixel quad pq) x channel quads cq (and cq+16 when the tile is 128 wide).
+    // Channel quads beyond K / N are read from a clamped (in-bounds) address and left as they come: they only feed
+    // rows / columns of the tile that are never written out.  A chunk whose 64 pixels are all real and ungathered
+    // takes the straight-line path (back-to-back loads); chunk tails and tap-shifted / strided reads are masked.
+    const int pq = tid & 15, cq = tid >> 4;
+    int ca[UA], cd[UD];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) ca[u] = (k0 + 4 * cq + 64 * u < p.K) ? k0 + 4 * cq + 64 * u : 0;
+#pragma unroll
+    for (int u = 0; u < UD; ++u) cd[u] = (n0 + 4 * cq + 64 * u < p.N) ? n0 + 4 * cq + 64 * u : 0;
+
+    f32x16 acc[UA][UD];
+#pragma unroll
+    for (int i = 0; i < UA; ++i)
+#pragma unroll
+        for (int j = 0; j < UD; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[UA][4], rd[UD][4];  // staging registers: [channel quad][pixel]
+    auto load_chunk = [&](int mc) {
+        if (p.flat && mc + MC <= mend) {
+            const float* ap = p.A + (long)(mc + 4 * pq) * p.lda;
+            const float* dp = p.dY + (long)(mc + 4 * pq) * p.ldd;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int u = 0; u < UA; ++u) ra[u][j] = *reinterpret_cast<const f32x4*>(ap + (long)j * p.lda + ca[u]);
+#pragma unroll
+                for (int u = 0; u < UD; ++u) rd[u][j] = *reinterpret_cast<const f32x4*>(dp + (long)j * p.ldd + cd[u]);
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mc + 4 * pq + j;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < UA; ++u) ra[u][j] = z;
+#pragma unroll
+            for (int u = 0; u < UD; ++u) rd[u][j] = z;
+            if (m < mend) {
+                long src = m;
+                if (!p.flat) {
+                    const unsigned um = (unsigned)m, jx = um % (unsigned)p.Wg, t = um / (unsigned)p.Wg;
+                    const int iy = (int)(t % (unsigned)p.Hg) * p.sa + dyo, ix = (int)jx * p.sa + dxo;
+                    src = (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa)
+                              ? ((long)(t / (unsigned)p.Hg) * p.Ha + iy) * (long)p.Wa + ix : -1;
+                }
+                if (src >= 0) {
+                    const float* ap = p.A + src * p.lda;
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) ra[u][j] = *reinterpret_cast<const f32x4*>(ap + ca[u]);
+                }
+                const float* dp = p.dY + (long)m * p.ldd;
+#pragma unroll
+                for (int u = 0; u < UD; ++u) rd[u][j] = *reinterpret_cast<const f32x4*>(dp + cd[u]);
+            }
+        }
+    };
+    // 4 pixels of one channel -> 4 bf16 hi + 4 bf16 lo, one ds_write_b64 each
+    auto store_unit = [&](uint16_t(*H)[LDM], uint16_t(*L)[LDM], int row, const f32x4* r) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned h01, l01, h23, l23;
+            split2(r[0][c], r[1][c], h01, l01);
+            split2(r[2][c], r[3][c], h23, l23);
+            const u32x2 hv = {h01, h23}, lv = {l01, l23};
+            *reinterpret_cast<u32x2*>(&H[row + c][4 * pq]) = hv;
+            *reinterpret_cast<u32x2*>(&L[row + c][4 * pq]) = lv;
+        }
+    };
+
+    if (mbeg < mend) load_chunk(mbeg);
+    for (int mc = mbeg; mc < mend; mc += MC) {
+        __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+        for (int u = 0; u < UA; ++u) store_unit(Ah, Al, 4 * cq + 64 * u, ra[u]);
+#pragma unroll
+        for (int u = 0; u < UD; ++u) store_unit(Dh, Dl, 4 * cq + 64 * u, rd[u]);
+        __syncthreads();
+        if (mc + MC < mend) load_chunk(mc + MC);  // in flight during the MFMA phase
+#pragma unroll
+        for (int ks = 0; ks < MC / 16; ++ks) {
+            bf16x8 ah[UA], al[UA], bh[UD], bl[UD];
+#pragma unroll
+            for (int i = 0; i < UA; ++i) {
+                const int r = wk * 32 * UA + i * 32 + fr;
+                ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[r][ks * 16 + fh * 8]);
+                al[i] = *reinterpret_cast<const bf16x8*>(&Al[r][ks * 16 + fh * 8]);
+            }
+#pragma unroll
+            for (int j = 0; j < UD; ++j) {
+                const int r = wn * 32 * UD + j * 32 + fr;
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Dh[r][ks * 16 + fh * 8]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&Dl[r][ks * 16 + fh * 8]);
+            }
+#pragma unroll
+            for (int i = 0; i < UA; ++i)
+#pragma unroll
+                for (int j = 0; j < UD; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // C/D layout of mfma_32x32: col (N index) = lane & 31, row (K index) = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    float* out = p.dW + (long)tap * p.K * p.N;
+#pragma unroll
+    for (int i = 0; i < UA; ++i)
+#pragma unroll
+        for (int j = 0; j < UD; ++j) {
+            const int n = n0 + wn * 32 * UD + j * 32 + fr;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wk * 32 * UA + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (k < p.K) atomicAdd(out + (long)k * p.N + n, acc[i][j][e]);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32 weights on the DEVICE, [src_taps][Cin][Cout] (cout_major = 0) or [src_taps][Cout][Cin] (cout_major = 1)
 // -> packed bf16 hi/lo planes [Npad][ntaps][Cpad] (the layout of emd_pack_weights_bf16).  Packed tap t comes from
 // source tap (sel >> 4t) & 15, so one kernel serves the forward pack, the flipped pack of the data gradient
@@ -139,13 +296,25 @@ extern "C" int emd_conv_wgrad_f32(const float* a, int lda, const float* dy, int 
         p.dyp |= (unsigned long long)(dyv + 64) << (7 * t);
         p.dxp |= (unsigned long long)(dxv + 64) << (7 * t);
     }
-    const int kt = (K + 63) / 64, nt = (N + 63) / 64;
-    long want = 2048 / ((long)kt * nt * ntaps);  // enough workgroups to fill the chip a few times
+    const bool mfma = K >= 32 && N >= 32;
+    EMD_REQUIRE(p.M < (1L << 31), EMD_E_UNSUPPORTED, "emd_conv_wgrad_f32: more than 2^31 pixels");
+    const int tk = mfma ? (K > 64 ? 128 : 64) : 64, tn = mfma ? (N > 64 ? 128 : 64) : 64;
+    const int kt = (K + tk - 1) / tk, nt = (N + tn - 1) / tn;
+    long want = (mfma ? 1024 : 2048) / ((long)kt * nt * ntaps);  // enough workgroups to fill the chip a few times
     if (want < 1) want = 1;
-    const long maxsplit = (p.M + 2047) / 2048;
+    const long maxsplit = (p.M + (mfma ? 511 : 2047)) / (mfma ? 512 : 2048);
     p.msplit = (int)(want < maxsplit ? want : maxsplit);
     if (p.msplit < 1) p.msplit = 1;
     EMD_REQUIRE((long)ntaps * p.msplit <= 65535, EMD_E_UNSUPPORTED, "emd_conv_wgrad_f32: grid too large");
+    if (mfma) {
+        const dim3 grid(kt, nt, ntaps * p.msplit);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (tk == 128 && tn == 128) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<2, 2>), grid, dim3(256), 0, st, p);
+        else if (tk == 128) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<2, 1>), grid, dim3(256), 0, st, p);
+        else if (tn == 128) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 1>), grid, dim3(256), 0, st, p);
+        return emd::check_launch("conv_wgrad_mfma_kernel");
+    }
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(kt, nt, ntaps * p.msplit), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return emd::check_launch("conv_wgrad_kernel");
 }

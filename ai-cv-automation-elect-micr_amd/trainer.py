@@ -108,7 +108,9 @@ class DenoiserTrainer:
             elif L.kind == "deconv":
                 self.pk_f[key] = [TO.DevPackedWeights(len(ops.deconv_phase_taps(ph)), L.cin, L.cout, device) for ph in range(4)]
                 self.pk_b[key] = TO.DevPackedWeights(9, L.cout, L.cin, device)
+        self.pk_b["cnn0"] = TO.DevPackedWeights(1, features0, 4, device)   # d loss / d (depthwise output), 4 padded channels
         self.dw_flip = {}
+        self._streams, self._graphs = [], {}
         self.repack()
         self.last = None
 
@@ -139,7 +141,7 @@ class DenoiserTrainer:
                 taps = w.shape[0]
                 self.pk_f[key].pack(w, taps, cout_major=False)
                 if key in self.pk_b:  # K = Cout, N = Cin: the same array read "cout_major"; taps reversed
-                    self.pk_b[key].pack(w, taps, cout_major=True, tap_sel=list(range(taps))[::-1])
+                    self.pk_b[key].pack(w.contiguous(), taps, cout_major=True, tap_sel=list(range(taps))[::-1])
             elif L.kind == "deconv":
                 w = self._w(key)
                 for ph in range(4):
@@ -147,7 +149,11 @@ class DenoiserTrainer:
                     self.pk_f[key][ph].pack(w, 9, cout_major=True, tap_sel=sel)
                 self.pk_b[key].pack(w, 9, cout_major=False)
             if L.kind == "sep" and L.stride == 1 and L.cin > 1:
-                self.dw_flip[key] = self._dw(key).flip(0).contiguous()
+                # taps reversed for the stride-1 data gradient; updated IN PLACE (a captured hipGraph keeps the pointer)
+                if key not in self.dw_flip:
+                    self.dw_flip[key] = self._dw(key).flip(0).contiguous()
+                else:
+                    self.dw_flip[key].copy_(self._dw(key).flip(0))
 
     def state_dict(self):
         """TF variable name -> numpy array (parameters and moving statistics)."""
@@ -280,8 +286,7 @@ class DenoiserTrainer:
         x, d = ctx["x"], ctx["d"]
         dr = self._bn_bwd(key, dy, ctx)
         TO.conv_wgrad(d, dr, self._gw(key))
-        dd = ops.conv1x1(dr, self.pk_b[key], self.ones, self.zeros, d, act=False, precision=self.precision) if key in self.pk_b \
-            else self._cin1_dd(dr, d)
+        dd = ops.conv1x1(dr, self.pk_b[key], self.ones, self.zeros, d, act=False, precision=self.precision)
         TO.dw3x3_wgrad(x, dd, self._gdw(key), stride=L.stride, rate=L.rate)
         if not need_dx:
             return
@@ -289,13 +294,6 @@ class DenoiserTrainer:
             self._put(gslot, x, lambda dst: ops.dw3x3(dd, self.dw_flip[key], dst))
         else:
             self._put(gslot, x, lambda dst: TO.dw3x3_bwd_data(dd, self._dw(key), dst, stride=L.stride))
-
-    def _cin1_dd(self, dr, d):
-        """cnn0: d loss / d (depthwise output) over the 4 padded channels = dr . pw4^T (K = 64, N = 4)."""
-        if "cnn0_b" not in self.pk_b:
-            self.pk_b["cnn0_b"] = TO.DevPackedWeights(1, features0, 4, self.device)
-        self.pk_b["cnn0_b"].pack(self.pad_w["cnn0_pw"], 1, cout_major=True)
-        return ops.conv1x1(dr, self.pk_b["cnn0_b"], self.ones, self.zeros, d, act=False, precision=self.precision)
 
     def _conv_bwd(self, key, dy, ctx, gslot, need_dx=True):
         L = self.layers[key]
@@ -499,10 +497,19 @@ class DenoiserTrainer:
         return out, result
 
     # ---- one training step -----------------------------------------------------------------------------------------
-    def train_step(self, lq, truth, tower_batch=1, learning_rate=None, group=None):
-        """One optimizer step on this rank's images (misc_py/denoiser-multi-gpu.py:1169-1206): every ``tower_batch``
-        images form a tower (gradient set); all sets of all ranks are averaged (:1040) and applied with Nesterov
-        momentum (:1064-1066).  Returns the device tensor [n_towers_local, 3] of (mse, loss, factor)."""
+    def _side_streams(self, n):
+        import torch
+
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        return self._streams[:n]
+
+    def local_gradients(self, lq, truth, tower_batch=1, streams=1):
+        """zero_grad + every tower of this rank's images (forward, loss, backward) -> device tensor [n_towers, 3] of
+        (mse, loss, factor); the gradient sets are summed into self.grads.  streams > 1: the towers are independent
+        (they only meet in the atomically accumulated parameter gradients), so they are issued round-robin on that
+        many HIP streams and overlap on the chip -- a single 512x512 tower leaves most of the 256 CUs idle in its
+        32x32 layers."""
         import torch
 
         B = lq.shape[0]
@@ -510,13 +517,67 @@ class DenoiserTrainer:
         n_local = B // tower_batch
         self.zero_grad()
         results = []
+        main = torch.cuda.current_stream()
+        side = self._side_streams(min(streams, n_local)) if streams > 1 else []
+        for s in side:
+            s.wait_stream(main)
         for k in range(n_local):
             sl = slice(k * tower_batch, (k + 1) * tower_batch)
-            _, res = self.tower(lq[sl].contiguous(), truth[sl].contiguous(), update_moving=(k == 0))
+            if side:
+                with torch.cuda.stream(side[k % len(side)]):
+                    _, res = self.tower(lq[sl].contiguous(), truth[sl].contiguous(), update_moving=(k == 0))
+                    res.record_stream(main)
+            else:
+                _, res = self.tower(lq[sl].contiguous(), truth[sl].contiguous(), update_moving=(k == 0))
             results.append(res)
+        for s in side:
+            main.wait_stream(s)
         self._unpad_grads()
-        world = sync_gradients(self.grads, self.moving, group)
-        TO.nesterov_step(self.params, self.grads, self.accum, self.lr if learning_rate is None else learning_rate,
-                         self.momentum, grad_scale=1.0 / (n_local * world))
-        self.repack()
         return torch.stack(results)
+
+    def apply_gradients(self, n_sets, learning_rate=None):
+        """Nesterov step on the summed gradient vector (n_sets = towers x ranks, :1040) + re-pack of the weights."""
+        TO.nesterov_step(self.params, self.grads, self.accum, self.lr if learning_rate is None else learning_rate,
+                         self.momentum, grad_scale=1.0 / n_sets)
+        self.repack()
+
+    def _warm(self):
+        """Launch every kernel family once outside of stream capture (code objects load on first use)."""
+        import torch
+
+        z = torch.zeros((1, 32, 32, 1), dtype=torch.float32, device=self.device)
+        keep = self.grads.clone(), {k: t.clone() for k, t in self.pad_g.items()}
+        self.tower(z, z, update_moving=False)
+        self.grads.copy_(keep[0])
+        for k, t in keep[1].items():
+            self.pad_g[k].copy_(t)
+        torch.cuda.synchronize()
+
+    def train_step(self, lq, truth, tower_batch=1, learning_rate=None, group=None, streams=1, graph=False):
+        """One optimizer step on this rank's images (misc_py/denoiser-multi-gpu.py:1169-1206): every ``tower_batch``
+        images form a tower (gradient set); all sets of all ranks are averaged (:1040) and applied with Nesterov
+        momentum (:1064-1066).  Returns the device tensor [n_towers_local, 3] of (mse, loss, factor).
+        graph=True: the whole local part (all towers on their streams) is captured once per input shape into a
+        hipGraph and replayed -- ~9000 launches per step become one."""
+        import torch
+
+        n_local = lq.shape[0] // tower_batch
+        if not graph:
+            results = self.local_gradients(lq, truth, tower_batch, streams)
+        else:
+            key = (tuple(lq.shape), tower_batch, streams)
+            if key not in self._graphs:
+                self._warm()
+                slq, str_ = torch.empty_like(lq), torch.empty_like(truth)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    sres = self.local_gradients(slq, str_, tower_batch, streams)
+                self._graphs[key] = (g, slq, str_, sres)
+            g, slq, str_, sres = self._graphs[key]
+            slq.copy_(lq)
+            str_.copy_(truth)
+            g.replay()
+            results = sres.clone()
+        world = sync_gradients(self.grads, self.moving, group)
+        self.apply_gradients(n_local * world, learning_rate)
+        return results

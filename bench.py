@@ -363,7 +363,7 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
     box = [None]
 
     def step():
-        box[0] = tr.train_step(x, t, tower_batch=tb)
+        box[0] = tr.train_step(x, t, tower_batch=tb, streams=a.train_streams, graph=not a.no_graph)
 
     ms = timer.run(step, steps, warmup)
     tflop = 3 * 5.38 / 32.0 * B * (S * S) / (512.0 * 512.0)   # forward + data gradient + weight gradient
@@ -371,7 +371,8 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
            "steps": steps, "warmup": warmup, "dtype": "bf16x3 GEMMs (split-bf16 MFMA inputs, fp32 accumulate), fp32 elsewhere",
            "config": {"workload": f"T: graph D' training step (misc_py/denoiser-multi-gpu.py), [{B},{S},{S},1] fp32 LQ/HQ pairs per GPU, "
                                   f"towers of {tb}, Nesterov momentum 0.9, lr 1e-3",
-                      "global_batch": B * world, "tower_batch": tb, "precision": a.precision, "parallelism": f"dp{world}",
+                      "global_batch": B * world, "tower_batch": tb, "streams": a.train_streams, "hip_graph": not a.no_graph,
+                      "precision": a.precision, "parallelism": f"dp{world}",
                       "algorithmic_tflop_per_step_per_gpu": round(tflop, 3)},
            "tflops_algorithmic": round(tflop / (ms / 1e3), 1),
            "loss_first_tower": float(box[0][0, 1].item())}
@@ -403,6 +404,8 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--train-batch", type=int, default=8, help="workload T: LQ/HQ pairs per GPU per step (bs=64 over 8 GPUs)")
     ap.add_argument("--tower-batch", type=int, default=1, help="workload T: images per tower (batch-norm statistics are per tower)")
+    ap.add_argument("--train-streams", type=int, default=8, help="workload T: HIP streams the towers are issued on")
+    ap.add_argument("--no-graph", action="store_true", help="workload T: launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3",
                     help="workload D matrix-core mode: bf16x3 = split-bf16 parity mode (default), bf16 = fast mode")

@@ -204,3 +204,34 @@ def test_train_steps_reference_regime_teacher_forced():
         assert rel_l2(flat(st, names) - flat(cur, names), flat(newp, names) - flat(cur, names)) < 1e-4
         for n, v in towers[0]["moving"].items():
             assert rel_l2(st[n], v) < 1e-5, n
+
+
+def test_streams_and_graph_match_eager():
+    """Towers issued on 4 HIP streams, and the same captured into a hipGraph and replayed, against the plain
+    one-stream eager step: same losses, same update (parameter gradients meet only through float atomics, so the
+    steps agree to summation order; smooth-regime weights keep the second step free of relu6 mask flips)."""
+    from emdenoise import trainer as TR
+
+    S = 64
+    w = weights(smooth=True)
+    names = [n for n in w if not n.endswith(("/moving_mean", "/moving_variance"))]
+    runs = {}
+    for mode, kw in (("eager", {}), ("streams", {"streams": 4}), ("graph", {"streams": 4, "graph": True})):
+        tr = TR.DenoiserTrainer(w, dev())
+        out = []
+        for step in range(3):   # a larger learning rate than the reference's: weights stale by one step would show
+            lq, hq = synthetic_pair(4, S, S, seed=200 + step)
+            res = tr.train_step(torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev()), tower_batch=1,
+                                learning_rate=0.003, **kw)
+            torch.cuda.synchronize()
+            out.append((res.cpu().numpy(), flat(tr.state_dict(), names), flat(tr.state_dict(), [n for n in w if n not in names])))
+        runs[mode] = out
+    p0 = flat(w, names)
+    for mode in ("streams", "graph"):
+        for step, tol in ((0, 1e-5), (1, 1e-4), (2, 1e-4)):
+            r, p, m = runs[mode][step]
+            re, pe, me = runs["eager"][step]
+            prev = p0 if step == 0 else runs["eager"][step - 1][1]
+            assert np.allclose(r[:, :2], re[:, :2], rtol=1e-5 if step == 0 else 1e-4), (mode, step)
+            assert rel_l2(p - prev, pe - prev) < tol, (mode, step, rel_l2(p - prev, pe - prev))
+            assert rel_l2(m, me) < 1e-5, (mode, step)
