@@ -133,6 +133,11 @@ def load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python ai-cv-automation-elect-micr_amd/build.py, or __graft_entry__.build()). "
             "There is no CPU fallback for this path.")
+    # PyTorch-ROCm ships its own libamdhip64; load it first so that this process has ONE HIP runtime -- the one that
+    # owns the streams and allocations handed to the library (loading libemdenoise.so first would bring in the system
+    # runtime beside it, and launches then fail with "no ROCm-capable device").
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
