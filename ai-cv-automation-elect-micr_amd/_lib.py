@@ -114,6 +114,16 @@ SIGNATURES = {
     # param grad accum n lr momentum grad_scale stream
     "emd_nesterov_step_f32": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_long, C.c_float, C.c_float, C.c_float,
                                         C.c_void_p]),
+    # ---- graph G (generator)
+    # x ldx w y ldy B H W C stride stream
+    "emd_dw3x3_reflect_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p]),
+    # x w49 a shift y ldy B H W Cout act stream
+    "emd_cin1_k7_reflect_f32": (C.c_int, [_c_float_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
+    # x ldx w bias y B H W Cin stream
+    "emd_conv3x3_cout1_reflect_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_float, _c_float_p] + [C.c_int] * 4 +
+                                      [C.c_void_p]),
+    # x mean var y B npix_img eps stream
+    "emd_instnorm_tanh_f32": (C.c_int, [_c_float_p] * 4 + [C.c_int, C.c_long, C.c_float, C.c_void_p]),
 }
 
 _lib = None

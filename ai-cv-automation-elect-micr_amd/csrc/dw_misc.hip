@@ -301,7 +301,10 @@ __global__ __launch_bounds__(256) void affine_relu6_kernel(const float* x, int l
     const float4 s = *reinterpret_cast<const float4*>(sc + c4 * 4);
     const float4 t = *reinterpret_cast<const float4*>(sh + c4 * 4);
     float4 o = make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
-    if (act) {
+    if (act == 4) {  // tf.nn.leaky_relu, alpha 0.2
+        o = make_float4(o.x > 0.f ? o.x : 0.2f * o.x, o.y > 0.f ? o.y : 0.2f * o.y, o.z > 0.f ? o.z : 0.2f * o.z,
+                        o.w > 0.f ? o.w : 0.2f * o.w);
+    } else if (act) {
         const float hi = act == 2 ? __builtin_inff() : (act == 3 ? 1.f : 6.f);  // 3: relu6 then clip to [0,1]
         o = make_float4(fminf(fmaxf(o.x, 0.f), hi), fminf(fmaxf(o.y, 0.f), hi), fminf(fmaxf(o.z, 0.f), hi),
                         fminf(fmaxf(o.w, 0.f), hi));
@@ -570,7 +573,7 @@ extern "C" int emd_resize_bilinear_f32(const float* x, int ldx, float* y, int ld
 extern "C" int emd_affine_act_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res,
                                   int ldres, float* y, int ldy, long npix, int C, int act, emd_stream_t stream) {
     EMD_REQUIRE(x && y && scale && shift, EMD_E_INVALID, "emd_affine_act_f32: null pointer");
-    EMD_REQUIRE(npix >= 0 && C >= 4 && act >= 0 && act <= 3, EMD_E_INVALID, "emd_affine_act_f32: bad argument");
+    EMD_REQUIRE(npix >= 0 && C >= 4 && act >= 0 && act <= 4, EMD_E_INVALID, "emd_affine_act_f32: bad argument");
     EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && emd::aligned16(x) &&
                     emd::aligned16(y) && emd::aligned16(scale) && emd::aligned16(shift) &&
                     (!res || (ldres % 4 == 0 && ldres >= C && emd::aligned16(res))), EMD_E_ALIGN,

@@ -279,7 +279,10 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
             float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (resp) rv = *reinterpret_cast<const float4*>(resp + pix * p.ldres + n);
             v.x = fmaf(v.x, s1.x, t1.x); v.y = fmaf(v.y, s1.y, t1.y); v.z = fmaf(v.z, s1.z, t1.z); v.w = fmaf(v.w, s1.w, t1.w);
-            if (p.act) {  // hi = 6 (relu6) or +inf (relu)
+            if (p.act == 4) {  // tf.nn.leaky_relu, alpha 0.2 (graph G)
+                v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
+                v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
+            } else if (p.act) {  // hi = 6 (relu6) or +inf (relu)
                 v.x = fminf(fmaxf(v.x, 0.f), hi); v.y = fminf(fmaxf(v.y, 0.f), hi);
                 v.z = fminf(fmaxf(v.z, 0.f), hi); v.w = fminf(fmaxf(v.w, 0.f), hi);
             }

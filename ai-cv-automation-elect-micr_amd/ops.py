@@ -14,7 +14,7 @@ from . import _lib
 
 PREC_BF16 = 1
 PREC_BF16X3 = 3
-ACT_NONE, ACT_RELU6, ACT_RELU, ACT_RELU6_CLIP01 = 0, 1, 2, 3
+ACT_NONE, ACT_RELU6, ACT_RELU, ACT_RELU6_CLIP01, ACT_LEAKY = 0, 1, 2, 3, 4
 
 
 def _act(a):
@@ -248,3 +248,49 @@ def bn_fold(mean, var, gamma, beta, eps=1e-3, stream=None):
     _lib.check(lib.emd_bn_fold_f32(_p(mean), _p(var), _p(gamma), _p(beta), C.c_float(eps), _p(scale), _p(shift),
                                    mean.numel(), _lib.stream_ptr(stream)), "emd_bn_fold_f32")
     return scale, shift
+
+
+# ---- graph G (the in-filling generator, misc_py/gan-infilling-100.py:133-374)
+def dw3x3_reflect(x: Act, w_dev, out: Act, stride=1, stream=None):
+    """Depthwise 3x3 over the reflect-padded (1 px) input, VALID."""
+    lib = _lib.load()
+    assert out.C == x.C and out.B == x.B and (out.H, out.W) == ((x.H - 1) // stride + 1, (x.W - 1) // stride + 1)
+    _lib.check(lib.emd_dw3x3_reflect_f32(x.ptr, x.ld, _p(w_dev), out.ptr, out.ld, x.B, x.H, x.W, x.C, stride,
+                                         _lib.stream_ptr(stream)), "emd_dw3x3_reflect_f32")
+    return out
+
+
+def cin1_k7_reflect(x_img, w49_dev, a_dev, shift_dev, out: Act, act=True, stream=None):
+    lib = _lib.load()
+    B, H, W = x_img.shape[0], x_img.shape[1], x_img.shape[2]
+    assert x_img.is_contiguous() and (out.B, out.H, out.W) == (B, H, W) and w49_dev.numel() == 49
+    _lib.check(lib.emd_cin1_k7_reflect_f32(_p(x_img), _p(w49_dev), _p(a_dev), _p(shift_dev), out.ptr, out.ld, B, H, W, out.C,
+                                           1 if act else 0, _lib.stream_ptr(stream)), "emd_cin1_k7_reflect_f32")
+    return out
+
+
+def conv3x3_cout1_reflect(x: Act, w_dev, bias: float, out_img, stream=None):
+    lib = _lib.load()
+    assert out_img.is_contiguous() and out_img.numel() == x.B * x.H * x.W
+    _lib.check(lib.emd_conv3x3_cout1_reflect_f32(x.ptr, x.ld, _p(w_dev), C.c_float(bias), _p(out_img), x.B, x.H, x.W, x.C,
+                                                 _lib.stream_ptr(stream)), "emd_conv3x3_cout1_reflect_f32")
+    return out_img
+
+
+def instnorm_tanh(x_img, out_img, eps=1e-3, stream=None):
+    """tanh(instance_norm(x)) of a 1-channel batch [B,H,W,1]; the per-image statistics are reduced on the device."""
+    import torch
+
+    lib = _lib.load()
+    B = x_img.shape[0]
+    npix = x_img.numel() // B
+    mean = torch.empty(B, dtype=torch.float32, device=x_img.device)
+    var = torch.empty_like(mean)
+    ws = torch.empty(max(lib.emd_bn_stats_workspace_bytes(npix, 1) // 8, 1), dtype=torch.float64, device=x_img.device)
+    for b in range(B):
+        _lib.check(lib.emd_bn_stats_f32(C.c_void_p(x_img.data_ptr() + 4 * b * npix), 1, C.c_long(npix), 1,
+                                        C.c_void_p(mean.data_ptr() + 4 * b), C.c_void_p(var.data_ptr() + 4 * b), _p(ws),
+                                        _lib.stream_ptr(stream)), "emd_bn_stats_f32")
+    _lib.check(lib.emd_instnorm_tanh_f32(_p(x_img), _p(mean), _p(var), _p(out_img), B, C.c_long(npix), C.c_float(eps),
+                                         _lib.stream_ptr(stream)), "emd_instnorm_tanh_f32")
+    return out_img

@@ -10,6 +10,8 @@ Workloads:
   D  BASELINE configs[2]: the modified-Xception encoder-decoder of machine_learning/denoiser.py on
      [32,512,512,1] (matrix cores in split-bf16 parity mode unless --precision bf16).
   X  the other graph BASELINE configs[2] can mean: misc_py/modified_Xception.py at 512x512.
+  G  BASELINE configs[4], the part that is built: the in-filling GAN's generator forward pass
+     (misc_py/gan-infilling-100.py:133-374) on [32,512,512,1]; rides along as "workload_G".
   T  BASELINE configs[3]: graph D' TRAINING (misc_py/denoiser-multi-gpu.py): --train-batch LQ/HQ pairs per GPU per
      step (default 8 = bs 64 over 8 GPUs), towers of --tower-batch images (default 1, the reference), one RCCL
      all-reduce of the flat gradient vector per step, Nesterov step.  Rides along as "workload_T"; --workload T
@@ -344,6 +346,45 @@ def bench_X(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     return out
 
 
+def bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
+    """BASELINE configs[4], the part that is built: the in-filling GAN's GENERATOR forward pass
+    (misc_py/gan-infilling-100.py:133-374) on 1/64-sampled 512x512 images (the discriminator and the adversarial
+    training step are not built yet)."""
+    from emdenoise import gan as GN
+
+    B, S = a.batch, a.size
+    steps, warmup = 5, 1
+    x_host = GN.gen_lq(2.0 * synthetic_lq(B, S, S, seed=77 + rank)[..., 0] - 1.0)[..., None]
+    weights = GN.synthetic_weights()
+    eng = GN.GeneratorEngine(weights, dev, a.precision)
+    x = torch.from_numpy(x_host).to(dev)
+    box = [None]
+
+    def step():
+        box[0] = eng.forward(x)
+
+    ms = timer.run(step, steps, warmup)
+    tflop = GN.algorithmic_flops(S) * B / 1e12
+    out = {"value": round(B * S * S / 1e6 * world / (ms / 1e3), 1), "unit": "MPx/s in-filled", "ms_per_step": round(ms, 3),
+           "steps": steps, "warmup": warmup,
+           "config": {"workload": f"G: in-filling generator forward (misc_py/gan-infilling-100.py), [{B},{S},{S},1] fp32 per GPU, "
+                                  "1/64 of the pixels given", "precision": a.precision,
+                      "algorithmic_tflop_per_step": round(tflop, 3)},
+           "tflops_algorithmic": round(tflop / (ms / 1e3), 1)}
+    if want_cpu:
+        from oracle import gan_graph as GG
+
+        torch.set_num_threads(CPU_THREADS)
+        t0 = time.perf_counter()
+        ref = GG.generator(x_host[:1], weights, S, dtype=torch.float32).numpy()
+        el = time.perf_counter() - t0
+        got = box[0][:1].cpu().numpy()
+        out["cpu_baseline"] = {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s in-filled", "cores": CPU_THREADS, "kind": "port",
+                               "sample": f"1 image ([1,{S},{S},1]), oracle/gan_graph.py (PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}
+        out["rel_l2_vs_oracle"] = float(f"{np.linalg.norm(got - ref) / np.linalg.norm(ref):.3e}")
+    return out
+
+
 def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
     """BASELINE configs[3]: graph D' TRAINING (misc_py/denoiser-multi-gpu.py): data-parallel steps of `--train-batch`
     512x512 LQ/HQ pairs per GPU (bs=64 over 8 GPUs => 8 per GPU), towers of `--tower-batch` images (1 = the
@@ -398,7 +439,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["K", "D", "X", "T", "both", "all"], default="all",
+    ap.add_argument("--workload", choices=["K", "D", "X", "T", "G", "both", "all"], default="all",
                     help="K and D: see the module docstring; X: misc_py/modified_Xception.py; all (default) = K primary, D and X alongside")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
@@ -462,7 +503,22 @@ def main():
                 raise
             res_T = {"error": f"{type(e).__name__}: {e}"}
 
+    res_G = None
+    if a.workload in ("G", "all"):
+        try:
+            res_G = bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
+        except Exception as e:
+            if a.workload == "G":
+                raise
+            res_G = {"error": f"{type(e).__name__}: {e}"}
+
     prim = res_D if primary_is_D else res_K
+    if prim is None and a.workload == "G":
+        prim, res_G = dict(res_G), None
+        prim["dtype"] = "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)"
+        prim["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel", "achieved": prim["tflops_algorithmic"],
+                            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(prim["tflops_algorithmic"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
     if prim is None and a.workload == "T":
         prim, res_T = res_T, None
     if prim is None:  # --workload X alone
@@ -473,7 +529,8 @@ def main():
                                      "frac": round((prim.get("tflops_algorithmic") or 0.0) / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None})
         res_X = None
     out = {
-        "metric": "megapixels/sec trained (512x512x1 LQ/HQ pairs)" if a.workload == "T" else "megapixels/sec restored (512x512x1 bs=32)",
+        "metric": {"T": "megapixels/sec trained (512x512x1 LQ/HQ pairs)", "G": "megapixels/sec in-filled (512x512x1 bs=32)"}.get(
+            a.workload, "megapixels/sec restored (512x512x1 bs=32)"),
         "value": round(prim["value"], 1),
         "unit": prim.get("unit", "MPx/s"),
         "n_gpus": world,
@@ -501,6 +558,8 @@ def main():
         out["workload_X"] = res_X
     if res_T is not None:
         out["workload_T"] = res_T
+    if res_G is not None:
+        out["workload_G"] = res_G
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -92,6 +92,7 @@ int emd_kernel_denoise_f32(const float* x, float* y, int B, int H, int W, int wi
 #define EMD_ACT_NONE 0
 #define EMD_ACT_RELU6 1 /* tf.nn.relu6: machine_learning/denoiser.py:83 */
 #define EMD_ACT_RELU 2  /* tf.nn.relu:  misc_py/modified_Xception.py:209, :222, :312 */
+#define EMD_ACT_LEAKY 4 /* tf.nn.leaky_relu, alpha 0.2: misc_py/gan-infilling-100.py:178 (matrix-core epilogues, emd_affine_act_f32) */
 #define EMD_ACT_RELU6_CLIP01 3 /* relu6 then tf.clip_by_value(.,0,1), misc_py/denoiser-multi-gpu.py:534-538 (emd_affine_act_f32 only) */
 
 /* Host-side weight packing for the matrix-core kernels (all pointers are HOST pointers).
@@ -290,6 +291,34 @@ int emd_denoise_loss_f32(const float* out, const float* truth, long n, float gra
 /* tf.train.MomentumOptimizer(lr, momentum, use_nesterov=True) (:1064-1066) on a flat parameter vector:
  * g = grad*grad_scale (1/number of gradient sets, :1040); accum = momentum*accum + g; param -= lr*(g + momentum*accum). */
 int emd_nesterov_step_f32(float* param, const float* grad, float* accum, long n, float lr, float momentum, float grad_scale,
+                          emd_stream_t stream);
+
+/* ================================================================================================
+ * Graph G: the in-filling GAN's generator (misc_py/gan-infilling-100.py:133-374), inference.  Its pointwise halves,
+ * SAME-padded separable convs and resizes are the graph-D entry points with act = EMD_ACT_LEAKY; what follows is what
+ * only G has.
+ * ================================================================================================ */
+
+/* Depthwise 3x3 over the tf.pad(REFLECT, 1) input, VALID, stride 1 or 2 -- the depthwise half of
+ * strided_conv_block(pad_size=(1,1)) (:205-243): output (oy,ox) reads input rows oy*s-1..oy*s+1, index -1 -> 1,
+ * H -> H-2.  x [B,H,W,C]; y [B,(H-1)/s+1,(W-1)/s+1,C]; w [3][3][C]. */
+int emd_dw3x3_reflect_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C, int stride,
+                          emd_stream_t stream);
+
+/* The first layer (:343-347): 7x7 separable conv on the 1-channel image, reflect-padded by 3, VALID:
+ * y[pix][n] = act(d[pix]*a[n] + shift[n]), d = 7x7 depthwise (w49), a = pointwise weight * folded BN scale;
+ * act != 0: leaky_relu(0.2).  x [B,H,W]; y [B,H,W,Cout] pixel stride ldy; Cout/4 must divide 64. */
+int emd_cin1_k7_reflect_f32(const float* x, const float* w49, const float* a, const float* shift, float* y, int ldy, int B,
+                            int H, int W, int Cout, int act, emd_stream_t stream);
+
+/* The last conv (:362-369): tf.pad(REFLECT,1) + slim.conv2d(1, 3, VALID) + bias, no activation.
+ * x [B,H,W,Cin]; w [3][3][Cin]; y [B,H,W]. */
+int emd_conv3x3_cout1_reflect_f32(const float* x, int ldx, const float* w, float bias, float* y, int B, int H, int W, int Cin,
+                                  emd_stream_t stream);
+
+/* _instance_norm with its fixed unit affine (:140-148) + tf.tanh (:372) on a 1-channel batch:
+ * y = tanh((x - mean[b]) * rsqrt(var[b] + eps)); mean/var per image (emd_bn_stats_f32 with C = 1 on each image). */
+int emd_instnorm_tanh_f32(const float* x, const float* mean, const float* var, float* y, int B, long npix_img, float eps,
                           emd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -1,0 +1,186 @@
+"""Graph G oracle: the in-filling GAN's GENERATOR (oracle; test infrastructure only).
+
+Restates ``generator_architecture`` of misc_py/gan-infilling-100.py:133-374 with the TF op semantics of
+oracle/tf_ops.py on PyTorch-CPU tensors.  PARITY UNPINNED (oracle/__init__.py).  Inference form: the batch norms
+(``train_batch_norm`` placeholder False, :164-174, :1509) use their moving statistics, epsilon 0.01.
+
+Things the reference does that are reproduced on purpose:
+  * separable convs are reflect-padded by ``pad_size`` and run VALID (:209-216); with stride 2 the window of output i
+    therefore starts at input row 2i-1 (reflected at -1), not at 2i as TF's SAME would;
+  * ``deconv_block`` (:259-266) calls ``conv_block(deconv, filters, pad_size)``: the third positional parameter of
+    conv_block is ``phase``, so ``pad_size`` is swallowed and those four separable convs run with SAME zero padding;
+  * ``_instance_norm`` (:140-148) creates two NON-trainable tf.Variables (shift 0, scale 1) per call: they are part
+    of the variable list (names GAN/Gen/Variable, Variable_1) but never change;
+  * the first layer is a 7x7 separable conv on the 1-channel image (:343-347); the output is
+    tanh(instance_norm(conv3x3 + bias)) (:362-372);
+  * ``xception_encoding_block`` (:268-285) references an undefined ``cnn1`` -- it is never called by the generator.
+Variables live under ``tf.variable_scope("GAN/Gen")`` with an inner ``reg`` scope (:353): default layer scopes are
+uniquified per parent scope, so the numbering restarts inside ``reg``.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import tf_ops as T
+
+# gan-infilling-100.py:40-62
+gen_features0, gen_features1, gen_features2, gen_features3 = 32, 64, 64, 32
+nin_features1, nin_features2, nin_features3 = 128, 256, 768
+nin_features_out1, nin_features_out2, nin_features_out3 = 256, 128, 64
+num_global_enhancer_blocks, num_local_enhancer_blocks = 8, 3
+BN_EPS_GEN = 0.01      # :167
+IN_EPS = 1e-3          # :146
+LEAKY = 0.2            # tf.nn.leaky_relu default
+
+
+class _Scope:
+    """tf default-name uniquifier with nested variable scopes (one counter per parent scope)."""
+
+    def __init__(self, root):
+        self.stack, self.counts = [root], {}
+
+    def push(self, name):
+        self.stack.append(name)
+
+    def pop(self):
+        self.stack.pop()
+
+    def unique(self, base):
+        parent = "/".join(self.stack)
+        k = self.counts.get((parent, base), 0)
+        self.counts[(parent, base)] = k + 1
+        return f"{parent}/{base}" if k == 0 else f"{parent}/{base}_{k}"
+
+
+def reflect_pad_t(x, p):
+    """tf.pad(mode="REFLECT") of H and W by p (:152-158): the border sample is not repeated."""
+    return F.pad(x.permute(0, 3, 1, 2), (p, p, p, p), mode="reflect").permute(0, 2, 3, 1)
+
+
+def depthwise_valid_t(x, w, stride):
+    """Depthwise conv, VALID padding (after an explicit reflect pad).  x [B,H,W,C]; w [k,k,C,1]."""
+    C = x.shape[-1]
+    wt = w.permute(2, 3, 0, 1).contiguous()
+    return F.conv2d(x.permute(0, 3, 1, 2), wt, None, stride=stride, groups=C).permute(0, 2, 3, 1)
+
+
+class _Gen:
+    def __init__(self, get, dtype):
+        self.get, self.dtype, self.sc = get, dtype, _Scope("GAN/Gen")
+        self.trace = None
+        self.calibrate = None  # optional dict: batch statistics of every BN input are written here AND used
+
+    def _bn(self, x, scope):
+        C = x.shape[-1]
+        beta, gamma = self.get(scope + "/beta", (C,)), self.get(scope + "/gamma", (C,))
+        mean, var = self.get(scope + "/moving_mean", (C,)), self.get(scope + "/moving_variance", (C,))
+        if self.calibrate is not None:  # used only to SYNTHESISE weights (tests/golden/make_synth_bn.py)
+            mean, var = x.mean(dim=(0, 1, 2)), x.var(dim=(0, 1, 2), unbiased=False)
+            self.calibrate[scope + "/moving_mean"] = mean.to(torch.float32).numpy().copy()
+            self.calibrate[scope + "/moving_variance"] = var.to(torch.float32).numpy().copy()
+            mean, var = mean.to(torch.float32).to(self.dtype), var.to(torch.float32).to(self.dtype)
+        return (x - mean) * (gamma / torch.sqrt(var + BN_EPS_GEN)) + beta
+
+    def batch_then_activ(self, x):
+        y = F.leaky_relu(self._bn(x, self.sc.unique("BatchNorm")), LEAKY)
+        if self.trace is not None:
+            self.trace.append(y)
+        return y
+
+    def instance_norm(self, x):
+        C = x.shape[-1]
+        shift = self.get(self.sc.unique("Variable"), (C,))   # tf.Variable(tf.zeros), trainable=False
+        scale = self.get(self.sc.unique("Variable"), (C,))   # tf.Variable(tf.ones), trainable=False
+        mu = x.mean(dim=(1, 2), keepdim=True)
+        var = x.var(dim=(1, 2), unbiased=False, keepdim=True)
+        return scale * ((x - mu) / torch.sqrt(var + IN_EPS)) + shift
+
+    # :205-243
+    def sep(self, x, filters, stride=1, k=3, pad=None):
+        scope = self.sc.unique("SeparableConv2d")
+        cin = x.shape[-1]
+        dw = self.get(scope + "/depthwise_weights", (k, k, cin, 1))
+        pw = self.get(scope + "/pointwise_weights", (1, 1, cin, filters))
+        if pad:
+            y = depthwise_valid_t(reflect_pad_t(x, pad), dw, stride)
+        else:
+            y = T.depthwise_conv2d_t(x, dw, stride=stride)
+        y = T.conv2d_t(y, pw, None)
+        y = self._bn(y, scope + "/BatchNorm")
+        return self.batch_then_activ(y)
+
+    # :259-266 -- pad_size lands in conv_block's `phase` parameter: SAME padding
+    def deconv_block(self, x, filters, size):
+        return self.sep(T.resize_bilinear_legacy_t(x, size, size), filters)
+
+    # :287-307
+    def middle_block(self, x, features):
+        m = self.sep(x, features, pad=1)
+        m = self.sep(m, features, pad=1)
+        m = self.sep(m, features, pad=1)
+        return m + x
+
+    # :326-339 (sizes are hard-coded for a 512-px input; kept proportional for smaller test crops)
+    def network_in_network(self, x, S):
+        n = self.sep(x, nin_features1, 2, pad=1)
+        n = self.sep(n, nin_features2, 2, pad=1)
+        n = self.sep(n, nin_features3, 2, pad=1)
+        for _ in range(num_global_enhancer_blocks):
+            n = self.middle_block(n, nin_features3)
+        n = self.deconv_block(n, nin_features_out1, S // 8)
+        n = self.deconv_block(n, nin_features_out2, S // 4)
+        return self.deconv_block(n, nin_features_out3, S // 2)
+
+    def build(self, inputs, S):
+        x = inputs.reshape(-1, S, S, 1)
+        enc = self.sep(x, gen_features0, 1, k=7, pad=3)
+        enc = self.sep(enc, gen_features1, 2, pad=1)
+        self.sc.push("reg")
+        enc = enc + self.network_in_network(enc, S)
+        for _ in range(num_local_enhancer_blocks):
+            enc = self.middle_block(enc, gen_features2)
+        enc = self.deconv_block(enc, gen_features3, S)
+        enc = self.sep(enc, gen_features3, 1, pad=1)
+        self.sc.pop()
+        scope = self.sc.unique("Conv")
+        w = self.get(scope + "/weights", (3, 3, gen_features3, 1))
+        b = self.get(scope + "/biases", (1,))
+        wt = w.permute(3, 2, 0, 1).contiguous()
+        enc = F.conv2d(reflect_pad_t(enc, 1).permute(0, 3, 1, 2), wt, b).permute(0, 2, 3, 1)
+        return torch.tanh(self.instance_norm(enc))
+
+
+def variable_specs(cropsize=64) -> "OrderedDict[str, tuple]":
+    """Names and shapes of every generator variable, in creation order."""
+    specs = OrderedDict()
+
+    def rec(name, shape):
+        specs[name] = tuple(int(s) for s in shape)
+        return torch.ones(shape, dtype=torch.float32)
+
+    with torch.no_grad():
+        _Gen(rec, torch.float32).build(torch.zeros(1, cropsize, cropsize, 1), cropsize)
+    return specs
+
+
+def generator(inputs, weights, cropsize=512, dtype=torch.float32, trace=None, calibrate=None):
+    """inputs [B,S,S,1] (-1 = missing pixel) -> torch [B,S,S,1] in (-1,1).  S a multiple of 16."""
+    cache = {}
+
+    def get(name, shape):
+        if name not in cache:
+            w = weights[name]
+            assert tuple(w.shape) == tuple(shape), (name, w.shape, shape)
+            cache[name] = torch.from_numpy(np.ascontiguousarray(w)).to(dtype)
+        return cache[name]
+
+    g = _Gen(get, dtype)
+    g.trace = trace
+    g.calibrate = calibrate
+    x = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(inputs))
+    with torch.no_grad():
+        return g.build(x.to(dtype), cropsize)

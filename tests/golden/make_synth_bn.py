@@ -57,9 +57,27 @@ def one_x():
           f"output mean {float(y.mean()):.4f} std {float(y.std()):.4f} min {float(y.min()):.3f} max {float(y.max()):.3f}")
 
 
+def one_g():
+    """Graph G (the in-filling generator, misc_py/gan-infilling-100.py:133-374): inputs are 1/64-sampled images
+    (-1 elsewhere) as the reference's gen_lq makes them; calibrated at 256x256 so the deepest maps are 16x16."""
+    from emdenoise import gan as GN
+    from oracle import gan_graph as GG
+
+    seed = GN.SYNTH_SEED
+    w = GN.synthetic_weights(seed, bn="tf_init")
+    assert list(w.keys()) == list(GG.variable_specs().keys()), "product and oracle disagree on the TF variable names"
+    x = GN.gen_lq(2.0 * synthetic_lq(2, 256, 256, seed=seed)[..., 0] - 1.0)[..., None]
+    calib = {}
+    y = GG.generator(x, w, cropsize=256, dtype=torch.float64, calibrate=calib)
+    out = os.path.join(ROOT, "ai-cv-automation-elect-micr_amd", "data", f"synth_bn_G_seed{seed}.npz")
+    np.savez_compressed(out, **calib)
+    print(f"wrote {out}: {len(calib)} vectors, {sum(v.size for v in calib.values())} floats, "
+          f"output mean {float(y.mean()):.4f} std {float(y.std()):.4f} min {float(y.min()):.3f} max {float(y.max()):.3f}")
+
+
 def main():
-    for variant in (sys.argv[1:] or ["D", "Dprime", "X"]):
-        one_x() if variant == "X" else one(variant)
+    for variant in (sys.argv[1:] or ["D", "Dprime", "X", "G"]):
+        {"X": one_x, "G": one_g}.get(variant, lambda v=variant: one(v))()
 
 
 if __name__ == "__main__":
