@@ -124,6 +124,10 @@ SIGNATURES = {
                                       [C.c_void_p]),
     # x mean var y B npix_img eps stream
     "emd_instnorm_tanh_f32": (C.c_int, [_c_float_p] * 4 + [C.c_int, C.c_long, C.c_float, C.c_void_p]),
+    # x ldx w bias y B K stream
+    "emd_fc_rows_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_float, _c_float_p, C.c_int, C.c_int, C.c_void_p]),
+    # a b c y n stream
+    "emd_max3_sigmoid_f32": (C.c_int, [_c_float_p] * 4 + [C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -129,6 +129,25 @@ __global__ __launch_bounds__(256) void instnorm_tanh_kernel(const float* __restr
     y[i] = tanhf((x[i] - mean[b]) * rsqrtf(var[b] + eps));
 }
 
+// Discriminator head (:560-567, :708): y[b] = sum_k x[b][k]*w[k] + bias -- one wave per row, shuffle reduction.
+__global__ __launch_bounds__(64) void fc_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                     float bias, float* __restrict__ y, int K) {
+    const float* row = x + (long)blockIdx.x * ldx;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 64) s = fmaf(row[k], w[k], s);
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    if (threadIdx.x == 0) y[blockIdx.x] = s + bias;
+}
+
+// output = sigmoid(max(small, medium, large))   (:708)
+__global__ void max3_sigmoid_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                    float* __restrict__ y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float m = fmaxf(a[i], fmaxf(b[i], c[i]));
+    y[i] = 1.f / (1.f + __expf(-m));
+}
+
 int blocks_for(long nthreads, unsigned* nb) {
     const long b = (nthreads + 255) / 256;
     if (b <= 0 || b > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "grid too large");
@@ -207,4 +226,21 @@ extern "C" int emd_instnorm_tanh_f32(const float* x, const float* mean, const fl
     hipLaunchKernelGGL(instnorm_tanh_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, mean, var, y,
                        npix_img, total, eps);
     return emd::check_launch("instnorm_tanh_kernel");
+}
+
+extern "C" int emd_fc_rows_f32(const float* x, int ldx, const float* w, float bias, float* y, int B, int K,
+                               emd_stream_t stream) {
+    EMD_REQUIRE(x && w && y, EMD_E_INVALID, "emd_fc_rows_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && K >= 1 && ldx >= K, EMD_E_INVALID, "emd_fc_rows_f32: bad shape");
+    if (B == 0) return EMD_OK;
+    hipLaunchKernelGGL(fc_rows_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), x, ldx, w, bias, y, K);
+    return emd::check_launch("fc_rows_kernel");
+}
+
+extern "C" int emd_max3_sigmoid_f32(const float* a, const float* b, const float* c, float* y, int n, emd_stream_t stream) {
+    EMD_REQUIRE(a && b && c && y, EMD_E_INVALID, "emd_max3_sigmoid_f32: null pointer");
+    EMD_REQUIRE(n >= 0, EMD_E_INVALID, "emd_max3_sigmoid_f32: bad size");
+    if (n == 0) return EMD_OK;
+    hipLaunchKernelGGL(max3_sigmoid_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, c, y, n);
+    return emd::check_launch("max3_sigmoid_kernel");
 }

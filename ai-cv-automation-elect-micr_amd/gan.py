@@ -260,3 +260,181 @@ def generator_architecture(inputs, phase=False, params=None, train_batch_norm=No
     if engine is None:
         raise ValueError("pass engine=GeneratorEngine(...)")
     return engine.forward(inputs)
+
+
+# ================================================================================================
+# Discriminator (misc_py/gan-infilling-100.py:376-710), inference: three branches (a 128-px crop; a 256-px crop
+# average-pooled to 128; a 384-px crop bilinear-resized to 128, :957-980) of five stride-2 separable convs
+# [BN (moving statistics) -> INSTANCE norm -> leaky_relu] at 32..512 channels, global mean, FC -> 1;
+# output = sigmoid(max of the three logits) (:708).  Returns the 15 feature maps too: the generator's
+# feature-matching loss walks them (:1029-1035).
+# ================================================================================================
+features1, features2, features3, features4, features5 = 32, 64, 128, 256, 512
+BN_EPS_DISCR = 1e-3
+DISCR_FEATURES = (features1, features2, features3, features4, features5)
+BRANCHES = ("small", "medium", "large")
+
+
+def discriminator_variable_specs():
+    """TF variable name -> shape, in creation order (scopes GAN/Discr/{small,medium,large})."""
+    out = OrderedDict()
+    for br in BRANCHES:
+        sc = _Scope("GAN/Discr/" + br)
+        cin = 1
+        for f in DISCR_FEATURES:
+            scope = sc.unique("SeparableConv2d")
+            out[scope + "/depthwise_weights"] = (3, 3, cin, 1)
+            out[scope + "/pointwise_weights"] = (1, 1, cin, f)
+            for leaf in ("beta", "gamma", "moving_mean", "moving_variance"):
+                out[f"{scope}/BatchNorm/{leaf}"] = (f,)
+            out[sc.unique("Variable")] = (f,)   # _instance_norm shift (zeros), frozen
+            out[sc.unique("Variable")] = (f,)   # _instance_norm scale (ones), frozen
+            cin = f
+        scope = sc.unique("fully_connected")
+        out[scope + "/weights"] = (features5, 1)
+        out[scope + "/biases"] = (1,)
+    return out
+
+
+def discriminator_synthetic_weights(seed: int = SYNTH_SEED + 1):
+    """Seeded discriminator weights.  Its activations are instance-normalised after every layer, so TF-initial moving
+    statistics would do; mildly random ones are used so that the batch-norm fold is exercised."""
+    rng = np.random.default_rng(seed)
+    w = OrderedDict()
+    shift_next = True
+    for name, shape in discriminator_variable_specs().items():
+        leaf = name.rsplit("/", 1)[1]
+        if leaf in ("depthwise_weights", "pointwise_weights"):
+            rf = shape[0] * shape[1]
+            lim = np.sqrt(6.0 / (rf * shape[2] + rf * shape[3]))
+            w[name] = rng.uniform(-lim, lim, shape).astype(np.float32)
+        elif leaf == "weights":
+            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            w[name] = rng.uniform(-lim, lim, shape).astype(np.float32)
+        elif leaf == "biases":
+            w[name] = rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+        elif leaf == "gamma":
+            w[name] = rng.uniform(0.8, 1.6, shape).astype(np.float32)
+        elif leaf == "beta":
+            w[name] = rng.uniform(-0.3, 0.3, shape).astype(np.float32)
+        elif leaf == "moving_mean":
+            w[name] = rng.uniform(-0.2, 0.2, shape).astype(np.float32)
+        elif leaf == "moving_variance":
+            w[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif leaf.startswith("Variable"):
+            w[name] = np.zeros(shape, np.float32) if shift_next else np.ones(shape, np.float32)
+            shift_next = not shift_next
+        else:
+            raise AssertionError(name)
+    return w
+
+
+def reflect_indices(n, pad):
+    idx = np.abs(np.arange(-pad, n + pad))
+    return np.where(idx >= n, 2 * n - 2 - idx, idx)
+
+
+def multiscale_crops(img, offsets):
+    """get_multiscale_crops (:957-980) on the device, with the tf.random_crop offsets given (parity needs them as
+    inputs): img torch [B,S,S,C] -> (small [B,S/4,S/4,C], medium [B,S/2,S/2,C], large crop [B,3S/4,3S/4,C]) taken from
+    the image reflect-padded by 3S/4.  Index gathers only; the large crop's resize to S/4 is done by the engine."""
+    import torch
+
+    B, S = img.shape[0], img.shape[1]
+    pad = (3 * S) // 4
+    ridx = torch.from_numpy(reflect_indices(S, pad)).to(img.device)
+
+    def crop(y0, x0, n):
+        return img[:, ridx[y0:y0 + n]][:, :, ridx[x0:x0 + n]].contiguous()
+
+    (ys, xs), (ym, xm), (yl, xl) = offsets
+    return crop(ys, xs, S // 4), crop(ym, xm, S // 2), crop(yl, xl, pad)
+
+
+class DiscriminatorEngine:
+    """Weights resident on one GPU + the launch sequence of discriminator_architecture (:569-630, :708)."""
+
+    def __init__(self, weights, device, precision="bf16x3"):
+        import torch
+
+        _lib.load()
+        self.device = device
+        self.precision = {"bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[precision]
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        self.P = {}
+        for br in BRANCHES:
+            sc = _Scope("GAN/Discr/" + br)
+            cin, layers = 1, []
+            for f in DISCR_FEATURES:
+                scope = sc.unique("SeparableConv2d")
+                shift_v, scale_v = weights[sc.unique("Variable")], weights[sc.unique("Variable")]
+                if np.any(shift_v != 0) or np.any(scale_v != 1):
+                    raise ValueError("the instance norm's shift/scale variables are frozen at 0/1 in the reference (:388-389)")
+                dw = weights[scope + "/depthwise_weights"][..., 0]
+                pw = weights[scope + "/pointwise_weights"][0]
+                b = scope + "/BatchNorm"
+                g = weights[b + "/gamma"].astype(np.float64) / np.sqrt(weights[b + "/moving_variance"].astype(np.float64) + BN_EPS_DISCR)
+                h = weights[b + "/beta"].astype(np.float64) - weights[b + "/moving_mean"].astype(np.float64) * g
+                cp = max(cin, 4)   # the 1-channel crop is processed as 4 channels (3 of zeros)
+                dwp, pwp = np.zeros((9, cp), np.float32), np.zeros((1, cp, f), np.float32)
+                dwp[:, :cin], pwp[:, :cin] = dw.reshape(9, cin), pw
+                layers.append({"dw": d(dwp), "pw": ops.PackedWeights(pwp, False, device), "scale": d(g), "shift": d(h), "cout": f})
+                cin = f
+            scope = sc.unique("fully_connected")
+            self.P[br] = {"layers": layers, "fc_w": d(weights[scope + "/weights"].reshape(features5)),
+                          "fc_b": float(weights[scope + "/biases"][0])}
+
+    def _instance_leaky(self, r):
+        """_instance_norm (per image, per channel, eps 1e-3, unit affine) + leaky_relu(0.2), in place."""
+        import torch
+
+        for b in range(r.B):
+            img = ops.Act(r.buf[b:b + 1], r.C, r.c0)
+            mean, var = ops.bn_batch_stats(img)
+            scale, shift = ops.bn_fold(mean, var, None, None, eps=IN_EPS)
+            ops.affine_act(img, scale, shift, img, act=ops.ACT_LEAKY)
+        return r
+
+    def _branch(self, br, x4, layers_out):
+        import torch
+
+        p = self.P[br]
+        x = ops.Act(x4)
+        if br == "medium":
+            x = ops.avgpool2x2(x, ops.Act.empty(x.B, x.H // 2, x.W // 2, 4, self.device))
+        for lp in p["layers"]:
+            Ho, Wo = -(-x.H // 2), -(-x.W // 2)
+            dd = ops.dw3x3(x, lp["dw"], ops.Act.empty(x.B, Ho, Wo, x.C, self.device), stride=2)
+            r = ops.conv1x1(dd, lp["pw"], lp["scale"], lp["shift"], ops.Act.empty(x.B, Ho, Wo, lp["cout"], self.device),
+                            act=False, precision=self.precision)
+            x = self._instance_leaky(r)
+            layers_out.append(x.buf)
+        B = x.B
+        means = torch.empty((B, features5), dtype=torch.float32, device=self.device)
+        for b in range(B):
+            m, _ = ops.bn_batch_stats(ops.Act(x.buf[b:b + 1]))
+            means[b].copy_(m)
+        logit = torch.empty(B, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().emd_fc_rows_f32(ops._p(means), features5, ops._p(p["fc_w"]), ops.C.c_float(p["fc_b"]),
+                                               ops._p(logit), B, features5, _lib.stream_ptr()), "emd_fc_rows_f32")
+        return logit
+
+    def forward(self, small, medium, large_crop):
+        """small [B,S/4,S/4,1], medium [B,S/2,S/2,1], large_crop [B,3S/4,3S/4,1] (torch CUDA float32, as
+        multiscale_crops returns them) -> (output [B], [15 feature maps [B,h,w,c]])."""
+        import torch
+
+        def pad4(t):
+            out = torch.zeros(t.shape[:3] + (4,), dtype=torch.float32, device=self.device)
+            out[..., 0:1].copy_(t)
+            return out
+
+        S4 = small.shape[1]
+        lg = ops.resize_bilinear(ops.Act(pad4(large_crop)), ops.Act.empty(small.shape[0], S4, S4, 4, self.device)).buf
+        layers = []
+        logits = [self._branch("small", pad4(small), layers), self._branch("medium", pad4(medium), layers),
+                  self._branch("large", lg, layers)]
+        out = torch.empty_like(logits[0])
+        _lib.check(_lib.load().emd_max3_sigmoid_f32(ops._p(logits[0]), ops._p(logits[1]), ops._p(logits[2]), ops._p(out),
+                                                    out.numel(), _lib.stream_ptr()), "emd_max3_sigmoid_f32")
+        return out, layers

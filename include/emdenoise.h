@@ -321,6 +321,11 @@ int emd_conv3x3_cout1_reflect_f32(const float* x, int ldx, const float* w, float
 int emd_instnorm_tanh_f32(const float* x, const float* mean, const float* var, float* y, int B, long npix_img, float eps,
                           emd_stream_t stream);
 
+/* Discriminator head (misc_py/gan-infilling-100.py:560-567, :708): a fully connected layer to ONE output per row,
+ * y[b] = x[b,:K].w + bias (x row stride ldx), and output = sigmoid(max(small, medium, large)). */
+int emd_fc_rows_f32(const float* x, int ldx, const float* w, float bias, float* y, int B, int K, emd_stream_t stream);
+int emd_max3_sigmoid_f32(const float* a, const float* b, const float* c, float* y, int n, emd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Host utility (no GPU): CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start).
  * Used by the TFRecord reader (emdenoise.input_pipeline) for the container that

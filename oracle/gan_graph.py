@@ -184,3 +184,111 @@ def generator(inputs, weights, cropsize=512, dtype=torch.float32, trace=None, ca
     x = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(inputs))
     with torch.no_grad():
         return g.build(x.to(dtype), cropsize)
+
+
+# ================================================================================================
+# Discriminator (misc_py/gan-infilling-100.py:376-710), inference form (phase=False: the separable convs' batch norms
+# use their moving statistics, epsilon 1e-3; "batch_then_activ" is an INSTANCE norm + leaky_relu, :413-416).
+# ================================================================================================
+features1, features2, features3, features4, features5 = 32, 64, 128, 256, 512
+BN_EPS_DISCR = 1e-3   # :401
+
+
+def reflect_indices(n, pad):
+    idx = np.arange(-pad, n + pad)
+    idx = np.abs(idx)
+    return np.where(idx >= n, 2 * n - 2 - idx, idx)
+
+
+def multiscale_crops(img, offsets):
+    """get_multiscale_crops (:957-980) with the tf.random_crop offsets given: img [B,S,S,C] is reflect-padded by 3S/4,
+    then small = S/4 crop, medium = S/2 crop, large = 3S/4 crop resized (legacy bilinear) to S/4.
+    offsets: ((y,x) small, (y,x) medium, (y,x) large) in the PADDED image.  The medium crop is returned at S/2: the
+    discriminator average-pools it (:585-588)."""
+    x = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
+    B, S = x.shape[0], x.shape[1]
+    pad = (3 * S) // 4
+    ridx = torch.from_numpy(reflect_indices(S, pad))
+    xp = x[:, ridx][:, :, ridx]
+    (ys, xs), (ym, xm), (yl, xl) = offsets
+    small = xp[:, ys:ys + S // 4, xs:xs + S // 4]
+    medium = xp[:, ym:ym + S // 2, xm:xm + S // 2]
+    large = xp[:, yl:yl + pad, xl:xl + pad]
+    return small, medium, T.resize_bilinear_legacy_t(large, S // 4, S // 4)
+
+
+class _Discr:
+    def __init__(self, get, dtype):
+        self.get, self.dtype, self.sc = get, dtype, _Scope("GAN/Discr")
+
+    def instance_norm(self, x):
+        C = x.shape[-1]
+        shift = self.get(self.sc.unique("Variable"), (C,))
+        scale = self.get(self.sc.unique("Variable"), (C,))
+        mu = x.mean(dim=(1, 2), keepdim=True)
+        var = x.var(dim=(1, 2), unbiased=False, keepdim=True)
+        return scale * ((x - mu) / torch.sqrt(var + IN_EPS)) + shift
+
+    # :440-463
+    def strided_conv_block(self, x, filters, stride):
+        scope = self.sc.unique("SeparableConv2d")
+        cin = x.shape[-1]
+        dw = self.get(scope + "/depthwise_weights", (3, 3, cin, 1))
+        pw = self.get(scope + "/pointwise_weights", (1, 1, cin, filters))
+        y = T.conv2d_t(T.depthwise_conv2d_t(x, dw, stride=stride), pw, None)
+        b = scope + "/BatchNorm"
+        beta, gamma = self.get(b + "/beta", (filters,)), self.get(b + "/gamma", (filters,))
+        mean, var = self.get(b + "/moving_mean", (filters,)), self.get(b + "/moving_variance", (filters,))
+        y = (y - mean) * (gamma / torch.sqrt(var + BN_EPS_DISCR)) + beta
+        return F.leaky_relu(self.instance_norm(y), LEAKY)
+
+    def branch(self, name, x, layers):
+        self.sc.push(name)
+        if name == "medium":
+            x = T.avg_pool2x2_same_t(x)
+        for f in (features1, features2, features3, features4, features5):
+            x = self.strided_conv_block(x, f, 2)
+            layers.append(x)
+        x = x.mean(dim=(1, 2))
+        scope = self.sc.unique("fully_connected")
+        w = self.get(scope + "/weights", (features5, 1))
+        b = self.get(scope + "/biases", (1,))
+        self.sc.pop()
+        return x @ w + b
+
+    def build(self, inputs):
+        layers = []
+        logits = [self.branch(n, x, layers) for n, x in zip(("small", "medium", "large"), inputs)]
+        out = torch.sigmoid(torch.cat(logits, dim=1).max(dim=1).values)
+        return [out] + layers
+
+
+def discriminator_variable_specs(cropsize=64):
+    specs = OrderedDict()
+
+    def rec(name, shape):
+        specs[name] = tuple(int(s) for s in shape)
+        return torch.ones(shape, dtype=torch.float32)
+
+    S = cropsize
+    with torch.no_grad():
+        _Discr(rec, torch.float32).build([torch.zeros(1, S // 4, S // 4, 1), torch.zeros(1, S // 2, S // 2, 1),
+                                          torch.zeros(1, S // 4, S // 4, 1)])
+    return specs
+
+
+def discriminator(inputs, weights, dtype=torch.float32):
+    """inputs: [small [B,S/4,S/4,1], medium [B,S/2,S/2,1], large [B,S/4,S/4,1]] -> [output [B]] + the 15 feature maps
+    (the list the generator's feature-matching loss walks, :1029-1035)."""
+    cache = {}
+
+    def get(name, shape):
+        if name not in cache:
+            w = weights[name]
+            assert tuple(w.shape) == tuple(shape), (name, w.shape, shape)
+            cache[name] = torch.from_numpy(np.ascontiguousarray(w)).to(dtype)
+        return cache[name]
+
+    xs = [(x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))).to(dtype) for x in inputs]
+    with torch.no_grad():
+        return _Discr(get, dtype).build(xs)

@@ -186,3 +186,48 @@ def test_generator_end_to_end(S, B):
     e = rel_l2(got, ref)
     print(f"G {S}px: rel L2 {e:.2e}")
     assert got.shape == ref.shape and np.isfinite(got).all() and e < 3e-4
+
+
+# ------------------------------------------------------------------------------------------------ discriminator
+def test_discriminator_variable_names():
+    from emdenoise import gan as GN
+    from oracle import gan_graph as GG
+
+    a, b = GN.discriminator_variable_specs(), GG.discriminator_variable_specs()
+    assert list(a.items()) == list(b.items()) and len(a) == 3 * (5 * 8 + 2)
+    assert a["GAN/Discr/medium/SeparableConv2d_4/pointwise_weights"] == (1, 1, 256, 512)
+    assert a["GAN/Discr/large/fully_connected/weights"] == (512, 1)
+
+
+def test_multiscale_crops_reflect_and_sizes():
+    """get_multiscale_crops (:957-980): reflect pad by 3S/4, crops of S/4, S/2 and 3S/4 (the last resized to S/4)."""
+    from oracle import gan_graph as GG
+
+    S = 16
+    img = np.arange(S * S, dtype=np.float64).reshape(1, S, S, 1)
+    small, medium, large = GG.multiscale_crops(img, ((0, 0), (12, 12), (5, 7)))
+    assert small.shape == (1, 4, 4, 1) and medium.shape == (1, 8, 8, 1) and large.shape == (1, 4, 4, 1)
+    assert float(small[0, 0, 0, 0]) == img[0, 12, 12, 0]            # padded (0,0) mirrors to (12,12) for pad 12
+    assert float(medium[0, 0, 0, 0]) == img[0, 0, 0, 0]             # padded (12,12) is the image origin
+    assert np.array_equal(GG.reflect_indices(4, 3), [3, 2, 1, 0, 1, 2, 3, 2, 1, 0])
+
+
+@gpu
+@pytest.mark.parametrize("S,B", [(256, 2), (512, 1)])
+def test_discriminator_forward(S, B):
+    from emdenoise import gan as GN
+    from oracle import gan_graph as GG
+
+    w = GN.discriminator_synthetic_weights()
+    img = (2.0 * synthetic_lq(B, S, S, seed=3 + S) - 1.0).astype(np.float32)
+    offsets = ((S // 3, S // 5), (S // 7, S // 2), (S // 4 + 3, S // 9))
+    ref = GG.discriminator(list(GG.multiscale_crops(img, offsets)), w, dtype=torch.float64)
+    x = torch.from_numpy(img).to(dev())
+    small, medium, large = GN.multiscale_crops(x, offsets)
+    out, layers = GN.DiscriminatorEngine(w, dev()).forward(small, medium, large)
+    torch.cuda.synchronize()
+    assert len(layers) == 15 == len(ref) - 1
+    worst = max(rel_l2(l.cpu().numpy(), r.numpy()) for l, r in zip(layers, ref[1:]) if r.shape[1] > 1)
+    print(f"discriminator {S}px: output {out.cpu().numpy()} vs {ref[0].numpy()}, worst feature map rel L2 {worst:.2e}")
+    assert worst < 3e-4
+    assert np.allclose(out.cpu().numpy(), ref[0].numpy(), rtol=1e-3, atol=1e-4)
