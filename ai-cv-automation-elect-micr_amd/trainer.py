@@ -553,6 +553,36 @@ class DenoiserTrainer:
             self.pad_g[k].copy_(t)
         torch.cuda.synchronize()
 
+    def _capture(self, lq, truth, tower_batch, streams, group):
+        """Capture local_gradients for this input shape into a hipGraph.  Returns (graph, static lq, static truth,
+        static results), or None if capture failed on ANY rank (all ranks then run eagerly: a rank that skipped the
+        graph while the others replay it would still meet them at the all-reduce, but the decision must be common
+        so that every rank's step has the same structure)."""
+        import torch
+        import torch.distributed as dist
+
+        entry, err = None, None
+        try:
+            self._warm()
+            slq, str_ = torch.empty_like(lq), torch.empty_like(truth)
+            g = torch.cuda.CUDAGraph()
+            # thread_local: other threads (e.g. the RCCL watchdog polling its events) may touch the runtime meanwhile
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                sres = self.local_gradients(slq, str_, tower_batch, streams)
+            entry = (g, slq, str_, sres)
+        except Exception as e:  # noqa: BLE001 -- fall back to eager launches
+            err = e
+            torch.cuda.synchronize()
+        ok = torch.tensor([1 if entry is not None else 0], dtype=torch.int32, device=self.device)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            import warnings
+
+            warnings.warn(f"hipGraph capture of the training step failed ({err}); launching eagerly")
+            return None
+        return entry
+
     def train_step(self, lq, truth, tower_batch=1, learning_rate=None, group=None, streams=1, graph=False):
         """One optimizer step on this rank's images (misc_py/denoiser-multi-gpu.py:1169-1206): every ``tower_batch``
         images form a tower (gradient set); all sets of all ranks are averaged (:1040) and applied with Nesterov
@@ -562,17 +592,12 @@ class DenoiserTrainer:
         import torch
 
         n_local = lq.shape[0] // tower_batch
-        if not graph:
+        key = (tuple(lq.shape), tower_batch, streams)
+        if graph and key not in self._graphs:
+            self._graphs[key] = self._capture(lq, truth, tower_batch, streams, group)
+        if not graph or self._graphs[key] is None:
             results = self.local_gradients(lq, truth, tower_batch, streams)
         else:
-            key = (tuple(lq.shape), tower_batch, streams)
-            if key not in self._graphs:
-                self._warm()
-                slq, str_ = torch.empty_like(lq), torch.empty_like(truth)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    sres = self.local_gradients(slq, str_, tower_batch, streams)
-                self._graphs[key] = (g, slq, str_, sres)
             g, slq, str_, sres = self._graphs[key]
             slq.copy_(lq)
             str_.copy_(truth)

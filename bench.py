@@ -417,6 +417,23 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
                       "algorithmic_tflop_per_step_per_gpu": round(tflop, 3)},
            "tflops_algorithmic": round(tflop / (ms / 1e3), 1),
            "loss_first_tower": float(box[0][0, 1].item())}
+    if world > 1:  # the step's only exchange, timed on its own (SURVEY.md 8d cfg 4): all-reduce of the flat gradient
+        from emdenoise.trainer import sync_gradients
+
+        for _ in range(2):
+            sync_gradients(tr.grads, tr.moving)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            sync_gradients(tr.grads, tr.moving)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 5
+        nbytes = tr.grads.numel() * 4
+        out["allreduce"] = {"ms": round(ar_ms, 3), "bytes": nbytes,
+                            "bus_GBps": round(2.0 * (world - 1) / world * nbytes / (ar_ms / 1e3) / 1e9, 1),
+                            "note": "RCCL all-reduce (sum) of the fp32 gradient vector + broadcast of the moving statistics"}
     out["roofline"] = {"bound": "mfma", "kernel": "whole step (gemm_conv + conv_wgrad dominate)", "achieved": out["tflops_algorithmic"],
                        "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(out["tflops_algorithmic"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
