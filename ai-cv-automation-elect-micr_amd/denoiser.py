@@ -210,18 +210,34 @@ def synthetic_weights(seed: int = SYNTH_SEED, bn: str = "calibrated", variant: s
 
 
 def load_weights(checkpoint_loc, variant="D"):
-    """Weights saved as ``<checkpoint_loc>/denoiser_weights.npz`` keyed by TF variable name.  Reading
-    TensorFlow checkpoint bundles directly is a later step."""
-    path = checkpoint_loc if checkpoint_loc.endswith(".npz") else os.path.join(checkpoint_loc, "denoiser_weights.npz")
-    z = np.load(path, allow_pickle=False)
+    """Weights for ``checkpoint_loc`` (the constructor argument of the reference's Denoiser, denoiser.py:587-589):
+      * a directory holding a TensorFlow checkpoint (``checkpoint`` + ``<prefix>.index`` + ``<prefix>.data-*``, what
+        tf.train.Saver wrote and ``tf.train.latest_checkpoint`` resolves, :621-626) or the prefix itself -- read
+        directly by emdenoise.tf_checkpoint, no TensorFlow needed; optimizer slots and global_step are ignored;
+      * a ``.npz`` file (or a directory holding ``denoiser_weights.npz``) keyed by TF variable name."""
+    from . import tf_checkpoint as ckpt
+
     specs = variable_specs(variant)
+    prefix = None
+    if os.path.isdir(checkpoint_loc):
+        prefix = ckpt.latest_checkpoint(checkpoint_loc)
+    elif os.path.exists(checkpoint_loc + ".index"):
+        prefix = checkpoint_loc
+    if prefix is not None:
+        z = ckpt.read_checkpoint(prefix, names=list(specs))
+        src = prefix + ".index"
+    else:
+        src = checkpoint_loc if checkpoint_loc.endswith(".npz") else os.path.join(checkpoint_loc, "denoiser_weights.npz")
+        npz = np.load(src, allow_pickle=False)
+        missing = [n for n in specs if n not in npz.files]
+        if missing:
+            raise KeyError(f"{src}: missing variable {missing[0]}")
+        z = {n: npz[n] for n in specs}
     w = OrderedDict()
     for name, shape in specs.items():
-        if name not in z.files:
-            raise KeyError(f"{path}: missing variable {name}")
         a = z[name]
         if tuple(a.shape) != tuple(shape):
-            raise ValueError(f"{name}: shape {a.shape} != {shape}")
+            raise ValueError(f"{src}: {name}: shape {a.shape} != {shape}")
         w[name] = a.astype(np.float32)
     return w
 

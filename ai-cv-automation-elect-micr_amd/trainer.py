@@ -162,6 +162,26 @@ class DenoiserTrainer:
             out[name] = (self.m if _is_moving(name) else self.v)[name].detach().cpu().numpy().copy()
         return out
 
+    def save_checkpoint(self, directory, global_step=0, name="model"):
+        """Write parameters, moving statistics, the optimizer's ``<variable>/Momentum`` slots and ``global_step`` as a
+        TensorFlow checkpoint bundle (what the reference's ``saver.save(sess, save_path=model_dir+"model/", ...)`` leaves,
+        misc_py/denoiser-multi-gpu.py:1226), readable by tf.train.Saver and by emdenoise.Denoiser(checkpoint_loc=dir)."""
+        import os
+
+        from . import tf_checkpoint as ckpt
+
+        tensors = dict(self.state_dict())
+        acc = self.accum.detach().cpu().numpy()
+        off = 0
+        for n, shape in self.trainable.items():
+            size = int(np.prod(shape))
+            tensors[n + "/Momentum"] = acc[off: off + size].reshape(shape).copy()
+            off += -(-size // 4) * 4
+        tensors["global_step"] = np.array(int(global_step), np.int64)
+        prefix = os.path.join(directory, f"{name}-{int(global_step)}")
+        ckpt.write_checkpoint(prefix, tensors)
+        return prefix
+
     def gradients(self):
         """TF variable name -> numpy gradient accumulated since zero_grad() (sum over towers)."""
         self._unpad_grads()

@@ -235,3 +235,20 @@ def test_streams_and_graph_match_eager():
             assert np.allclose(r[:, :2], re[:, :2], rtol=1e-5 if step == 0 else 1e-4), (mode, step)
             assert rel_l2(p - prev, pe - prev) < tol, (mode, step, rel_l2(p - prev, pe - prev))
             assert rel_l2(m, me) < 1e-5, (mode, step)
+
+
+def test_trainer_checkpoint_round_trip(tmp_path):
+    """The trainer writes a TensorFlow checkpoint bundle that the inference engine's loader reads back."""
+    from emdenoise import denoiser as D
+    from emdenoise import tf_checkpoint as ck
+    from emdenoise import trainer as TR
+
+    tr = TR.DenoiserTrainer(weights(), dev())
+    lq, hq = synthetic_pair(1, 64, 64, seed=9)
+    tr.train_step(torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev()))
+    prefix = tr.save_checkpoint(str(tmp_path), global_step=1)
+    st = tr.state_dict()
+    loaded = D.load_weights(str(tmp_path), variant="Dprime")
+    assert list(loaded) == list(st) and all(np.array_equal(loaded[k], st[k]) for k in st)
+    everything = ck.read_checkpoint(prefix)
+    assert int(everything["global_step"]) == 1 and float(np.abs(everything["nn/1x1/kernel/Momentum"]).max()) > 0
