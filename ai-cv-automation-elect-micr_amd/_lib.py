@@ -124,6 +124,9 @@ SIGNATURES = {
                                       [C.c_void_p]),
     # x mean var y B npix_img eps stream
     "emd_instnorm_tanh_f32": (C.c_int, [_c_float_p] * 4 + [C.c_int, C.c_long, C.c_float, C.c_void_p]),
+    "emd_sep3x3_fused_reflect_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
+                                               _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     # x ldx w bias y B K stream
     "emd_fc_rows_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_float, _c_float_p, C.c_int, C.c_int, C.c_void_p]),
     # a b c y n stream

@@ -35,6 +35,7 @@ struct SepParams {
     const float* shift2;
     int H, W, Cin, Cpad, N;
     int ldx, ldy, ldres, act;
+    int reflect;          // 1: the patch border is tf.pad(REFLECT) of the image (graph G), 0: zero (TF SAME)
 };
 
 template <int BN, int PASSES>
@@ -74,7 +75,11 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
         long long o = -1;
         if (idx < NPX * 8) {
             const int ppx = idx >> 3, py = ppx / PW, px = ppx - py * PW;
-            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            if (p.reflect) {  // index -1 -> 1, H -> H-2
+                gy = gy < 0 ? -gy : (gy >= p.H ? 2 * p.H - 2 - gy : gy);
+                gx = gx < 0 ? -gx : (gx >= p.W ? 2 * p.W - 2 - gx : gx);
+            }
             if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) o = (img + (long)gy * p.W + gx) * p.ldx + (idx & 7) * 4;
         }
         poff[q] = o;
@@ -228,7 +233,12 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             f32x4 rv = zero;
             if (resp) rv = *reinterpret_cast<const f32x4*>(resp + pix * p.ldres + n);
             v = v * s1 + t1;
-            if (p.act) v = __builtin_elementwise_min(__builtin_elementwise_max(v, zero), six);
+            if (p.act == 4) {  // tf.nn.leaky_relu, alpha 0.2 (graph G)
+                const f32x4 neg = v * 0.2f;
+                v = __builtin_elementwise_max(v, neg);
+            } else if (p.act) {
+                v = __builtin_elementwise_min(__builtin_elementwise_max(v, zero), six);
+            }
             if (p.scale2) v = __builtin_elementwise_min(__builtin_elementwise_max(v * s2 + t2, zero), six);
             *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = v + rv;
         }
@@ -252,11 +262,10 @@ extern "C" int emd_sep3x3_fused_supported(int H, int W, int Cin, int Cout, int s
            Cout >= 4 && Cout <= 128;
 }
 
-extern "C" int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, const uint16_t* whi,
-                                    const uint16_t* wlo, const float* scale1, const float* shift1,
-                                    const float* scale2, const float* shift2, const float* res, int ldres,
-                                    float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
-                                    int precision, emd_stream_t stream) {
+static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                           const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                           const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                           int precision, int reflect, emd_stream_t stream) {
     EMD_REQUIRE(x && dw && whi && scale1 && shift1 && y, EMD_E_INVALID, "emd_sep3x3_fused_f32: null pointer");
     EMD_REQUIRE(precision == 1 || precision == 3, EMD_E_INVALID, "emd_sep3x3_fused_f32: bad precision");
     EMD_REQUIRE(precision == 1 || wlo, EMD_E_INVALID, "emd_sep3x3_fused_f32: the split-bf16 mode needs the lo plane");
@@ -276,7 +285,27 @@ extern "C" int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, co
     p.x = x; p.dw = dw; p.Whi = whi; p.Wlo = wlo; p.y = y; p.res = res;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
-    p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act;
+    p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act; p.reflect = reflect;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return Cout <= 64 ? launch<64>(p, B, precision, st) : launch<128>(p, B, precision, st);
+}
+
+extern "C" int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, const uint16_t* whi,
+                                    const uint16_t* wlo, const float* scale1, const float* shift1,
+                                    const float* scale2, const float* shift2, const float* res, int ldres,
+                                    float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                                    int precision, emd_stream_t stream) {
+    return sep_fused_entry(x, ldx, dw, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, B, H, W, Cin, Cout, act,
+                           precision, 0, stream);
+}
+
+// The same with the depthwise stage reading the tf.pad(REFLECT, 1) border instead of zeros: graph G's
+// strided_conv_block(stride 1, pad_size=(1,1)) (misc_py/gan-infilling-100.py:205-243); act is usually EMD_ACT_LEAKY.
+extern "C" int emd_sep3x3_fused_reflect_f32(const float* x, int ldx, const float* dw, const uint16_t* whi,
+                                            const uint16_t* wlo, const float* scale1, const float* shift1,
+                                            const float* scale2, const float* shift2, const float* res, int ldres,
+                                            float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                                            int precision, emd_stream_t stream) {
+    return sep_fused_entry(x, ldx, dw, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, B, H, W, Cin, Cout, act,
+                           precision, 1, stream);
 }

@@ -321,6 +321,13 @@ int emd_conv3x3_cout1_reflect_f32(const float* x, int ldx, const float* w, float
 int emd_instnorm_tanh_f32(const float* x, const float* mean, const float* var, float* y, int B, long npix_img, float eps,
                           emd_stream_t stream);
 
+/* emd_sep3x3_fused_f32 with the depthwise stage reading the tf.pad(REFLECT, 1) border instead of zeros: the
+ * stride-1 strided_conv_block(pad_size=(1,1)) of graph G (:205-243).  Same arguments and support rule. */
+int emd_sep3x3_fused_reflect_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                                 const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                                 const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout,
+                                 int act, int precision, emd_stream_t stream);
+
 /* Discriminator head (misc_py/gan-infilling-100.py:560-567, :708): a fully connected layer to ONE output per row,
  * y[b] = x[b,:K].w + bias (x row stride ldx), and output = sigmoid(max(small, medium, large)). */
 int emd_fc_rows_f32(const float* x, int ldx, const float* w, float bias, float* y, int B, int K, emd_stream_t stream);

@@ -231,3 +231,25 @@ def test_discriminator_forward(S, B):
     print(f"discriminator {S}px: output {out.cpu().numpy()} vs {ref[0].numpy()}, worst feature map rel L2 {worst:.2e}")
     assert worst < 3e-4
     assert np.allclose(out.cpu().numpy(), ref[0].numpy(), rtol=1e-3, atol=1e-4)
+
+
+@gpu
+@pytest.mark.parametrize("B,H,W,ci,co", [(2, 16, 32, 64, 64), (1, 8, 16, 32, 32), (1, 24, 16, 128, 64)])
+def test_sep_fused_reflect_leaky(B, H, W, ci, co):
+    """One launch: reflect-padded depthwise 3x3 -> pointwise -> affine -> leaky_relu (+ residual)."""
+    from emdenoise import ops
+    from oracle import gan_graph as GG
+    from oracle import tf_ops as T
+    from tests.test_ops_gpu import out_act, rnd, t64, to_act
+
+    x, dw, pw = rnd((B, H, W, ci), 30), rnd((3, 3, ci, 1), 31, 0.4), rnd((1, 1, ci, co), 32, 0.15)
+    s, t, r = rnd((co,), 33, 0.2) + 1, rnd((co,), 34, 0.3), rnd((B, H, W, co), 35)
+    d = GG.depthwise_valid_t(GG.reflect_pad_t(t64(x), 1), t64(dw), 1)
+    ref = (torch.nn.functional.leaky_relu(T.conv2d_t(d, t64(pw)) * t64(s) + t64(t), 0.2) + t64(r)).numpy()
+    dd = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    assert ops.sep_fused_supported(to_act(x), co, 1, 1)
+    out = out_act(B, H, W, co)
+    ops.sep_fused(to_act(x), dd(dw[..., 0].reshape(9, ci)), ops.PackedWeights(pw[0], False, dev()), dd(s), dd(t), out,
+                  act=ops.ACT_LEAKY, res=to_act(r), reflect=True)
+    torch.cuda.synchronize()
+    assert rel_l2(out.torch().cpu().numpy(), ref) < 2e-5
