@@ -111,12 +111,13 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
 
 __global__ __launch_bounds__(256) void chan_reduce_final(const double* __restrict__ part, int nslab, int C,
                                                          float* __restrict__ s1, float* __restrict__ s2, int accumulate) {
-    __shared__ double sm[2][4][64];
-    const int l = threadIdx.x & 63, k0 = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + l;
+    // 16 channels x 16 slab lanes per workgroup
+    __shared__ double sm[2][16][16 + 1];
+    const int l = threadIdx.x & 15, k0 = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + l;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int k = k0; k < nslab; k += 4) {
+        for (int k = k0; k < nslab; k += 16) {
             s += part[((long)k * 2 + 0) * C + c];
             q += part[((long)k * 2 + 1) * C + c];
         }
@@ -124,8 +125,12 @@ __global__ __launch_bounds__(256) void chan_reduce_final(const double* __restric
     sm[1][k0][l] = q;
     __syncthreads();
     if (k0 != 0 || c >= C) return;
-    s = sm[0][0][l] + sm[0][1][l] + sm[0][2][l] + sm[0][3][l];
-    q = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
+    s = q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        s += sm[0][k][l];
+        q += sm[1][k][l];
+    }
     if (accumulate) atomicAdd(s1 + c, (float)s);  // bias gradients: towers on different streams add concurrently
     else s1[c] = (float)s;
     if (s2) s2[c] = (float)q;
@@ -269,7 +274,7 @@ extern "C" int emd_bn_bwd_reduce_f32(const float* dy, int ldd, const float* x, i
     else
         hipLaunchKernelGGL(chan_reduce_partial, dim3((C + 63) / 64, (unsigned)ns), dim3(256), 0, st, dy, ldd, x, ldx, mean,
                            rstd, mscale, mshift, mask, npix, C, rps, ws);
-    hipLaunchKernelGGL(chan_reduce_final, dim3((C + 63) / 64), dim3(256), 0, st, static_cast<const double*>(ws), (int)ns, C, s1,
+    hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16), dim3(256), 0, st, static_cast<const double*>(ws), (int)ns, C, s1,
                        x ? s2 : nullptr, accumulate_s1);
     return emd::check_launch("chan_reduce");
 }

@@ -87,6 +87,65 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
     }
 }
 
+// Stride-1 (rate 1, SAME) form of the above for the big layers: a thread owns (column ox, 4 channels) and walks down
+// a strip of TH output rows keeping the three live input rows x[.][ox-1..ox+1] in registers, so every output pixel
+// costs 4 vector loads (3 of x, 1 of dy) instead of 10; neighbouring lanes share the x loads through L1.
+// Block = 16 channel quads x 16 columns; grid (ceil(C/64), ceil(W/16), B * strips).
+template <int TH>
+__global__ __launch_bounds__(256) void dw_wgrad_roll_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
+                                                            int ldd, float* __restrict__ dw, int H, int W, int C, int nstrip) {
+    const int cl = (threadIdx.x & 15) * 4;
+    const int c = blockIdx.x * 64 + cl;
+    const int ox = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int b = blockIdx.z / nstrip, y0 = (blockIdx.z % nstrip) * TH;
+    float4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f4zero();
+    if (c < C && ox < W) {
+        const float* xb = x + ((long)b * H) * W * ldx + c;
+        const float* db = dy + ((long)b * H) * W * ldd + c;
+        const bool hl = ox > 0, hr = ox + 1 < W;
+        auto row = [&](int iy, float4& l, float4& m, float4& r) {
+            l = m = r = f4zero();
+            if (iy >= 0 && iy < H) {
+                const float* rp = xb + ((long)iy * W + ox) * ldx;
+                m = *reinterpret_cast<const float4*>(rp);
+                if (hl) l = *reinterpret_cast<const float4*>(rp - ldx);
+                if (hr) r = *reinterpret_cast<const float4*>(rp + ldx);
+            }
+        };
+        float4 a0, a1, a2, b0, b1, b2, c0, c1, c2;   // rows oy-1, oy, oy+1
+        row(y0 - 1, a0, a1, a2);
+        row(y0, b0, b1, b2);
+        const int y1 = y0 + TH < H ? y0 + TH : H;
+        for (int oy = y0; oy < y1; ++oy) {
+            row(oy + 1, c0, c1, c2);
+            const float4 g = *reinterpret_cast<const float4*>(db + ((long)oy * W + ox) * ldd);
+            acc[0] = fma4(a0, g, acc[0]); acc[1] = fma4(a1, g, acc[1]); acc[2] = fma4(a2, g, acc[2]);
+            acc[3] = fma4(b0, g, acc[3]); acc[4] = fma4(b1, g, acc[4]); acc[5] = fma4(b2, g, acc[5]);
+            acc[6] = fma4(c0, g, acc[6]); acc[7] = fma4(c1, g, acc[7]); acc[8] = fma4(c2, g, acc[8]);
+            a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
+        }
+    }
+    __shared__ float red[16][9][64 + 1];
+    const int plane = threadIdx.x >> 4;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        red[plane][t][cl + 0] = acc[t].x; red[plane][t][cl + 1] = acc[t].y;
+        red[plane][t][cl + 2] = acc[t].z; red[plane][t][cl + 3] = acc[t].w;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+        const int t = i / 64, l = i % 64;
+        const int cc = blockIdx.x * 64 + l;
+        if (cc >= C) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += red[k][t][l];
+        atomicAdd(dw + (long)t * C + cc, sum);
+    }
+}
+
 // dx[b,iy,ix,c] = sum_{ky,kx} dy[b,oy,ox,c] * w[t][c]  over the (oy,ox) with oy*s + ky*r - pt == iy (same for x).
 // SCALAR: dy has one channel (data gradient of the 3x3 conv to one output channel).
 template <bool SCALAR>
@@ -260,6 +319,15 @@ int launch_wgrad(const float* x, int ldx, const float* dy, int ldd, float* dw, i
                  int rate, hipStream_t st) {
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const long npix = (long)B * Ho * Wo;
+    if (!SCALAR && stride == 1 && rate == 1 && H >= 64 && W >= 64) {  // the large maps: rolling-window form
+        constexpr int TH = 32;
+        const int nstrip = (H + TH - 1) / TH;
+        if ((long)B * nstrip <= 65535 && (W + 15) / 16 <= 65535) {
+            hipLaunchKernelGGL(dw_wgrad_roll_kernel<TH>, dim3((C + 63) / 64, (W + 15) / 16, B * nstrip), dim3(256), 0, st, x, ldx,
+                               dy, ldd, dw, H, W, C, nstrip);
+            return emd::check_launch("dw_wgrad_roll_kernel");
+        }
+    }
     long nslab = (npix + 63) / 64;  // >= 4 pixels per pixel lane; few enough slabs to keep the atomics cheap
     if (nslab > 512) nslab = 512;
     const long pps = (npix + nslab - 1) / nslab;

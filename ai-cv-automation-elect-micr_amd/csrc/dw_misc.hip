@@ -382,12 +382,13 @@ __global__ __launch_bounds__(256) void bn_stats_partial_v4(const float* __restri
 
 __global__ __launch_bounds__(256) void bn_stats_final(const double* __restrict__ part, int nslab, int C, long npix,
                                                       float* __restrict__ mean, float* __restrict__ var) {
-    __shared__ double sm[2][4][64];
-    const int l = threadIdx.x & 63, k0 = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + l;
+    // 16 channels x 16 slab lanes per workgroup: the <= 512 slabs of a channel are summed by 16 lanes
+    __shared__ double sm[2][16][16 + 1];
+    const int l = threadIdx.x & 15, k0 = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + l;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int k = k0; k < nslab; k += 4) {
+        for (int k = k0; k < nslab; k += 16) {
             s += part[((long)k * 2 + 0) * C + c];
             q += part[((long)k * 2 + 1) * C + c];
         }
@@ -395,8 +396,12 @@ __global__ __launch_bounds__(256) void bn_stats_final(const double* __restrict__
     sm[1][k0][l] = q;
     __syncthreads();
     if (k0 != 0 || c >= C) return;
-    s = sm[0][0][l] + sm[0][1][l] + sm[0][2][l] + sm[0][3][l];
-    q = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
+    s = q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        s += sm[0][k][l];
+        q += sm[1][k][l];
+    }
     const double m = s / (double)npix;
     double v = q / (double)npix - m * m;
     mean[c] = (float)m;
@@ -612,7 +617,7 @@ extern "C" int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float
     else
         hipLaunchKernelGGL(bn_stats_partial, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, npix, C,
                            rows_per_slab, ws);
-    hipLaunchKernelGGL(bn_stats_final, dim3((C + 63) / 64), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
+    hipLaunchKernelGGL(bn_stats_final, dim3((C + 15) / 16), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
                        npix, mean, var);
     return emd::check_launch("bn_stats");
 }

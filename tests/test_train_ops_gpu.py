@@ -154,7 +154,7 @@ def test_conv_data_gradient(B, H, W, ci, co, k, stride, rate):
 
 # ------------------------------------------------------------------------------------------------ depthwise
 @pytest.mark.parametrize("B,H,W,Cc,stride", [(2, 16, 16, 64, 1), (1, 13, 9, 128, 1), (1, 8, 8, 728, 1), (2, 16, 16, 64, 2),
-                                             (1, 9, 7, 256, 2), (2, 12, 12, 4, 1), (2, 64, 64, 64, 1)])
+                                             (1, 9, 7, 256, 2), (2, 12, 12, 4, 1), (2, 64, 64, 64, 1), (1, 70, 80, 128, 1), (3, 64, 72, 4, 1)])
 def test_dw3x3_backward(B, H, W, Cc, stride):
     from emdenoise import ops, train_ops as TO
     from oracle import tf_ops as T
