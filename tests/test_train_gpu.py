@@ -203,8 +203,8 @@ def test_train_steps_reference_regime_teacher_forced():
         st = tr.state_dict()
         upd = rel_l2(flat(st, names) - flat(cur, names), flat(newp, names) - flat(cur, names))
         assert upd < 3e-4, (step, upd)      # fp32 rounding of the parameter update itself
-        for n, v in towers[0]["moving"].items():
-            assert rel_l2(st[n], v) < 3e-5, (step, n, rel_l2(st[n], v))
+        for n, v in towers[0]["moving"].items():   # (absolute floor: a moving mean can sit near zero)
+            assert np.allclose(st[n], v, rtol=1e-4, atol=1e-6), (step, n, rel_l2(st[n], v))
 
 
 def test_streams_and_graph_match_eager():
