@@ -131,6 +131,18 @@ SIGNATURES = {
     "emd_fc_rows_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_float, _c_float_p, C.c_int, C.c_int, C.c_void_p]),
     # a b c y n stream
     "emd_max3_sigmoid_f32": (C.c_int, [_c_float_p] * 4 + [C.c_int, C.c_void_p]),
+    # ---- graph G training
+    # logit3 label mode grad_scale result2 dlogit3 stream
+    "emd_gan_head_f32": (C.c_int, [_c_float_p, C.c_float, C.c_int, C.c_float, _c_float_p, _c_float_p, C.c_void_p]),
+    # x w dlogit dw db dx K stream
+    "emd_fc_row_bwd_f32": (C.c_int, [_c_float_p] * 6 + [C.c_int, C.c_void_p]),
+    # v y ldy npix C alpha stream
+    "emd_bcast_rows_f32": (C.c_int, [_c_float_p, _c_float_p, C.c_int, C.c_long, C.c_int, C.c_float, C.c_void_p]),
+    "emd_sumsq_workspace_bytes": (C.c_size_t, []),
+    # x n scale out workspace stream
+    "emd_sumsq_f32": (C.c_int, [_c_float_p, C.c_long, C.c_float, _c_float_p, C.c_void_p, C.c_void_p]),
+    # param grad m v n lr_t beta1 beta2 eps grad_scale gnorm_sq clip_norm stream
+    "emd_adam_step_f32": (C.c_int, [_c_float_p] * 4 + [C.c_long] + [C.c_float] * 5 + [_c_float_p, C.c_float, C.c_void_p]),
 }
 
 _lib = None

@@ -19,6 +19,7 @@ namespace {
 __device__ __forceinline__ float grad_mask(float dy, float z, int mask) {
     if (mask == 1) return (z > 0.f && z < 6.f) ? dy : 0.f;   // tf.nn.relu6 (Relu6Grad: 0 < z < 6)
     if (mask == 2) return (z > 0.f && z <= 1.f) ? dy : 0.f;  // relu6 then tf.clip_by_value(., 0, 1) (passes on [0,1])
+    if (mask == 3) return z > 0.f ? dy : 0.2f * dy;           // tf.nn.leaky_relu, alpha 0.2 (graph G)
     return dy;
 }
 
@@ -262,7 +263,7 @@ extern "C" int emd_bn_bwd_reduce_f32(const float* dy, int ldd, const float* x, i
                                      const float* rstd, const float* mscale, const float* mshift, int mask, long npix,
                                      int C, float* s1, float* s2, int accumulate_s1, void* workspace, emd_stream_t stream) {
     EMD_REQUIRE(dy && s1 && workspace, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: null pointer");
-    EMD_REQUIRE(npix >= 1 && C >= 1 && mask >= 0 && mask <= 2, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: bad argument");
+    EMD_REQUIRE(npix >= 1 && C >= 1 && mask >= 0 && mask <= 3, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: bad argument");
     EMD_REQUIRE(!x || (mean && rstd && s2), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: x needs mean, rstd and s2");
     EMD_REQUIRE(!mask || (x && mscale && mshift), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: a mask needs x, mscale, mshift");
     const long ns = emd::reduce_slabs(npix), rps = emd::reduce_rows_per_slab(npix);
@@ -283,7 +284,7 @@ extern "C" int emd_bn_bwd_apply_f32(const float* dy, int ldd, const float* x, in
                                     const float* mean, const float* m2, const float* mscale, const float* mshift,
                                     int mask, float* dx, int ldo, long npix, int C, emd_stream_t stream) {
     EMD_REQUIRE(dy && x && K && m1 && mean && m2 && dx, EMD_E_INVALID, "emd_bn_bwd_apply_f32: null pointer");
-    EMD_REQUIRE(npix >= 1 && C >= 1 && mask >= 0 && mask <= 2 && (!mask || (mscale && mshift)), EMD_E_INVALID,
+    EMD_REQUIRE(npix >= 1 && C >= 1 && mask >= 0 && mask <= 3 && (!mask || (mscale && mshift)), EMD_E_INVALID,
                 "emd_bn_bwd_apply_f32: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (C % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && emd::aligned16(dy) && emd::aligned16(x) &&

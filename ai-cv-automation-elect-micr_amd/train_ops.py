@@ -10,7 +10,7 @@ import ctypes as C
 from . import _lib
 from .ops import PREC_BF16X3, Act, _p
 
-MASK_NONE, MASK_RELU6, MASK_RELU6_CLIP = 0, 1, 2
+MASK_NONE, MASK_RELU6, MASK_RELU6_CLIP, MASK_LEAKY = 0, 1, 2, 3
 BN_EPS = 1e-3
 BN_DECAY = 0.999  # tf.contrib.layers.batch_norm default
 
@@ -202,3 +202,50 @@ def nesterov_step(param, grad, accum, lr, momentum=0.9, grad_scale=1.0, stream=N
     _lib.check(_lib.load().emd_nesterov_step_f32(_p(param), _p(grad), _p(accum), C.c_long(param.numel()), C.c_float(lr),
                                                  C.c_float(momentum), C.c_float(grad_scale), _lib.stream_ptr(stream)),
                "emd_nesterov_step_f32")
+
+
+# ---- graph G training (misc_py/gan-infilling-100.py:982-1088, :1378-1379, :1429-1431)
+def gan_head(logit3, label, mode, grad_scale=1.0, stream=None):
+    """-> (result2 = [out, loss], dlogit3) device tensors.  mode 0: discriminator loss, 1: generator loss."""
+    import torch
+
+    res = torch.empty(2, dtype=torch.float32, device=logit3.device)
+    dl = torch.empty(3, dtype=torch.float32, device=logit3.device)
+    _lib.check(_lib.load().emd_gan_head_f32(_p(logit3), C.c_float(label), mode, C.c_float(grad_scale), _p(res), _p(dl),
+                                            _lib.stream_ptr(stream)), "emd_gan_head_f32")
+    return res, dl
+
+
+def fc_row_bwd(x, w, dlogit, dw, db, stream=None):
+    import torch
+
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().emd_fc_row_bwd_f32(_p(x), _p(w), _p(dlogit), _p(dw), _p(db), _p(dx), x.numel(),
+                                              _lib.stream_ptr(stream)), "emd_fc_row_bwd_f32")
+    return dx
+
+
+def bcast_rows(v, out: Act, alpha, stream=None):
+    _lib.check(_lib.load().emd_bcast_rows_f32(_p(v), out.ptr, out.ld, C.c_long(out.B * out.H * out.W), out.C, C.c_float(alpha),
+                                              _lib.stream_ptr(stream)), "emd_bcast_rows_f32")
+    return out
+
+
+def sumsq(x, scale=1.0, stream=None):
+    import torch
+
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.emd_sumsq_workspace_bytes() // 8, dtype=torch.float64, device=x.device)
+    _lib.check(lib.emd_sumsq_f32(_p(x), C.c_long(x.numel()), C.c_float(scale), _p(out), _p(ws), _lib.stream_ptr(stream)),
+               "emd_sumsq_f32")
+    return out
+
+
+def adam_step(param, grad, m, v, step, lr, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0, gnorm_sq=None, clip_norm=0.0,
+              stream=None):
+    """``step`` = the 1-based step count t (bias correction lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t), as TF computes it)."""
+    lr_t = lr * (1.0 - beta2 ** step) ** 0.5 / (1.0 - beta1 ** step)
+    _lib.check(_lib.load().emd_adam_step_f32(_p(param), _p(grad), _p(m), _p(v), C.c_long(param.numel()), C.c_float(lr_t),
+                                             C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(grad_scale),
+                                             _p(gnorm_sq), C.c_float(clip_norm), _lib.stream_ptr(stream)), "emd_adam_step_f32")

@@ -241,7 +241,7 @@ int emd_conv1x1_s2_bwd_data_f32(const float* dy, int ldd, const uint16_t* whi, c
  *   rstd2 for the double norm: gamma1/beta1 non-NULL), and, if mm2 != NULL, the moving-average updates
  *   (mm1/mv1: BN1's, double norm only; bias: the conv bias that precedes a single BN, may be NULL).
  * emd_bn_bwd_reduce_f32: s1[c] = sum g, s2[c] = sum g*(x-mean)*rstd, g = dy*mask(x*mscale+mshift);
- *   mask 0 none, 1 relu6 (0<z<6), 2 relu6 then clip [0,1] (0<z<=1).  x == NULL: s1 only (a bias gradient).
+ *   mask 0 none, 1 relu6 (0<z<6), 2 relu6 then clip [0,1] (0<z<=1), 3 leaky_relu 0.2 (graph G).  x == NULL: s1 only.
  *   accumulate_s1 != 0: s1 += (bias gradients).  workspace: emd_chan_reduce_workspace_bytes(npix, C) bytes.
  * emd_bn_bwd_prep_f32: (s1, t=s2) -> K, m1, m2 for the apply step; dgamma1, dgamma2, dbeta2 += .
  * emd_bn_bwd_apply_f32: dx = K*(g - m1 - (x-mean)*m2); dx may be dy.  C = 1 is allowed (the final layer). */
@@ -332,6 +332,31 @@ int emd_sep3x3_fused_reflect_f32(const float* x, int ldx, const float* dw, const
  * y[b] = x[b,:K].w + bias (x row stride ldx), and output = sigmoid(max(small, medium, large)). */
 int emd_fc_rows_f32(const float* x, int ldx, const float* w, float bias, float* y, int B, int K, emd_stream_t stream);
 int emd_max3_sigmoid_f32(const float* a, const float* b, const float* c, float* y, int n, emd_stream_t stream);
+
+/* ================================================================================================
+ * Training side of graph G (misc_py/gan-infilling-100.py:982-1088 towers, :1378-1379 / :1429-1431 optimizers).  The
+ * convolution gradients are the graph-D' entry points with mask 3 (leaky_relu) in emd_bn_bwd_{reduce,apply}_f32.
+ * ================================================================================================ */
+
+/* Head of one tower (batch_size 1, :74): out = sigmoid(max(logit3)); mode 0: discriminator loss
+ * -log(clip(1-|label-out|, 1e-8, 1-1e-8)) (:1080); mode 1: generator loss -log(clip(out, 1e-8, 1)) (:1037).
+ * result2 = {out, loss}; dlogit3 = grad_scale * dloss/dlogit (arg-max branch only).  All device pointers. */
+int emd_gan_head_f32(const float* logit3, float label, int mode, float grad_scale, float* result2, float* dlogit3,
+                     emd_stream_t stream);
+/* Backward of emd_fc_rows_f32 for one row: dw[k] += x[k]*g, *db += g, dx[k] = w[k]*g with g = *dlogit (device). */
+int emd_fc_row_bwd_f32(const float* x, const float* w, const float* dlogit, float* dw, float* db, float* dx, int K,
+                       emd_stream_t stream);
+/* Gradient of tf.reduce_mean(x, [1,2]) (:578): y[p][c] = v[c]*alpha for every pixel p of [npix, C]. */
+int emd_bcast_rows_f32(const float* v, float* y, int ldy, long npix, int C, float alpha, emd_stream_t stream);
+/* out[0] = |scale*x|^2 of a flat vector (double accumulation): the global norm of clip_gradients_by_norm.
+ * workspace: emd_sumsq_workspace_bytes() bytes. */
+size_t emd_sumsq_workspace_bytes(void);
+int emd_sumsq_f32(const float* x, long n, float scale, float* out, void* workspace, emd_stream_t stream);
+/* tf.train.AdamOptimizer(lr, beta1 = 0.5) inside tf.contrib.estimator.clip_gradients_by_norm(., clip_norm):
+ * g = grad*grad_scale*clip_norm/max(sqrt(*gnorm_sq), clip_norm) (gnorm_sq NULL: no clipping); m, v moment updates;
+ * param -= lr_t*m/(sqrt(v)+eps), lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) computed by the caller. */
+int emd_adam_step_f32(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
+                      float eps, float grad_scale, const float* gnorm_sq, float clip_norm, emd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Host utility (no GPU): CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start).

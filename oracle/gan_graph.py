@@ -218,8 +218,10 @@ def multiscale_crops(img, offsets):
 
 
 class _Discr:
-    def __init__(self, get, dtype):
+    def __init__(self, get, dtype, training=False):
         self.get, self.dtype, self.sc = get, dtype, _Scope("GAN/Discr")
+        self.training = training      # phase=True: the separable convs' batch norms use batch statistics (:399-409)
+        self.moving_updates = {} if training else None   # decay 0.9997 (batch_decay_discr, :110)
 
     def instance_norm(self, x):
         C = x.shape[-1]
@@ -239,6 +241,12 @@ class _Discr:
         b = scope + "/BatchNorm"
         beta, gamma = self.get(b + "/beta", (filters,)), self.get(b + "/gamma", (filters,))
         mean, var = self.get(b + "/moving_mean", (filters,)), self.get(b + "/moving_variance", (filters,))
+        if self.training:
+            bm, bv = y.mean(dim=(0, 1, 2)), y.var(dim=(0, 1, 2), unbiased=False)
+            n = y.shape[0] * y.shape[1] * y.shape[2]
+            self.moving_updates[b + "/moving_mean"] = mean.detach() - (mean.detach() - bm.detach()) * (1.0 - 0.9997)
+            self.moving_updates[b + "/moving_variance"] = var.detach() - (var.detach() - bv.detach() * (n / max(n - 1, 1))) * (1.0 - 0.9997)
+            mean, var = bm, bv
         y = (y - mean) * (gamma / torch.sqrt(var + BN_EPS_DISCR)) + beta
         return F.leaky_relu(self.instance_norm(y), LEAKY)
 
@@ -292,3 +300,65 @@ def discriminator(inputs, weights, dtype=torch.float32):
     xs = [(x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))).to(dtype) for x in inputs]
     with torch.no_grad():
         return _Discr(get, dtype).build(xs)
+
+
+# ================================================================================================
+# Training towers (misc_py/gan-infilling-100.py:1048-1088 discriminator, :982-1046 generator) and the optimizer
+# (:1378-1379, :1429-1431: Adam beta1 0.5 wrapped in clip_gradients_by_norm), via PyTorch autograd.
+# ================================================================================================
+def _leaves(weights, dtype, trainable):
+    leaves = {}
+
+    def get(name, shape):
+        if name not in leaves:
+            w = weights[name]
+            assert tuple(w.shape) == tuple(shape), (name, w.shape, shape)
+            t = torch.from_numpy(np.ascontiguousarray(w)).to(dtype)
+            if trainable(name):
+                t.requires_grad_(True)
+            leaves[name] = t
+        return leaves[name]
+
+    return leaves, get
+
+
+def _is_trainable(name):
+    leaf = name.rsplit("/", 1)[1]
+    return not (leaf.startswith("moving_") or leaf.startswith("Variable"))
+
+
+def discriminator_tower(image, label, weights, offsets, adapt=1.0, dtype=torch.float64):
+    """_discriminator_tower_fn (:1048-1088) for ONE image [1,S,S,1] (batch_size = 1, :74): crops, discriminator with
+    phase=True, tower_loss = -log(clip(1 - |label - D|, 1e-8, 1 - 1e-8)) + 5e-5 * sum l2_loss(v) over the trainable
+    discriminator variables; gradients of adapt * tower_loss.  -> dict(output, loss, grads, moving)."""
+    leaves, get = _leaves(weights, dtype, _is_trainable)
+    x = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image))
+    crops = multiscale_crops(x.to(dtype), offsets)
+    d = _Discr(get, dtype, training=True)
+    out = d.build(list(crops))[0]
+    names = [n for n, v in leaves.items() if v.requires_grad]
+    l2 = sum(0.5 * (leaves[n] ** 2).sum() for n in names)
+    loss = -torch.log(torch.clamp(1.0 - torch.abs(float(label) - out), 1e-8, 1.0 - 1e-8)).sum() + 5e-5 * l2
+    grads = torch.autograd.grad(float(adapt) * loss, [leaves[n] for n in names], allow_unused=True)
+    return {"output": out.detach().numpy(), "loss": float(loss.detach()),
+            "grads": {n: (g.numpy() if g is not None else np.zeros(tuple(leaves[n].shape))) for n, g in zip(names, grads)},
+            "moving": {n: v.numpy() for n, v in d.moving_updates.items()}}
+
+
+def clip_by_global_norm(grads, clip_norm):
+    """tf.clip_by_global_norm as clip_gradients_by_norm applies it: g * clip_norm / max(global_norm, clip_norm)."""
+    gn = float(np.sqrt(sum(float((np.asarray(g, np.float64) ** 2).sum()) for g in grads.values())))
+    scale = clip_norm / max(gn, clip_norm)
+    return {n: g * scale for n, g in grads.items()}, gn
+
+
+def adam_step(params, grads, m, v, t, lr, beta1=0.5, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer(lr, beta1): lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t); m, v moments; var -= lr_t*m/(sqrt(v)+eps).
+    t = the 1-based step count.  Dicts of numpy arrays; returns (params, m, v)."""
+    lr_t = lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    new_p, new_m, new_v = {}, {}, {}
+    for n, g in grads.items():
+        new_m[n] = beta1 * m[n] + (1.0 - beta1) * g
+        new_v[n] = beta2 * v[n] + (1.0 - beta2) * g * g
+        new_p[n] = params[n] - lr_t * new_m[n] / (np.sqrt(new_v[n]) + eps)
+    return new_p, new_m, new_v
