@@ -143,6 +143,23 @@ SIGNATURES = {
     "emd_sumsq_f32": (C.c_int, [_c_float_p, C.c_long, C.c_float, _c_float_p, C.c_void_p, C.c_void_p]),
     # param grad m v n lr_t beta1 beta2 eps grad_scale gnorm_sq clip_norm stream
     "emd_adam_step_f32": (C.c_int, [_c_float_p] * 4 + [C.c_long] + [C.c_float] * 5 + [_c_float_p, C.c_float, C.c_void_p]),
+    # x ldx dy ldd dw B H W C stride stream
+    "emd_dw3x3_reflect_wgrad_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p] + [C.c_int] * 5 + [C.c_void_p]),
+    # dy ldd w dx ldx B H W C stride stream
+    "emd_dw3x3_reflect_bwd_data_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p]),
+    # x ldx dy dw B H W Cin stream
+    "emd_conv3x3_cout1_reflect_wgrad_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p] + [C.c_int] * 4 + [C.c_void_p]),
+    # dy w dx ldx B H W Cin stream
+    "emd_conv3x3_cout1_reflect_bwd_data_f32": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 4 + [C.c_void_p]),
+    "emd_dw7_c1_reflect_f32": (C.c_int, [_c_float_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "emd_dw7_c1_reflect_wgrad_f32": (C.c_int, [_c_float_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "emd_tanh_bwd_f32": (C.c_int, [_c_float_p] * 3 + [C.c_long, C.c_void_p]),
+    # a b n weight dy accumulate loss_acc stream
+    "emd_l1_feature_f32": (C.c_int, [_c_float_p, _c_float_p, C.c_long, C.c_float, _c_float_p, C.c_int, _c_float_p, C.c_void_p]),
+    # dcrop ldc dimg y0 x0 n S stream
+    "emd_crop_scatter_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p] + [C.c_int] * 4 + [C.c_void_p]),
+    "emd_bn_infer_fold2_f32": (C.c_int, [_c_float_p] * 8 + [C.c_float, C.c_int] + [_c_float_p] * 6 + [C.c_void_p]),
+    "emd_bn_infer_grads_f32": (C.c_int, [_c_float_p] * 4 + [C.c_int] + [_c_float_p] * 4 + [C.c_void_p]),
 }
 
 _lib = None

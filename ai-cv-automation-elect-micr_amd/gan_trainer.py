@@ -147,27 +147,28 @@ class DiscriminatorTrainer:
     def _E(self, B, H, W, Cc):
         return ops.Act.empty(B, H, W, Cc, self.device)
 
-    def tower(self, image, label, offsets, adapt=1.0, update_moving=True):
-        """image: torch CUDA float32 [1,S,S,1]; label, adapt: host floats (the reference feeds them through placeholders,
-        :1554-1556, :1729-1736).  Adds adapt * d(data loss)/d(parameters) into self.grads (the l2 term is added by
-        ``step``).  -> device tensor [out, data loss]."""
+    def prepare_inputs(self, small, medium, large):
+        """The three crops ([1,n,n,1] torch tensors; the large one at 3S/4) -> 4-channel branch inputs at S/4 (channel 0
+        real): the medium crop is average-pooled (:585-588), the large one bilinearly resized (:975)."""
         import torch
 
-        assert image.shape[0] == 1 and image.shape[3] == 1, "one image per tower (batch_size = 1 in the reference)"
-        dev = self.device
-
         def pad4(t):
-            out = torch.zeros(t.shape[:3] + (4,), dtype=torch.float32, device=dev)
+            out = torch.zeros(t.shape[:3] + (4,), dtype=torch.float32, device=self.device)
             out[..., 0:1].copy_(t)
             return out
 
-        self._pad_dirty = True
-        small, medium, large = multiscale_crops(image, offsets)
         S4 = small.shape[1]
-        inputs = {"small": ops.Act(pad4(small)),
-                  "medium": ops.avgpool2x2(ops.Act(pad4(medium)), self._E(1, S4, S4, 4)),
-                  "large": ops.resize_bilinear(ops.Act(pad4(large)), self._E(1, S4, S4, 4))}
-        saved, logits, means = {}, [], {}
+        self._raw_inputs = {"medium": ops.Act(pad4(medium)), "large": ops.Act(pad4(large))}
+        return {"small": ops.Act(pad4(small)),
+                "medium": ops.avgpool2x2(self._raw_inputs["medium"], self._E(1, S4, S4, 4)),
+                "large": ops.resize_bilinear(self._raw_inputs["large"], self._E(1, S4, S4, 4))}
+
+    def forward(self, inputs, update_moving=False):
+        """discriminator_architecture(phase=True) on the prepared inputs -> (logits [3] device tensor, saved contexts).
+        saved[br] = (per-layer dicts x, d, r, fold, y; pooled mean)."""
+        import torch
+
+        saved, logits = {}, []
         for br in BRANCHES:
             x, ctxs = inputs[br], []
             for lay in self.L[br]["layers"]:
@@ -183,36 +184,65 @@ class DiscriminatorTrainer:
                 fold = TO.bn_train_fold(mean, var, self.ones[:f], self.zeros[:f], Ho * Wo, gamma1=self.v[b + "/gamma"],
                                         beta1=self.v[b + "/beta"], moving=mv, eps=BN_EPS_DISCR, decay=BN_DECAY_DISCR)
                 y = ops.affine_act(r, fold["scale"], fold["shift"], self._E(1, Ho, Wo, f), act=ops.ACT_LEAKY)
-                ctxs.append({"x": x, "d": d, "r": r, "fold": fold})
+                ctxs.append({"x": x, "d": d, "r": r, "fold": fold, "y": y})
                 x = y
             mean, _ = ops.bn_batch_stats(x)         # tf.reduce_mean(., [1,2]) (:578)
             fc = self.L[br]["fc"]
-            logit = torch.empty(1, dtype=torch.float32, device=dev)
+            logit = torch.empty(1, dtype=torch.float32, device=self.device)
             _lib.check(_lib.load().emd_fc_rows_f32(ops._p(mean), features5, ops._p(self.v[fc + "/weights"]),
                                                    ops.C.c_float(0.0), ops._p(logit), 1, features5, _lib.stream_ptr()),
                        "emd_fc_rows_f32")
             logits.append(logit + self.v[fc + "/biases"])
-            saved[br], means[br] = (ctxs, x), mean
-        result, dlogit = TO.gan_head(torch.cat(logits), float(label), 0, grad_scale=float(adapt))
-        # ---- reverse pass, branch by branch (only the arg-max branch has a non-zero dlogit)
+            saved[br] = (ctxs, mean)
+        return torch.cat(logits), saved
+
+    def backward(self, saved, dlogit, weight_grads=True, feature_targets=None, feature_weight=0.0, loss_acc=None,
+                 input_grads=False):
+        """Reverse pass of ``forward``.  weight_grads: accumulate parameter gradients (the discriminator's own step);
+        feature_targets[br][li]: the NATURAL image's feature map of that layer -- the generator's feature-matching term
+        feature_weight * mean|f - f_natural| (:1027-1035) is added to *loss_acc and its gradient to the layer's output
+        gradient; input_grads: also return d loss / d (4-channel branch input) per branch."""
+        out = {}
         for k, br in enumerate(BRANCHES):
-            ctxs, last = saved[br]
+            ctxs, mean = saved[br]
+            last = ctxs[-1]["y"]
             fc = self.L[br]["fc"]
-            dmean = TO.fc_row_bwd(means[br], self.v[fc + "/weights"].view(features5), dlogit[k:k + 1],
-                                  self.g[fc + "/weights"].view(features5), self.g[fc + "/biases"])
+            if weight_grads:
+                dmean = TO.fc_row_bwd(mean, self.v[fc + "/weights"].view(features5), dlogit[k:k + 1],
+                                      self.g[fc + "/weights"].view(features5), self.g[fc + "/biases"])
+            else:
+                dmean = TO.fc_row_bwd(mean, self.v[fc + "/weights"].view(features5), dlogit[k:k + 1],
+                                      self.scratch[:features5], self.scratch[features5: features5 + 1])
             dy = TO.bcast_rows(dmean, self._E(1, last.H, last.W, features5), 1.0 / (last.H * last.W))
             for li in reversed(range(len(ctxs))):
                 lay, c = self.L[br]["layers"][li], ctxs[li]
+                if feature_targets is not None:
+                    TO.l1_feature(c["y"].buf, feature_targets[br][li], feature_weight, dy.buf, True, loss_acc)
                 b = lay["scope"] + "/BatchNorm"
                 f = lay["cout"]
+                dg1 = self.g[b + "/gamma"] if weight_grads else self.scratch[2 * features5: 2 * features5 + f]
                 dr = TO.bn_backward(dy, c["r"], c["fold"], self.ones[:f], self.scratch[:f], self.scratch[features5: features5 + f],
-                                    c["r"], mask=TO.MASK_LEAKY, gamma1=self.v[b + "/gamma"], dgamma1=self.g[b + "/gamma"],
-                                    eps=BN_EPS_DISCR)
-                TO.conv_wgrad(c["d"], dr, self._gpw(lay))
+                                    c["r"], mask=TO.MASK_LEAKY, gamma1=self.v[b + "/gamma"], dgamma1=dg1, eps=BN_EPS_DISCR)
+                if weight_grads:
+                    TO.conv_wgrad(c["d"], dr, self._gpw(lay))
                 dd = ops.conv1x1(dr, lay["pk_b"], self.ones, self.zeros, c["d"], act=False, precision=self.precision)
-                TO.dw3x3_wgrad(c["x"], dd, self._gdw(lay), stride=2)
-                if li > 0:
+                if weight_grads:
+                    TO.dw3x3_wgrad(c["x"], dd, self._gdw(lay), stride=2)
+                if li > 0 or input_grads:
                     dy = TO.dw3x3_bwd_data(dd, self._dw(lay), self._E(1, c["x"].H, c["x"].W, c["x"].C), stride=2)
+            if input_grads:
+                out[br] = dy
+        return out
+
+    def tower(self, image, label, offsets, adapt=1.0, update_moving=True):
+        """image: torch CUDA float32 [1,S,S,1]; label, adapt: host floats (the reference feeds them through placeholders,
+        :1554-1556, :1729-1736).  Adds adapt * d(data loss)/d(parameters) into self.grads (the l2 term is added by
+        ``step``).  -> device tensor [out, data loss]."""
+        assert image.shape[0] == 1 and image.shape[3] == 1, "one image per tower (batch_size = 1 in the reference)"
+        self._pad_dirty = True
+        logits, saved = self.forward(self.prepare_inputs(*multiscale_crops(image, offsets)), update_moving)
+        result, dlogit = TO.gan_head(logits, float(label), 0, grad_scale=float(adapt))
+        self.backward(saved, dlogit)
         return result
 
     # ---- one optimizer step
@@ -237,5 +267,328 @@ class DiscriminatorTrainer:
         self.t += 1
         TO.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.t, self.lr if learning_rate is None else learning_rate,
                      beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_DISCR)
+        self.repack()
+        return torch.stack(res)
+
+
+# ================================================================================================
+# Generator side: _generator_tower_fn (:982-1046) and _train_op (:1330-1388).
+# ================================================================================================
+BN_EPS_GEN = 0.01
+CLIP_GEN = 50.0                # :1379
+WEIGHT_NATURAL_STATS = 12.0    # :1035
+
+
+class GeneratorTrainer:
+    """Generator parameters, gradients and Adam moments on one GPU + the generator tower's forward / reverse pass.
+
+    As the reference's loop evaluates it (:1660-1680): the generator's batch norms stay on their MOVING statistics
+    (``batch_norm_on_ph: False``), so each separable conv is depthwise -> pointwise -> fixed affine -> leaky_relu and
+    there is no l2 term (decay = 0, :1039); concat(output, truth) is cropped once; the discriminator (phase=True, its
+    parameters frozen here) scores the generated crops and supplies 15 feature maps of the generated and of the natural
+    crops; loss = -log(clip(D(fake), 1e-8, 1)) + 12 * sum_l mean|f_l(fake) - f_l(natural)|.  The reverse pass goes
+    through the discriminator (data gradients only), the crops, and the generator (weight + batch-norm gamma/beta
+    gradients)."""
+
+    def __init__(self, weights, discriminator: DiscriminatorTrainer, device, precision="bf16x3", learning_rate=0.0002):
+        import torch
+
+        from . import gan as GN
+
+        _lib.load()
+        self.device, self.D = device, discriminator
+        self.precision = {"bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[precision]
+        self.lr = learning_rate
+        self.layers, self.conv_scope, self.in_vars = GN.declare_layers()
+        specs = GN.variable_specs()
+        self.trainable = OrderedDict((n, s) for n, s in specs.items() if not _frozen(n))
+        self.frozen = OrderedDict((n, s) for n, s in specs.items() if _frozen(n))
+
+        def flat(names, fill=None):
+            offs, n = {}, 0
+            for name, shape in names.items():
+                offs[name] = n
+                n += -(-int(np.prod(shape)) // 4) * 4
+            buf = torch.zeros(n, dtype=torch.float32, device=device)
+            views = OrderedDict((name, buf[offs[name]: offs[name] + int(np.prod(shape))].view(shape)) for name, shape in names.items())
+            if fill is not None:
+                host = np.zeros(n, np.float32)
+                for name, shape in names.items():
+                    host[offs[name]: offs[name] + int(np.prod(shape))] = np.asarray(fill[name], np.float32).reshape(-1)
+                buf.copy_(torch.from_numpy(host))
+            return buf, views
+
+        self.params, self.v = flat(self.trainable, weights)
+        self.grads, self.g = flat(self.trainable)
+        self.adam_m, _ = flat(self.trainable)
+        self.adam_v, _ = flat(self.trainable)
+        self.moving, self.m = flat(self.frozen, weights)
+        self.t = 0
+        cmax = max(L.cout for L in self.layers.values())
+        self.ones = torch.ones(cmax, dtype=torch.float32, device=device)
+        self.zeros = torch.zeros(cmax, dtype=torch.float32, device=device)
+        self.pw4 = torch.zeros(1, 4, GN.gen_features0, device=device)      # first layer's pointwise weights, K padded to 4
+        self.gpw4 = torch.zeros_like(self.pw4)
+        self.pk_f, self.pk_b, self.fold = {}, {}, {}
+        for key, L in self.layers.items():
+            cin = max(L.cin, 4)
+            self.pk_f[key] = TO.DevPackedWeights(1, cin, L.cout, device)
+            self.pk_b[key] = TO.DevPackedWeights(1, L.cout, cin, device)
+        self._pad_dirty = False
+        self.repack()
+
+    # ---- parameters
+    def _pw(self, key):
+        L = self.layers[key]
+        return self.pw4 if L.cin == 1 else self.v[L.scope + "/pointwise_weights"].view(1, L.cin, L.cout)
+
+    def _gpw(self, key):
+        L = self.layers[key]
+        return self.gpw4 if L.cin == 1 else self.g[L.scope + "/pointwise_weights"].view(1, L.cin, L.cout)
+
+    def _dw(self, key):
+        L = self.layers[key]
+        return self.v[L.scope + "/depthwise_weights"].view(L.k * L.k, L.cin)
+
+    def _gdw(self, key):
+        L = self.layers[key]
+        return self.g[L.scope + "/depthwise_weights"].view(L.k * L.k, L.cin)
+
+    def repack(self):
+        """Parameters -> packed bf16 weights (both orientations), flipped depthwise taps, and the per-layer folds of the
+        two inference-mode batch norms (all on the device; runs after every optimizer step)."""
+        L0 = self.layers["enc0"]
+        self.pw4[0, 0].copy_(self.v[L0.scope + "/pointwise_weights"].view(L0.cout))
+        if not hasattr(self, "dw_flip"):
+            self.dw_flip = {}
+        for key, L in self.layers.items():
+            w = self._pw(key)
+            self.pk_f[key].pack(w, 1, cout_major=False)
+            self.pk_b[key].pack(w.contiguous(), 1, cout_major=True)
+            b1, b2 = L.scope + "/BatchNorm", L.outer_bn
+            self.fold[key] = TO.bn_infer_fold2(self.v[b1 + "/gamma"], self.v[b1 + "/beta"], self.m[b1 + "/moving_mean"],
+                                               self.m[b1 + "/moving_variance"], self.v[b2 + "/gamma"], self.v[b2 + "/beta"],
+                                               self.m[b2 + "/moving_mean"], self.m[b2 + "/moving_variance"], BN_EPS_GEN)
+            if not L.reflect and L.stride == 1:
+                flipped = self._dw(key).flip(0)
+                if key not in self.dw_flip:
+                    self.dw_flip[key] = flipped.contiguous()
+                else:
+                    self.dw_flip[key].copy_(flipped)
+
+    def zero_grad(self):
+        self._pad_dirty = False
+        self.grads.zero_()
+        self.gpw4.zero_()
+
+    def _unpad_grads(self):
+        if not self._pad_dirty:
+            return
+        self._pad_dirty = False
+        L0 = self.layers["enc0"]
+        self.g[L0.scope + "/pointwise_weights"].view(L0.cout).copy_(self.gpw4[0, 0])
+
+    def gradients(self):
+        self._unpad_grads()
+        return OrderedDict((n, t.detach().cpu().numpy().copy()) for n, t in self.g.items())
+
+    def state_dict(self):
+        from . import gan as GN
+
+        out = OrderedDict()
+        for name in GN.variable_specs():
+            out[name] = (self.m if _frozen(name) else self.v)[name].detach().cpu().numpy().copy()
+        return out
+
+    # ---- forward blocks
+    def _E(self, B, H, W, Cc):
+        return ops.Act.empty(B, H, W, Cc, self.device)
+
+    def _sep_fwd(self, key, x, res=None, x_img=None):
+        L, f = self.layers[key], self.fold[key]
+        if L.cin == 1:     # 7x7 depthwise on the image -> channel 0 of a 4-channel tensor -> K = 4 pointwise GEMM
+            d = TO.dw7_c1_reflect(x_img, self._dw(key).view(49), self._E(x_img.shape[0], x_img.shape[1], x_img.shape[2], 4))
+            Ho, Wo = d.H, d.W
+        else:
+            Ho, Wo = (x.H - 1) // L.stride + 1, (x.W - 1) // L.stride + 1
+            d = self._E(x.B, Ho, Wo, L.cin)
+            if L.reflect:
+                ops.dw3x3_reflect(x, self._dw(key), d, stride=L.stride)
+            else:
+                ops.dw3x3(x, self._dw(key), d, stride=L.stride)
+        r = ops.conv1x1(d, self.pk_f[key], self.ones, self.zeros, self._E(d.B, Ho, Wo, L.cout), act=False, precision=self.precision)
+        y = ops.affine_act(r, f["scale"], f["shift"], self._E(d.B, Ho, Wo, L.cout), act=ops.ACT_LEAKY, res=res)
+        return y, {"x": x, "d": d, "r": r, "x_img": x_img}
+
+    def _sep_bwd(self, key, dy, ctx, need_dx=True):
+        """dy = d loss / d (layer output, before the residual add's other branch) -> d loss / d (layer input)."""
+        import torch
+
+        L, f = self.layers[key], self.fold[key]
+        r, d, x = ctx["r"], ctx["d"], ctx["x"]
+        Cc = L.cout
+        dev = self.device
+        s1, t1, t2 = (torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(3))
+        TO.chan_reduce(dy, s1, r, f["mprime"], f["rprime"], t2, f["scale"], f["shift"], TO.MASK_LEAKY)
+        TO.chan_reduce(dy, s1, r, f["mean1"], f["rstd1"], t1, f["scale"], f["shift"], TO.MASK_LEAKY)
+        b1, b2 = L.scope + "/BatchNorm", L.outer_bn
+        TO.bn_infer_grads(s1, t1, t2, f["a2"], self.g[b1 + "/gamma"], self.g[b1 + "/beta"], self.g[b2 + "/gamma"], self.g[b2 + "/beta"])
+        z = self.zeros[:Cc]
+        _lib.check(_lib.load().emd_bn_bwd_apply_f32(dy.ptr, dy.ld, r.ptr, r.ld, ops._p(f["scale"]), ops._p(z), ops._p(z), ops._p(z),
+                                                    ops._p(f["scale"]), ops._p(f["shift"]), TO.MASK_LEAKY, r.ptr, r.ld,
+                                                    ops.C.c_long(r.B * r.H * r.W), Cc, _lib.stream_ptr()), "emd_bn_bwd_apply_f32")
+        dr = r
+        TO.conv_wgrad(d, dr, self._gpw(key))
+        dd = ops.conv1x1(dr, self.pk_b[key], self.ones, self.zeros, d, act=False, precision=self.precision)
+        if L.cin == 1:
+            TO.dw7_c1_reflect_wgrad(ctx["x_img"], dd, self._gdw(key).view(49))
+            return None
+        if L.reflect:
+            TO.dw3x3_reflect_wgrad(x, dd, self._gdw(key), stride=L.stride)
+        else:
+            TO.dw3x3_wgrad(x, dd, self._gdw(key), stride=L.stride)
+        if not need_dx:
+            return None
+        dx = self._E(x.B, x.H, x.W, x.C)
+        if L.reflect:
+            TO.dw3x3_reflect_bwd_data(dd, self._dw(key), dx, stride=L.stride)
+        elif L.stride == 1:
+            ops.dw3x3(dd, self.dw_flip[key], dx)
+        else:
+            TO.dw3x3_bwd_data(dd, self._dw(key), dx, stride=L.stride)
+        return dx
+
+    # ---- one tower
+    def tower(self, lq, truth, offsets):
+        """lq, truth: torch CUDA float32 [1,S,S,1] (missing pixels of lq = -1).  Adds the generator gradients into
+        self.grads.  -> (output [1,S,S,1], device tensor [D(fake), adversarial loss], device tensor [stat loss * 12])."""
+        import torch
+
+        from . import gan as GN
+
+        assert lq.shape[0] == 1 and lq.shape[3] == 1 and truth.shape == lq.shape
+        S = lq.shape[1]
+        dev = self.device
+        self._pad_dirty = True
+        C = {}
+        # ---------------- generator forward (:341-372)
+        enc0, C["enc0"] = self._sep_fwd("enc0", None, x_img=lq)
+        enc1, C["enc1"] = self._sep_fwd("enc1", enc0)
+        n, C["nin_down0"] = self._sep_fwd("nin_down0", enc1)
+        n, C["nin_down1"] = self._sep_fwd("nin_down1", n)
+        n, C["nin_down2"] = self._sep_fwd("nin_down2", n)
+
+        def middle_fwd(prefix, x):
+            t, C[prefix + "_0"] = self._sep_fwd(prefix + "_0", x)
+            t, C[prefix + "_1"] = self._sep_fwd(prefix + "_1", t)
+            y, C[prefix + "_2"] = self._sep_fwd(prefix + "_2", t, res=x)
+            return y
+
+        for i in range(GN.num_global_enhancer_blocks):
+            n = middle_fwd(f"nin_mid{i}", n)
+
+        def up_fwd(key, x, size, res=None):
+            up = ops.resize_bilinear(x, self._E(x.B, size, size, x.C))
+            y, C[key] = self._sep_fwd(key, up, res=res)
+            C[key]["pre_resize"] = x
+            return y
+
+        n = up_fwd("nin_up0", n, S // 8)
+        n = up_fwd("nin_up1", n, S // 4)
+        enc = up_fwd("nin_up2", n, S // 2, res=enc1)                     # enc += network_in_network(enc)  (:355)
+        for i in range(GN.num_local_enhancer_blocks):
+            enc = middle_fwd(f"local{i}", enc)
+        enc = up_fwd("up", enc, S)
+        last, C["last_sep"] = self._sep_fwd("last_sep", enc)
+        w_last = self.v[self.conv_scope + "/weights"].view(9, GN.gen_features3)
+        raw = torch.empty((1, S, S, 1), dtype=torch.float32, device=dev)
+        # the conv bias sits in front of an instance norm: it cancels in the output and its gradient is zero
+        ops.conv3x3_cout1_reflect(last, w_last, 0.0, raw)
+        rawa = ops.Act(raw)
+        mean, var = ops.bn_batch_stats(rawa)
+        fold_in = TO.bn_train_fold(mean, var, self.ones[:1], self.zeros[:1], S * S, eps=GN.IN_EPS)
+        out = torch.empty_like(raw)
+        _lib.check(_lib.load().emd_instnorm_tanh_f32(ops._p(raw), ops._p(mean), ops._p(var), ops._p(out), 1, ops.C.c_long(S * S),
+                                                     ops.C.c_float(GN.IN_EPS), _lib.stream_ptr()), "emd_instnorm_tanh_f32")
+        # ---------------- discriminator on the generated and on the natural crops (same offsets, :1008-1015)
+        D = self.D
+        crops_f = multiscale_crops(out, offsets)
+        crops_n = multiscale_crops(truth, offsets)
+        in_f = D.prepare_inputs(*crops_f)
+        raw_f = D._raw_inputs
+        logits_f, saved_f = D.forward(in_f)
+        _, saved_n = D.forward(D.prepare_inputs(*crops_n))
+        targets = {br: [c["y"].buf for c in saved_n[br][0]] for br in BRANCHES}
+        result, dlogit = TO.gan_head(logits_f, 0.0, 1)
+        stat = torch.zeros(1, dtype=torch.float32, device=dev)
+        din = D.backward(saved_f, dlogit, weight_grads=False, feature_targets=targets, feature_weight=WEIGHT_NATURAL_STATS,
+                         loss_acc=stat, input_grads=True)
+        # ---------------- crops backward -> d loss / d output
+        dout = torch.zeros((1, S, S, 1), dtype=torch.float32, device=dev)
+        S4, S2, S34 = S // 4, S // 2, (3 * S) // 4
+        (ys, xs), (ym, xm), (yl, xl) = offsets
+        TO.crop_scatter(din["small"].buf, 4, dout, ys, xs, S4, S)
+        dmed = TO.avgpool2x2_bwd(din["medium"], self._E(1, S2, S2, 4))
+        TO.crop_scatter(dmed.buf, 4, dout, ym, xm, S2, S)
+        dlarge = TO.resize_bilinear_bwd(din["large"], self._E(1, S34, S34, 4))
+        TO.crop_scatter(dlarge.buf, 4, dout, yl, xl, S34, S)
+        del raw_f
+        # ---------------- generator backward
+        g = TO.tanh_bwd(dout, out)
+        scr = torch.zeros(2, dtype=torch.float32, device=dev)
+        draw = TO.bn_backward(ops.Act(g), rawa, fold_in, self.ones[:1], scr[0:1], scr[1:2], ops.Act(g), mask=TO.MASK_NONE,
+                              eps=GN.IN_EPS)
+        TO.conv3x3_cout1_reflect_wgrad(last, draw.buf, self.g[self.conv_scope + "/weights"].view(9, GN.gen_features3))
+        TO.chan_reduce(draw, self.g[self.conv_scope + "/biases"], accumulate_s1=True)
+        dy = TO.conv3x3_cout1_reflect_bwd_data(draw.buf, w_last, self._E(1, S, S, GN.gen_features3))
+        dy = self._sep_bwd("last_sep", dy, C["last_sep"])
+
+        def up_bwd(key, dy):
+            dup = self._sep_bwd(key, dy, C[key])
+            x = C[key]["pre_resize"]
+            return TO.resize_bilinear_bwd(dup, self._E(x.B, x.H, x.W, x.C))
+
+        def middle_bwd(prefix, dy):      # y = sep2(sep1(sep0(x))) + x
+            t = self._sep_bwd(prefix + "_2", dy, C[prefix + "_2"])
+            t = self._sep_bwd(prefix + "_1", t, C[prefix + "_1"])
+            t = self._sep_bwd(prefix + "_0", t, C[prefix + "_0"])
+            return TO.axpy(t, dy)        # + the identity branch
+
+        dy = up_bwd("up", dy)
+        for i in reversed(range(GN.num_local_enhancer_blocks)):
+            dy = middle_bwd(f"local{i}", dy)
+        d_enc1 = dy                                        # enc1 + nin(enc1): the identity branch
+        dn = up_bwd("nin_up2", dy)
+        dn = up_bwd("nin_up1", dn)
+        dn = up_bwd("nin_up0", dn)
+        for i in reversed(range(GN.num_global_enhancer_blocks)):
+            dn = middle_bwd(f"nin_mid{i}", dn)
+        dn = self._sep_bwd("nin_down2", dn, C["nin_down2"])
+        dn = self._sep_bwd("nin_down1", dn, C["nin_down1"])
+        dn = self._sep_bwd("nin_down0", dn, C["nin_down0"])
+        d_enc1 = TO.axpy(dn, d_enc1)
+        d_enc0 = self._sep_bwd("enc1", d_enc1, C["enc1"])
+        self._sep_bwd("enc0", d_enc0, C["enc0"], need_dx=False)
+        return out, result, stat
+
+    # ---- one optimizer step
+    def step(self, lq, truth, offsets, learning_rate=None, group=None):
+        """_train_op (:1330-1388) on this rank's towers: lq, truth torch [T,S,S,1]; the towers' gradient sets are averaged,
+        clipped to global norm 50 and applied by Adam(beta1 = 0.5).  -> device tensor [T, 3] (D(fake), -log D, 12*stat)."""
+        import torch
+
+        T = lq.shape[0]
+        self.zero_grad()
+        res = []
+        for k in range(T):
+            _, r, st = self.tower(lq[k:k + 1].contiguous(), truth[k:k + 1].contiguous(), offsets[k])
+            res.append(torch.cat([r, st]))
+        self._unpad_grads()
+        world = sync_gradients(self.grads, self.moving, group)
+        scale = 1.0 / (T * world)
+        gn2 = TO.sumsq(self.grads, scale=scale)
+        self.t += 1
+        TO.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.t, self.lr if learning_rate is None else learning_rate,
+                     beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_GEN)
         self.repack()
         return torch.stack(res)

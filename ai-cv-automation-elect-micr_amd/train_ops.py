@@ -249,3 +249,73 @@ def adam_step(param, grad, m, v, step, lr, beta1=0.5, beta2=0.999, eps=1e-8, gra
     _lib.check(_lib.load().emd_adam_step_f32(_p(param), _p(grad), _p(m), _p(v), C.c_long(param.numel()), C.c_float(lr_t),
                                              C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(grad_scale),
                                              _p(gnorm_sq), C.c_float(clip_norm), _lib.stream_ptr(stream)), "emd_adam_step_f32")
+
+
+def dw3x3_reflect_wgrad(x: Act, dy: Act, dw_dev, stride=1, stream=None):
+    _lib.check(_lib.load().emd_dw3x3_reflect_wgrad_f32(x.ptr, x.ld, dy.ptr, dy.ld, _p(dw_dev), x.B, x.H, x.W, x.C, stride,
+                                                       _lib.stream_ptr(stream)), "emd_dw3x3_reflect_wgrad_f32")
+
+
+def dw3x3_reflect_bwd_data(dy: Act, w_dev, dx: Act, stride=1, stream=None):
+    _lib.check(_lib.load().emd_dw3x3_reflect_bwd_data_f32(dy.ptr, dy.ld, _p(w_dev), dx.ptr, dx.ld, dx.B, dx.H, dx.W, dx.C, stride,
+                                                          _lib.stream_ptr(stream)), "emd_dw3x3_reflect_bwd_data_f32")
+    return dx
+
+
+def conv3x3_cout1_reflect_wgrad(x: Act, dy_img, dw_dev, stream=None):
+    _lib.check(_lib.load().emd_conv3x3_cout1_reflect_wgrad_f32(x.ptr, x.ld, _p(dy_img), _p(dw_dev), x.B, x.H, x.W, x.C,
+                                                               _lib.stream_ptr(stream)), "emd_conv3x3_cout1_reflect_wgrad_f32")
+
+
+def conv3x3_cout1_reflect_bwd_data(dy_img, w_dev, dx: Act, stream=None):
+    _lib.check(_lib.load().emd_conv3x3_cout1_reflect_bwd_data_f32(_p(dy_img), _p(w_dev), dx.ptr, dx.ld, dx.B, dx.H, dx.W, dx.C,
+                                                                  _lib.stream_ptr(stream)), "emd_conv3x3_cout1_reflect_bwd_data_f32")
+    return dx
+
+
+def dw7_c1_reflect(x_img, w49, d4: Act, stream=None):
+    _lib.check(_lib.load().emd_dw7_c1_reflect_f32(_p(x_img), _p(w49), d4.ptr, d4.B, d4.H, d4.W, _lib.stream_ptr(stream)),
+               "emd_dw7_c1_reflect_f32")
+    return d4
+
+
+def dw7_c1_reflect_wgrad(x_img, dd4: Act, dw49, stream=None):
+    _lib.check(_lib.load().emd_dw7_c1_reflect_wgrad_f32(_p(x_img), dd4.ptr, _p(dw49), dd4.B, dd4.H, dd4.W,
+                                                        _lib.stream_ptr(stream)), "emd_dw7_c1_reflect_wgrad_f32")
+
+
+def tanh_bwd(dy, y, stream=None):
+    import torch
+
+    g = torch.empty_like(dy)
+    _lib.check(_lib.load().emd_tanh_bwd_f32(_p(dy), _p(y), _p(g), C.c_long(dy.numel()), _lib.stream_ptr(stream)), "emd_tanh_bwd_f32")
+    return g
+
+
+def l1_feature(a, b, weight, dy, accumulate, loss_acc, stream=None):
+    """a, b, dy: contiguous torch tensors of one feature map; loss_acc: device float[1] accumulator."""
+    assert a.is_contiguous() and b.is_contiguous() and dy.is_contiguous() and a.numel() == b.numel() == dy.numel()
+    _lib.check(_lib.load().emd_l1_feature_f32(_p(a), _p(b), C.c_long(a.numel()), C.c_float(weight), _p(dy), 1 if accumulate else 0,
+                                              _p(loss_acc), _lib.stream_ptr(stream)), "emd_l1_feature_f32")
+
+
+def crop_scatter(dcrop, ldc, dimg, y0, x0, n, S, stream=None):
+    _lib.check(_lib.load().emd_crop_scatter_f32(_p(dcrop), ldc, _p(dimg), int(y0), int(x0), int(n), int(S), _lib.stream_ptr(stream)),
+               "emd_crop_scatter_f32")
+
+
+def bn_infer_fold2(g1, b1, m1, v1, g2, b2, m2, v2, eps, stream=None):
+    """-> dict(scale, shift, mprime, rprime, rstd1, a2, mean1) for an inference-mode double batch norm."""
+    import torch
+
+    out = {k: torch.empty_like(g1) for k in ("scale", "shift", "mprime", "rprime", "rstd1", "a2")}
+    _lib.check(_lib.load().emd_bn_infer_fold2_f32(_p(g1), _p(b1), _p(m1), _p(v1), _p(g2), _p(b2), _p(m2), _p(v2), C.c_float(eps),
+                                                  g1.numel(), _p(out["scale"]), _p(out["shift"]), _p(out["mprime"]), _p(out["rprime"]),
+                                                  _p(out["rstd1"]), _p(out["a2"]), _lib.stream_ptr(stream)), "emd_bn_infer_fold2_f32")
+    out["mean1"] = m1
+    return out
+
+
+def bn_infer_grads(s1, t1, t2, a2, dg1, db1, dg2, db2, stream=None):
+    _lib.check(_lib.load().emd_bn_infer_grads_f32(_p(s1), _p(t1), _p(t2), _p(a2), s1.numel(), _p(dg1), _p(db1), _p(dg2), _p(db2),
+                                                  _lib.stream_ptr(stream)), "emd_bn_infer_grads_f32")

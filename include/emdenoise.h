@@ -358,6 +358,39 @@ int emd_sumsq_f32(const float* x, long n, float scale, float* out, void* workspa
 int emd_adam_step_f32(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
                       float eps, float grad_scale, const float* gnorm_sq, float clip_norm, emd_stream_t stream);
 
+/* Generator-side training (the generator tower, :982-1046; its batch norms stay on MOVING statistics while the tower
+ * gradients are evaluated, :1667).
+ * Reflect-padded depthwise 3x3 backward (shapes as emd_dw3x3_reflect_f32; dw += ; dx written) and the same for the last
+ * 3x3 conv to one channel (dy [B,H,W]). */
+int emd_dw3x3_reflect_wgrad_f32(const float* x, int ldx, const float* dy, int ldd, float* dw, int B, int H, int W, int C,
+                                int stride, emd_stream_t stream);
+int emd_dw3x3_reflect_bwd_data_f32(const float* dy, int ldd, const float* w, float* dx, int ldx, int B, int H, int W, int C,
+                                   int stride, emd_stream_t stream);
+int emd_conv3x3_cout1_reflect_wgrad_f32(const float* x, int ldx, const float* dy, float* dw, int B, int H, int W, int Cin,
+                                        emd_stream_t stream);
+int emd_conv3x3_cout1_reflect_bwd_data_f32(const float* dy, const float* w, float* dx, int ldx, int B, int H, int W, int Cin,
+                                           emd_stream_t stream);
+/* First layer for training: d4[pix] = (7x7 reflect depthwise of the 1-channel image, 0, 0, 0) -- the pointwise half
+ * then runs as a K = 4 GEMM -- and dw49[t] += sum x[reflect(p + t)] * dd4[p][0]. */
+int emd_dw7_c1_reflect_f32(const float* x, const float* w49, float* d4, int B, int H, int W, emd_stream_t stream);
+int emd_dw7_c1_reflect_wgrad_f32(const float* x, const float* dd4, float* dw49, int B, int H, int W, emd_stream_t stream);
+/* g = dy * (1 - y^2): tf.tanh (:372). */
+int emd_tanh_bwd_f32(const float* dy, const float* y, float* g, long n, emd_stream_t stream);
+/* One feature-matching term (:1027-1035): *loss_acc += weight*mean|a-b|; dy (accumulate ? += : =) weight*sign(a-b)/n. */
+int emd_l1_feature_f32(const float* a, const float* b, long n, float weight, float* dy, int accumulate, float* loss_acc,
+                       emd_stream_t stream);
+/* Gradient of one crop of get_multiscale_crops (:957-980): channel 0 of dcrop [n,n,ldc] is added into dimg [S,S] at
+ * the mirror image of padded position (y0+i, x0+j) (padding 3S/4, REFLECT). */
+int emd_crop_scatter_f32(const float* dcrop, int ldc, float* dimg, int y0, int x0, int n, int S, emd_stream_t stream);
+/* Inference-mode double batch norm of a generator separable conv: (scale, shift) of the forward affine and the vectors
+ * its parameter gradients need (see csrc/gan_train.hip); emd_bn_infer_grads_f32 adds them (s1 = sum g,
+ * t1 = sum g*(r-mu1)/s1, t2 = sum g*(z1-mu2)/s2 from emd_bn_bwd_reduce_f32). */
+int emd_bn_infer_fold2_f32(const float* g1, const float* b1, const float* m1, const float* v1, const float* g2,
+                           const float* b2, const float* m2, const float* v2, float eps, int C, float* scale, float* shift,
+                           float* mprime, float* rprime, float* rstd1, float* a2, emd_stream_t stream);
+int emd_bn_infer_grads_f32(const float* s1, const float* t1, const float* t2, const float* a2, int C, float* dg1, float* db1,
+                           float* dg2, float* db2, emd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Host utility (no GPU): CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start).
  * Used by the TFRecord reader (emdenoise.input_pipeline) for the container that

@@ -362,3 +362,31 @@ def adam_step(params, grads, m, v, t, lr, beta1=0.5, beta2=0.999, eps=1e-8):
         new_v[n] = beta2 * v[n] + (1.0 - beta2) * g * g
         new_p[n] = params[n] - lr_t * new_m[n] / (np.sqrt(new_v[n]) + eps)
     return new_p, new_m, new_v
+
+
+def generator_tower(lq, truth, gen_weights, discr_weights, offsets, dtype=torch.float64):
+    """_generator_tower_fn (:982-1046) for ONE image (batch_size = 1), as the training loop runs it: the generator with
+    its batch norms on MOVING statistics (batch_norm_on_ph is fed False while the tower gradients are evaluated, :1667,
+    so decay = 0 and there is no l2 term, :1039-1042); concat(output, truth) is cropped ONCE (the same offsets for both,
+    :1008-1015); the discriminator runs with phase=True on the generated and on the natural crops;
+        loss = -log(clip(D(fake), 1e-8, 1)) + 12 * sum_l mean|f_l(fake) - f_l(natural)|   (:1027-1037)
+    gradients w.r.t. the trainable GENERATOR variables only.  -> dict(output, d_fake, loss, grads)."""
+    leaves, get = _leaves(gen_weights, dtype, _is_trainable)
+    g = _Gen(get, dtype)
+    x = lq if isinstance(lq, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(lq))
+    t = truth if isinstance(truth, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(truth))
+    S = x.shape[1]
+    out = g.build(x.to(dtype), S)
+    both = multiscale_crops(torch.cat([out, t.to(dtype).reshape(out.shape)], dim=3), offsets)
+    fake = [c[..., 0:1] for c in both]
+    natural = [c[..., 1:2].detach() for c in both]
+    dleaves, dget = _leaves(discr_weights, dtype, lambda n: False)
+    dfake = _Discr(dget, dtype, training=True).build(fake)
+    dnat = _Discr(dget, dtype, training=True).build(natural)
+    stat = sum((a - b).abs().mean() for a, b in zip(dfake[1:], dnat[1:]))
+    loss = -torch.log(torch.clamp(dfake[0], 1e-8, 1.0)).sum() + 12.0 * stat
+    names = [n for n, v in leaves.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    return {"output": out.detach().numpy(), "d_fake": dfake[0].detach().numpy(), "loss": float(loss.detach()),
+            "stat_loss": float(stat.detach()),
+            "grads": {n: (gr.numpy() if gr is not None else np.zeros(tuple(leaves[n].shape))) for n, gr in zip(names, grads)}}

@@ -99,3 +99,59 @@ def test_discriminator_step_matches_oracle_optimizer():
         upd = rel_l2(flat(st, names) - flat(cur, names), flat(newp, names) - flat(cur, names))
         worst = sorted(((float(np.abs((st[n] - cur[n]) - (newp[n] - cur[n])).max()), n) for n in names), reverse=True)[:4]
         assert upd < 2e-3, (step, upd, worst)
+
+
+def test_generator_tower_gradients():
+    """_generator_tower_fn (:982-1046): adversarial + feature-matching loss through the discriminator, the crops and
+    the generator, against the oracle's autograd (float64).  Mask-flip tolerance as above (leaky_relu kinks)."""
+    from emdenoise import gan as GN
+    from emdenoise import gan_trainer as GT
+    from oracle import gan_graph as GG
+
+    wg, wd = GN.synthetic_weights(), GN.discriminator_synthetic_weights()
+    hq = images(1, 31)
+    lq = GN.gen_lq(hq[..., 0])[..., None]
+    ref = GG.generator_tower(lq, hq, wg, wd, OFFSETS)
+    D = GT.DiscriminatorTrainer(wd, dev())
+    tr = GT.GeneratorTrainer(wg, D, dev())
+    tr.zero_grad()
+    out, res, stat = tr.tower(torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev()), OFFSETS)
+    res, stat = res.cpu().numpy(), float(stat.cpu().numpy()[0])
+    g = tr.gradients()
+    names = [n for n in g if np.abs(ref["grads"][n]).max() > 1e-9]
+    a, b = flat(g, names), flat(ref["grads"], names)
+    worst = sorted(((rel_l2(g[n], ref["grads"][n]), n) for n in names), reverse=True)[:3]
+    print(f"G tower: out {rel_l2(out.cpu().numpy(), ref['output']):.2e}; D(fake) {res[0]:.6f} vs {ref['d_fake'][0]:.6f}; "
+          f"loss {res[1] + stat:.4f} vs {ref['loss']:.4f}; stat {stat / 12:.5f} vs {ref['stat_loss']:.5f}; "
+          f"grads rel-l2 {rel_l2(a, b):.2e} cos {cosine(a, b):.5f}; worst {worst}")
+    assert rel_l2(out.cpu().numpy(), ref["output"]) < 1e-3    # north-star bar for images; measured 3e-4 (unfused training forward)
+    assert abs(res[0] - ref["d_fake"][0]) < 1e-4 and abs(res[1] + stat - ref["loss"]) < 2e-3 * ref["loss"]
+    assert rel_l2(a, b) < 8e-2 and cosine(a, b) > 0.997
+
+
+def test_generator_step_optimizer_arithmetic():
+    """One generator step: the tower's gradient, clipped to global norm 50, through Adam(beta1 0.5), checked on the
+    trainer's own gradient; the discriminator's parameters must not move."""
+    from emdenoise import gan as GN
+    from emdenoise import gan_trainer as GT
+    from oracle import gan_graph as GG
+
+    wg, wd = GN.synthetic_weights(), GN.discriminator_synthetic_weights()
+    hq = images(1, 41)
+    lq = GN.gen_lq(hq[..., 0])[..., None]
+    D = GT.DiscriminatorTrainer(wd, dev())
+    tr = GT.GeneratorTrainer(wg, D, dev(), learning_rate=2e-4)
+    names = list(tr.trainable)
+    cur, dcur = tr.state_dict(), D.state_dict()
+    res = tr.step(torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev()), [OFFSETS]).cpu().numpy()
+    g = {n: np.asarray(v, np.float64) for n, v in tr.gradients().items()}
+    own, gn = GG.clip_by_global_norm(g, 50.0)
+    zeros = {n: np.zeros_like(v) for n, v in g.items()}
+    newp, _, _ = GG.adam_step({n: np.asarray(cur[n], np.float64) for n in names}, own, zeros, dict(zeros), 1, 2e-4)
+    st = tr.state_dict()
+    upd = rel_l2(flat(st, names) - flat(cur, names), flat(newp, names) - flat(cur, names))
+    print(f"G step: D(fake) {res[0, 0]:.5f}, -log D {res[0, 1]:.4f}, 12*stat {res[0, 2]:.3f}; |g| {gn:.1f} (clip 50); update rel-l2 {upd:.2e}")
+    assert gn > 50.0, "this configuration is meant to exercise the clipping"
+    assert upd < 2e-3
+    dst = D.state_dict()
+    assert all(np.array_equal(dst[n], dcur[n]) for n in dcur)
