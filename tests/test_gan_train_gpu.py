@@ -155,3 +155,142 @@ def test_generator_step_optimizer_arithmetic():
     assert upd < 2e-3
     dst = D.state_dict()
     assert all(np.array_equal(dst[n], dcur[n]) for n in dcur)
+
+
+# ------------------------------------------------------------------------------------------------ per-kernel checks
+def _t64(a):
+    return torch.from_numpy(np.asarray(a, np.float64))
+
+
+@pytest.mark.parametrize("B,H,W,Cc,stride", [(2, 12, 16, 64, 1), (1, 9, 7, 128, 1), (2, 12, 16, 64, 2), (1, 7, 10, 768, 2), (1, 2, 2, 64, 1)])
+def test_dw3x3_reflect_backward(B, H, W, Cc, stride):
+    from emdenoise import train_ops as TO
+    from oracle import gan_graph as GG
+    from tests.test_ops_gpu import out_act, rnd, to_act
+
+    x = _t64(rnd((B, H, W, Cc), 1)).requires_grad_(True)
+    w = _t64(rnd((3, 3, Cc, 1), 2, 0.4)).requires_grad_(True)
+    y = GG.depthwise_valid_t(GG.reflect_pad_t(x, 1), w, stride)
+    dy = rnd(tuple(y.shape), 3)
+    gx, gw = torch.autograd.grad(y, (x, w), _t64(dy))
+    xa, dya = to_act(x.detach().numpy().astype(np.float32), ld=Cc + 8, c0=4), to_act(dy)
+    dw = torch.zeros((9, Cc), dtype=torch.float32, device=dev())
+    TO.dw3x3_reflect_wgrad(xa, dya, dw, stride=stride)
+    wdev = torch.from_numpy(w.detach().numpy().reshape(9, Cc).astype(np.float32)).to(dev())
+    dx = TO.dw3x3_reflect_bwd_data(dya, wdev, out_act(B, H, W, Cc), stride=stride)
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().numpy().reshape(3, 3, Cc, 1), gw.numpy()) < 2e-5
+    assert rel_l2(dx.torch().cpu().numpy(), gx.numpy()) < 2e-6
+
+
+def test_first_and_last_layer_backward():
+    from emdenoise import train_ops as TO
+    from oracle import gan_graph as GG
+    from tests.test_ops_gpu import out_act, rnd, to_act
+
+    B, H, W = 1, 20, 24
+    d32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    # 7x7 reflect depthwise on the 1-channel image: forward into channel 0 of a 4-channel tensor, and dW
+    x = rnd((B, H, W, 1), 4)
+    w = _t64(rnd((7, 7, 1, 1), 5, 0.2)).requires_grad_(True)
+    y = GG.depthwise_valid_t(GG.reflect_pad_t(_t64(x), 3), w, 1)
+    dd = rnd((B, H, W, 1), 6)
+    (gw,) = torch.autograd.grad(y, w, _t64(dd))
+    d4 = TO.dw7_c1_reflect(d32(x), d32(w.detach().numpy().reshape(49)), out_act(B, H, W, 4))
+    dd4 = np.zeros((B, H, W, 4), np.float32)
+    dd4[..., 0:1] = dd
+    dw49 = torch.zeros(49, dtype=torch.float32, device=dev())
+    TO.dw7_c1_reflect_wgrad(d32(x), to_act(dd4), dw49)
+    torch.cuda.synchronize()
+    got = d4.torch().cpu().numpy()
+    assert rel_l2(got[..., 0:1], y.detach().numpy()) < 2e-6 and np.all(got[..., 1:] == 0)
+    assert rel_l2(dw49.cpu().numpy().reshape(7, 7, 1, 1), gw.numpy()) < 2e-5
+    # last conv (reflect pad + 3x3 -> 1 channel): dW and dx
+    xin = _t64(rnd((B, H, W, 32), 7)).requires_grad_(True)
+    wl = _t64(rnd((3, 3, 32, 1), 8, 0.2)).requires_grad_(True)
+    yl = GG.depthwise_valid_t(GG.reflect_pad_t(xin, 1), wl, 1).sum(-1, keepdim=True)
+    dyl = rnd((B, H, W, 1), 9)
+    gx, gwl = torch.autograd.grad(yl, (xin, wl), _t64(dyl))
+    dwl = torch.zeros((9, 32), dtype=torch.float32, device=dev())
+    TO.conv3x3_cout1_reflect_wgrad(to_act(xin.detach().numpy().astype(np.float32)), d32(dyl), dwl)
+    dx = TO.conv3x3_cout1_reflect_bwd_data(d32(dyl), d32(wl.detach().numpy().reshape(9, 32)), out_act(B, H, W, 32))
+    torch.cuda.synchronize()
+    assert rel_l2(dwl.cpu().numpy().reshape(3, 3, 32, 1), gwl.numpy()) < 2e-5
+    assert rel_l2(dx.torch().cpu().numpy(), gx.numpy()) < 2e-6
+
+
+def test_feature_loss_crop_scatter_and_tanh():
+    from emdenoise import gan as GN
+    from emdenoise import train_ops as TO
+    from oracle import gan_graph as GG
+    from tests.test_ops_gpu import rnd
+
+    d32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    a, b = rnd((1, 8, 8, 64), 10), rnd((1, 8, 8, 64), 11)
+    at = _t64(a).requires_grad_(True)
+    loss = 12.0 * (at - _t64(b)).abs().mean()
+    (ga,) = torch.autograd.grad(loss, at)
+    base = rnd((1, 8, 8, 64), 12)
+    dy, acc = d32(base), torch.zeros(1, dtype=torch.float32, device=dev())
+    TO.l1_feature(d32(a), d32(b), 12.0, dy, True, acc)
+    torch.cuda.synchronize()
+    assert abs(float(acc.cpu()[0]) - float(loss)) < 1e-5 * float(loss)
+    assert rel_l2(dy.cpu().numpy() - base, ga.numpy()) < 1e-5
+    # crops: gradient of multiscale_crops w.r.t. the image = scatter of the crop gradients through the mirrored indices
+    S = 32
+    img = _t64(rnd((1, S, S, 1), 13)).requires_grad_(True)
+    offs = ((3, 40), (0, 9), (30, 2))
+    crops = GG.multiscale_crops(img, offs)
+    # the large crop comes back resized; take its gradient at the 3S/4 crop itself for this check
+    pad = (3 * S) // 4
+    ridx = torch.from_numpy(GG.reflect_indices(S, pad))
+    xp = img[:, ridx][:, :, ridx]
+    large = xp[:, 30:30 + pad, 2:2 + pad]
+    gs, gm, gl = rnd(tuple(crops[0].shape), 14), rnd(tuple(crops[1].shape), 15), rnd(tuple(large.shape), 16)
+    (gi,) = torch.autograd.grad((crops[0] * _t64(gs)).sum() + (crops[1] * _t64(gm)).sum() + (large * _t64(gl)).sum(), img)
+    dimg = torch.zeros((1, S, S, 1), dtype=torch.float32, device=dev())
+    for gcrop, (y0, x0) in zip((gs, gm, gl), offs):
+        n = gcrop.shape[1]
+        g4 = np.zeros((1, n, n, 4), np.float32)
+        g4[..., 0:1] = gcrop
+        TO.crop_scatter(d32(g4), 4, dimg, y0, x0, n, S)
+    torch.cuda.synchronize()
+    assert rel_l2(dimg.cpu().numpy(), gi.numpy()) < 2e-6
+    small_dev, _, _ = GN.multiscale_crops(d32(img.detach().numpy()), offs)
+    assert np.array_equal(small_dev.cpu().numpy(), crops[0].detach().numpy().astype(np.float32))
+    # tanh
+    y, dyt = np.tanh(rnd((1000,), 17)), rnd((1000,), 18)
+    assert rel_l2(TO.tanh_bwd(d32(dyt), d32(y)).cpu().numpy(), dyt * (1 - y.astype(np.float64) ** 2)) < 1e-6
+
+
+def test_bn_inference_parameter_gradients():
+    """Two moving-statistics batch norms + leaky_relu after a pointwise conv: the fold and d(gamma, beta) of both."""
+    from emdenoise import ops
+    from emdenoise import train_ops as TO
+    from tests.test_ops_gpu import out_act, rnd, to_act
+
+    Cc, eps = 64, 0.01
+    d32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    r = rnd((2, 8, 8, Cc), 20, 1.5)
+    P = {k: _t64(v).requires_grad_(k[0] in "gb") for k, v in {
+        "g1": rnd((Cc,), 21, 0.3) + 1, "b1": rnd((Cc,), 22, 0.3), "m1": rnd((Cc,), 23, 0.3), "v1": np.abs(rnd((Cc,), 24)) + 0.5,
+        "g2": rnd((Cc,), 25, 0.3) + 1, "b2": rnd((Cc,), 26, 0.3), "m2": rnd((Cc,), 27, 0.3), "v2": np.abs(rnd((Cc,), 28)) + 0.5}.items()}
+    rt = _t64(r).requires_grad_(True)
+    z1 = (rt - P["m1"]) * (P["g1"] / torch.sqrt(P["v1"] + eps)) + P["b1"]
+    z = (z1 - P["m2"]) * (P["g2"] / torch.sqrt(P["v2"] + eps)) + P["b2"]
+    y = torch.nn.functional.leaky_relu(z, 0.2)
+    dy = rnd((2, 8, 8, Cc), 29)
+    gr, gg1, gb1, gg2, gb2 = torch.autograd.grad(y, (rt, P["g1"], P["b1"], P["g2"], P["b2"]), _t64(dy))
+    dv = {k: d32(v.detach().numpy()) for k, v in P.items()}
+    f = TO.bn_infer_fold2(dv["g1"], dv["b1"], dv["m1"], dv["v1"], dv["g2"], dv["b2"], dv["m2"], dv["v2"], eps)
+    ra, dya = to_act(r), to_act(dy)
+    ya = ops.affine_act(ra, f["scale"], f["shift"], out_act(2, 8, 8, Cc), act=ops.ACT_LEAKY)
+    s1, t1, t2 = (torch.empty(Cc, dtype=torch.float32, device=dev()) for _ in range(3))
+    TO.chan_reduce(dya, s1, ra, f["mprime"], f["rprime"], t2, f["scale"], f["shift"], TO.MASK_LEAKY)
+    TO.chan_reduce(dya, s1, ra, f["mean1"], f["rstd1"], t1, f["scale"], f["shift"], TO.MASK_LEAKY)
+    grads = [torch.zeros(Cc, dtype=torch.float32, device=dev()) for _ in range(4)]
+    TO.bn_infer_grads(s1, t1, t2, f["a2"], *grads)
+    torch.cuda.synchronize()
+    assert rel_l2(ya.torch().cpu().numpy(), y.detach().numpy()) < 2e-6
+    for got, ref in zip(grads, (gg1, gb1, gg2, gb2)):
+        assert rel_l2(got.cpu().numpy(), ref.numpy()) < 2e-5
