@@ -592,3 +592,32 @@ class GeneratorTrainer:
                      beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_GEN)
         self.repack()
         return torch.stack(res)
+
+
+def gan_iteration(G: GeneratorTrainer, D: DiscriminatorTrainer, lq, truth, offsets, lr_gen=0.0002, label_real=1.0, label_fake=0.0,
+                  adapts=None, group=None):
+    """One iteration of the reference's training loop (:1650-1790), deterministic parts: (1) the generator towers on
+    this rank's [T,S,S,1] batch and the generator's Adam step (:1660-1700); (2) the discriminator trained on the T
+    generated images (label_fake) and the T natural ones (label_real) with learning rate lr_gen/2 (:1645) -- 2T towers,
+    one Adam step (:1720-1790).  The reference's random label flips and its ``adapt`` heuristics are host-side choices:
+    pass ``adapts`` / labels to reproduce them.  -> (generator results [T,3], discriminator results [2T,2])."""
+    import torch
+
+    T = lq.shape[0]
+    G.zero_grad()
+    outs, res_g = [], []
+    for k in range(T):
+        out, r, st = G.tower(lq[k:k + 1].contiguous(), truth[k:k + 1].contiguous(), offsets[k])
+        outs.append(out)
+        res_g.append(torch.cat([r, st]))
+    G._unpad_grads()
+    world = sync_gradients(G.grads, G.moving, group)
+    scale = 1.0 / (T * world)
+    gn2 = TO.sumsq(G.grads, scale=scale)
+    G.t += 1
+    TO.adam_step(G.params, G.grads, G.adam_m, G.adam_v, G.t, lr_gen, beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_GEN)
+    G.repack()
+    images = torch.cat(outs + [truth[k:k + 1] for k in range(T)])
+    labels = [label_fake] * T + [label_real] * T
+    res_d = D.step(images, labels, list(offsets) + list(offsets), adapts=adapts, learning_rate=lr_gen / 2, group=group)
+    return torch.stack(res_g), res_d

@@ -12,6 +12,8 @@ Workloads:
   X  the other graph BASELINE configs[2] can mean: misc_py/modified_Xception.py at 512x512.
   G  BASELINE configs[4], the part that is built: the in-filling GAN's generator forward pass
      (misc_py/gan-infilling-100.py:133-374) on [32,512,512,1]; rides along as "workload_G".
+  A  BASELINE configs[4]: one iteration of the in-filling GAN's adversarial training loop (generator towers through
+     the discriminator + Adam, discriminator towers + Adam) on --gan-batch images per GPU; rides along as "workload_A".
   T  BASELINE configs[3]: graph D' TRAINING (misc_py/denoiser-multi-gpu.py): --train-batch LQ/HQ pairs per GPU per
      step (default 8 = bs 64 over 8 GPUs), towers of --tower-batch images (default 1, the reference), one RCCL
      all-reduce of the flat gradient vector per step, Nesterov step.  Rides along as "workload_T"; --workload T
@@ -385,6 +387,53 @@ def bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     return out
 
 
+def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
+    """BASELINE configs[4]: one iteration of the in-filling GAN's training loop (misc_py/gan-infilling-100.py:1650-1790)
+    on `--gan-batch` 512x512 images per GPU: generator towers through the discriminator (feature matching), generator
+    Adam step, then the discriminator trained on the generated and the natural images (2T towers) and its Adam step."""
+    from emdenoise import gan as GN, gan_trainer as GT
+
+    T, S = a.gan_batch, a.size
+    steps = a.steps if (a.steps is not None and a.workload == "A") else 3
+    warmup = a.warmup if (a.warmup is not None and a.workload == "A") else 1
+    hq = (2.0 * synthetic_lq(T, S, S, seed=177 + rank) - 1.0).astype(np.float32)
+    lq = GN.gen_lq(hq[..., 0])[..., None]
+    D = GT.DiscriminatorTrainer(GN.discriminator_synthetic_weights(), dev, a.precision)
+    G = GT.GeneratorTrainer(GN.synthetic_weights(), D, dev, a.precision)
+    rng = np.random.default_rng(5 + rank)
+    pad = (3 * S) // 4
+    offsets = [tuple((int(rng.integers(0, S + 2 * pad - n + 1)), int(rng.integers(0, S + 2 * pad - n + 1))) for n in (S // 4, S // 2, pad))
+               for _ in range(T)]
+    x, t = torch.from_numpy(lq).to(dev), torch.from_numpy(hq).to(dev)
+    box = [None]
+
+    def step():
+        box[0] = GT.gan_iteration(G, D, x, t, offsets)
+
+    ms = timer.run(step, steps, warmup)
+    rg, rd = box[0]
+    out = {"value": round(T * S * S / 1e6 * world / (ms / 1e3), 2), "unit": "MPx/s trained (GAN)", "ms_per_step": round(ms, 3),
+           "steps": steps, "warmup": warmup, "dtype": "bf16x3 GEMMs (split-bf16 MFMA inputs, fp32 accumulate), fp32 elsewhere",
+           "config": {"workload": f"A: in-filling GAN training iteration (misc_py/gan-infilling-100.py), [{T},{S},{S},1] fp32 per GPU: "
+                                  f"{T} generator towers + Adam, {2 * T} discriminator towers + Adam",
+                      "global_batch": T * world, "precision": a.precision, "parallelism": f"dp{world}"},
+           "d_fake_first": float(rg[0, 0].item()), "d_out_first": float(rd[0, 0].item())}
+    out["roofline"] = {"bound": "hbm", "kernel": "whole iteration (<= 128-channel separable convs at 256-512 px dominate)",
+                       "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
+    if want_cpu:
+        from oracle import gan_graph as GG
+
+        torch.set_num_threads(CPU_THREADS)
+        t0 = time.perf_counter()
+        GG.generator_tower(lq[:1], hq[:1], GN.synthetic_weights(), GN.discriminator_synthetic_weights(), offsets[0])
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s trained (GAN)", "cores": CPU_THREADS, "kind": "port",
+                               "sample": f"ONE generator tower ([1,{S},{S},1]: generator + 2 discriminator passes, forward + backward), "
+                                         f"oracle/gan_graph.py generator_tower (PyTorch-CPU autograd, float64, {CPU_THREADS} threads), "
+                                         f"{el:.1f} s; discriminator towers and optimizer steps not included"}
+    return out
+
+
 def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
     """BASELINE configs[3]: graph D' TRAINING (misc_py/denoiser-multi-gpu.py): data-parallel steps of `--train-batch`
     512x512 LQ/HQ pairs per GPU (bs=64 over 8 GPUs => 8 per GPU), towers of `--tower-batch` images (1 = the
@@ -456,12 +505,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["K", "D", "X", "T", "G", "both", "all"], default="all",
+    ap.add_argument("--workload", choices=["K", "D", "X", "T", "G", "A", "both", "all"], default="all",
                     help="K and D: see the module docstring; X: misc_py/modified_Xception.py; all (default) = K primary, D and X alongside")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--train-batch", type=int, default=8, help="workload T: LQ/HQ pairs per GPU per step (bs=64 over 8 GPUs)")
     ap.add_argument("--tower-batch", type=int, default=1, help="workload T: images per tower (batch-norm statistics are per tower)")
+    ap.add_argument("--gan-batch", type=int, default=4, help="workload A: images per GPU per GAN iteration")
     ap.add_argument("--train-streams", type=int, default=8, help="workload T: HIP streams the towers are issued on")
     ap.add_argument("--no-graph", action="store_true", help="workload T: launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -529,7 +579,18 @@ def main():
                 raise
             res_G = {"error": f"{type(e).__name__}: {e}"}
 
+    res_A = None
+    if a.workload in ("A", "all"):
+        try:
+            res_A = bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu and a.workload == "A")
+        except Exception as e:
+            if a.workload == "A":
+                raise
+            res_A = {"error": f"{type(e).__name__}: {e}"}
+
     prim = res_D if primary_is_D else res_K
+    if prim is None and a.workload == "A":
+        prim, res_A = res_A, None
     if prim is None and a.workload == "G":
         prim, res_G = dict(res_G), None
         prim["dtype"] = "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)"
@@ -546,7 +607,8 @@ def main():
                                      "frac": round((prim.get("tflops_algorithmic") or 0.0) / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None})
         res_X = None
     out = {
-        "metric": {"T": "megapixels/sec trained (512x512x1 LQ/HQ pairs)", "G": "megapixels/sec in-filled (512x512x1 bs=32)"}.get(
+        "metric": {"T": "megapixels/sec trained (512x512x1 LQ/HQ pairs)", "G": "megapixels/sec in-filled (512x512x1 bs=32)",
+                   "A": "megapixels/sec trained (in-filling GAN, 512x512x1)"}.get(
             a.workload, "megapixels/sec restored (512x512x1 bs=32)"),
         "value": round(prim["value"], 1),
         "unit": prim.get("unit", "MPx/s"),
@@ -562,7 +624,7 @@ def main():
         "config": prim["config"],
         "roofline": prim["roofline"],
     }
-    for k in ("cpu_baseline", "rel_l2_vs_oracle", "depthwise", "kernel_family_ms", "tflops_algorithmic", "loss_first_tower"):
+    for k in ("cpu_baseline", "rel_l2_vs_oracle", "depthwise", "kernel_family_ms", "tflops_algorithmic", "loss_first_tower", "d_fake_first", "d_out_first"):
         if k in prim:
             out[k] = prim[k]
     if not primary_is_D and res_D is not None:
@@ -577,6 +639,8 @@ def main():
         out["workload_T"] = res_T
     if res_G is not None:
         out["workload_G"] = res_G
+    if res_A is not None:
+        out["workload_A"] = res_A
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
