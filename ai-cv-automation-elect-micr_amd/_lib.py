@@ -158,6 +158,10 @@ SIGNATURES = {
     "emd_l1_feature_f32": (C.c_int, [_c_float_p, _c_float_p, C.c_long, C.c_float, _c_float_p, C.c_int, _c_float_p, C.c_void_p]),
     # dcrop ldc dimg y0 x0 n S stream
     "emd_crop_scatter_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p] + [C.c_int] * 4 + [C.c_void_p]),
+    # dcrop ldc dimg yx_dev n S stream
+    "emd_crop_scatter_dev_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    # param grad m v n lr_t_dev beta1 beta2 eps grad_scale gnorm_sq clip_norm stream
+    "emd_adam_step_dev_f32": (C.c_int, [_c_float_p] * 4 + [C.c_long, _c_float_p] + [C.c_float] * 4 + [_c_float_p, C.c_float, C.c_void_p]),
     "emd_bn_infer_fold2_f32": (C.c_int, [_c_float_p] * 8 + [C.c_float, C.c_int] + [_c_float_p] * 6 + [C.c_void_p]),
     "emd_bn_infer_grads_f32": (C.c_int, [_c_float_p] * 4 + [C.c_int] + [_c_float_p] * 4 + [C.c_void_p]),
 }

@@ -86,9 +86,11 @@ __global__ void sumsq_final(const double* __restrict__ part, int nblk, float sca
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr_t,
                                                    float beta1, float beta2, float eps, float grad_scale,
-                                                   const float* __restrict__ gnorm_sq, float clip_norm) {
+                                                   const float* __restrict__ gnorm_sq, float clip_norm,
+                                                   const float* __restrict__ lr_t_dev) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (lr_t_dev) lr_t = lr_t_dev[0];
     float s = grad_scale;
     if (gnorm_sq) {
         const float gn = sqrtf(gnorm_sq[0]);
@@ -299,9 +301,13 @@ __global__ __launch_bounds__(256) void l1_feature_kernel(const float* __restrict
 // Gradient of get_multiscale_crops (:957-980) for one crop: channel 0 of dcrop [n,n,ldc] is added into dimg [S,S]
 // at the mirrored position of padded coordinate (y0+i, x0+j), pad = 3S/4.
 __global__ __launch_bounds__(256) void crop_scatter_kernel(const float* __restrict__ dcrop, int ldc, float* __restrict__ dimg,
-                                                           int y0, int x0, int n, int S, int pad) {
+                                                           int y0, int x0, const int* __restrict__ yx_dev, int n, int S, int pad) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= n * n) return;
+    if (yx_dev) {  // offsets living on the device: a captured hipGraph is replayed with new crops
+        y0 = yx_dev[0];
+        x0 = yx_dev[1];
+    }
     const int i = idx / n, j = idx % n;
     const int iy = reflect(y0 + i - pad, S), ix = reflect(x0 + j - pad, S);
     atomicAdd(dimg + (long)iy * S + ix, dcrop[(long)idx * ldc]);
@@ -397,9 +403,9 @@ extern "C" int emd_sumsq_f32(const float* x, long n, float scale, float* out, vo
     return emd::check_launch("sumsq");
 }
 
-extern "C" int emd_adam_step_f32(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1,
-                                 float beta2, float eps, float grad_scale, const float* gnorm_sq, float clip_norm,
-                                 emd_stream_t stream) {
+static int adam_entry(float* param, const float* grad, float* m, float* v, long n, float lr_t, const float* lr_t_dev,
+                      float beta1, float beta2, float eps, float grad_scale, const float* gnorm_sq, float clip_norm,
+                      emd_stream_t stream) {
     EMD_REQUIRE(param && grad && m && v, EMD_E_INVALID, "emd_adam_step_f32: null pointer");
     EMD_REQUIRE(n >= 0 && (!gnorm_sq || clip_norm > 0.f), EMD_E_INVALID, "emd_adam_step_f32: bad argument");
     if (n == 0) return EMD_OK;
@@ -407,8 +413,21 @@ extern "C" int emd_adam_step_f32(float* param, const float* grad, float* m, floa
     int rc = blocks_for(n, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad, m, v, n, lr_t, beta1,
-                       beta2, eps, grad_scale, gnorm_sq, clip_norm);
+                       beta2, eps, grad_scale, gnorm_sq, clip_norm, lr_t_dev);
     return emd::check_launch("adam_kernel");
+}
+
+extern "C" int emd_adam_step_f32(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1,
+                                 float beta2, float eps, float grad_scale, const float* gnorm_sq, float clip_norm,
+                                 emd_stream_t stream) {
+    return adam_entry(param, grad, m, v, n, lr_t, nullptr, beta1, beta2, eps, grad_scale, gnorm_sq, clip_norm, stream);
+}
+
+extern "C" int emd_adam_step_dev_f32(float* param, const float* grad, float* m, float* v, long n, const float* lr_t_dev,
+                                     float beta1, float beta2, float eps, float grad_scale, const float* gnorm_sq,
+                                     float clip_norm, emd_stream_t stream) {
+    EMD_REQUIRE(lr_t_dev, EMD_E_INVALID, "emd_adam_step_dev_f32: null pointer");
+    return adam_entry(param, grad, m, v, n, 0.f, lr_t_dev, beta1, beta2, eps, grad_scale, gnorm_sq, clip_norm, stream);
 }
 
 static bool vec_ok(const float* a, int ld, int C) { return C >= 4 && C % 4 == 0 && ld % 4 == 0 && ld >= C && emd::aligned16(a); }
@@ -521,7 +540,16 @@ extern "C" int emd_crop_scatter_f32(const float* dcrop, int ldc, float* dimg, in
     EMD_REQUIRE(S >= 4 && n >= 1 && ldc >= 1 && y0 >= 0 && x0 >= 0 && y0 + n <= S + 2 * pad && x0 + n <= S + 2 * pad, EMD_E_INVALID,
                 "emd_crop_scatter_f32: crop outside the padded image");
     hipLaunchKernelGGL(crop_scatter_kernel, dim3((n * n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), dcrop, ldc,
-                       dimg, y0, x0, n, S, pad);
+                       dimg, y0, x0, nullptr, n, S, pad);
+    return emd::check_launch("crop_scatter_kernel");
+}
+
+extern "C" int emd_crop_scatter_dev_f32(const float* dcrop, int ldc, float* dimg, const int* yx_dev, int n, int S,
+                                        emd_stream_t stream) {
+    EMD_REQUIRE(dcrop && dimg && yx_dev, EMD_E_INVALID, "emd_crop_scatter_dev_f32: null pointer");
+    EMD_REQUIRE(S >= 4 && n >= 1 && ldc >= 1, EMD_E_INVALID, "emd_crop_scatter_dev_f32: bad shape");
+    hipLaunchKernelGGL(crop_scatter_kernel, dim3((n * n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), dcrop, ldc,
+                       dimg, 0, 0, yx_dev, n, S, (3 * S) / 4);
     return emd::check_launch("crop_scatter_kernel");
 }
 

@@ -339,21 +339,36 @@ def reflect_indices(n, pad):
     return np.where(idx >= n, 2 * n - 2 - idx, idx)
 
 
+_RIDX_CACHE = {}
+
+
 def multiscale_crops(img, offsets):
     """get_multiscale_crops (:957-980) on the device, with the tf.random_crop offsets given (parity needs them as
     inputs): img torch [B,S,S,C] -> (small [B,S/4,S/4,C], medium [B,S/2,S/2,C], large crop [B,3S/4,3S/4,C]) taken from
-    the image reflect-padded by 3S/4.  Index gathers only; the large crop's resize to S/4 is done by the engine."""
+    the image reflect-padded by 3S/4.  Index gathers only; the large crop's resize to S/4 is done by the engine.
+    offsets: ((y,x),(y,x),(y,x)) host integers, or an integer DEVICE tensor [3,2] (no host round trip: the gather
+    indices are computed on the device, so a captured hipGraph can be replayed with new crops)."""
     import torch
 
     B, S = img.shape[0], img.shape[1]
     pad = (3 * S) // 4
-    ridx = torch.from_numpy(reflect_indices(S, pad)).to(img.device)
+    key = (S, str(img.device))
+    if key not in _RIDX_CACHE:   # uploaded once (a host-to-device copy is not allowed inside stream capture)
+        _RIDX_CACHE[key] = torch.from_numpy(reflect_indices(S, pad)).to(img.device)
+    ridx = _RIDX_CACHE[key]
+    on_device = isinstance(offsets, torch.Tensor)
+    off = offsets.to(torch.int64) if on_device else None
 
-    def crop(y0, x0, n):
-        return img[:, ridx[y0:y0 + n]][:, :, ridx[x0:x0 + n]].contiguous()
+    def crop(k, n):
+        if on_device:
+            ar = torch.arange(n, device=img.device)
+            rows, cols = ridx[off[k, 0] + ar], ridx[off[k, 1] + ar]
+        else:
+            y0, x0 = offsets[k]
+            rows, cols = ridx[y0:y0 + n], ridx[x0:x0 + n]
+        return img[:, rows][:, :, cols].contiguous()
 
-    (ys, xs), (ym, xm), (yl, xl) = offsets
-    return crop(ys, xs, S // 4), crop(ym, xm, S // 2), crop(yl, xl, pad)
+    return crop(0, S // 4), crop(1, S // 2), crop(2, pad)
 
 
 class DiscriminatorEngine:

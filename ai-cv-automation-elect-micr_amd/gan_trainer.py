@@ -246,17 +246,33 @@ class DiscriminatorTrainer:
         return result
 
     # ---- one optimizer step
-    def step(self, images, labels, offsets, adapts=None, learning_rate=None, group=None):
+    def step(self, images, labels, offsets, adapts=None, learning_rate=None, group=None, streams=1, lr_t_dev=None):
         """_discriminator_train_op (:1390-1440) on this rank's towers: images torch [T,S,S,1] (generated and real ones
         with their labels, :1720-1775); the towers' gradients are averaged, clipped to global norm 15 and applied by
-        Adam(beta1 = 0.5).  offsets: one ((y,x),(y,x),(y,x)) per tower.  -> device tensor [T, 2] of (out, data loss)."""
+        Adam(beta1 = 0.5).  offsets: one ((y,x),(y,x),(y,x)) per tower, or an integer device tensor [T,3,2].
+        streams > 1: the towers are issued round-robin on that many HIP streams (they meet only in atomically
+        accumulated gradients).  lr_t_dev: Adam's bias-corrected rate on the device (for a replayed hipGraph; the caller
+        refreshes it and counts the steps).  -> device tensor [T, 2] of (out, data loss)."""
         import torch
 
         T = images.shape[0]
         adapts = [1.0] * T if adapts is None else list(adapts)
         self.zero_grad()
-        res = [self.tower(images[k:k + 1].contiguous(), labels[k], offsets[k], adapt=adapts[k], update_moving=(k == 0))
-               for k in range(T)]
+        main = torch.cuda.current_stream()
+        side = _side_streams(self, min(streams, T)) if streams > 1 else []
+        for s_ in side:
+            s_.wait_stream(main)
+        res = []
+        for k in range(T):
+            if side:
+                with torch.cuda.stream(side[k % len(side)]):
+                    r = self.tower(images[k:k + 1].contiguous(), labels[k], offsets[k], adapt=adapts[k], update_moving=(k == 0))
+                    r.record_stream(main)
+            else:
+                r = self.tower(images[k:k + 1].contiguous(), labels[k], offsets[k], adapt=adapts[k], update_moving=(k == 0))
+            res.append(r)
+        for s_ in side:
+            main.wait_stream(s_)
         self._unpad_grads()
         # + adapt * 5e-5 * d(sum l2_loss)/dv = adapt * 5e-5 * v, summed over the towers
         n4 = self.params.numel() // 4
@@ -264,11 +280,22 @@ class DiscriminatorTrainer:
         world = sync_gradients(self.grads, self.moving, group)
         scale = 1.0 / (T * world)
         gn2 = TO.sumsq(self.grads, scale=scale)
-        self.t += 1
+        if lr_t_dev is None:
+            self.t += 1
         TO.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.t, self.lr if learning_rate is None else learning_rate,
-                     beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_DISCR)
+                     beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_DISCR, lr_t_dev=lr_t_dev)
         self.repack()
         return torch.stack(res)
+
+
+def _side_streams(obj, n):
+    import torch
+
+    if not hasattr(obj, "_streams"):
+        obj._streams = []
+    while len(obj._streams) < n:
+        obj._streams.append(torch.cuda.Stream(device=obj.device))
+    return obj._streams[:n]
 
 
 # ================================================================================================
@@ -368,7 +395,8 @@ class GeneratorTrainer:
             b1, b2 = L.scope + "/BatchNorm", L.outer_bn
             self.fold[key] = TO.bn_infer_fold2(self.v[b1 + "/gamma"], self.v[b1 + "/beta"], self.m[b1 + "/moving_mean"],
                                                self.m[b1 + "/moving_variance"], self.v[b2 + "/gamma"], self.v[b2 + "/beta"],
-                                               self.m[b2 + "/moving_mean"], self.m[b2 + "/moving_variance"], BN_EPS_GEN)
+                                               self.m[b2 + "/moving_mean"], self.m[b2 + "/moving_variance"], BN_EPS_GEN,
+                                               out=self.fold.get(key))
             if not L.reflect and L.stride == 1:
                 flipped = self._dw(key).flip(0)
                 if key not in self.dw_flip:
@@ -526,12 +554,16 @@ class GeneratorTrainer:
         # ---------------- crops backward -> d loss / d output
         dout = torch.zeros((1, S, S, 1), dtype=torch.float32, device=dev)
         S4, S2, S34 = S // 4, S // 2, (3 * S) // 4
-        (ys, xs), (ym, xm), (yl, xl) = offsets
-        TO.crop_scatter(din["small"].buf, 4, dout, ys, xs, S4, S)
+        if isinstance(offsets, torch.Tensor):   # int32 device tensor [3,2]: the kernel reads the offsets itself
+            off32 = offsets.to(torch.int32).contiguous()
+            where = [dict(y0=0, x0=0, yx_dev=off32[k]) for k in range(3)]
+        else:
+            where = [dict(y0=y, x0=x) for (y, x) in offsets]
+        TO.crop_scatter(din["small"].buf, 4, dout, n=S4, S=S, **where[0])
         dmed = TO.avgpool2x2_bwd(din["medium"], self._E(1, S2, S2, 4))
-        TO.crop_scatter(dmed.buf, 4, dout, ym, xm, S2, S)
+        TO.crop_scatter(dmed.buf, 4, dout, n=S2, S=S, **where[1])
         dlarge = TO.resize_bilinear_bwd(din["large"], self._E(1, S34, S34, 4))
-        TO.crop_scatter(dlarge.buf, 4, dout, yl, xl, S34, S)
+        TO.crop_scatter(dlarge.buf, 4, dout, n=S34, S=S, **where[2])
         del raw_f
         # ---------------- generator backward
         g = TO.tanh_bwd(dout, out)
@@ -595,29 +627,97 @@ class GeneratorTrainer:
 
 
 def gan_iteration(G: GeneratorTrainer, D: DiscriminatorTrainer, lq, truth, offsets, lr_gen=0.0002, label_real=1.0, label_fake=0.0,
-                  adapts=None, group=None):
+                  adapts=None, group=None, streams=1, lr_t_dev=None):
     """One iteration of the reference's training loop (:1650-1790), deterministic parts: (1) the generator towers on
     this rank's [T,S,S,1] batch and the generator's Adam step (:1660-1700); (2) the discriminator trained on the T
     generated images (label_fake) and the T natural ones (label_real) with learning rate lr_gen/2 (:1645) -- 2T towers,
     one Adam step (:1720-1790).  The reference's random label flips and its ``adapt`` heuristics are host-side choices:
-    pass ``adapts`` / labels to reproduce them.  -> (generator results [T,3], discriminator results [2T,2])."""
+    pass ``adapts`` / labels to reproduce them.  offsets: per-tower host tuples or an integer device tensor [T,3,2].
+    streams: HIP streams the towers of each phase are spread over.  lr_t_dev: device tensor [2] with the two
+    bias-corrected Adam rates (generator, discriminator) when the iteration runs inside a replayed hipGraph (GanLoop).
+    -> (generator results [T,3], discriminator results [2T,2])."""
     import torch
 
     T = lq.shape[0]
     G.zero_grad()
+    main = torch.cuda.current_stream()
+    side = _side_streams(G, min(streams, T)) if streams > 1 else []
+    for s_ in side:
+        s_.wait_stream(main)
     outs, res_g = [], []
     for k in range(T):
-        out, r, st = G.tower(lq[k:k + 1].contiguous(), truth[k:k + 1].contiguous(), offsets[k])
+        if side:
+            with torch.cuda.stream(side[k % len(side)]):
+                out, r, st = G.tower(lq[k:k + 1].contiguous(), truth[k:k + 1].contiguous(), offsets[k])
+                rr = torch.cat([r, st])
+                out.record_stream(main)
+                rr.record_stream(main)
+        else:
+            out, r, st = G.tower(lq[k:k + 1].contiguous(), truth[k:k + 1].contiguous(), offsets[k])
+            rr = torch.cat([r, st])
         outs.append(out)
-        res_g.append(torch.cat([r, st]))
+        res_g.append(rr)
+    for s_ in side:
+        main.wait_stream(s_)
     G._unpad_grads()
     world = sync_gradients(G.grads, G.moving, group)
     scale = 1.0 / (T * world)
     gn2 = TO.sumsq(G.grads, scale=scale)
-    G.t += 1
-    TO.adam_step(G.params, G.grads, G.adam_m, G.adam_v, G.t, lr_gen, beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_GEN)
+    if lr_t_dev is None:
+        G.t += 1
+    TO.adam_step(G.params, G.grads, G.adam_m, G.adam_v, G.t, lr_gen, beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_GEN,
+                 lr_t_dev=None if lr_t_dev is None else lr_t_dev[0:1])
     G.repack()
     images = torch.cat(outs + [truth[k:k + 1] for k in range(T)])
     labels = [label_fake] * T + [label_real] * T
-    res_d = D.step(images, labels, list(offsets) + list(offsets), adapts=adapts, learning_rate=lr_gen / 2, group=group)
+    offs2 = torch.cat([offsets, offsets]) if isinstance(offsets, torch.Tensor) else list(offsets) + list(offsets)
+    res_d = D.step(images, labels, offs2, adapts=adapts, learning_rate=lr_gen / 2, group=group, streams=streams,
+                   lr_t_dev=None if lr_t_dev is None else lr_t_dev[1:2])
     return torch.stack(res_g), res_d
+
+
+class GanLoop:
+    """gan_iteration captured once into a hipGraph and replayed: inputs, crop offsets and the two Adam rates live in
+    static device buffers that are refreshed before every replay (new random crops and the bias correction do not need a
+    re-capture); the towers of each phase run on ``streams`` HIP streams inside the graph.  Labels (label_fake /
+    label_real) and adapt = 1 are constants of the captured graph.  Single-process use (a captured graph cannot hold
+    the gradient all-reduce)."""
+
+    def __init__(self, G: GeneratorTrainer, D: DiscriminatorTrainer, streams=4, label_real=1.0, label_fake=0.0):
+        self.G, self.D, self.streams = G, D, streams
+        self.labels = (label_real, label_fake)
+        self.graph = None
+
+    def iteration(self, lq, truth, offsets, lr_gen=0.0002):
+        """lq, truth: torch CUDA [T,S,S,1]; offsets: per-tower ((y,x),(y,x),(y,x)) host integers."""
+        import torch
+
+        G, D = self.G, self.D
+        dev = G.device
+        off = torch.tensor(np.asarray(offsets, np.int32).reshape(lq.shape[0], 3, 2), dtype=torch.int32)
+        lr = torch.tensor([TO.adam_lr_t(lr_gen, G.t + 1, ADAM_BETA1), TO.adam_lr_t(lr_gen / 2, D.t + 1, ADAM_BETA1)], dtype=torch.float32)
+        if self.graph is None:
+            self.s_lq, self.s_truth = torch.empty_like(lq), torch.empty_like(truth)
+            self.s_off, self.s_lr = off.to(dev), lr.to(dev)
+            # one eager pass outside capture: every kernel family is loaded (state is restored afterwards)
+            keep = [t.clone() for t in (G.params, G.adam_m, G.adam_v, G.moving, D.params, D.adam_m, D.adam_v, D.moving)]
+            self.s_lq.copy_(lq)
+            self.s_truth.copy_(truth)
+            gan_iteration(G, D, self.s_lq, self.s_truth, self.s_off, lr_gen, *self.labels, streams=self.streams, lr_t_dev=self.s_lr)
+            for t, k in zip((G.params, G.adam_m, G.adam_v, G.moving, D.params, D.adam_m, D.adam_v, D.moving), keep):
+                t.copy_(k)
+            G.repack()
+            D.repack()
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.res = gan_iteration(G, D, self.s_lq, self.s_truth, self.s_off, lr_gen, *self.labels, streams=self.streams,
+                                         lr_t_dev=self.s_lr)
+        self.s_lq.copy_(lq)
+        self.s_truth.copy_(truth)
+        self.s_off.copy_(off)
+        self.s_lr.copy_(lr)
+        self.graph.replay()
+        G.t += 1
+        D.t += 1
+        return self.res[0].clone(), self.res[1].clone()

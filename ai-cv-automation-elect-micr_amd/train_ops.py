@@ -242,10 +242,20 @@ def sumsq(x, scale=1.0, stream=None):
     return out
 
 
+def adam_lr_t(lr, step, beta1=0.5, beta2=0.999):
+    return lr * (1.0 - beta2 ** step) ** 0.5 / (1.0 - beta1 ** step)
+
+
 def adam_step(param, grad, m, v, step, lr, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0, gnorm_sq=None, clip_norm=0.0,
-              stream=None):
+              stream=None, lr_t_dev=None):
     """``step`` = the 1-based step count t (bias correction lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t), as TF computes it)."""
-    lr_t = lr * (1.0 - beta2 ** step) ** 0.5 / (1.0 - beta1 ** step)
+    if lr_t_dev is not None:   # lr_t lives on the device (a replayed hipGraph): the caller refreshes it every step
+        _lib.check(_lib.load().emd_adam_step_dev_f32(_p(param), _p(grad), _p(m), _p(v), C.c_long(param.numel()), _p(lr_t_dev),
+                                                     C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(grad_scale),
+                                                     _p(gnorm_sq), C.c_float(clip_norm), _lib.stream_ptr(stream)),
+                   "emd_adam_step_dev_f32")
+        return
+    lr_t = adam_lr_t(lr, step, beta1, beta2)
     _lib.check(_lib.load().emd_adam_step_f32(_p(param), _p(grad), _p(m), _p(v), C.c_long(param.numel()), C.c_float(lr_t),
                                              C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(grad_scale),
                                              _p(gnorm_sq), C.c_float(clip_norm), _lib.stream_ptr(stream)), "emd_adam_step_f32")
@@ -299,16 +309,23 @@ def l1_feature(a, b, weight, dy, accumulate, loss_acc, stream=None):
                                               _p(loss_acc), _lib.stream_ptr(stream)), "emd_l1_feature_f32")
 
 
-def crop_scatter(dcrop, ldc, dimg, y0, x0, n, S, stream=None):
+def crop_scatter(dcrop, ldc, dimg, y0, x0, n, S, stream=None, yx_dev=None):
+    """yx_dev: int32 device tensor [2] = (y0, x0) read by the kernel (then y0, x0 are ignored)."""
+    if yx_dev is not None:
+        _lib.check(_lib.load().emd_crop_scatter_dev_f32(_p(dcrop), ldc, _p(dimg), _p(yx_dev), int(n), int(S),
+                                                        _lib.stream_ptr(stream)), "emd_crop_scatter_dev_f32")
+        return
     _lib.check(_lib.load().emd_crop_scatter_f32(_p(dcrop), ldc, _p(dimg), int(y0), int(x0), int(n), int(S), _lib.stream_ptr(stream)),
                "emd_crop_scatter_f32")
 
 
-def bn_infer_fold2(g1, b1, m1, v1, g2, b2, m2, v2, eps, stream=None):
-    """-> dict(scale, shift, mprime, rprime, rstd1, a2, mean1) for an inference-mode double batch norm."""
+def bn_infer_fold2(g1, b1, m1, v1, g2, b2, m2, v2, eps, stream=None, out=None):
+    """-> dict(scale, shift, mprime, rprime, rstd1, a2, mean1) for an inference-mode double batch norm.  ``out``: a dict
+    from a previous call, rewritten IN PLACE (a captured hipGraph keeps pointing at the same vectors)."""
     import torch
 
-    out = {k: torch.empty_like(g1) for k in ("scale", "shift", "mprime", "rprime", "rstd1", "a2")}
+    if out is None:
+        out = {k: torch.empty_like(g1) for k in ("scale", "shift", "mprime", "rprime", "rstd1", "a2")}
     _lib.check(_lib.load().emd_bn_infer_fold2_f32(_p(g1), _p(b1), _p(m1), _p(v1), _p(g2), _p(b2), _p(m2), _p(v2), C.c_float(eps),
                                                   g1.numel(), _p(out["scale"]), _p(out["shift"]), _p(out["mprime"]), _p(out["rprime"]),
                                                   _p(out["rstd1"]), _p(out["a2"]), _lib.stream_ptr(stream)), "emd_bn_infer_fold2_f32")

@@ -407,8 +407,12 @@ def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     x, t = torch.from_numpy(lq).to(dev), torch.from_numpy(hq).to(dev)
     box = [None]
 
+    loop = GT.GanLoop(G, D, streams=a.train_streams) if (world == 1 and not a.no_graph) else None
+
     def step():
-        box[0] = GT.gan_iteration(G, D, x, t, offsets)
+        # single GPU: the iteration is replayed from a hipGraph (towers on --train-streams streams; crop offsets and Adam
+        # rates live on the device); multi-GPU: eager, because the gradient all-reduces sit between the phases
+        box[0] = loop.iteration(x, t, offsets) if loop is not None else GT.gan_iteration(G, D, x, t, offsets, streams=a.train_streams)
 
     ms = timer.run(step, steps, warmup)
     rg, rd = box[0]
@@ -416,7 +420,8 @@ def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
            "steps": steps, "warmup": warmup, "dtype": "bf16x3 GEMMs (split-bf16 MFMA inputs, fp32 accumulate), fp32 elsewhere",
            "config": {"workload": f"A: in-filling GAN training iteration (misc_py/gan-infilling-100.py), [{T},{S},{S},1] fp32 per GPU: "
                                   f"{T} generator towers + Adam, {2 * T} discriminator towers + Adam",
-                      "global_batch": T * world, "precision": a.precision, "parallelism": f"dp{world}"},
+                      "global_batch": T * world, "precision": a.precision, "parallelism": f"dp{world}",
+                      "streams": a.train_streams, "hip_graph": loop is not None},
            "d_fake_first": float(rg[0, 0].item()), "d_out_first": float(rd[0, 0].item())}
     out["roofline"] = {"bound": "hbm", "kernel": "whole iteration (<= 128-channel separable convs at 256-512 px dominate)",
                        "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}

@@ -357,6 +357,11 @@ int emd_sumsq_f32(const float* x, long n, float scale, float* out, void* workspa
  * param -= lr_t*m/(sqrt(v)+eps), lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) computed by the caller. */
 int emd_adam_step_f32(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
                       float eps, float grad_scale, const float* gnorm_sq, float clip_norm, emd_stream_t stream);
+/* The same with lr_t (which changes every step through the bias correction) read from DEVICE memory, so that the
+ * optimizer step can live inside a replayed hipGraph. */
+int emd_adam_step_dev_f32(float* param, const float* grad, float* m, float* v, long n, const float* lr_t_dev, float beta1,
+                          float beta2, float eps, float grad_scale, const float* gnorm_sq, float clip_norm,
+                          emd_stream_t stream);
 
 /* Generator-side training (the generator tower, :982-1046; its batch norms stay on MOVING statistics while the tower
  * gradients are evaluated, :1667).
@@ -382,6 +387,8 @@ int emd_l1_feature_f32(const float* a, const float* b, long n, float weight, flo
 /* Gradient of one crop of get_multiscale_crops (:957-980): channel 0 of dcrop [n,n,ldc] is added into dimg [S,S] at
  * the mirror image of padded position (y0+i, x0+j) (padding 3S/4, REFLECT). */
 int emd_crop_scatter_f32(const float* dcrop, int ldc, float* dimg, int y0, int x0, int n, int S, emd_stream_t stream);
+/* The same with the offset pair (y0, x0) read from DEVICE memory: a captured hipGraph is replayed with new crops. */
+int emd_crop_scatter_dev_f32(const float* dcrop, int ldc, float* dimg, const int* yx_dev, int n, int S, emd_stream_t stream);
 /* Inference-mode double batch norm of a generator separable conv: (scale, shift) of the forward affine and the vectors
  * its parameter gradients need (see csrc/gan_train.hip); emd_bn_infer_grads_f32 adds them (s1 = sum g,
  * t1 = sum g*(r-mu1)/s1, t2 = sum g*(z1-mu2)/s2 from emd_bn_bwd_reduce_f32). */

@@ -294,3 +294,60 @@ def test_bn_inference_parameter_gradients():
     assert rel_l2(ya.torch().cpu().numpy(), y.detach().numpy()) < 2e-6
     for got, ref in zip(grads, (gg1, gb1, gg2, gb2)):
         assert rel_l2(got.cpu().numpy(), ref.numpy()) < 2e-5
+
+
+def test_gan_loop_graph_replay():
+    """gan_iteration captured into a hipGraph (towers on 2 streams; crop offsets and Adam rates refreshed on the device).
+    (a) The first replay equals the eager single-stream iteration to summation order.  (b) Every later replay is checked
+    against an eager tower evaluated on the loop's OWN current state just before the replay: D(fake), the adversarial
+    and the feature-matching loss must agree -- stale weights, folds, crops or rates inside the graph would show; the
+    free-running trajectories themselves separate quickly (Adam's first steps are +-lr per weight, so summation-order
+    noise in near-zero gradients flips signs)."""
+    from emdenoise import gan as GN
+    from emdenoise import gan_trainer as GT
+
+    wg, wd = GN.synthetic_weights(), GN.discriminator_synthetic_weights()
+    rng = np.random.default_rng(3)
+    pad = (3 * S) // 4
+    offs = [[tuple((int(rng.integers(0, S + 2 * pad - n + 1)), int(rng.integers(0, S + 2 * pad - n + 1))) for n in (S // 4, S // 2, pad))
+             for _ in range(2)] for _ in range(3)]
+
+    def batch(it):
+        hq = images(2, 50 + it)
+        lq = GN.gen_lq(hq[..., 0])[..., None]
+        return torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev())
+
+    # (a) first iteration, eager vs graph
+    De, Ge = GT.DiscriminatorTrainer(wd, dev()), None
+    Ge = GT.GeneratorTrainer(wg, De, dev())
+    x, t = batch(0)
+    eg, ed = GT.gan_iteration(Ge, De, x, t, offs[0])
+    D = GT.DiscriminatorTrainer(wd, dev())
+    G = GT.GeneratorTrainer(wg, D, dev())
+    loop = GT.GanLoop(G, D, streams=2)
+    gnames, dnames = list(G.trainable), list(D.trainable)
+    g0, d0 = flat(wg, gnames), flat(wd, dnames)
+    rg, rd = loop.iteration(x, t, offs[0])
+    torch.cuda.synchronize()
+    ug = rel_l2(flat(G.state_dict(), gnames) - g0, flat(Ge.state_dict(), gnames) - g0)
+    ud = rel_l2(flat(D.state_dict(), dnames) - d0, flat(De.state_dict(), dnames) - d0)
+    print(f"iteration 0: update diff G {ug:.2e} D {ud:.2e}")
+    assert np.allclose(rg.cpu().numpy(), eg.cpu().numpy(), rtol=1e-4) and np.allclose(rd.cpu().numpy(), ed.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    assert ug < 1e-3 and ud < 1e-3 and G.t == 1 and D.t == 1
+    # (b) later replays against eager towers on the loop's own state
+    for it in (1, 2):
+        x, t = batch(it)
+        before = flat(G.state_dict(), gnames)
+        want = []
+        for k in range(2):
+            G.zero_grad()
+            _, r, st = G.tower(x[k:k + 1].contiguous(), t[k:k + 1].contiguous(), offs[it][k])
+            want.append(np.concatenate([r.cpu().numpy(), st.cpu().numpy()]))
+        rg, rd = loop.iteration(x, t, offs[it])
+        torch.cuda.synchronize()
+        got = rg.cpu().numpy()
+        print(f"iteration {it}: replay {got[:, 0]} vs eager-on-same-state {[w[0] for w in want]}")
+        assert np.allclose(got, np.stack(want), rtol=2e-5, atol=1e-6), (it, got, want)
+        moved = np.abs(flat(G.state_dict(), gnames) - before)
+        assert 0.1 * 2e-4 < np.median(moved[moved > 0]) < 2.5 * 2e-4      # the weights did move: Adam's early steps are ~lr per weight
+    assert G.t == 3 and D.t == 3
