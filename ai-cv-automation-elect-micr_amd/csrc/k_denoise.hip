@@ -386,6 +386,144 @@ __global__ __launch_bounds__(NW * 64) void k3_tile(const float* __restrict__ x, 
     store_row(a + R - 1, o1);
 }
 
+// k3_roll<RW, NW>  (D4-symmetric maps, depth 2): the software-pipelined form of k3_tile.  A wave owns 512 columns
+// (8 pixels per lane) x RW output rows and WALKS DOWN them: for every input row i it evaluates the separable terms
+// V_i, M_i once (output row r = V_{r-1} + M_r + V_{r+1}), keeping acc_r = V_{r-1} + M_r and V_r in registers, while
+// the loads of rows i+1 and i+2 are already in flight and finished rows are being stored.  No LDS exchange and no
+// barrier: a wave's load -> compute -> store chain overlaps with itself instead of relying on other waves.  The
+// arithmetic around the six transcendentals per pixel is packed (v_pk_fma/add/mul_f32, two pixels per instruction).
+template <int RW, int NW>
+__global__ __launch_bounds__(NW * 64) void k3_roll(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                   int depth, const float* __restrict__ params) {
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    constexpr int NP = 4;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seg = blockIdx.x;
+    const size_t img_off = (size_t)blockIdx.z * (size_t)(H * W);
+    const K3Params q = load_k3<MODE_SYM>(params, depth);
+    const int base = seg * 512;
+    const int px[2] = {base + lane * 4, base + 256 + lane * 4};
+    const bool act[2] = {px[0] < W, px[1] < W};
+    const bool has_left = seg > 0, has_right = base + 512 < W;   // wave-uniform
+    const float* img = x + img_off;
+    float* out = y + img_off;
+    const int a = (blockIdx.y * NW + wv) * RW;                   // first output row of this wave
+    if (a >= H) return;
+    const int nrows = a + RW <= H ? RW : H - a;
+
+    struct Raw { float4 g[2]; float ext; };
+    auto load_row = [&](int r, Raw& p) {
+        int rr = reflect_idx(r, H);
+        rr = rr < 0 ? 0 : (rr >= H ? H - 1 : rr);
+        const float* row = img + rr * W;
+        p.g[0] = p.g[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        p.ext = 0.f;
+        if (act[0]) p.g[0] = *reinterpret_cast<const float4*>(row + px[0]);
+        if (act[1]) p.g[1] = *reinterpret_cast<const float4*>(row + px[1]);
+        if (has_left && lane == 0) p.ext = row[base - 1];
+        if (has_right && lane == 63) p.ext = row[base + 512];
+    };
+    auto sig2 = [](f2 p, float ws, float bs, float aa) -> f2 {
+        const f2 arg = __builtin_elementwise_fma(p, (f2){ws, ws}, (f2){bs, bs});
+        const f2 e = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+        const f2 d = e + 1.0f;
+        const f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        return r * aa;
+    };
+    auto terms = [&](const Raw& p, f2 (&V)[NP], f2 (&M)[NP]) {
+        const f2 pv[NP] = {{p.g[0].x, p.g[0].y}, {p.g[0].z, p.g[0].w}, {p.g[1].x, p.g[1].y}, {p.g[1].z, p.g[1].w}};
+        f2 E[NP], C[NP], Z[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            Z[j] = sig2(pv[j], q.ws[4], q.bs[4], q.a[4]);
+            E[j] = sig2(pv[j], q.ws[1], q.bs[1], q.a[1]);
+            C[j] = sig2(pv[j], q.ws[0], q.bs[0], q.a[0]);
+        }
+        float Eext = 0.f, Cext = 0.f;
+        if (has_left || has_right) {
+            Eext = sig_term(p.ext, q.ws[1], q.bs[1], q.a[1]);
+            Cext = sig_term(p.ext, q.ws[0], q.bs[0], q.a[0]);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int o = 2 * g;
+            float El = __shfl_up(E[o + 1].y, 1), Cl = __shfl_up(C[o + 1].y, 1);
+            float Er = __shfl_down(E[o].x, 1), Cr = __shfl_down(C[o].x, 1);
+            if (g == 1) {
+                const float e = __shfl(E[1].y, 63), c = __shfl(C[1].y, 63);
+                if (lane == 0) { El = e; Cl = c; }
+            } else {
+                const float e = __shfl(E[2].x, 0), c = __shfl(C[2].x, 0);
+                if (lane == 63) { Er = e; Cr = c; }
+                if (lane == 0 && has_left) { El = Eext; Cl = Cext; }
+            }
+            if (g == 1 && lane == 63 && has_right) { Er = Eext; Cr = Cext; }
+            if (px[g] == 0) { El = E[o].y; Cl = C[o].y; }
+            if (px[g] + 4 >= W) { Er = E[o + 1].x; Cr = C[o + 1].x; }
+            const f2 eL = {El, E[o].x}, eM = {E[o].y, E[o + 1].x}, eR = {E[o + 1].y, Er};
+            const f2 cL = {Cl, C[o].x}, cM = {C[o].y, C[o + 1].x}, cR = {C[o + 1].y, Cr};
+            M[o] = Z[o] + (eL + eM);
+            M[o + 1] = Z[o + 1] + (eM + eR);
+            V[o] = E[o] + (cL + cM);
+            V[o + 1] = E[o + 1] + (cM + cR);
+        }
+    };
+    auto store_row = [&](int orow, const f2 (&v)[NP]) {
+        float* o = out + orow * W;
+        if (act[0]) *reinterpret_cast<float4*>(o + px[0]) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+        if (act[1]) *reinterpret_cast<float4*>(o + px[1]) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+    };
+
+    // input rows a-1 .. a+nrows; three raw-row buffers rotate, loads run two rows ahead of the arithmetic
+    Raw r0, r1, r2;
+    load_row(a - 1, r0);
+    load_row(a, r1);
+    load_row(a + 1, r2);
+    f2 acc[NP], carry[NP], V[NP], M[NP];
+    terms(r0, V, M);                                  // row a-1: only V is needed
+#pragma unroll
+    for (int j = 0; j < NP; ++j) carry[j] = V[j];
+    load_row(a + 2, r0);
+    terms(r1, V, M);                                  // row a
+    load_row(a + 3, r1);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { acc[j] = carry[j] + M[j]; carry[j] = V[j]; }
+    // steady state, three rows per trip so that the buffer rotation is static
+    int i = a + 1;                                    // next input row to evaluate; it sits in r2, then r0, then r1
+    const int last = a + nrows;                       // last input row (the halo below)
+#define EMD_K3_STEP(RAWCUR, RAWNEXT3)                                              \
+    if (i <= last) {                                                               \
+        terms(RAWCUR, V, M);                                                       \
+        if (i + 3 <= last) load_row(i + 3, RAWNEXT3);                              \
+        f2 o[NP];                                                                  \
+        _Pragma("unroll") for (int j = 0; j < NP; ++j) o[j] = acc[j] + V[j];       \
+        store_row(i - 1, o);                                                       \
+        _Pragma("unroll") for (int j = 0; j < NP; ++j) { acc[j] = carry[j] + M[j]; carry[j] = V[j]; } \
+        ++i;                                                                       \
+    }
+    for (int trip = 0; trip < (RW + 3) / 3; ++trip) {
+        EMD_K3_STEP(r2, r2)   // evaluates row i (in r2), then refills r2 with row i+3
+        EMD_K3_STEP(r0, r0)
+        EMD_K3_STEP(r1, r1)
+    }
+#undef EMD_K3_STEP
+}
+
+template <int RW, int NW>
+int launch_k3_roll(const float* x, float* y, int B, int H, int W, int depth, const float* params, hipStream_t st) {
+    const int nseg = (W + 511) / 512;
+    const int nstrip = (H + NW * RW - 1) / (NW * RW);
+    if ((long)H * W >= 0x7fffffffL || nstrip > 65535)
+        return emd::fail(EMD_E_UNSUPPORTED, "emd_kernel_denoise_f32: image too large for the tiled kernel");
+    for (int b0 = 0; b0 < B; b0 += 65535) {
+        const int nb = B - b0 < 65535 ? B - b0 : 65535;
+        const size_t off = (size_t)b0 * H * W;
+        hipLaunchKernelGGL((k3_roll<RW, NW>), dim3(nseg, nstrip, nb), dim3(NW * 64), 0, st, x + off, y + off, H, W, depth, params);
+    }
+    return emd::check_launch("k3_roll");
+}
+
 template <int R, int NW>
 int launch_k3_tile(const float* x, float* y, int B, int H, int W, int depth, const float* params,
                    hipStream_t st) {
@@ -430,7 +568,20 @@ extern "C" int emd_kernel_denoise_f32(const float* x, float* y, int B, int H, in
     if (fast) {
         constexpr int R = 8;
         if (depth == 1) return launch_k3<MODE_LIN, R>(x, y, B, H, W, depth, params, st);
-        if (flags & EMD_K_SYMMETRIC) return launch_k3_tile<2, 8>(x, y, B, H, W, depth, params, st);
+        if (flags & EMD_K_SYMMETRIC) {
+#ifndef EMD_K_RW
+#define EMD_K_RW 8
+#endif
+#ifndef EMD_K_NW
+#define EMD_K_NW 2
+#endif
+#ifdef EMD_K_TILE
+            return launch_k3_tile<2, 8>(x, y, B, H, W, depth, params, st);
+#else
+            if (H >= 3) return launch_k3_roll<EMD_K_RW, EMD_K_NW>(x, y, B, H, W, depth, params, st);
+            return launch_k3_tile<2, 8>(x, y, B, H, W, depth, params, st);
+#endif
+        }
         return launch_k3<MODE_GEN, R>(x, y, B, H, W, depth, params, st);
     }
     const long total = (long)B * H * W;

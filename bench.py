@@ -199,13 +199,13 @@ def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     achieved = alg_bytes / (launch_us * 1e-6) / 1e9
     tr = pmc_traffic()
     traffic = None
-    if tr and "K:k3_tile<2, 8>" in tr and (B, H, W) == (32, 512, 512):
-        traffic = round(tr["K:k3_tile<2, 8>"]["hbm_bytes_per_launch_corrected"])
+    if tr and "K:k3_roll<8, 2>" in tr and (B, H, W) == (32, 512, 512):
+        traffic = round(tr["K:k3_roll<8, 2>"]["hbm_bytes_per_launch_corrected"])
     out = {
         "value": B * H * W / 1e6 * world / (ms / 1e3), "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "f32",
         "config": {"workload": f"K: kernel denoiser depth 2 width 3 (noise-removal-kernels.py), [{B},{H},{W},1] fp32 per GPU",
                    "global_batch": B * world, "image": f"{H}x{W}x1", "sharding": f"{world} x {B} whole images, no collective"},
-        "roofline": {"bound": "hbm", "kernel": "k3_tile<2,8>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": "k3_roll<8,2>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2x FETCH correction)",
                      "algorithmic_bytes_per_launch": alg_bytes,

@@ -19,7 +19,7 @@ for wl in ("K", "D"):
             for r in csv.DictReader(open(f)):
                 nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
                 if "rocclr" in nm: continue
-                if wl == "K" and int(r["Grid_Size"]) < 500000: continue
+                if wl == "K" and int(r["Grid_Size"]) < 100000: continue
                 per[nm][c].append(float(r["Counter_Value"]))
     for nm, d in per.items():
         n = max(len(v) for v in d.values())
