@@ -49,6 +49,17 @@ SIGNATURES = {
     # x ldx w y ldy B H W C stride rate stream
     "emd_dw3x3_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "emd_split32_ld": (C.c_int, [C.c_int]),
+    # x ldx y ldy npix C stream
+    "emd_to_split32_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
+    # x ldx w y ldy B H W C stride rate stream
+    "emd_dw3x3_split32_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "emd_conv1x1_split32_supported": (C.c_int, [C.c_long, C.c_int, C.c_int]),
+    # xs ldx whi wlo scale1 shift1 scale2 shift2 res ldres y ldy M Cin Cout act stream
+    "emd_conv1x1_split32_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p,
+                                          _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_long, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p]),
     # x w9 a shift y ldy B H W Cout stride act stream
     "emd_cin1_f32": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

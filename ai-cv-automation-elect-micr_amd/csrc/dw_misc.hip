@@ -8,9 +8,27 @@
 // Layout rule for all of them: channels are innermost, a lane owns 4 consecutive channels (one 16-B
 // access) and consecutive lanes own consecutive channel groups, then consecutive pixels along W, so
 // a wavefront's access is one contiguous run of NHWC memory whenever C >= 4*64/pixels-per-wave.
-#include "emd_common.hpp"
+#include "mfma_common.hpp"
 
 namespace {
+
+// Output stage of the depthwise kernels.  SPLIT = false: 4 fp32 channels at y + pix*ldy + 4*c4.  SPLIT = true: the
+// split32 layout consumed by emd_conv1x1_split32_f32 (gemm_split.hip): the value is split into bf16 hi + lo here, once,
+// instead of in every N-tile of the GEMM; pixel pitch ldy 4-byte units, channel group g = c/32 at byte 128 g:
+// 32 x hi | 32 x lo.  Threads with c4 >= C4 (the padding up to a multiple of 32 channels) store zeros.
+template <bool SPLIT>
+__device__ __forceinline__ void dw_store(float* __restrict__ y, long pix, int ldy, int c4, float4 v) {
+    if (!SPLIT) {
+        *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = v;
+    } else {
+        unsigned h0, l0, h1, l1;
+        emd::split2(v.x, v.y, h0, l0);
+        emd::split2(v.z, v.w, h1, l1);
+        unsigned char* o = reinterpret_cast<unsigned char*>(y) + pix * (long)ldy * 4 + (c4 >> 3) * 128 + (c4 & 7) * 8;
+        *reinterpret_cast<emd::u32x2*>(o) = emd::u32x2{h0, h1};
+        *reinterpret_cast<emd::u32x2*>(o + 64) = emd::u32x2{l0, l1};
+    }
+}
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
@@ -32,14 +50,17 @@ __device__ __forceinline__ float cout1_out(float s, float pre_bias, int pre_relu
 // down a strip of TH output rows with the three live input rows' horizontal partial sums in registers:
 // an input row is read once per strip (3 shifted 16-B loads) and turned into its contribution as the
 // top / middle / bottom row of a window.  TF SAME: pad 1 on every side.
-template <int TH>
+template <int TH, bool SPLIT = false>
 __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x, int ldx,
                                                      const float* __restrict__ w, float* __restrict__ y,
-                                                     int ldy, int H, int W, int C4, long nthreads, int nstrip) {
+                                                     int ldy, int H, int W, int C4, long nthreads, int nstrip, int C4t) {
+    // C4t = channel quads per pixel that have a thread: C4, or ceil32(C)/4 when the split32 padding is written too
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;
-    const int c4 = (int)(tid % C4);
-    long t = tid / C4;
+    const int c4o = (int)(tid % C4t);
+    const bool padq = SPLIT && c4o >= C4;
+    const int c4 = padq ? C4 - 1 : c4o;
+    long t = tid / C4t;
     const int ox = (int)(t % W);
     t /= W;
     const int strip = (int)(t % nstrip);
@@ -51,7 +72,6 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
     for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(w + k * C + c4 * 4);
 
     const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
-    float* yb = y + (b * H) * (long)W * ldy + c4 * 4;
     const int oy0 = strip * TH;
     const bool hasl = ox > 0, hasr = ox + 1 < W;
 
@@ -71,7 +91,7 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
         }
         if (tt >= 2) {
             const int oy = oy0 + tt - 2;
-            if (oy < H) *reinterpret_cast<float4*>(yb + ((long)oy * W + ox) * ldy) = add4(s0, h2);
+            if (oy < H) dw_store<SPLIT>(y, (b * H + oy) * (long)W + ox, ldy, c4o, padq ? f4zero() : add4(s0, h2));
         }
         s0 = add4(s1, h1);
         s1 = h0;
@@ -79,14 +99,17 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
 }
 
 // Depthwise 3x3, any stride / rate: one output pixel x 4 channels per thread (9 loads).
+template <bool SPLIT = false>
 __global__ __launch_bounds__(256) void dw3x3_generic(const float* __restrict__ x, int ldx,
                                                      const float* __restrict__ w, float* __restrict__ y,
                                                      int ldy, int H, int W, int C4, int Ho, int Wo,
-                                                     int stride, int rate, int pt, int pl, long nthreads) {
+                                                     int stride, int rate, int pt, int pl, long nthreads, int C4t) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;
-    const int c4 = (int)(tid % C4);
-    long t = tid / C4;
+    const int c4o = (int)(tid % C4t);
+    const bool padq = SPLIT && c4o >= C4;
+    const int c4 = padq ? C4 - 1 : c4o;
+    long t = tid / C4t;
     const int ox = (int)(t % Wo);
     t /= Wo;
     const int oy = (int)(t % Ho);
@@ -107,7 +130,7 @@ __global__ __launch_bounds__(256) void dw3x3_generic(const float* __restrict__ x
             acc = fma4(wk, v, acc);
         }
     }
-    *reinterpret_cast<float4*>(y + ((b * Ho + oy) * (long)Wo + ox) * ldy + c4 * 4) = acc;
+    dw_store<SPLIT>(y, (b * Ho + oy) * (long)Wo + ox, ldy, c4o, padq ? f4zero() : acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -464,45 +487,65 @@ inline int grid_for(long nthreads, unsigned* blocks) {
     return EMD_OK;
 }
 
-}  // namespace
-
-extern "C" int emd_dw3x3_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W,
-                             int C, int stride, int rate, emd_stream_t stream) {
-    EMD_REQUIRE(x && w && y, EMD_E_INVALID, "emd_dw3x3_f32: null pointer");
-    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1 && C >= 4, EMD_E_INVALID, "emd_dw3x3_f32: bad shape");
-    EMD_REQUIRE(stride == 1 || stride == 2, EMD_E_UNSUPPORTED, "emd_dw3x3_f32: stride must be 1 or 2");
-    EMD_REQUIRE(rate >= 1 && (rate == 1 || stride == 1), EMD_E_UNSUPPORTED, "emd_dw3x3_f32: rate > 1 needs stride 1");
-    EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C, EMD_E_ALIGN,
-                "emd_dw3x3_f32: C, ldx, ldy must be multiples of 4 and ld >= C");
-    EMD_REQUIRE(emd::aligned16(x) && emd::aligned16(y) && emd::aligned16(w), EMD_E_ALIGN,
-                "emd_dw3x3_f32: pointers must be 16-byte aligned");
+template <bool SPLIT>
+int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
+                 int stride, int rate, emd_stream_t stream) {
+    (void)who;
+    EMD_REQUIRE(x && w && y, EMD_E_INVALID, "emd_dw3x3: null pointer");
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1 && C >= 4, EMD_E_INVALID, "emd_dw3x3: bad shape");
+    EMD_REQUIRE(stride == 1 || stride == 2, EMD_E_UNSUPPORTED, "emd_dw3x3: stride must be 1 or 2");
+    EMD_REQUIRE(rate >= 1 && (rate == 1 || stride == 1), EMD_E_UNSUPPORTED, "emd_dw3x3: rate > 1 needs stride 1");
+    const int Cp = (C + 31) / 32 * 32;
+    if (SPLIT) {
+        EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldx >= C && ldy % 32 == 0 && ldy >= Cp, EMD_E_ALIGN,
+                    "emd_dw3x3_split32_f32: C, ldx multiples of 4; ldy a multiple of 32, >= ceil32(C)");
+        EMD_REQUIRE(emd::aligned16(x) && (reinterpret_cast<uintptr_t>(y) & 127u) == 0 && emd::aligned16(w), EMD_E_ALIGN,
+                    "emd_dw3x3_split32_f32: x, w 16-byte and y 128-byte aligned");
+    } else {
+        EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C, EMD_E_ALIGN,
+                    "emd_dw3x3_f32: C, ldx, ldy must be multiples of 4 and ld >= C");
+        EMD_REQUIRE(emd::aligned16(x) && emd::aligned16(y) && emd::aligned16(w), EMD_E_ALIGN,
+                    "emd_dw3x3_f32: pointers must be 16-byte aligned");
+    }
     if (B == 0) return EMD_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int Ho, Wo;
     const int pt = same_pad_before(H, 3, stride, rate, &Ho);
     const int pl = same_pad_before(W, 3, stride, rate, &Wo);
-    const int C4 = C / 4;
+    const int C4 = C / 4, C4t = SPLIT ? Cp / 4 : C4;
     unsigned nb;
     if (stride == 1 && rate == 1) {
         // strip height: 16 rows (input re-read factor 18/16) measured 1-4 % faster than 8 on the 256^2/512^2 layers;
         // short images keep 8 so that small maps still spread over the chip
         const int TH = H >= 64 ? 16 : 8;
         const int nstrip = (H + TH - 1) / TH;
-        const long nthreads = (long)B * nstrip * W * C4;
+        const long nthreads = (long)B * nstrip * W * C4t;
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
         if (TH == 16)
-            hipLaunchKernelGGL(dw3x3_s1_roll<16>, dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip);
+            hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t);
         else
-            hipLaunchKernelGGL(dw3x3_s1_roll<8>, dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip);
+            hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t);
         return emd::check_launch("dw3x3_s1_roll");
     }
-    const long nthreads = (long)B * Ho * Wo * C4;
+    const long nthreads = (long)B * Ho * Wo * C4t;
     int rc = grid_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
-    hipLaunchKernelGGL(dw3x3_generic, dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, Ho, Wo, stride, rate, pt,
-                       pl, nthreads);
+    hipLaunchKernelGGL((dw3x3_generic<SPLIT>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, Ho, Wo, stride, rate, pt,
+                       pl, nthreads, C4t);
     return emd::check_launch("dw3x3_generic");
+}
+
+}  // namespace
+
+extern "C" int emd_dw3x3_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W,
+                             int C, int stride, int rate, emd_stream_t stream) {
+    return dw3x3_launch<false>("emd_dw3x3_f32", x, ldx, w, y, ldy, B, H, W, C, stride, rate, stream);
+}
+
+extern "C" int emd_dw3x3_split32_f32(const float* x, int ldx, const float* w, void* y, int ldy, int B, int H, int W,
+                                     int C, int stride, int rate, emd_stream_t stream) {
+    return dw3x3_launch<true>("emd_dw3x3_split32_f32", x, ldx, w, static_cast<float*>(y), ldy, B, H, W, C, stride, rate, stream);
 }
 
 extern "C" int emd_cin1_f32(const float* x, const float* w9, const float* a, const float* shift, float* y, int ldy,

@@ -175,6 +175,69 @@ def dw3x3(x: Act, w_dev, out: Act, stride=1, rate=1, stream=None):
     return out
 
 
+class SplitAct:
+    """A split32 activation tensor [B,H,W,C] (include/emdenoise.h: every value as bf16 hi + bf16 lo, 32-channel groups of
+    128 bytes); ``buf`` is a float32 torch tensor [B,H,W,ld] of the same bytes, ld = C rounded up to 32."""
+
+    __slots__ = ("buf", "B", "H", "W", "C", "ld")
+
+    def __init__(self, B, H, W, Cc, device):
+        import torch
+
+        self.B, self.H, self.W, self.C = B, H, W, Cc
+        self.ld = _lib.load().emd_split32_ld(Cc)
+        self.buf = torch.empty((B, H, W, self.ld), dtype=torch.float32, device=device)
+        assert self.buf.data_ptr() % 128 == 0
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.buf.data_ptr())
+
+    def to_float(self):
+        """hi + lo as float32 [B,H,W,C] (test helper)."""
+        import torch
+
+        g = self.buf.view(torch.bfloat16).view(self.B, self.H, self.W, self.ld // 32, 2, 32).float()
+        return (g[..., 0, :] + g[..., 1, :]).reshape(self.B, self.H, self.W, self.ld)[..., : self.C]
+
+
+def to_split32(x: Act, out: SplitAct | None = None, stream=None):
+    lib = _lib.load()
+    if out is None:
+        out = SplitAct(x.B, x.H, x.W, x.C, x.buf.device)
+    assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, x.C)
+    _lib.check(lib.emd_to_split32_f32(x.ptr, x.ld, out.ptr, out.ld, C.c_long(x.B * x.H * x.W), x.C,
+                                      _lib.stream_ptr(stream)), "emd_to_split32_f32")
+    return out
+
+
+def dw3x3_split32(x: Act, w_dev, out: SplitAct, stride=1, rate=1, stream=None):
+    lib = _lib.load()
+    assert out.C == x.C and out.B == x.B and (out.H, out.W) == (-(-x.H // stride), -(-x.W // stride))
+    _lib.check(lib.emd_dw3x3_split32_f32(x.ptr, x.ld, _p(w_dev), out.ptr, out.ld, x.B, x.H, x.W, x.C, stride, rate,
+                                         _lib.stream_ptr(stream)), "emd_dw3x3_split32_f32")
+    return out
+
+
+def conv1x1_split32_supported(npix: int, cin: int, cout: int) -> bool:
+    return bool(_lib.load().emd_conv1x1_split32_supported(C.c_long(npix), cin, cout))
+
+
+def conv1x1_split32(x: SplitAct, w: PackedWeights, scale1, shift1, out: Act, act=True, scale2=None, shift2=None,
+                    res: Act | None = None, stream=None):
+    """Pointwise conv on a split32 input (split-bf16 precision; bit-identical to conv1x1 on the fp32 twin)."""
+    lib = _lib.load()
+    assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, w.cout) and w.cin == x.C and w.taps == 1
+    if res is not None:
+        assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
+    rc = lib.emd_conv1x1_split32_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
+                                     res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
+                                     out.ptr, out.ld, C.c_long(x.B * x.H * x.W), x.C, w.cout, _act(act),
+                                     _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_conv1x1_split32_f32")
+    return out
+
+
 def cin1(x_img, w9_dev, a_dev, shift_dev, out: Act, stride=1, act=True, stream=None):
     """x_img: torch CUDA float32 [B,H,W] or [B,H,W,1] contiguous."""
     lib = _lib.load()

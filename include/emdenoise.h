@@ -159,6 +159,29 @@ int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, const uint16_
 int emd_dw3x3_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
                   int stride, int rate, emd_stream_t stream);
 
+/* ---- "split32" activations: the pointwise GEMM fed entirely by LDS-DMA (csrc/gemm_split.hip).
+ * A split32 tensor [npix][C] holds every value as bf16 hi + bf16 lo (x = hi + lo + O(2^-17 x), both round-to-nearest):
+ * pixel pitch ld in 4-byte units (ld % 32 == 0, ld >= emd_split32_ld(C) = C rounded up to 32); inside a pixel, channel
+ * group g = c/32 occupies bytes [128 g, 128 g + 128): 32 x hi, then 32 x lo; channels C..ld are zero.  Same bytes and
+ * pitch as the fp32 NHWC tensor it stands for; base address 128-byte aligned.
+ *
+ * emd_dw3x3_split32_f32     = emd_dw3x3_f32 whose result is written in split32 form (the depthwise half of
+ *                             slim.separable_convolution2d, machine_learning/denoiser.py:113-131).
+ * emd_to_split32_f32        converts an fp32 tensor (pitch ldx floats).
+ * emd_conv1x1_split32_f32   = emd_conv1x1_f32 (stride 1, EMD_PREC_BF16X3) on a split32 input: the pointwise half + BN x2
+ *                             + relu6 + residual (:123, :134, :246); results are bit-identical to emd_conv1x1_f32 on the
+ *                             fp32 twin of xs.  M = number of pixels.  256 x 128 tiles, 512 threads, K step 32, both
+ *                             operands by global_load_lds_dwordx4, XOR-swizzled LDS rows.
+ * emd_conv1x1_split32_supported: 1 where this kernel is the better choice (Cin, Cout >= 128 and >= 256 tiles). */
+int emd_split32_ld(int C);
+int emd_to_split32_f32(const float* x, int ldx, void* y, int ldy, long npix, int C, emd_stream_t stream);
+int emd_dw3x3_split32_f32(const float* x, int ldx, const float* w, void* y, int ldy, int B, int H, int W, int C,
+                          int stride, int rate, emd_stream_t stream);
+int emd_conv1x1_split32_supported(long M, int Cin, int Cout);
+int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                            const float* shift1, const float* scale2, const float* shift2, const float* res,
+                            int ldres, float* y, int ldy, long M, int Cin, int Cout, int act, emd_stream_t stream);
+
 /* Layers fed by the 1-channel image: y[pix][n] = act( d[pix]*a[n] + shift[n] ).
  * w9 != NULL: d = 3x3 SAME depthwise of x with the 9 weights w9 (stride 1)  -- cnn0 (denoiser.py:252),
  *             a[n] = pointwise_weights[0][n] * folded BN scale;

@@ -1,0 +1,142 @@
+"""GPU parity tests of the split32 path (csrc/gemm_split.hip): the depthwise kernels writing pre-split bf16 hi/lo
+activations, the converter, and the LDS-DMA pointwise GEMM that consumes them.  Checked three ways:
+  * against the oracle's TF-op restatement (oracle/tf_ops.py, float64): 2e-5 relative L2 (split-bf16 bar);
+  * bit for bit against emd_conv1x1_f32 (the register-staged kernel computes the same products in the same order);
+  * the split32 tensor itself: hi + lo reproduces the fp32 value to 2^-16 relative, padding channels are zero.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_X3 = 2e-5
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def rnd(shape, seed, scale=1.0, positive=False):
+    r = np.random.default_rng(seed)
+    a = r.standard_normal(shape) * scale
+    if positive:
+        a = np.abs(a)
+    return a.astype(np.float32)
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def t64(a):
+    return torch.from_numpy(np.asarray(a, np.float64))
+
+
+def up(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+@pytest.mark.parametrize("C", [32, 40, 728, 100])
+def test_to_split32_layout(C):
+    from emdenoise import ops
+
+    x = rnd((2, 5, 7, C), 11, 3.0)
+    xa = ops.Act(up(x))
+    sp = ops.to_split32(xa)
+    torch.cuda.synchronize()
+    assert sp.ld == -(-C // 32) * 32
+    back = sp.to_float().cpu().numpy()
+    assert np.max(np.abs(back - x) / np.maximum(np.abs(x), 1e-30)) < 2.0 ** -15.9
+    raw = sp.buf.view(torch.bfloat16).view(2, 5, 7, sp.ld // 32, 2, 32).float().cpu().numpy()
+    hi = raw[..., 0, :].reshape(2, 5, 7, sp.ld)
+    lo = raw[..., 1, :].reshape(2, 5, 7, sp.ld)
+    # hi is the round-to-nearest bf16 of x; the padding channels are exactly zero in both planes
+    ref_hi = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(hi[..., :C], ref_hi)
+    assert not hi[..., C:].any() and not lo[..., C:].any()
+
+
+@pytest.mark.parametrize("B,H,W,C,stride,rate", [(2, 16, 16, 728, 1, 1), (1, 64, 64, 40, 1, 1), (2, 17, 13, 64, 2, 1),
+                                                  (1, 32, 32, 96, 1, 6), (1, 70, 33, 256, 1, 1)])
+def test_dw3x3_split32_equals_dw3x3_then_split(B, H, W, C, stride, rate):
+    from emdenoise import ops
+
+    x = rnd((B, H, W, C), 21)
+    w = rnd((9, C), 22, 0.3)
+    xa, wd = ops.Act(up(x)), up(w)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    plain = ops.dw3x3(xa, wd, ops.Act.empty(B, Ho, Wo, C, dev()), stride=stride, rate=rate)
+    want = ops.to_split32(plain)
+    got = ops.SplitAct(B, Ho, Wo, C, dev())
+    got.buf.fill_(float("nan"))
+    ops.dw3x3_split32(xa, wd, got, stride=stride, rate=rate)
+    torch.cuda.synchronize()
+    assert torch.equal(got.buf.view(torch.int32), want.buf.view(torch.int32))
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,res,extra", [
+    (2, 32, 32, 728, 728, True, False),    # middle flow (M tail: 2048 rows = 8 tiles exactly)
+    (1, 24, 20, 728, 728, False, True),    # M = 480: one full tile + a ragged one; ASPP's extra BN
+    (1, 16, 16, 256, 728, False, False),   # cnn3
+    (1, 40, 40, 384, 256, True, False),    # deconv2_a
+    (1, 8, 8, 160, 132, False, False),     # N tail inside the second N tile, K = 5 steps
+    (1, 8, 8, 48, 128, False, False),      # K tail with an all-padding half step
+])
+def test_conv1x1_split32(B, H, W, ci, co, res, extra):
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 1, positive=True)
+    w = rnd((1, 1, ci, co), 2, scale=(2.0 / (ci + co)) ** 0.5)
+    s1, t1 = rnd((co,), 3, 0.3) + 1.0, rnd((co,), 4, 0.5)
+    s2, t2 = rnd((co,), 5, 0.2) + 1.0, rnd((co,), 6, 0.3)
+    r = rnd((B, H, W, co), 7)
+    ref = T.relu6_t(T.conv2d_t(t64(x), t64(w), None) * t64(s1) + t64(t1))
+    if extra:
+        ref = T.relu6_t(ref * t64(s2) + t64(t2))
+    if res:
+        ref = ref + t64(r)
+    pw = ops.PackedWeights(w[0], False, dev())
+    xa = ops.Act(up(x))
+    kw = dict(scale2=up(s2) if extra else None, shift2=up(t2) if extra else None, res=ops.Act(up(r)) if res else None)
+    # the split32 output sits in a channel slice of a wider NaN-filled buffer (tf.concat targets, denoiser.py:203)
+    wide = torch.full((B, H, W, co + 8), float("nan"), dtype=torch.float32, device=dev())
+    got = ops.conv1x1_split32(ops.to_split32(xa), pw, up(s1), up(t1), ops.Act(wide, co, 4), **kw)
+    old = ops.conv1x1(xa, pw, up(s1), up(t1), ops.Act.empty(B, H, W, co, dev()), precision=ops.PREC_BF16X3, **kw)
+    torch.cuda.synchronize()
+    assert rel_l2(got.torch().cpu().numpy(), ref.numpy()) < TOL_X3
+    assert torch.equal(got.torch(), old.torch()), "split32 GEMM must reproduce emd_conv1x1_f32 bit for bit"
+    assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
+
+
+def test_conv1x1_split32_full_size_identity():
+    """BASELINE size (B=32, 32x32x728 -> 728): bit-identical to the register-staged kernel over all 32768 rows."""
+    from emdenoise import ops
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.rand((32, 32, 32, 728), generator=g).mul_(3.0).to(dev())
+    w = (np.random.default_rng(6).standard_normal((1, 728, 728)) * 0.04).astype(np.float32)
+    pw = ops.PackedWeights(w, False, dev())
+    s, t = torch.ones(728, device=dev()), torch.zeros(728, device=dev())
+    xa = ops.Act(x)
+    a = ops.conv1x1_split32(ops.to_split32(xa), pw, s, t, ops.Act.empty(32, 32, 32, 728, dev()))
+    b = ops.conv1x1(xa, pw, s, t, ops.Act.empty(32, 32, 32, 728, dev()))
+    torch.cuda.synchronize()
+    assert torch.equal(a.buf, b.buf)
+
+
+def test_split32_argument_checks():
+    from emdenoise import _lib, ops
+
+    lib = _lib.load()
+    x = ops.Act.empty(1, 4, 4, 64, dev())
+    sp = ops.SplitAct(1, 4, 4, 64, dev())
+    # ldy not a multiple of 32
+    assert lib.emd_to_split32_f32(x.ptr, x.ld, sp.ptr, 68, 16, 64, None) != 0
+    assert b"multiple of 32" in lib.emd_last_error()
+    assert lib.emd_conv1x1_split32_supported(32768, 728, 728) == 1
+    assert lib.emd_conv1x1_split32_supported(32768, 64, 728) == 0
+    assert lib.emd_conv1x1_split32_supported(1024, 728, 728) == 0
