@@ -20,6 +20,8 @@
 // DMA's SOURCE address (the DMA writes LDS linearly: wave base + lane*16) and on the ds_read_b128 fragment address,
 // which makes every 16-lane group of a fragment read cover all 64 banks once.  Against the 128x128 register-staged
 // kernel this moves 25 % fewer L2 bytes per flop and removes ~250 VALU + ~24 ds_write per wave and K step.
+#include <cstdlib>
+
 #include "mfma_common.hpp"
 
 namespace {
@@ -41,23 +43,30 @@ struct SplitGemmParams {
     int N, Cin, Ktot;
     int ldc, ldres, act;
     int n_mtiles, n_ntiles;
+    unsigned wlo_delta;       // persistent kernel: byte distance Wlo - Whi (one allocation)
+    long long* stamps;        // dev builds only: 5 s_memtime stamps per workgroup (NULL otherwise)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int SBM = 256, SBN = 128, SBK = 32;
-constexpr int A_STAGE = SBM * 128, W_STAGE = SBN * 128, STAGE = A_STAGE + W_STAGE;   // 48 KB
-constexpr int EPI_LD = SBN + 4;                                                       // fp32 staging row (floats)
-constexpr int EPI_BYTES = SBM * EPI_LD * 4;                                           // 132 KB
-constexpr int SMEM_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+constexpr int SBN = 128, SBK = 32;
 
-__global__ __launch_bounds__(512, 2) void gemm_split_kernel(const SplitGemmParams p) {
+// BM = 256: 8 waves, one workgroup per CU; BM = 128: 4 waves, two workgroups per CU.  NS = LDS stages (DMA runs NS-1 K steps ahead).
+template <int BM, int NS, bool PIPE = false>
+__global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmParams p) {
+    constexpr int NW = BM / 32;                                                       // waves
+    constexpr int NT = NW * 64;
+    constexpr int A_STAGE = BM * 128, W_STAGE = SBN * 128, STAGE = A_STAGE + W_STAGE;
+    constexpr int EPI_LD = SBN + 4;                                                   // fp32 staging row (floats)
+    constexpr int EPI_BYTES = BM * EPI_LD * 4;
+    constexpr int SMEM_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
+    constexpr int WQ = SBN / NW / 8;                                                  // W pieces (8 rows) per wave
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = tid >> 6;           // 0..7
+    const int wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
 
     // XCD-aware tile mapping (bijective for any grid size): the N-tiles of one M-tile are neighbours in one XCD
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const SplitGemmParam
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int mt = bid / p.n_ntiles, nt = bid % p.n_ntiles;
-    const long m0 = (long)mt * SBM;
+    const long m0 = (long)mt * BM;
     const int n0 = nt * SBN;
 
     // ---- LDS-DMA source addresses.  One wave instruction = 64 lanes x 16 B = 8 rows x 128 B, written linearly.
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const SplitGemmParam
     // A: wave wv fills rows [32 wv, 32 wv + 32) in 4 pieces; W: rows [16 wv, 16 wv + 16) in 2 pieces.
     const int drow = lane >> 3, dchunk = lane & 7;
     const unsigned char* asrc[4];
-    const unsigned char* wsrc[2];
+    const unsigned char* wsrc[WQ];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = wv * 32 + q * 8 + drow;
@@ -86,8 +95,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const SplitGemmParam
         asrc[q] = p.A + m * p.lda_bytes + c * 16;
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = wv * 16 + q * 8 + drow;
+    for (int q = 0; q < WQ; ++q) {
+        const int row = wv * (WQ * 8) + q * 8 + drow;
         const int c = dchunk ^ ((row >> 1) & 7);
         const uint16_t* plane = (c & 4) ? p.Wlo : p.Whi;  // logical chunks 0-3: hi, 4-7: lo
         wsrc[q] = reinterpret_cast<const unsigned char*>(plane + (long)(n0 + row) * p.Ktot + (c & 3) * 8);
@@ -99,9 +108,9 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const SplitGemmParam
         for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (long)kt * 128), (lptr_t)(sb + (wv * 32 + q * 8) * 128), 16, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < WQ; ++q)
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[q] + (long)kt * 64),
-                                             (lptr_t)(sb + A_STAGE + (wv * 16 + q * 8) * 128), 16, 0, 0);
+                                             (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
     };
 
     f32x16 acc[2][2];
@@ -120,41 +129,115 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const SplitGemmParam
     const int w_off = A_STAGE + (wn * 64 + fr) * 128;    // + j*32*128
 
     const int nk = (p.Cin + SBK - 1) / SBK;
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed (every wave waits for its own DMA pieces, then the barrier), and every wave has
-        // finished reading the other stage (its MFMAs of step kt-1 consumed those reads)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
-        const unsigned char* sb = smem + (kt & 1) * STAGE;
-        const int kvalid = p.Cin - kt * SBK;
+    long long t0 = 0, t1 = 0, r0 = 0;
+    if (p.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    struct Frags { bf16x8 ah[2], al[2], bh[2], bl[2]; };
+    auto load_frags = [&](Frags& f, const unsigned char* sb, int ks) {
+        const int ch = ((ks * 2 + fh) ^ sw) << 4;    // hi plane chunk; lo = same with bit 2 flipped
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks * 16 >= kvalid) break;                // all-padding half step (block-uniform)
-            const int ch = ((ks * 2 + fh) ^ sw) << 4;    // hi plane chunk; lo = same with bit 2 flipped
-            bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + ch);
-                al[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + (ch ^ 64));
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + ch);
-                bl[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + (ch ^ 64));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {           // small terms first (as gemm_conv.hip)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + ch);
+            f.al[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + (ch ^ 64));
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + ch);
+            f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + (ch ^ 64));
+        }
+    };
+    auto mfma12 = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {           // small terms first (as gemm_conv.hip)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+    if constexpr (PIPE) {
+        // Three stages; the barrier at the top of step kt certifies tile kt+1 (DMA issued one step earlier), so the
+        // fragments of a tile's first half step are read during the previous tile's last MFMAs: no ds_read latency
+        // is exposed at the barrier.  Fragment sets f0 / f1 alternate between the two half steps.
+        static_assert(NS == 3, "the pipelined loop needs three stages");
+        issue(0, 0);
+        issue(1, 1 < nk ? 1 : nk - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
+        Frags f0, f1;
+        load_frags(f0, smem, 0);
+        int s0 = 0, s1 = 1, s2 = 2;   // stage of tile kt / kt+1 / the one being refilled (held tile kt-1)
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            {
+                const int nx = kt + 2;
+                issue(s2, nx < nk ? nx : nk - 1);   // beyond the end: re-read the last tile into a stage nobody computes on
+            }
+            load_frags(f1, smem + s0 * STAGE, 1);
+            mfma12(f0);
+            load_frags(f0, smem + s1 * STAGE, 0);
+            mfma12(f1);
+            // issue order of the step (hipcc otherwise sinks every fragment read next to its first use and waits for it
+            // there).  The DMA pieces write LDS, so the compiler keeps every ds_read of the step behind them: first half step
+            // = 12 MFMAs on f0 with the 6 DMA pieces, then the 8 reads of f1, between them; second half step = 12 MFMAs
+            // on f1 with the 8 reads of the next tile's f0 between them
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // VMEM (LDS-DMA piece)
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            const int t = s0; s0 = s1; s1 = s2; s2 = t;
+        }
+    } else {
+    // prologue: NS-1 tiles in flight.  One DMA "group" = the 4 + WQ pieces a wave issues per tile; a tile that does not
+    // exist is still issued (re-reading the last one into a stage nobody reads) so that the counted waits stay uniform
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s, s < nk ? s : nk - 1);
+    int st_c = 0, st_l = NS - 1;   // stage being computed / stage being loaded
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed: every wave waits until only its NS-2 youngest groups are outstanding, then the barrier;
+        // and every wave has finished reading the stage that is about to be refilled (its MFMAs of step kt-1 consumed them)
+        if (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (4 + WQ)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt == 0 && p.stamps) t1 = __builtin_amdgcn_s_memtime();
+        {
+            const int nx = kt + NS - 1;
+            issue(st_l, nx < nk ? nx : nk - 1);
+        }
+        const unsigned char* sb = smem + st_c * STAGE;
+        const int kvalid = p.Cin - kt * SBK;
+        Frags f;
+        load_frags(f, sb, 0);
+        mfma12(f);
+        if (kvalid > 16) {                               // else: all-padding half step (block-uniform)
+            load_frags(f, sb, 1);
+            mfma12(f);
+        }
+        st_c = st_c + 1 == NS ? 0 : st_c + 1;
+        st_l = st_l + 1 == NS ? 0 : st_l + 1;
     }
-    __syncthreads();  // all fragment reads done before the staging tile overlays the stages
+    }
+    long long t2 = 0, t3 = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMA groups of the last steps
+    __syncthreads();  // all fragment reads (and DMA writes) done before the staging tile overlays the stages
+    if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue (as gemm_conv.hip): accumulators -> fp32 LDS tile -> per-channel affine(s), activation, residual,
     // 16-byte loads and stores along the channel axis.  C/D layout of mfma_32x32: col = lane&31,
@@ -170,8 +253,9 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const SplitGemmParam
                 stage[r][wn * 64 + j * 32 + fr] = acc[i][j][e];
             }
     __syncthreads();
+    if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
     constexpr int C4 = SBN / 4;             // 32 float4 chunks per staged row
-    constexpr int ROWS_PER_PASS = 512 / C4; // 16
+    constexpr int ROWS_PER_PASS = NT / C4;
     const int ec = (tid % C4) * 4, er = tid / C4;
     const int n = n0 + ec;
     if (n < p.N) {                          // N % 4 == 0: a chunk is all inside or all outside
@@ -186,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const SplitGemmParam
         float* __restrict__ outp = p.C;
         const float hi = p.act == 2 ? __builtin_inff() : 6.f;
 #pragma unroll 4
-        for (int r = er; r < SBM; r += ROWS_PER_PASS) {
+        for (int r = er; r < BM; r += ROWS_PER_PASS) {
             const long pix = m0 + r;
             if (pix >= p.M) break;
             float4 v = *reinterpret_cast<const float4*>(&stage[r][ec]);
@@ -207,6 +291,302 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const SplitGemmParam
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             *reinterpret_cast<float4*>(outp + pix * p.ldc + n) = v;
         }
+    }
+    if (p.stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* o = p.stamps + (long)blockIdx.x * 8;
+        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = __builtin_amdgcn_s_memtime();
+        o[5] = ((long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) << 32) |   // HW_REG_XCC_ID
+               (unsigned)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);              // HW_REG_HW_ID
+        o[6] = r0; o[7] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// Persistent form of the same GEMM: one workgroup per CU walks over its tiles (vb = blockIdx.x, + gridDim.x, ...) and the
+// three-stage DMA / fragment pipeline simply runs on across tile boundaries: during a tile's last two K steps the first
+// two K steps of the NEXT tile are already being fetched, so only the first tile of a workgroup pays a prologue.  The
+// epilogue never goes through LDS and is not a phase of its own: when a tile's K loop ends, its accumulators get the
+// per-channel affine(s) + activation in registers (o[64]) and are stored -- straight from the MFMA C/D layout, 32 lanes x 4 B
+// = one 128-byte run of one pixel per half wave -- in 8 blocks of 8 dwords per lane during the next tile's K loop: block s
+// leaves at the first K step of the s-th eighth of the loop, the residual values of block s+1 are requested there.  The
+// non-persistent kernel spends 8 % of a workgroup's life in the prologue and 16 % in an exposed epilogue (all CUs reach it at
+// once, in lockstep rounds: 7.7 TB/s of store demand), a third more with a residual; here only the last tile's is exposed.
+// Needs Cin >= 256 (8 K steps), M % 256 == 0, and the lo weight plane within 2 GB behind the hi plane.
+__global__ __launch_bounds__(512, 2) void gemm_split_persist_kernel(const SplitGemmParams p) {
+    constexpr int BM = 256, NS = 3, WQ = 2;
+    constexpr int A_STAGE = BM * 128, W_STAGE = SBN * 128, STAGE = A_STAGE + W_STAGE;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int drow = lane >> 3, dchunk = lane & 7;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int sw = (fr >> 1) & 7;
+    const int a_off = (wm * 64 + fr) * 128;
+    const int w_off = A_STAGE + (wn * 64 + fr) * 128;
+    const int nblk = p.n_mtiles * p.n_ntiles;
+    const int nk = (p.Cin + SBK - 1) / SBK;
+
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, r0 = 0;
+    if (p.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    f32x16 acc[2][2];
+    float o[64];      // the previous tile's finished values, block s = o[8s .. 8s+8)
+    float rres[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) rres[c] = 0.f;
+    long pm0 = 0;
+    int pn0 = 0;
+
+    // block s = (i, j, h) = (s>>2, (s>>1)&1, s&1) of the finished tile: accumulator elements e = 8h .. 8h+7 of MFMA tile
+    // (i, j): rows (e&3) + 8*(e>>2) + 4*(lane>>5) of the 32x32 tile, column lane & 31.  Address = uniform base (scalar
+    // unit) + one per-lane 32-bit offset.
+    const unsigned lrow = wm * 64 + 4 * fh, lcol = wn * 64 + fr;
+    const unsigned loff_c = lrow * (unsigned)p.ldc + lcol, loff_r = lrow * (unsigned)p.ldres + lcol;
+    auto load_res = [&](int sblk) {
+        if (!p.res) return;
+        const int rb = (sblk >> 2) * 32 + (sblk & 1) * 16, cb = ((sblk >> 1) & 1) * 32;
+        const bool nv = (int)(pn0 + cb + lcol) < p.N;
+        const float* ub = p.res + (pm0 + rb) * p.ldres + pn0 + cb;
+        if (nv) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rres[c] = (ub + ((c & 3) + 8 * (c >> 2)) * p.ldres)[loff_r];
+        }
+    };
+    // all eight sums first (one wait for the residual values), then eight stores back to back
+#define EMD_STORE8(S)                                                                                   \
+    {                                                                                                   \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) rres[c] += o[8 * (S) + c];                        \
+        if (nv) {                                                                                       \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c)(ub + ((c & 3) + 8 * (c >> 2)) * p.ldc)[loff_c] = rres[c]; \
+        }                                                                                               \
+    }
+    auto store8 = [&](int sblk) {
+        const int rb = (sblk >> 2) * 32 + (sblk & 1) * 16, cb = ((sblk >> 1) & 1) * 32;
+        const bool nv = (int)(pn0 + cb + lcol) < p.N;
+        float* ub = p.C + (pm0 + rb) * p.ldc + pn0 + cb;
+        switch (sblk) {   // uniform; static register indices inside each case
+            case 0: EMD_STORE8(0) break;
+            case 1: EMD_STORE8(1) break;
+            case 2: EMD_STORE8(2) break;
+            case 3: EMD_STORE8(3) break;
+            case 4: EMD_STORE8(4) break;
+            case 5: EMD_STORE8(5) break;
+            case 6: EMD_STORE8(6) break;
+            default: EMD_STORE8(7) break;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) rres[c] = 0.f;
+    };
+#undef EMD_STORE8
+
+    struct Frags { bf16x8 ah[2], al[2], bh[2], bl[2]; };
+    auto load_frags = [&](Frags& f, const unsigned char* sb, int ks) {
+        const int ch = ((ks * 2 + fh) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + ch);
+            f.al[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + (ch ^ 64));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + ch);
+            f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + (ch ^ 64));
+        }
+    };
+    auto mfma12 = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    // lane l of a DMA piece fills physical chunk (l & 7) of row (l >> 3) with logical chunk (l & 7) ^ ((row >> 1) & 7);
+    // rows of pieces q and q+2 (A) differ by 16 (same swizzle), those of q and q+1 by 8 (chunk ^ 4).  DMA sources =
+    // uniform tile base (scalar registers) + per-lane 32-bit offset that does not depend on the tile.
+    unsigned aoff[2], woff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = wv * 32 + q * 8 + drow;
+        const int c = dchunk ^ ((row >> 1) & 7);
+        aoff[q] = (unsigned)row * (unsigned)p.lda_bytes + c * 16;
+        const int wrow = wv * 16 + q * 8 + drow;
+        const int wc = dchunk ^ ((wrow >> 1) & 7);
+        woff[q] = (unsigned)wrow * (unsigned)p.Ktot * 2u + (wc & 3) * 16 + ((wc & 4) ? p.wlo_delta : 0u);
+    }
+    auto issue = [&](int stage, const unsigned char* abase, const unsigned char* wbase, int kt) {
+        unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(abase + (long)kt * 128 + (long)(q >> 1) * 16 * p.lda_bytes + aoff[q & 1]),
+                                             (lptr_t)(sb + (wv * 32 + q * 8) * 128), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (long)kt * 64 + woff[q]),
+                                             (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
+    };
+    auto tile_origin = [&](int vb, long& m0, int& n0) {   // XCD-aware tile mapping (bijective for any grid size)
+        const int q = nblk >> 3, r = nblk & 7, xcd = vb & 7, loc = vb >> 3;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        m0 = (long)(bid / p.n_ntiles) * BM;
+        n0 = (bid % p.n_ntiles) * SBN;
+    };
+
+    int vb = blockIdx.x;           // the launcher guarantees gridDim.x <= nblk
+    long m0;
+    int n0;
+    tile_origin(vb, m0, n0);
+    const unsigned char* abase = p.A + m0 * p.lda_bytes;
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.Whi + (long)n0 * p.Ktot);
+    issue(0, abase, wbase, 0);
+    issue(1, abase, wbase, 1);     // nk >= 8
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
+    Frags f0, f1;
+    load_frags(f0, smem, 0);
+    int s0 = 0, s1 = 1, s2 = 2;    // stage of K step kt / kt+1 / the one being refilled
+    bool have_prev = false, first_step = true;
+    // the DMA of the coming step, prepared one step ahead so that the scalar arithmetic sits between MFMAs, not between
+    // the barrier and the first instruction that matters
+    const unsigned char* dma_a = abase + 2 * 128;
+    const unsigned char* dma_w = wbase + 2 * 64;
+    int pend = 0;                  // vector-memory operations issued after the last DMA group (stores, residual loads)
+
+    while (true) {
+        // the tile after this one (its first two K steps are fetched during this tile's last two)
+        const int vbn = vb + (int)gridDim.x;
+        const bool has_next = vbn < nblk;
+        long m0n = m0;
+        int n0n = n0;
+        if (has_next) tile_origin(vbn, m0n, n0n);
+        const unsigned char* abase_n = p.A + m0n * p.lda_bytes;
+        const unsigned char* wbase_n = reinterpret_cast<const unsigned char*>(p.Whi + (long)n0n * p.Ktot);
+
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        int sblk = 0;
+        int seg_k = __builtin_amdgcn_readfirstlane(have_prev ? 0 : -1);   // K step at whose end block sblk of the previous tile leaves
+
+        for (int kt = 0; kt < nk; ++kt) {
+            if (!first_step) {
+                // K step kt+1 has landed for every wave (the stores / residual loads issued behind its DMA may stay in
+                // flight), and every wave is done reading the stage about to be refilled
+                if (pend == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (pend == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            first_step = false;
+            issue(s2, dma_a, dma_w, 0);
+            load_frags(f1, smem + s0 * STAGE, 1);
+            mfma12(f0);
+            load_frags(f0, smem + s1 * STAGE, 0);
+            mfma12(f1);
+            {
+                const int nx = kt + 3;         // the step after this one fetches K step kt+3: beyond this tile's end that is the
+                const bool cur = nx < nk;      // next tile's first K steps (for the last tile: its own again, into a stage nobody computes on)
+                dma_a = (cur ? abase : abase_n) + (long)(cur ? nx : nx - nk) * 128;
+                dma_w = (cur ? wbase : wbase_n) + (long)(cur ? nx : nx - nk) * 64;
+            }
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            const int t = s0; s0 = s1; s1 = s2; s2 = t;
+            __builtin_amdgcn_sched_barrier(0);
+            pend = 0;
+            if (kt == seg_k) {   // uniform: block sblk of the previous tile leaves behind this step's DMA
+                store8(sblk);
+                ++sblk;
+                seg_k = sblk < 8 ? (sblk * nk) >> 3 : -1;
+                pend = 8;
+                if (sblk < 8 && p.res) {
+                    load_res(sblk);
+                    pend = 16;
+                }
+            }
+        }
+        if (p.stamps && !have_prev) t3 = __builtin_amdgcn_s_memtime();
+
+        // the finished tile: affine(s) + activation in registers.  One clamp form for every activation code:
+        // v = min(max(v, slope*v), hi) -- none: slope 1, hi inf; relu6: 0, 6; relu: 0, inf; leaky relu: 0.2, inf
+        {
+            const float hi = p.act == 1 ? 6.f : __builtin_inff();
+            const float slope = p.act == 0 ? 1.f : (p.act == 4 ? 0.2f : 0.f);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + fr;
+                const bool nv = n < p.N;
+                const float s1v = nv ? p.scale1[n] : 0.f, t1v = nv ? p.shift1[n] : 0.f;
+                if (p.scale2) {
+                    const float s2v = nv ? p.scale2[n] : 1.f, t2v = nv ? p.shift2[n] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            float v = fmaf(acc[i][j][e], s1v, t1v);
+                            v = fminf(fmaxf(v, slope * v), hi);
+                            o[i * 32 + j * 16 + e] = fminf(fmaxf(fmaf(v, s2v, t2v), 0.f), hi);
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float v = fmaf(acc[i][j][e], s1v, t1v);
+                            o[i * 32 + j * 16 + e] = fminf(fmaxf(v, slope * v), hi);
+                        }
+                }
+            }
+        }
+        pm0 = m0;
+        pn0 = n0;
+        have_prev = true;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scale / shift loads above were waited for: nothing is in flight
+        pend = 0;
+        if (p.res) {
+            load_res(0);
+            pend = 8;
+        }
+        if (!has_next) break;
+        vb = vbn; m0 = m0n; n0 = n0n; abase = abase_n; wbase = wbase_n;
+    }
+    if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
+    for (int sblk = 0; sblk < 8; ++sblk) {
+        if (sblk > 0) load_res(sblk);
+        store8(sblk);
+    }
+    if (p.stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* o8 = p.stamps + (long)blockIdx.x * 8;
+        o8[0] = t0; o8[1] = t1; o8[2] = t2; o8[3] = t3; o8[4] = __builtin_amdgcn_s_memtime();
+        o8[5] = ((long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) << 32) |
+                (unsigned)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);
+        o8[6] = r0; o8[7] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -230,6 +610,9 @@ __global__ __launch_bounds__(256) void to_split32_kernel(const float* __restrict
 
 }  // namespace
 
+static int g_variant_override = -1;
+static long long* g_stamps = nullptr;
+
 extern "C" int emd_split32_ld(int C) { return C < 1 ? 0 : (C + 31) / 32 * 32; }
 
 extern "C" int emd_to_split32_f32(const float* x, int ldx, void* y, int ldy, long npix, int C, emd_stream_t stream) {
@@ -251,7 +634,7 @@ extern "C" int emd_to_split32_f32(const float* x, int ldx, void* y, int ldy, lon
 extern "C" int emd_conv1x1_split32_supported(long M, int Cin, int Cout) {
     // worth it where the GEMM is matrix-core bound and the grid fills the chip with 256 x 128 tiles
     if (Cin < 128 || Cout < 128 || Cout % 4) return 0;
-    const long tiles = ((M + SBM - 1) / SBM) * ((Cout + SBN - 1) / SBN);
+    const long tiles = ((M + 255) / 256) * ((Cout + SBN - 1) / SBN);
     return tiles >= 256 ? 1 : 0;
 }
 
@@ -276,10 +659,33 @@ extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* 
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.M = M; p.lda_bytes = (long)ldx * 4; p.N = Cout; p.Cin = Cin; p.Ktot = (Cin + kBK - 1) / kBK * kBK;
     p.ldc = ldy; p.ldres = ldres; p.act = act;
-    p.n_mtiles = (int)((M + SBM - 1) / SBM);
+    // dev knobs (A/B builds only): EMD_SPLIT_VARIANT = 0 (256-row tiles, 2 stages), 1 (256, 3), 2 (128, 2)
+    static const int variant = [] { const char* e = getenv("EMD_SPLIT_VARIANT"); return e ? atoi(e) : 0; }();
+    int v = variant;
+    if (g_variant_override >= 0) v = g_variant_override;
+    p.stamps = g_stamps;
+    const int bm = v == 2 ? 128 : 256;
+    p.n_mtiles = (int)((M + bm - 1) / bm);
     p.n_ntiles = (Cout + SBN - 1) / SBN;
     const long nblk = (long)p.n_mtiles * p.n_ntiles;
     if (nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "emd_conv1x1_split32_f32: grid too large");
-    hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)nblk), dim3(512), 0, static_cast<hipStream_t>(stream), p);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (v == 1) hipLaunchKernelGGL((gemm_split_kernel<256, 3>), dim3((unsigned)nblk), dim3(512), 0, st, p);
+    else if (v == 3) hipLaunchKernelGGL((gemm_split_kernel<256, 3, true>), dim3((unsigned)nblk), dim3(512), 0, st, p);
+    else if (v == 4 && Cin >= 256 && M % 256 == 0 && wlo > whi &&
+             (reinterpret_cast<uintptr_t>(wlo) - reinterpret_cast<uintptr_t>(whi)) < 0x7fffffffu && (long)256 * p.lda_bytes < 0x7fffffffL) {
+        p.wlo_delta = (unsigned)(reinterpret_cast<uintptr_t>(wlo) - reinterpret_cast<uintptr_t>(whi));
+        int ncu = 256;
+        static const int cus = [] { int d = 0, n = 0; if (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) return n; return 256; }();
+        ncu = cus;
+        const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
+        hipLaunchKernelGGL(gemm_split_persist_kernel, dim3(grid), dim3(512), 0, st, p);
+    }
+    else if (v == 2) hipLaunchKernelGGL((gemm_split_kernel<128, 2>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_split_kernel<256, 2>), dim3((unsigned)nblk), dim3(512), 0, st, p);
     return emd::check_launch("gemm_split_kernel");
 }
+
+// dev hooks (not in the header): kernel variant and stamp buffer for tools/gemm_split_bench.py
+extern "C" void emd_debug_split_variant(int v) { g_variant_override = v; }
+extern "C" void emd_debug_split_stamps(void* buf) { g_stamps = static_cast<long long*>(buf); }

@@ -74,9 +74,15 @@ class PackedWeights:
         _lib.check(lib.emd_pack_weights_bf16(w.ctypes.data, taps, cin, cout, 1 if cout_major else 0,
                                              hi.ctypes.data, lo.ctypes.data), "emd_pack_weights_bf16")
         self.taps, self.cin, self.cout = taps, cin, cout
-        # uint16 planes travel as int16 torch tensors (same bits)
-        self.hi = torch.from_numpy(hi.view(np.int16)).to(device)
-        self.lo = torch.from_numpy(lo.view(np.int16)).to(device)
+        # uint16 planes travel as int16 torch tensors (same bits); one allocation, lo right behind hi (128-byte aligned):
+        # the persistent split32 GEMM addresses both planes from one base
+        npad = -(-n // 64) * 64
+        both = torch.empty(2 * npad, dtype=torch.int16, device=device)
+        both[:n].copy_(torch.from_numpy(hi.view(np.int16)))
+        both[npad:npad + n].copy_(torch.from_numpy(lo.view(np.int16)))
+        self._planes = both
+        self.hi = both[:n]
+        self.lo = both[npad:npad + n]
 
 
 def conv1x1(x: Act, w: PackedWeights, scale1, shift1, out: Act, stride=1, act=True, scale2=None, shift2=None,
