@@ -55,6 +55,9 @@ SIGNATURES = {
     # x ldx w y ldy B H W C stride rate stream
     "emd_dw3x3_split32_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # x ldx w y ldy B H W C stride stream
+    "emd_dw3x3_reflect_split32_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, C.c_int, C.c_void_p]),
     "emd_conv1x1_split32_supported": (C.c_int, [C.c_long, C.c_int, C.c_int]),
     # xs ldx whi wlo scale1 shift1 scale2 shift2 res ldres y ldy M Cin Cout act stream
     "emd_conv1x1_split32_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p,

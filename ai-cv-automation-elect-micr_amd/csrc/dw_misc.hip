@@ -12,24 +12,6 @@
 
 namespace {
 
-// Output stage of the depthwise kernels.  SPLIT = false: 4 fp32 channels at y + pix*ldy + 4*c4.  SPLIT = true: the
-// split32 layout consumed by emd_conv1x1_split32_f32 (gemm_split.hip): the value is split into bf16 hi + lo here, once,
-// instead of in every N-tile of the GEMM; pixel pitch ldy 4-byte units, channel group g = c/32 at byte 128 g:
-// 32 x hi | 32 x lo.  Threads with c4 >= C4 (the padding up to a multiple of 32 channels) store zeros.
-template <bool SPLIT>
-__device__ __forceinline__ void dw_store(float* __restrict__ y, long pix, int ldy, int c4, float4 v) {
-    if (!SPLIT) {
-        *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = v;
-    } else {
-        unsigned h0, l0, h1, l1;
-        emd::split2(v.x, v.y, h0, l0);
-        emd::split2(v.z, v.w, h1, l1);
-        unsigned char* o = reinterpret_cast<unsigned char*>(y) + pix * (long)ldy * 4 + (c4 >> 3) * 128 + (c4 & 7) * 8;
-        *reinterpret_cast<emd::u32x2*>(o) = emd::u32x2{h0, h1};
-        *reinterpret_cast<emd::u32x2*>(o + 64) = emd::u32x2{l0, l1};
-    }
-}
-
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
@@ -91,7 +73,7 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
         }
         if (tt >= 2) {
             const int oy = oy0 + tt - 2;
-            if (oy < H) dw_store<SPLIT>(y, (b * H + oy) * (long)W + ox, ldy, c4o, padq ? f4zero() : add4(s0, h2));
+            if (oy < H) emd::dw_store<SPLIT>(y, (b * H + oy) * (long)W + ox, ldy, c4o, padq ? f4zero() : add4(s0, h2));
         }
         s0 = add4(s1, h1);
         s1 = h0;
@@ -130,7 +112,7 @@ __global__ __launch_bounds__(256) void dw3x3_generic(const float* __restrict__ x
             acc = fma4(wk, v, acc);
         }
     }
-    dw_store<SPLIT>(y, (b * Ho + oy) * (long)Wo + ox, ldy, c4o, padq ? f4zero() : acc);
+    emd::dw_store<SPLIT>(y, (b * Ho + oy) * (long)Wo + ox, ldy, c4o, padq ? f4zero() : acc);
 }
 
 // ------------------------------------------------------------------------------------------------

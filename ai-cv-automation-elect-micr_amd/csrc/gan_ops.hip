@@ -3,7 +3,7 @@
 // image (:343-347) and its output is tanh(instance_norm(3x3 conv)) (:362-372); activations are leaky_relu(0.2).
 // The pointwise halves, the SAME-padded separable convs of deconv_block and the resizes are the graph-D kernels.
 // All HBM-bound, fp32.
-#include "emd_common.hpp"
+#include "mfma_common.hpp"
 
 namespace {
 
@@ -20,13 +20,17 @@ __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : 0.2f * v;
 
 // Depthwise 3x3 over the reflect-padded (1 px) input, VALID, stride 1 or 2: output (oy,ox) reads rows
 // oy*s-1 .. oy*s+1 (reflected).  One output pixel x 4 channels per thread.
+template <bool SPLIT = false>
 __global__ __launch_bounds__(256) void dw3x3_reflect_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                             float* __restrict__ y, int ldy, int H, int W, int C4, int Ho,
-                                                            int Wo, int stride, long nthreads) {
+                                                            int Wo, int stride, long nthreads, int C4t) {
+    // C4t = channel quads per pixel that have a thread: C4, or ceil32(C)/4 when the split32 padding is written too
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;
-    const int c4 = (int)(tid % C4);
-    long t = tid / C4;
+    const int c4o = (int)(tid % C4t);
+    const bool padq = SPLIT && c4o >= C4;
+    const int c4 = padq ? C4 - 1 : c4o;
+    long t = tid / C4t;
     const int ox = (int)(t % Wo);
     t /= Wo;
     const int oy = (int)(t % Ho);
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(256) void dw3x3_reflect_kernel(const float* __restr
                        *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx), acc);
         }
     }
-    *reinterpret_cast<float4*>(y + ((b * Ho + oy) * (long)Wo + ox) * ldy + c4 * 4) = acc;
+    emd::dw_store<SPLIT>(y, (b * Ho + oy) * (long)Wo + ox, ldy, c4o, padq ? f4zero() : acc);
 }
 
 // First layer: d = (7x7 depthwise of the reflect-padded 1-channel image), y[pix][n] = leaky(d*a[n] + shift[n]).
@@ -157,22 +161,40 @@ int blocks_for(long nthreads, unsigned* nb) {
 
 }  // namespace
 
-extern "C" int emd_dw3x3_reflect_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
-                                     int stride, emd_stream_t stream) {
+template <bool SPLIT>
+static int dw3x3_reflect_launch(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
+                                int stride, emd_stream_t stream) {
     EMD_REQUIRE(x && w && y, EMD_E_INVALID, "emd_dw3x3_reflect_f32: null pointer");
     EMD_REQUIRE(B >= 0 && H >= 2 && W >= 2 && C >= 4 && (stride == 1 || stride == 2), EMD_E_INVALID,
                 "emd_dw3x3_reflect_f32: bad shape (reflect padding needs H, W >= 2)");
-    EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && emd::aligned16(x) &&
-                    emd::aligned16(y) && emd::aligned16(w), EMD_E_ALIGN, "emd_dw3x3_reflect_f32: alignment");
+    const int Cp = (C + 31) / 32 * 32;
+    if (SPLIT)
+        EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldx >= C && ldy % 32 == 0 && ldy >= Cp && emd::aligned16(x) &&
+                        (reinterpret_cast<uintptr_t>(y) & 127u) == 0 && emd::aligned16(w),
+                    EMD_E_ALIGN, "emd_dw3x3_reflect_split32_f32: C, ldx multiples of 4; ldy a multiple of 32, >= ceil32(C); y 128-byte aligned");
+    else
+        EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && emd::aligned16(x) &&
+                        emd::aligned16(y) && emd::aligned16(w), EMD_E_ALIGN, "emd_dw3x3_reflect_f32: alignment");
     if (B == 0) return EMD_OK;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;  // VALID on the (H+2) x (W+2) padded input
-    const long nthreads = (long)B * Ho * Wo * (C / 4);
+    const int C4t = SPLIT ? Cp / 4 : C / 4;
+    const long nthreads = (long)B * Ho * Wo * C4t;
     unsigned nb;
     int rc = blocks_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
-    hipLaunchKernelGGL(dw3x3_reflect_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w, y, ldy, H,
-                       W, C / 4, Ho, Wo, stride, nthreads);
+    hipLaunchKernelGGL((dw3x3_reflect_kernel<SPLIT>), dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w, y, ldy,
+                       H, W, C / 4, Ho, Wo, stride, nthreads, C4t);
     return emd::check_launch("dw3x3_reflect_kernel");
+}
+
+extern "C" int emd_dw3x3_reflect_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
+                                     int stride, emd_stream_t stream) {
+    return dw3x3_reflect_launch<false>(x, ldx, w, y, ldy, B, H, W, C, stride, stream);
+}
+
+extern "C" int emd_dw3x3_reflect_split32_f32(const float* x, int ldx, const float* w, void* y, int ldy, int B, int H, int W,
+                                             int C, int stride, emd_stream_t stream) {
+    return dw3x3_reflect_launch<true>(x, ldx, w, static_cast<float*>(y), ldy, B, H, W, C, stride, stream);
 }
 
 extern "C" int emd_cin1_k7_reflect_f32(const float* x, const float* w49, const float* a, const float* shift, float* y,

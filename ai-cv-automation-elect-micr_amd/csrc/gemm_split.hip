@@ -632,10 +632,13 @@ extern "C" int emd_to_split32_f32(const float* x, int ldx, void* y, int ldy, lon
 }
 
 extern "C" int emd_conv1x1_split32_supported(long M, int Cin, int Cout) {
-    // worth it where the GEMM is matrix-core bound and the grid fills the chip with 256 x 128 tiles
-    if (Cin < 128 || Cout < 128 || Cout % 4) return 0;
+    // Where the pair (depthwise with split32 output, this GEMM) beats (depthwise, emd_conv1x1_f32) on MI355X
+    // (tools/gemm_split_bench.py): matrix-core bound shapes whose grid fills the chip with 256 x 128 tiles.  On the
+    // HBM-bound layers (K <= 256 at 128^2 and up) the 8-byte stores of the split depthwise output cost more than the GEMM gains.
+    if (Cout < 128 || Cout % 4 || Cin % 4) return 0;
+    if (!(Cin >= 512 || (Cin >= 384 && Cout >= 256))) return 0;
     const long tiles = ((M + 255) / 256) * ((Cout + SBN - 1) / SBN);
-    return tiles >= 256 ? 1 : 0;
+    return tiles >= 192 ? 1 : 0;
 }
 
 extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo,
@@ -659,8 +662,10 @@ extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* 
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.M = M; p.lda_bytes = (long)ldx * 4; p.N = Cout; p.Cin = Cin; p.Ktot = (Cin + kBK - 1) / kBK * kBK;
     p.ldc = ldy; p.ldres = ldres; p.act = act;
-    // dev knobs (A/B builds only): EMD_SPLIT_VARIANT = 0 (256-row tiles, 2 stages), 1 (256, 3), 2 (128, 2)
-    static const int variant = [] { const char* e = getenv("EMD_SPLIT_VARIANT"); return e ? atoi(e) : 0; }();
+    // kernel variant: 3 = 256-row tiles, 3 stages, pipelined K loop (the default: fastest on every shape measured);
+    // dev knobs for A/B runs: EMD_SPLIT_VARIANT / emd_debug_split_variant = 0 (256 rows, 2 stages), 1 (256, 3, plain loop),
+    // 2 (128 rows, 2 stages, two workgroups per CU), 4 (persistent, epilogue stores inside the next tile's K loop)
+    static const int variant = [] { const char* e = getenv("EMD_SPLIT_VARIANT"); return e ? atoi(e) : 3; }();
     int v = variant;
     if (g_variant_override >= 0) v = g_variant_override;
     p.stamps = g_stamps;
@@ -671,7 +676,7 @@ extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* 
     if (nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "emd_conv1x1_split32_f32: grid too large");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (v == 1) hipLaunchKernelGGL((gemm_split_kernel<256, 3>), dim3((unsigned)nblk), dim3(512), 0, st, p);
-    else if (v == 3) hipLaunchKernelGGL((gemm_split_kernel<256, 3, true>), dim3((unsigned)nblk), dim3(512), 0, st, p);
+    else if (v == 0) hipLaunchKernelGGL((gemm_split_kernel<256, 2>), dim3((unsigned)nblk), dim3(512), 0, st, p);
     else if (v == 4 && Cin >= 256 && M % 256 == 0 && wlo > whi &&
              (reinterpret_cast<uintptr_t>(wlo) - reinterpret_cast<uintptr_t>(whi)) < 0x7fffffffu && (long)256 * p.lda_bytes < 0x7fffffffL) {
         p.wlo_delta = (unsigned)(reinterpret_cast<uintptr_t>(wlo) - reinterpret_cast<uintptr_t>(whi));
@@ -682,7 +687,7 @@ extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* 
         hipLaunchKernelGGL(gemm_split_persist_kernel, dim3(grid), dim3(512), 0, st, p);
     }
     else if (v == 2) hipLaunchKernelGGL((gemm_split_kernel<128, 2>), dim3((unsigned)nblk), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_split_kernel<256, 2>), dim3((unsigned)nblk), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gemm_split_kernel<256, 3, true>), dim3((unsigned)nblk), dim3(512), 0, st, p);
     return emd::check_launch("gemm_split_kernel");
 }
 

@@ -26,4 +26,22 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigne
     lo = __builtin_bit_cast(unsigned, l);
 }
 
+// Output stage of the depthwise kernels.  SPLIT = false: 4 fp32 channels at y + pix*ldy + 4*c4.  SPLIT = true: the
+// split32 layout consumed by emd_conv1x1_split32_f32 (gemm_split.hip): the value is split into bf16 hi + lo here, once,
+// instead of in every N-tile of the GEMM; pixel pitch ldy 4-byte units, channel group g = c/32 at byte 128 g:
+// 32 x hi | 32 x lo.  Threads with c4 >= C4 (the padding up to a multiple of 32 channels) store zeros.
+template <bool SPLIT>
+__device__ __forceinline__ void dw_store(float* __restrict__ y, long pix, int ldy, int c4, float4 v) {
+    if (!SPLIT) {
+        *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = v;
+    } else {
+        unsigned h0, l0, h1, l1;
+        split2(v.x, v.y, h0, l0);
+        split2(v.z, v.w, h1, l1);
+        unsigned char* o = reinterpret_cast<unsigned char*>(y) + pix * (long)ldy * 4 + (c4 >> 3) * 128 + (c4 & 7) * 8;
+        *reinterpret_cast<u32x2*>(o) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(o + 64) = u32x2{l0, l1};
+    }
+}
+
 }  // namespace emd

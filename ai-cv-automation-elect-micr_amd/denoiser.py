@@ -325,10 +325,15 @@ class DenoiserEngine:
                 out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
             return ops.sep_fused(x, p["dw"], p["pw"], p["scale"], p["shift"], out, scale2=p.get("scale2"),
                                  shift2=p.get("shift2"), res=res, precision=self.precision)
-        tmp = ops.Act.empty(x.B, Ho, Wo, L.cin, self.device)
-        ops.dw3x3(x, p["dw"], tmp, stride=L.stride, rate=L.rate)
         if out is None:
             out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
+        if self.precision == ops.PREC_BF16X3 and ops.conv1x1_split32_supported(x.B * Ho * Wo, L.cin, L.cout):
+            # matrix-core bound layers (the 728-channel flow): the depthwise kernel writes its result pre-split into
+            # bf16 hi/lo, the pointwise GEMM gets both operands by LDS-DMA (csrc/gemm_split.hip); same arithmetic
+            return ops.sep_split32(x, p["dw"], p["pw"], p["scale"], p["shift"], out, stride=L.stride, rate=L.rate,
+                                   scale2=p.get("scale2"), shift2=p.get("shift2"), res=res)
+        tmp = ops.Act.empty(x.B, Ho, Wo, L.cin, self.device)
+        ops.dw3x3(x, p["dw"], tmp, stride=L.stride, rate=L.rate)
         ops.conv1x1(tmp, p["pw"], p["scale"], p["shift"], out, scale2=p.get("scale2"), shift2=p.get("shift2"),
                     res=res, precision=self.precision)
         return out

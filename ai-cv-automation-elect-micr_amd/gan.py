@@ -191,6 +191,10 @@ class GeneratorEngine:
             out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
             return ops.sep_fused(x, p["dw"], p["pw"], p["scale"], p["shift"], out, act=ops.ACT_LEAKY, res=res,
                                  precision=self.precision, reflect=L.reflect)
+        if self.precision == ops.PREC_BF16X3 and ops.conv1x1_split32_supported(x.B * Ho * Wo, L.cin, L.cout):
+            out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
+            return ops.sep_split32(x, p["dw"], p["pw"], p["scale"], p["shift"], out, stride=L.stride, act=ops.ACT_LEAKY,
+                                   res=res, reflect=L.reflect)
         d = ops.Act.empty(x.B, Ho, Wo, L.cin, self.device)
         if L.reflect:
             ops.dw3x3_reflect(x, p["dw"], d, stride=L.stride)

@@ -225,6 +225,25 @@ def dw3x3_split32(x: Act, w_dev, out: SplitAct, stride=1, rate=1, stream=None):
     return out
 
 
+def dw3x3_reflect_split32(x: Act, w_dev, out: SplitAct, stride=1, stream=None):
+    lib = _lib.load()
+    assert out.C == x.C and out.B == x.B and (out.H, out.W) == ((x.H - 1) // stride + 1, (x.W - 1) // stride + 1)
+    _lib.check(lib.emd_dw3x3_reflect_split32_f32(x.ptr, x.ld, _p(w_dev), out.ptr, out.ld, x.B, x.H, x.W, x.C, stride,
+                                                 _lib.stream_ptr(stream)), "emd_dw3x3_reflect_split32_f32")
+    return out
+
+
+def sep_split32(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, stride=1, rate=1, act=True, scale2=None,
+                shift2=None, res: Act | None = None, reflect=False, stream=None):
+    """Separable conv as depthwise (split32 output) -> LDS-DMA pointwise GEMM; the intermediate exists only in split form."""
+    d = SplitAct(out.B, out.H, out.W, x.C, x.buf.device)
+    if reflect:
+        dw3x3_reflect_split32(x, dw_dev, d, stride=stride, stream=stream)
+    else:
+        dw3x3_split32(x, dw_dev, d, stride=stride, rate=rate, stream=stream)
+    return conv1x1_split32(d, w, scale1, shift1, out, act=act, scale2=scale2, shift2=shift2, res=res, stream=stream)
+
+
 def conv1x1_split32_supported(npix: int, cin: int, cout: int) -> bool:
     return bool(_lib.load().emd_conv1x1_split32_supported(C.c_long(npix), cin, cout))
 

@@ -247,8 +247,12 @@ class XceptionEngine:
             """depthwise -> pointwise (raw) -> batch-statistics BN (beta only) -> relu [+ res] (:302-323)."""
             L, p = next(it)
             Ho, Wo = -(-a.H // L.stride), -(-a.W // L.stride)
-            tmp = ops.dw3x3(a, p["dw"], E(Ho, Wo, L.cin), stride=L.stride)
-            y = ops.conv1x1(tmp, p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout), act=ops.ACT_NONE, precision=prec)
+            if prec == ops.PREC_BF16X3 and ops.conv1x1_split32_supported(a.B * Ho * Wo, L.cin, L.cout):
+                y = ops.sep_split32(a, p["dw"], p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout), stride=L.stride,
+                                    act=ops.ACT_NONE)
+            else:
+                tmp = ops.dw3x3(a, p["dw"], E(Ho, Wo, L.cin), stride=L.stride)
+                y = ops.conv1x1(tmp, p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout), act=ops.ACT_NONE, precision=prec)
             mean, var = ops.bn_batch_stats(y)
             scale, shift = ops.bn_fold(mean, var, None, p["beta"], BN_EPS)
             if trace is not None:   # the oracle traces the SEP output before the residual add

@@ -177,6 +177,8 @@ int emd_split32_ld(int C);
 int emd_to_split32_f32(const float* x, int ldx, void* y, int ldy, long npix, int C, emd_stream_t stream);
 int emd_dw3x3_split32_f32(const float* x, int ldx, const float* w, void* y, int ldy, int B, int H, int W, int C,
                           int stride, int rate, emd_stream_t stream);
+int emd_dw3x3_reflect_split32_f32(const float* x, int ldx, const float* w, void* y, int ldy, int B, int H, int W, int C,
+                                  int stride, emd_stream_t stream); /* emd_dw3x3_reflect_f32 (graph G) with split32 output */
 int emd_conv1x1_split32_supported(long M, int Cin, int Cout);
 int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
                             const float* shift1, const float* scale2, const float* shift2, const float* res,

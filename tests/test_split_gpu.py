@@ -77,6 +77,44 @@ def test_dw3x3_split32_equals_dw3x3_then_split(B, H, W, C, stride, rate):
     assert torch.equal(got.buf.view(torch.int32), want.buf.view(torch.int32))
 
 
+@pytest.mark.parametrize("B,H,W,C,stride", [(1, 32, 32, 768, 1), (2, 17, 13, 40, 2)])
+def test_dw3x3_reflect_split32_equals_reflect_then_split(B, H, W, C, stride):
+    from emdenoise import ops
+
+    x = rnd((B, H, W, C), 31)
+    w = rnd((9, C), 32, 0.3)
+    xa, wd = ops.Act(up(x)), up(w)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    want = ops.to_split32(ops.dw3x3_reflect(xa, wd, ops.Act.empty(B, Ho, Wo, C, dev()), stride=stride))
+    got = ops.SplitAct(B, Ho, Wo, C, dev())
+    got.buf.fill_(float("nan"))
+    ops.dw3x3_reflect_split32(xa, wd, got, stride=stride)
+    torch.cuda.synchronize()
+    assert torch.equal(got.buf.view(torch.int32), want.buf.view(torch.int32))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_conv1x1_split32_kernel_variants_agree(variant):
+    """Every tile / stage / loop variant of the GEMM (dev knob) gives the default kernel's bits; 4 = the persistent form."""
+    from emdenoise import _lib, ops
+
+    lib = _lib.load()
+    x = rnd((4, 32, 32, 512), 41, positive=True)          # M = 4096 = 16 tiles of 256 rows
+    w = rnd((1, 512, 384), 42, scale=0.05)
+    r = rnd((4, 32, 32, 384), 43)
+    pw = ops.PackedWeights(w, False, dev())
+    s1, t1 = up(rnd((384,), 44, 0.3) + 1.0), up(rnd((384,), 45, 0.5))
+    xs = ops.to_split32(ops.Act(up(x)))
+    ref = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(4, 32, 32, 384, dev()), res=ops.Act(up(r)))
+    try:
+        lib.emd_debug_split_variant(variant)
+        got = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(4, 32, 32, 384, dev()), res=ops.Act(up(r)))
+        torch.cuda.synchronize()
+    finally:
+        lib.emd_debug_split_variant(-1)
+    assert torch.equal(got.buf, ref.buf)
+
+
 @pytest.mark.parametrize("B,H,W,ci,co,res,extra", [
     (2, 32, 32, 728, 728, True, False),    # middle flow (M tail: 2048 rows = 8 tiles exactly)
     (1, 24, 20, 728, 728, False, True),    # M = 480: one full tile + a ragged one; ASPP's extra BN
@@ -138,5 +176,7 @@ def test_split32_argument_checks():
     assert lib.emd_to_split32_f32(x.ptr, x.ld, sp.ptr, 68, 16, 64, None) != 0
     assert b"multiple of 32" in lib.emd_last_error()
     assert lib.emd_conv1x1_split32_supported(32768, 728, 728) == 1
+    assert lib.emd_conv1x1_split32_supported(524288, 384, 256) == 1
+    assert lib.emd_conv1x1_split32_supported(524288, 256, 256) == 0
     assert lib.emd_conv1x1_split32_supported(32768, 64, 728) == 0
     assert lib.emd_conv1x1_split32_supported(1024, 728, 728) == 0
