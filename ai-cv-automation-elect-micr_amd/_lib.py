@@ -59,6 +59,14 @@ SIGNATURES = {
     "emd_dw3x3_reflect_split32_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_void_p]),
     "emd_conv1x1_split32_supported": (C.c_int, [C.c_long, C.c_int, C.c_int]),
+    # xs ldx whi wlo scale1 shift1 scale2 shift2 res ldres y ldy B H W Cin Cout stride rate act out_split stream
+    "emd_conv3x3_split32_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p,
+                                          _c_float_p, _c_float_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # xs ldx whi[4] wlo[4] scale1 shift1 y ldy B H W Cin Cout act out_split stream
+    "emd_deconv3x3s2_split32_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, C.c_void_p,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p]),
     # xs ldx whi wlo scale1 shift1 scale2 shift2 res ldres y ldy M Cin Cout act stream
     "emd_conv1x1_split32_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p,
                                           _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_long, C.c_int, C.c_int,

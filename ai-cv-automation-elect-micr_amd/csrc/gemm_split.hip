@@ -302,6 +302,277 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolutions from split32 activations: dense 3x3 (stride 1/2, dilation), the four output phases of the
+// 3x3 stride-2 transposed convolution, strided 1x1 -- the row map and tap list of gemm_conv.hip on the pipelined LDS-DMA
+// structure above.  K runs over (tap, 32-channel step); the DMA source of an A row is the tap's source pixel, or a line of
+// zeros for TF-SAME padding and rows beyond M (an 8 KB zero buffer, so that "+ K step" needs no per-row select).  The
+// row -> destination pixel table lives in LDS behind the staging tile.  Output: fp32 NHWC, or split32 (out_split) when the
+// consumer is another of these GEMMs -- a chain of convolutions then never materialises an fp32 activation.
+struct SplitConvParams {
+    SplitGemmParams g;
+    int ntaps, Cpad, nkc;        // W tap stride (elements), 32-channel steps per tap
+    int flat;                    // 1: source pixel = dest pixel = m
+    int Hg, Wg, Ha, Wa, Hc, Wc, sa, sc, py, px;
+    unsigned long long dyp, dxp; // per-tap source offsets, 7 bits each, biased by 64
+    int out_split;
+};
+
+__device__ __attribute__((aligned(128))) unsigned char g_zero_buf[8192];
+
+__global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConvParams cp) {
+    const SplitGemmParams& p = cp.g;
+    constexpr int BM = 256, NS = 3, WQ = 2;
+    constexpr int A_STAGE = BM * 128, W_STAGE = SBN * 128, STAGE = A_STAGE + W_STAGE;
+    constexpr int EPI_LD = SBN + 4;
+    constexpr int EPI_BYTES = BM * EPI_LD * 4;
+    constexpr int SMEM_BYTES = NS * STAGE > EPI_BYTES + BM * 8 ? NS * STAGE : EPI_BYTES + BM * 8;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int nblk = p.n_mtiles * p.n_ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.n_ntiles, nt = bid % p.n_ntiles;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * SBN;
+
+    // this lane's four DMA rows: grid position (b, i, j) of row m, kept as (pixel index of (b,0,0) in the source, i, j)
+    const int drow = lane >> 3, dchunk = lane & 7;
+    int pi[4], pj[4], pb[4], pc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wv * 32 + q * 8 + drow;
+        pc[q] = (dchunk ^ ((row >> 1) & 7)) * 16;
+        const long m = m0 + row;
+        if (m < p.M) {
+            if (cp.flat) {
+                pi[q] = 0; pj[q] = 0; pb[q] = (int)m;
+            } else {
+                const int j = (int)(m % cp.Wg);
+                const long t = m / cp.Wg;
+                pi[q] = (int)(t % cp.Hg); pj[q] = j; pb[q] = (int)(t / cp.Hg) * cp.Ha * cp.Wa;
+            }
+        } else {
+            pi[q] = -(1 << 20); pj[q] = 0; pb[q] = 0;    // beyond M: every tap reads zeros
+        }
+    }
+    const unsigned char* asrc[4];
+    auto set_tap = [&](int tap) {
+        const int dy = (int)((cp.dyp >> (7 * tap)) & 127) - 64, dx = (int)((cp.dxp >> (7 * tap)) & 127) - 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            long pix;
+            bool ok;
+            if (cp.flat) {
+                pix = pb[q];
+                ok = pi[q] >= 0;
+            } else {
+                const int iy = pi[q] * cp.sa + dy, ix = pj[q] * cp.sa + dx;
+                ok = iy >= 0 && iy < cp.Ha && ix >= 0 && ix < cp.Wa;
+                pix = (long)pb[q] + (long)iy * cp.Wa + ix;
+            }
+            asrc[q] = (ok ? p.A + pix * p.lda_bytes : g_zero_buf) + pc[q];
+        }
+    };
+    const unsigned char* wsrc[WQ];
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+        const int row = wv * (WQ * 8) + q * 8 + drow;
+        const int c = dchunk ^ ((row >> 1) & 7);
+        const uint16_t* plane = (c & 4) ? p.Wlo : p.Whi;
+        wsrc[q] = reinterpret_cast<const unsigned char*>(plane + (long)(n0 + row) * p.Ktot + (c & 3) * 8);
+    }
+    auto issue = [&](int stage, int tap, int kc) {
+        unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (long)kc * 128), (lptr_t)(sb + (wv * 32 + q * 8) * 128), 16, 0, 0);
+        const long wk = ((long)tap * cp.Cpad + (long)kc * 32) * 2;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[q] + wk), (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int sw = (fr >> 1) & 7;
+    const int a_off = (wm * 64 + fr) * 128;
+    const int w_off = A_STAGE + (wn * 64 + fr) * 128;
+
+    struct Frags { bf16x8 ah[2], al[2], bh[2], bl[2]; };
+    auto load_frags = [&](Frags& f, const unsigned char* sb, int ks) {
+        const int ch = ((ks * 2 + fh) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + ch);
+            f.al[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + (ch ^ 64));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + ch);
+            f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + (ch ^ 64));
+        }
+    };
+    auto mfma12 = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    // (dtap, dkc): the K step the next DMA fetches; it stops advancing at the last one (the two surplus issues at the end
+    // re-read it into a stage nobody computes on)
+    const int total = cp.ntaps * cp.nkc;
+    int dtap = 0, dkc = 0, dstep = 0;
+    auto advance = [&]() {
+        if (dstep + 1 < total) {
+            ++dstep;
+            if (++dkc == cp.nkc) {
+                dkc = 0;
+                ++dtap;
+                set_tap(dtap);
+            }
+        }
+    };
+    set_tap(0);
+    issue(0, dtap, dkc);
+    advance();
+    issue(1, dtap, dkc);
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+    load_frags(f0, smem, 0);
+    int s0 = 0, s1 = 1, s2 = 2;
+    for (int st = 0; st < total; ++st) {
+        if (st > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        issue(s2, dtap, dkc);
+        load_frags(f1, smem + s0 * STAGE, 1);
+        mfma12(f0);
+        load_frags(f0, smem + s1 * STAGE, 0);
+        mfma12(f1);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        const int t = s0; s0 = s1; s1 = s2; s2 = t;
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- epilogue: accumulators -> fp32 LDS tile; row -> destination pixel table behind it
+    float(*stage)[EPI_LD] = reinterpret_cast<float(*)[EPI_LD]>(smem);
+    long long* rowP = reinterpret_cast<long long*>(smem + EPI_BYTES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                stage[r][wn * 64 + j * 32 + fr] = acc[i][j][e];
+            }
+    if (tid < BM) {
+        const long m = m0 + tid;
+        long long dst = -1;
+        if (m < p.M) {
+            if (cp.flat) {
+                dst = m;
+            } else {
+                const int j = (int)(m % cp.Wg);
+                const long t = m / cp.Wg;
+                const int i = (int)(t % cp.Hg);
+                const long b = t / cp.Hg;
+                dst = (b * cp.Hc + (i * cp.sc + cp.py)) * (long)cp.Wc + (j * cp.sc + cp.px);
+            }
+        }
+        rowP[tid] = dst;
+    }
+    __syncthreads();
+    constexpr int C4 = SBN / 4;
+    constexpr int ROWS_PER_PASS = 512 / C4;
+    const int ec = (tid % C4) * 4, er = tid / C4;
+    const int n = n0 + ec;
+    const int Np = cp.out_split ? (p.N + 31) / 32 * 32 : p.N;   // split32 output: the padding channels are written (zeros)
+    if (n < Np) {
+        const bool real = n < p.N;                               // N % 4 == 0: a chunk is all inside or all outside
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = s1, s2 = make_float4(1.f, 1.f, 1.f, 1.f), t2 = s1;
+        if (real) {
+            s1 = *reinterpret_cast<const float4*>(p.scale1 + n);
+            t1 = *reinterpret_cast<const float4*>(p.shift1 + n);
+            if (p.scale2) {
+                s2 = *reinterpret_cast<const float4*>(p.scale2 + n);
+                t2 = *reinterpret_cast<const float4*>(p.shift2 + n);
+            }
+        }
+        const float* __restrict__ resp = real ? p.res : nullptr;
+        const float hi = p.act == 1 ? 6.f : __builtin_inff();
+        const float slope = p.act == 0 ? 1.f : (p.act == 4 ? 0.2f : 0.f);   // v = min(max(v, slope*v), hi): every act code
+#pragma unroll 4
+        for (int r = er; r < BM; r += ROWS_PER_PASS) {
+            const long long pix = rowP[r];
+            if (pix < 0) continue;
+            float4 v = *reinterpret_cast<const float4*>(&stage[r][ec]);
+            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (resp) rv = *reinterpret_cast<const float4*>(resp + pix * p.ldres + n);
+            v.x = fmaf(v.x, s1.x, t1.x); v.y = fmaf(v.y, s1.y, t1.y); v.z = fmaf(v.z, s1.z, t1.z); v.w = fmaf(v.w, s1.w, t1.w);
+            v.x = fminf(fmaxf(v.x, slope * v.x), hi); v.y = fminf(fmaxf(v.y, slope * v.y), hi);
+            v.z = fminf(fmaxf(v.z, slope * v.z), hi); v.w = fminf(fmaxf(v.w, slope * v.w), hi);
+            if (p.scale2) {
+                v.x = fminf(fmaxf(fmaf(v.x, s2.x, t2.x), 0.f), hi); v.y = fminf(fmaxf(fmaf(v.y, s2.y, t2.y), 0.f), hi);
+                v.z = fminf(fmaxf(fmaf(v.z, s2.z, t2.z), 0.f), hi); v.w = fminf(fmaxf(fmaf(v.w, s2.w, t2.w), 0.f), hi);
+            }
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            if (!real) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cp.out_split) {
+                unsigned h0, l0, h1, l1;
+                split2(v.x, v.y, h0, l0);
+                split2(v.z, v.w, h1, l1);
+                unsigned char* o = reinterpret_cast<unsigned char*>(p.C) + pix * (long)p.ldc * 4 + (n >> 5) * 128 + (n & 31) * 2;
+                *reinterpret_cast<u32x2*>(o) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(o + 64) = u32x2{l0, l1};
+            } else {
+                *reinterpret_cast<float4*>(p.C + pix * p.ldc + n) = v;
+            }
+        }
+    }
+}
+
 // Persistent form of the same GEMM: one workgroup per CU walks over its tiles (vb = blockIdx.x, + gridDim.x, ...) and the
 // three-stage DMA / fragment pipeline simply runs on across tile boundaries: during a tile's last two K steps the first
 // two K steps of the NEXT tile are already being fetched, so only the first tile of a workgroup pays a prologue.  The
@@ -689,6 +960,123 @@ extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* 
     else if (v == 2) hipLaunchKernelGGL((gemm_split_kernel<128, 2>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_split_kernel<256, 3, true>), dim3((unsigned)nblk), dim3(512), 0, st, p);
     return emd::check_launch("gemm_split_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------- convolutions on split32 input
+namespace {
+
+void set_taps(SplitConvParams& c, int n, const int* dy, const int* dx) {
+    c.ntaps = n;
+    c.dyp = c.dxp = 0;
+    for (int t = 0; t < n; ++t) {
+        c.dyp |= (unsigned long long)((dy ? dy[t] : 0) + 64) << (7 * t);
+        c.dxp |= (unsigned long long)((dx ? dx[t] : 0) + 64) << (7 * t);
+    }
+}
+
+int conv_checks(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1, const float* shift1,
+                const float* scale2, const float* shift2, const float* res, int ldres, void* y, int ldy, int Cin, int Cout,
+                int out_split) {
+    EMD_REQUIRE(xs && whi && wlo && scale1 && shift1 && y, EMD_E_INVALID, "split32 conv: null pointer");
+    EMD_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), EMD_E_INVALID, "split32 conv: scale2/shift2 must come together");
+    EMD_REQUIRE(Cin >= 1 && Cin <= 2048 && Cout >= 4 && Cout % 4 == 0, EMD_E_INVALID, "split32 conv: 1 <= Cin <= 2048, Cout a multiple of 4");
+    EMD_REQUIRE(ldx % 32 == 0 && ldx >= emd_split32_ld(Cin) && (reinterpret_cast<uintptr_t>(xs) & 127u) == 0, EMD_E_ALIGN,
+                "split32 conv: xs 128-byte aligned, ldx a multiple of 32, >= ceil32(Cin)");
+    if (out_split)
+        EMD_REQUIRE(ldy % 32 == 0 && ldy >= emd_split32_ld(Cout) && (reinterpret_cast<uintptr_t>(y) & 127u) == 0, EMD_E_ALIGN,
+                    "split32 conv: split32 output needs y 128-byte aligned, ldy a multiple of 32, >= ceil32(Cout)");
+    else
+        EMD_REQUIRE(ldy % 4 == 0 && ldy >= Cout && emd::aligned16(y), EMD_E_ALIGN, "split32 conv: ldy a multiple of 4, >= Cout; y 16-byte aligned");
+    EMD_REQUIRE(!res || (ldres % 4 == 0 && ldres >= Cout && emd::aligned16(res)), EMD_E_ALIGN, "split32 conv: res alignment");
+    EMD_REQUIRE(emd::aligned16(scale1) && emd::aligned16(shift1) && (!scale2 || (emd::aligned16(scale2) && emd::aligned16(shift2))) &&
+                    emd::aligned16(whi) && emd::aligned16(wlo),
+                EMD_E_ALIGN, "split32 conv: weight planes and scale/shift vectors must be 16-byte aligned");
+    return EMD_OK;
+}
+
+int launch_conv(SplitConvParams& c, hipStream_t st) {
+    SplitGemmParams& p = c.g;
+    c.Cpad = (p.Cin + kBK - 1) / kBK * kBK;
+    c.nkc = (p.Cin + SBK - 1) / SBK;
+    p.Ktot = c.ntaps * c.Cpad;
+    p.n_mtiles = (int)((p.M + 255) / 256);
+    p.n_ntiles = (p.N + SBN - 1) / SBN;
+    p.stamps = nullptr;
+    const long nblk = (long)p.n_mtiles * p.n_ntiles;
+    if (nblk <= 0 || nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "split32 conv: grid too large");
+    hipLaunchKernelGGL(gemm_split_conv_kernel, dim3((unsigned)nblk), dim3(512), 0, st, c);
+    return emd::check_launch("gemm_split_conv_kernel");
+}
+
+}  // namespace
+
+extern "C" int emd_conv3x3_split32_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                                       const float* shift1, const float* scale2, const float* shift2, const float* res,
+                                       int ldres, void* y, int ldy, int B, int H, int W, int Cin, int Cout, int stride,
+                                       int rate, int act, int out_split, emd_stream_t stream) {
+    int rc = conv_checks(xs, ldx, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, Cin, Cout, out_split);
+    if (rc != EMD_OK) return rc;
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_conv3x3_split32_f32: bad shape");
+    EMD_REQUIRE(stride == 1 || stride == 2, EMD_E_UNSUPPORTED, "emd_conv3x3_split32_f32: stride must be 1 or 2");
+    EMD_REQUIRE(rate >= 1 && rate <= 31 && (rate == 1 || stride == 1), EMD_E_UNSUPPORTED,
+                "emd_conv3x3_split32_f32: rate must be 1..31, and 1 when stride is 2");
+    if (B == 0) return EMD_OK;
+    SplitConvParams c{};
+    SplitGemmParams& p = c.g;
+    p.A = static_cast<const unsigned char*>(xs); p.Whi = whi; p.Wlo = wlo; p.C = static_cast<float*>(y); p.res = res;
+    p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
+    p.lda_bytes = (long)ldx * 4; p.N = Cout; p.Cin = Cin; p.ldc = ldy; p.ldres = ldres; p.act = act;
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    const int eff = 2 * rate + 1;
+    int pth = (Ho - 1) * stride + eff - H, ptw = (Wo - 1) * stride + eff - W;  // TF SAME: total padding
+    if (pth < 0) pth = 0;
+    if (ptw < 0) ptw = 0;
+    const int pt = pth / 2, pl = ptw / 2;
+    p.M = (long)B * Ho * Wo;
+    c.flat = 0; c.out_split = out_split ? 1 : 0;
+    c.Hg = Ho; c.Wg = Wo; c.Ha = H; c.Wa = W; c.Hc = Ho; c.Wc = Wo; c.sa = stride; c.sc = 1; c.py = c.px = 0;
+    int dy[9], dx[9];
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+            dy[ky * 3 + kx] = ky * rate - pt;
+            dx[ky * 3 + kx] = kx * rate - pl;
+        }
+    set_taps(c, 9, dy, dx);
+    return launch_conv(c, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int emd_deconv3x3s2_split32_f32(const void* xs, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4],
+                                           const float* scale1, const float* shift1, void* y, int ldy, int B, int H, int W,
+                                           int Cin, int Cout, int act, int out_split, emd_stream_t stream) {
+    EMD_REQUIRE(whi && wlo, EMD_E_INVALID, "emd_deconv3x3s2_split32_f32: null weight table");
+    for (int ph = 0; ph < 4; ++ph) {
+        int rc = conv_checks(xs, ldx, whi[ph], wlo[ph], scale1, shift1, nullptr, nullptr, nullptr, 0, y, ldy, Cin, Cout, out_split);
+        if (rc != EMD_OK) return rc;
+    }
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_deconv3x3s2_split32_f32: bad shape");
+    if (B == 0) return EMD_OK;
+    for (int ph = 0; ph < 4; ++ph) {
+        SplitConvParams c{};
+        SplitGemmParams& p = c.g;
+        int ky[4], kx[4];
+        const int nt = emd_deconv_phase_taps(ph, ky, kx);
+        p.A = static_cast<const unsigned char*>(xs); p.Whi = whi[ph]; p.Wlo = wlo[ph]; p.C = static_cast<float*>(y); p.res = nullptr;
+        p.scale1 = scale1; p.shift1 = shift1; p.scale2 = p.shift2 = nullptr;
+        p.lda_bytes = (long)ldx * 4; p.N = Cout; p.Cin = Cin; p.ldc = ldy; p.ldres = 0; p.act = act;
+        p.M = (long)B * H * W;
+        c.flat = 0; c.out_split = out_split ? 1 : 0;
+        c.Hg = H; c.Wg = W; c.Ha = H; c.Wa = W; c.Hc = 2 * H; c.Wc = 2 * W; c.sa = 1; c.sc = 2;
+        c.py = ph >> 1; c.px = ph & 1;
+        int dy[4], dx[4];
+        for (int t = 0; t < nt; ++t) {  // kernel index 2 reads the previous input sample
+            dy[t] = ky[t] == 2 ? -1 : 0;
+            dx[t] = kx[t] == 2 ? -1 : 0;
+        }
+        set_taps(c, nt, dy, dx);
+        int rc = launch_conv(c, static_cast<hipStream_t>(stream));
+        if (rc != EMD_OK) return rc;
+    }
+    return EMD_OK;
 }
 
 // dev hooks (not in the header): kernel variant and stamp buffer for tools/gemm_split_bench.py

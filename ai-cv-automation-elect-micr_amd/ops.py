@@ -244,6 +244,31 @@ def sep_split32(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, stri
     return conv1x1_split32(d, w, scale1, shift1, out, act=act, scale2=scale2, shift2=shift2, res=res, stream=stream)
 
 
+def conv3x3_split32(x: SplitAct, w: PackedWeights, scale1, shift1, out, stride=1, rate=1, act=True, scale2=None, shift2=None,
+                    res: Act | None = None, stream=None):
+    """Dense 3x3 conv on a split32 input; ``out`` an Act (fp32) or a SplitAct (split32 output for a following split32 conv)."""
+    lib = _lib.load()
+    Ho, Wo = -(-x.H // stride), -(-x.W // stride)
+    assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, w.cout) and w.cin == x.C and w.taps == 9
+    rc = lib.emd_conv3x3_split32_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
+                                     res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
+                                     out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, stride, rate, _act(act),
+                                     1 if isinstance(out, SplitAct) else 0, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_conv3x3_split32_f32")
+    return out
+
+
+def deconv3x3s2_split32(x: SplitAct, w_phases, scale1, shift1, out, act=True, stream=None):
+    lib = _lib.load()
+    assert len(w_phases) == 4 and (out.B, out.H, out.W) == (x.B, 2 * x.H, 2 * x.W) and out.C == w_phases[0].cout
+    hi = (C.c_void_p * 4)(*[w.hi.data_ptr() for w in w_phases])
+    lo = (C.c_void_p * 4)(*[w.lo.data_ptr() for w in w_phases])
+    rc = lib.emd_deconv3x3s2_split32_f32(x.ptr, x.ld, hi, lo, _p(scale1), _p(shift1), out.ptr, out.ld, x.B, x.H, x.W, x.C,
+                                         out.C, _act(act), 1 if isinstance(out, SplitAct) else 0, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_deconv3x3s2_split32_f32")
+    return out
+
+
 def conv1x1_split32_supported(npix: int, cin: int, cout: int) -> bool:
     return bool(_lib.load().emd_conv1x1_split32_supported(C.c_long(npix), cin, cout))
 

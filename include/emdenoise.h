@@ -180,6 +180,18 @@ int emd_dw3x3_split32_f32(const float* x, int ldx, const float* w, void* y, int 
 int emd_dw3x3_reflect_split32_f32(const float* x, int ldx, const float* w, void* y, int ldy, int B, int H, int W, int C,
                                   int stride, emd_stream_t stream); /* emd_dw3x3_reflect_f32 (graph G) with split32 output */
 int emd_conv1x1_split32_supported(long M, int Cin, int Cout);
+/* Dense 3x3 convolution (emd_conv3x3_f32: TF SAME, stride 1/2, dilation) and the 3x3 stride-2 transposed convolution
+ * (emd_deconv3x3s2_f32) on a split32 input, same packed weights, same arithmetic (bit-identical results); out_split != 0
+ * writes y itself as a split32 tensor (pitch ldy 4-byte units, % 32; channels Cout..ceil32(Cout) zero) for a following
+ * split32 convolution -- tf.layers.conv2d / conv2d_transpose chains (misc_py/modified_Xception.py:215-229, :538-621;
+ * machine_learning/denoiser.py:141-148) then never write an fp32 activation.  Cin <= 2048. */
+int emd_conv3x3_split32_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                            const float* shift1, const float* scale2, const float* shift2, const float* res, int ldres,
+                            void* y, int ldy, int B, int H, int W, int Cin, int Cout, int stride, int rate, int act,
+                            int out_split, emd_stream_t stream);
+int emd_deconv3x3s2_split32_f32(const void* xs, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4],
+                                const float* scale1, const float* shift1, void* y, int ldy, int B, int H, int W, int Cin,
+                                int Cout, int act, int out_split, emd_stream_t stream);
 int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
                             const float* shift1, const float* scale2, const float* shift2, const float* res,
                             int ldres, float* y, int ldy, long M, int Cin, int Cout, int act, emd_stream_t stream);

@@ -180,3 +180,61 @@ def test_split32_argument_checks():
     assert lib.emd_conv1x1_split32_supported(524288, 256, 256) == 0
     assert lib.emd_conv1x1_split32_supported(32768, 64, 728) == 0
     assert lib.emd_conv1x1_split32_supported(1024, 728, 728) == 0
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,stride,rate,two_stage", [
+    (2, 16, 16, 64, 128, 1, 1, True),     # X conv_block: conv + bias -> relu -> BN -> relu
+    (1, 33, 21, 96, 132, 1, 1, False),    # ragged M, N tail, K tail (96 = 3 x 32)
+    (1, 32, 32, 728, 728, 1, 6, False),   # D' ASPP rate branch
+    (2, 18, 14, 40, 128, 2, 1, False),    # stride 2 (TF SAME: pad 0 before, 1 after), K padding inside a 32-group
+])
+@pytest.mark.parametrize("out_split", [False, True])
+def test_conv3x3_split32_equals_conv3x3(B, H, W, ci, co, stride, rate, two_stage, out_split):
+    from emdenoise import ops
+
+    x = rnd((B, H, W, ci), 51)
+    w = rnd((9, ci, co), 52, scale=(2.0 / (9 * ci + co)) ** 0.5)
+    s1, t1 = up(rnd((co,), 53, 0.3) + 1.0), up(rnd((co,), 54, 0.5))
+    s2 = up(rnd((co,), 55, 0.2) + 1.0) if two_stage else None
+    t2 = up(rnd((co,), 56, 0.3)) if two_stage else None
+    pw = ops.PackedWeights(w, False, dev())
+    xa = ops.Act(up(x))
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    act = ops.ACT_RELU if two_stage else ops.ACT_RELU6
+    want = ops.conv3x3(xa, pw, s1, t1, ops.Act.empty(B, Ho, Wo, co, dev()), stride=stride, rate=rate, act=act, scale2=s2, shift2=t2)
+    xs = ops.to_split32(xa)
+    if out_split:
+        got = ops.SplitAct(B, Ho, Wo, co, dev())
+        got.buf.fill_(float("nan"))
+        ops.conv3x3_split32(xs, pw, s1, t1, got, stride=stride, rate=rate, act=act, scale2=s2, shift2=t2)
+        torch.cuda.synchronize()
+        assert torch.equal(got.buf.view(torch.int32), ops.to_split32(want).buf.view(torch.int32))
+    else:
+        got = ops.conv3x3_split32(xs, pw, s1, t1, ops.Act.empty(B, Ho, Wo, co, dev()), stride=stride, rate=rate, act=act,
+                                  scale2=s2, shift2=t2)
+        torch.cuda.synchronize()
+        assert torch.equal(got.buf, want.buf)
+
+
+@pytest.mark.parametrize("B,H,W,ci,co", [(2, 8, 8, 256, 256), (1, 13, 9, 64, 132)])
+@pytest.mark.parametrize("out_split", [False, True])
+def test_deconv3x3s2_split32_equals_deconv(B, H, W, ci, co, out_split):
+    from emdenoise import ops
+
+    x = rnd((B, H, W, ci), 61)
+    w = rnd((3, 3, co, ci), 62, scale=(2.0 / (9 * ci + co)) ** 0.5)   # slim.conv2d_transpose layout [kh,kw,Cout,Cin]
+    s1, t1 = up(rnd((co,), 63, 0.3) + 1.0), up(rnd((co,), 64, 0.5))
+    phases = ops.pack_deconv(w, dev())
+    xa = ops.Act(up(x))
+    want = ops.deconv3x3s2(xa, phases, s1, t1, ops.Act.empty(B, 2 * H, 2 * W, co, dev()))
+    xs = ops.to_split32(xa)
+    if out_split:
+        got = ops.SplitAct(B, 2 * H, 2 * W, co, dev())
+        got.buf.fill_(float("nan"))
+        ops.deconv3x3s2_split32(xs, phases, s1, t1, got)
+        torch.cuda.synchronize()
+        assert torch.equal(got.buf.view(torch.int32), ops.to_split32(want).buf.view(torch.int32))
+    else:
+        got = ops.deconv3x3s2_split32(xs, phases, s1, t1, ops.Act.empty(B, 2 * H, 2 * W, co, dev()))
+        torch.cuda.synchronize()
+        assert torch.equal(got.buf, want.buf)
