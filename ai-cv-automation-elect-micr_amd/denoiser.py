@@ -338,24 +338,39 @@ class DenoiserEngine:
                     res=res, precision=self.precision)
         return out
 
-    def _conv1x1(self, key, x, out=None, res=None):
+    def _split_gemm_ok(self, npix, cout, ktot):
+        """The LDS-DMA split32 GEMMs (csrc/gemm_split.hip) pay where the GEMM is matrix-core bound and 256 x 128 tiles fill the chip."""
+        return (self.precision == ops.PREC_BF16X3 and cout >= 128 and ktot >= 512
+                and (-(-npix // 256)) * (-(-cout // 128)) >= 192)
+
+    def _conv1x1(self, key, x, out=None, res=None, xs=None):
+        """xs: x already converted to split32 (shared by several consumers, e.g. the ASPP branches)."""
         L, p = self.layers[key], self.P[key]
         Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
         if out is None:
             out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
+        if xs is not None and L.stride == 1 and self._split_gemm_ok(x.B * Ho * Wo, L.cout, L.cin):
+            return ops.conv1x1_split32(xs, p["pw"], p["scale"], p["shift"], out, act=bool(L.bn), res=res)
         ops.conv1x1(x, p["pw"], p["scale"], p["shift"], out, stride=L.stride, act=bool(L.bn), res=res,
                     precision=self.precision)
         return out
 
-    def _conv3x3(self, key, x, out=None):
+    def _conv3x3(self, key, x, out=None, xs=None):
         """Dense (dilated) 3x3 conv + bias + BN + relu6: the twin's ASPP rate branches (denoiser-multi-gpu.py:306-328)."""
         L, p = self.layers[key], self.P[key]
         if out is None:
             out = ops.Act.empty(x.B, x.H, x.W, L.cout, self.device)
+        if L.stride == 1 and self._split_gemm_ok(x.B * x.H * x.W, L.cout, 9 * L.cin):
+            xs = xs if xs is not None else ops.to_split32(x)
+            return ops.conv3x3_split32(xs, p["pw"], p["scale"], p["shift"], out, rate=L.rate)
         return ops.conv3x3(x, p["pw"], p["scale"], p["shift"], out, stride=L.stride, rate=L.rate, precision=self.precision)
 
     def _deconv(self, key, x, out):
-        p = self.P[key]
+        L, p = self.layers[key], self.P[key]
+        # measured (tools/conv_split_bench.py): converting the input (fp32 -> split32, one pass) + the LDS-DMA GEMM beats the
+        # register-staged GEMM where K = taps x Cin >= 1024 per output phase (deconv2to1: 2.72 -> 0.18 + 2.17 ms)
+        if L.cin >= 256 and self._split_gemm_ok(x.B * x.H * x.W, L.cout, 4 * L.cin):
+            return ops.deconv3x3s2_split32(ops.to_split32(x), p["phases"], p["scale"], p["shift"], out)
         return ops.deconv3x3s2(x, p["phases"], p["scale"], p["shift"], out, precision=self.precision)
 
     # ---- the graph
@@ -411,7 +426,8 @@ class DenoiserEngine:
         # ASPP (:152-216): the five branches write straight into their slices of the 3640-channel concat
         af = aspp_filters
         cat = E(S16, 5 * af)
-        self._conv1x1("aspp_conv1x1", cur, out=cat.slice(0, af))
+        curs = ops.to_split32(cur) if self._split_gemm_ok(B * S16 * S16, af, cur.C) else None   # shared by the GEMM branches
+        self._conv1x1("aspp_conv1x1", cur, out=cat.slice(0, af), xs=curs)
         if self.variant == "D":
             self._sep("aspp_small", cur, out=cat.slice(af, af))
             self._sep("aspp_medium", cur, out=cat.slice(2 * af, af))
@@ -422,16 +438,16 @@ class DenoiserEngine:
         else:
             # the training twin (denoiser-multi-gpu.py:306-345): dense dilated 3x3 branches, and a real image-level
             # branch: avg-pool 2x2 -> 1x1 conv + bias -> bilinear back to [aspp,aspp] -> BN -> relu6
-            self._conv3x3("aspp_small", cur, out=cat.slice(af, af))
-            self._conv3x3("aspp_medium", cur, out=cat.slice(2 * af, af))
-            self._conv3x3("aspp_large", cur, out=cat.slice(3 * af, af))
+            self._conv3x3("aspp_small", cur, out=cat.slice(af, af), xs=curs)
+            self._conv3x3("aspp_medium", cur, out=cat.slice(2 * af, af), xs=curs)
+            self._conv3x3("aspp_large", cur, out=cat.slice(3 * af, af), xs=curs)
             pooled = ops.avgpool2x2(cur, ops.Act.empty(B, -(-S16 // 2), -(-S16 // 2), af, dev))
             img_lvl = self._conv1x1("aspp_image_conv", pooled)
             up = ops.resize_bilinear(img_lvl, E(S16, af))
             ops.affine_relu6(up, P["aspp_pooling_bn"]["scale"], P["aspp_pooling_bn"]["shift"], cat.slice(4 * af, af))
             del pooled, img_lvl, up
         aspp = self._conv1x1("aspp_reduce", cat)
-        del cur, cat, t
+        del cur, cat, t, curs
         # decoder (:350-384)
         ops.resize_bilinear(aspp, concat2.slice(0, aspp_output))            # deconv3 (:350)
         t = self._sep("deconv2_a", concat2)

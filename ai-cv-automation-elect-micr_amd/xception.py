@@ -218,7 +218,30 @@ class XceptionEngine:
         B, S = x.shape[0], x.shape[1]
         assert x.shape[2] == S and S % 64 == 0, "square crops with side a multiple of 64"
         dev, prec, RELU = self.device, self.precision, ops.ACT_RELU
-        it = iter(zip(self.layers, self.P))
+        seq = list(zip(self.layers, self.P))
+        pos = [0]
+
+        class _It:   # next(it) with look-ahead: the decoder decides per layer whether its consumer takes split32 input
+            def __next__(self_inner):
+                pos[0] += 1
+                return seq[pos[0] - 1]
+        it = _It()
+
+        def split_ok(L, npix_in):
+            """This conv / deconv layer runs on the LDS-DMA split32 GEMM (ops.conv3x3_split32 / deconv3x3s2_split32)."""
+            if prec != ops.PREC_BF16X3 or L.kind not in ("conv", "deconv") or (L.kind == "conv" and L.k != 3):
+                return False
+            m = npix_in if L.kind == "deconv" or L.stride == 1 else npix_in // (L.stride * L.stride)
+            return L.cout >= 128 and L.cin >= 32 and (-(-m // 256)) * (-(-L.cout // 128)) >= 192
+
+        def next_takes_split(npix_out):
+            return pos[0] < len(seq) and split_ok(seq[pos[0]][0], npix_out)
+
+        def as_split(a):
+            return a if isinstance(a, ops.SplitAct) else ops.to_split32(a)
+
+        def host(a):
+            return (a.to_float() if isinstance(a, ops.SplitAct) else a.torch()).cpu().numpy()
         E = lambda H, W, Cc: ops.Act.empty(B, H, W, Cc, dev)
 
         def conv_bn_relu(a, out=None):
@@ -235,12 +258,17 @@ class XceptionEngine:
             return r
 
         def conv_block(a):
-            """conv3x3 + bias -> relu -> BN -> relu (:215-229): two-stage epilogue."""
+            """conv3x3 + bias -> relu -> BN -> relu (:215-229): two-stage epilogue.  Where the GEMM is matrix-core bound it
+            runs from a split32 input, and writes split32 when the next layer does too (no fp32 activation in between)."""
             L, p = next(it)
-            r = ops.conv3x3(a, p["pw"], p["one"], p["bias"], E(a.H, a.W, L.cout), act=RELU, precision=prec,
-                            scale2=p["g"], shift2=p["h"])
+            if split_ok(L, B * a.H * a.W):
+                out = (ops.SplitAct(B, a.H, a.W, L.cout, dev) if next_takes_split(B * a.H * a.W) else E(a.H, a.W, L.cout))
+                r = ops.conv3x3_split32(as_split(a), p["pw"], p["one"], p["bias"], out, act=RELU, scale2=p["g"], shift2=p["h"])
+            else:
+                r = ops.conv3x3(a, p["pw"], p["one"], p["bias"], E(a.H, a.W, L.cout), act=RELU, precision=prec,
+                                scale2=p["g"], shift2=p["h"])
             if trace is not None:
-                trace.append(r.torch().cpu().numpy())
+                trace.append(host(r))
             return r
 
         def sep(a, res=None):
@@ -261,9 +289,14 @@ class XceptionEngine:
 
         def deconv(a):
             L, p = next(it)
-            r = ops.deconv3x3s2(a, p["phases"], p["scale"], p["shift"], E(2 * a.H, 2 * a.W, L.cout), act=RELU, precision=prec)
+            if split_ok(L, B * a.H * a.W):
+                out = (ops.SplitAct(B, 2 * a.H, 2 * a.W, L.cout, dev) if next_takes_split(4 * B * a.H * a.W)
+                       else E(2 * a.H, 2 * a.W, L.cout))
+                r = ops.deconv3x3s2_split32(as_split(a), p["phases"], p["scale"], p["shift"], out, act=RELU)
+            else:
+                r = ops.deconv3x3s2(a, p["phases"], p["scale"], p["shift"], E(2 * a.H, 2 * a.W, L.cout), act=RELU, precision=prec)
             if trace is not None:
-                trace.append(r.torch().cpu().numpy())
+                trace.append(host(r))
             return r
 
         # entry flow: the 1-channel image as a 4-channel tensor (3 zero channels) feeds the 9-tap GEMM
