@@ -320,11 +320,14 @@ struct SplitConvParams {
 
 __device__ __attribute__((aligned(128))) unsigned char g_zero_buf[8192];
 
+// BN = 128: 2 x 2 MFMA tiles per wave, 3 stages.  BN = 64 (the 64-channel 512^2 layers): 2 x 1 tiles per wave, a K step is half
+// as long, so 4 stages (the whole 160 KB) keep the DMA three K steps ahead and one of its groups may stay in flight across the barrier.
+template <int BN>
 __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConvParams cp) {
     const SplitGemmParams& p = cp.g;
-    constexpr int BM = 256, NS = 3, WQ = 2;
-    constexpr int A_STAGE = BM * 128, W_STAGE = SBN * 128, STAGE = A_STAGE + W_STAGE;
-    constexpr int EPI_LD = SBN + 4;
+    constexpr int BM = 256, NS = BN == 128 ? 3 : 4, WQ = BN / 64, TN = BN / 64;
+    constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128, STAGE = A_STAGE + W_STAGE;
+    constexpr int EPI_LD = BN + 4;
     constexpr int EPI_BYTES = BM * EPI_LD * 4;
     constexpr int SMEM_BYTES = NS * STAGE > EPI_BYTES + BM * 8 ? NS * STAGE : EPI_BYTES + BM * 8;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
     }
     const int mt = bid / p.n_ntiles, nt = bid % p.n_ntiles;
     const long m0 = (long)mt * BM;
-    const int n0 = nt * SBN;
+    const int n0 = nt * BN;
 
     // this lane's four DMA rows: grid position (b, i, j) of row m, kept as (pixel index of (b,0,0) in the source, i, j)
     const int drow = lane >> 3, dchunk = lane & 7;
@@ -400,19 +403,19 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[q] + wk), (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
     const int sw = (fr >> 1) & 7;
     const int a_off = (wm * 64 + fr) * 128;
-    const int w_off = A_STAGE + (wn * 64 + fr) * 128;
+    const int w_off = A_STAGE + (wn * (BN / 2) + fr) * 128;
 
-    struct Frags { bf16x8 ah[2], al[2], bh[2], bl[2]; };
+    struct Frags { bf16x8 ah[2], al[2], bh[TN], bl[TN]; };
     auto load_frags = [&](Frags& f, const unsigned char* sb, int ks) {
         const int ch = ((ks * 2 + fh) ^ sw) << 4;
 #pragma unroll
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
             f.al[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + (ch ^ 64));
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
             f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + ch);
             f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + (ch ^ 64));
         }
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TN; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
@@ -452,18 +455,20 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
         }
     };
     set_tap(0);
-    issue(0, dtap, dkc);
-    advance();
-    issue(1, dtap, dkc);
-    advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+        issue(s, dtap, dkc);
+        advance();
+    }
+    // K steps 0 and 1 landed; NS-3 younger DMA groups (4 + WQ pieces each) may stay in flight across every barrier
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * (4 + WQ)) : "memory");
     __builtin_amdgcn_s_barrier();
     Frags f0, f1;
     load_frags(f0, smem, 0);
-    int s0 = 0, s1 = 1, s2 = 2;
+    int s0 = 0, s1 = 1, s2 = NS - 1;   // stage of K step st / st+1 / the one being refilled (held step st-1)
     for (int st = 0; st < total; ++st) {
         if (st > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * (4 + WQ)) : "memory");
             __builtin_amdgcn_s_barrier();
         }
         issue(s2, dtap, dkc);
@@ -471,24 +476,46 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
         mfma12(f0);
         load_frags(f0, smem + s1 * STAGE, 0);
         mfma12(f1);
+        if constexpr (TN == 2) {
 #pragma unroll
-        for (int g = 0; g < 6; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        }
+            for (int g = 0; g < 6; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        } else {   // 6 MFMAs per half step: 5 DMA pieces, then the 6 reads of f1; second half: the 6 reads of the next f0
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            }
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        const int t = s0; s0 = s1; s1 = s2; s2 = t;
+        s2 = s0;                                   // the stage just computed on is refilled next
+        s0 = s1;
+        s1 = s1 + 1 == NS ? 0 : s1 + 1;
         __builtin_amdgcn_sched_barrier(0);
         advance();
     }
@@ -501,11 +528,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                stage[r][wn * 64 + j * 32 + fr] = acc[i][j][e];
+                stage[r][wn * (BN / 2) + j * 32 + fr] = acc[i][j][e];
             }
     if (tid < BM) {
         const long m = m0 + tid;
@@ -524,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
         rowP[tid] = dst;
     }
     __syncthreads();
-    constexpr int C4 = SBN / 4;
+    constexpr int C4 = BN / 4;
     constexpr int ROWS_PER_PASS = 512 / C4;
     const int ec = (tid % C4) * 4, er = tid / C4;
     const int n = n0 + ec;
@@ -999,12 +1026,14 @@ int launch_conv(SplitConvParams& c, hipStream_t st) {
     c.Cpad = (p.Cin + kBK - 1) / kBK * kBK;
     c.nkc = (p.Cin + SBK - 1) / SBK;
     p.Ktot = c.ntaps * c.Cpad;
+    const int bn = p.N <= 64 ? 64 : 128;
     p.n_mtiles = (int)((p.M + 255) / 256);
-    p.n_ntiles = (p.N + SBN - 1) / SBN;
+    p.n_ntiles = (p.N + bn - 1) / bn;
     p.stamps = nullptr;
     const long nblk = (long)p.n_mtiles * p.n_ntiles;
     if (nblk <= 0 || nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "split32 conv: grid too large");
-    hipLaunchKernelGGL(gemm_split_conv_kernel, dim3((unsigned)nblk), dim3(512), 0, st, c);
+    if (bn == 64) hipLaunchKernelGGL(gemm_split_conv_kernel<64>, dim3((unsigned)nblk), dim3(512), 0, st, c);
+    else hipLaunchKernelGGL(gemm_split_conv_kernel<128>, dim3((unsigned)nblk), dim3(512), 0, st, c);
     return emd::check_launch("gemm_split_conv_kernel");
 }
 

@@ -223,6 +223,8 @@ class XceptionEngine:
 
         class _It:   # next(it) with look-ahead: the decoder decides per layer whether its consumer takes split32 input
             def __next__(self_inner):
+                if pos[0] >= len(seq):
+                    raise StopIteration
                 pos[0] += 1
                 return seq[pos[0] - 1]
         it = _It()
@@ -232,7 +234,8 @@ class XceptionEngine:
             if prec != ops.PREC_BF16X3 or L.kind not in ("conv", "deconv") or (L.kind == "conv" and L.k != 3):
                 return False
             m = npix_in if L.kind == "deconv" or L.stride == 1 else npix_in // (L.stride * L.stride)
-            return L.cout >= 128 and L.cin >= 32 and (-(-m // 256)) * (-(-L.cout // 128)) >= 192
+            bn = 64 if L.cout <= 64 else 128
+            return L.cout >= 32 and L.cin >= 32 and (-(-m // 256)) * (-(-L.cout // bn)) >= 192
 
         def next_takes_split(npix_out):
             return pos[0] < len(seq) and split_ok(seq[pos[0]][0], npix_out)

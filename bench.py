@@ -240,6 +240,7 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     fam = {}
     orig = {}
     dw_bytes_box = [0.0]
+    pw_flops_box = [0.0]
 
     def wrap(name):
         f = getattr(ops, name)
@@ -251,15 +252,19 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
             r = f(*args, **kw)
             e1.record()
             fam.setdefault(name, []).append((e0, e1))
-            if name == "dw3x3":  # algorithmic bytes of THIS launch: fp32 in + out
-                xin, out = args[0], args[2]
+            if name in ("dw3x3", "dw3x3_split32"):  # algorithmic bytes of THIS launch: fp32 in + out;
+                xin, out = args[0], args[2]          # a split32 output has the bytes of its fp32 twin
                 dw_bytes_box[0] += 4.0 * xin.C * (xin.B * xin.H * xin.W + out.B * out.H * out.W)
+            if name == "conv1x1_split32":            # issued flops of THIS pointwise launch (3 bf16 MFMA passes)
+                xin, wgt = args[0], args[1]
+                pw_flops_box[0] += 6.0 * xin.B * xin.H * xin.W * wgt.cin * wgt.cout
             return r
 
         setattr(ops, name, g)
 
     for name in ("conv1x1", "conv3x3", "deconv3x3s2", "sep_fused", "dw3x3", "cin1", "conv3x3_cout1", "resize_bilinear",
-                 "affine_relu6", "affine_act", "bn_batch_stats", "avgpool2x2"):
+                 "affine_relu6", "affine_act", "bn_batch_stats", "avgpool2x2", "conv1x1_split32", "conv3x3_split32",
+                 "deconv3x3s2_split32", "dw3x3_split32", "to_split32"):
         wrap(name)
     try:
         step()
@@ -270,7 +275,9 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     fam_ms = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) for k, v in fam.items()}
     # matrix-core time: the implicit-GEMM launches plus the fused separable convs (whose pointwise halves carry
     # part of the algorithmic flops)
-    gemm_ms = sum(fam_ms.get(k, 0.0) for k in ("conv1x1", "conv3x3", "deconv3x3s2", "sep_fused"))
+    gemm_ms = sum(fam_ms.get(k, 0.0) for k in ("conv1x1", "conv3x3", "deconv3x3s2", "sep_fused", "conv1x1_split32",
+                                               "conv3x3_split32", "deconv3x3s2_split32"))
+    dw_ms = fam_ms.get("dw3x3", 0.0) + fam_ms.get("dw3x3_split32", 0.0)
     scale = (B / 32.0) * (H * W) / (512.0 * 512.0)
     alg_flops = 2.0 * D_GMAC_MATRIX_B32_512 * 1e9 * scale
     achieved = alg_flops / (gemm_ms * 1e-3) / 1e12
@@ -287,7 +294,7 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
         "config": {"workload": f"D: modified-Xception encoder-decoder (machine_learning/denoiser.py), [{B},{H},{W},1] fp32 per GPU",
                    "global_batch": B * world, "image": f"{H}x{W}x1", "precision": a.precision,
                    "sharding": f"{world} x {B} whole images, no collective"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel + sep_fused_kernel (every matrix-core launch of one step)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel + gemm_split*_kernel + sep_fused_kernel (every matrix-core launch of one step)",
                      "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_note": "HBM bytes per step over the family (PMC run of 4 forwards, profiles/r01_pmc_traffic.json)",
@@ -295,10 +302,15 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
                      "issued_tflops": round(achieved * passes, 1),
                      "kernel_ms_per_step": round(gemm_ms, 3),
                      "how": "HIP events around every launch of the family in one extra step"},
-        "depthwise": {"bound": "hbm", "kernel": "dw3x3_s1_roll / dw3x3_generic (standalone launches only)",
-                      "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(fam_ms.get("dw3x3", 0.0), 3),
-                      "achieved_GBps": round(dw_bytes / (fam_ms.get("dw3x3", 1e9) * 1e-3) / 1e9, 1),
-                      "frac_of_8TBps": round(dw_bytes / (fam_ms.get("dw3x3", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+        "depthwise": {"bound": "hbm", "kernel": "dw3x3_s1_roll / dw3x3_generic, fp32 or split32 output (standalone launches only)",
+                      "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(dw_ms, 3),
+                      "achieved_GBps": round(dw_bytes / (max(dw_ms, 1e-9) * 1e-3) / 1e9, 1),
+                      "frac_of_8TBps": round(dw_bytes / (max(dw_ms, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+        "pointwise": {"bound": "mfma", "kernel": "gemm_split_kernel<256,3,true> (the 1x1 halves of the 728-channel separable convs, LDS-DMA from split32)",
+                      "launches": len(fam.get("conv1x1_split32", [])), "issued_flops_per_step": pw_flops_box[0],
+                      "ms_per_step": round(fam_ms.get("conv1x1_split32", 0.0), 3),
+                      "issued_tflops": round(pw_flops_box[0] / (max(fam_ms.get("conv1x1_split32", 0.0), 1e-9) * 1e-3) / 1e12, 1),
+                      "frac_of_2500": round(pw_flops_box[0] / (max(fam_ms.get("conv1x1_split32", 0.0), 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
         "kernel_family_ms": {k: round(v, 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])},
     }
     if want_cpu:
@@ -632,7 +644,7 @@ def main():
         "config": prim["config"],
         "roofline": prim["roofline"],
     }
-    for k in ("cpu_baseline", "rel_l2_vs_oracle", "depthwise", "kernel_family_ms", "tflops_algorithmic", "loss_first_tower", "d_fake_first", "d_out_first"):
+    for k in ("cpu_baseline", "rel_l2_vs_oracle", "depthwise", "pointwise", "kernel_family_ms", "tflops_algorithmic", "loss_first_tower", "d_fake_first", "d_out_first"):
         if k in prim:
             out[k] = prim[k]
     if not primary_is_D and res_D is not None:

@@ -187,6 +187,8 @@ def test_split32_argument_checks():
     (1, 33, 21, 96, 132, 1, 1, False),    # ragged M, N tail, K tail (96 = 3 x 32)
     (1, 32, 32, 728, 728, 1, 6, False),   # D' ASPP rate branch
     (2, 18, 14, 40, 128, 2, 1, False),    # stride 2 (TF SAME: pad 0 before, 1 after), K padding inside a 32-group
+    (2, 24, 24, 64, 64, 1, 1, True),      # 64-wide N tile (4-stage kernel): X's 512^2 conv_blocks
+    (1, 17, 19, 32, 36, 1, 1, False),     # 64-wide N tile with an N tail, a single K step per tap
 ])
 @pytest.mark.parametrize("out_split", [False, True])
 def test_conv3x3_split32_equals_conv3x3(B, H, W, ci, co, stride, rate, two_stage, out_split):
@@ -216,7 +218,7 @@ def test_conv3x3_split32_equals_conv3x3(B, H, W, ci, co, stride, rate, two_stage
         assert torch.equal(got.buf, want.buf)
 
 
-@pytest.mark.parametrize("B,H,W,ci,co", [(2, 8, 8, 256, 256), (1, 13, 9, 64, 132)])
+@pytest.mark.parametrize("B,H,W,ci,co", [(2, 8, 8, 256, 256), (1, 13, 9, 64, 132), (2, 16, 16, 128, 64)])
 @pytest.mark.parametrize("out_split", [False, True])
 def test_deconv3x3s2_split32_equals_deconv(B, H, W, ci, co, out_split):
     from emdenoise import ops

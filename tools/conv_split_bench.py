@@ -14,6 +14,8 @@ SHAPES = {  # name: (kind, B, H, W, Cin, Cout)
     "X_dc_128to256": ("deconv", 32, 128, 128, 192, 128),
     "X_dc_64to128": ("deconv", 32, 64, 64, 256, 192),
     "Dp_aspp_r6": ("conv6", 32, 32, 32, 728, 728),
+    "X_c3_512x64": ("conv", 32, 512, 512, 64, 64),
+    "X_dc_256to512": ("deconv", 32, 256, 256, 128, 64),
 }
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(SHAPES)
 reps = int(os.environ.get("GB_REPS", "5")); rounds = int(os.environ.get("GB_ROUNDS", "3"))
