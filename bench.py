@@ -287,7 +287,7 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     traffic = None
     if tr and (B, H, W) == (32, 512, 512):  # HBM bytes of all gemm_conv launches of one step
         traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_sampled"] / 4.0
-                            for k, v in tr.items() if k.startswith("D:gemm_conv_kernel")))
+                            for k, v in tr.items() if k.startswith("D:gemm_conv_kernel") or k.startswith("D:gemm_split")))
     out = {
         "value": B * H * W / 1e6 * world / (ms / 1e3), "ms_per_step": ms, "steps": steps, "warmup": warmup,
         "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)" if passes == 3 else "bf16",
