@@ -399,6 +399,42 @@ def bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     return out
 
 
+def bench_S(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
+    """the small separable autoencoder of misc_py/apply_autoencoders.py (:91-187), the reference's
+    own size: 160x160 crops, encoding_features 16, a batch of `--batch` crops per GPU with per-image batch statistics."""
+    from emdenoise import autoencoder as AE
+
+    B, S = a.batch, 160
+    steps, warmup = 10, 2
+    x_host = synthetic_lq(B, S, S, seed=160 + rank)
+    x_host = (x_host / x_host.mean(axis=(1, 2, 3), keepdims=True)).astype(np.float32)
+    weights = AE.synthetic_weights(16)
+    eng = AE.AutoencoderEngine(weights, dev, 16)
+    x = torch.from_numpy(x_host).to(dev)
+    box = [None]
+
+    def step():
+        box[0] = eng.forward(x)
+
+    ms = timer.run(step, steps, warmup)
+    out = {"value": round(B * S * S / 1e6 * world / (ms / 1e3), 1), "unit": "MPx/s", "ms_per_step": round(ms, 3),
+           "steps": steps, "warmup": warmup,
+           "config": {"workload": f"S: separable autoencoder (misc_py/apply_autoencoders.py), [{B},{S},{S},1] fp32 per GPU, "
+                                  "encoding_features 16, per-image batch-statistics norms", "precision": "bf16x3"}}
+    if want_cpu:
+        from oracle import autoencoder_graph as AG
+
+        torch.set_num_threads(CPU_THREADS)
+        t0 = time.perf_counter()
+        ref = AG.architecture(x_host, weights, 16, dtype=torch.float32).numpy()
+        el = time.perf_counter() - t0
+        got = box[0].cpu().numpy()
+        out["cpu_baseline"] = {"value": round(B * S * S / 1e6 / el, 4), "unit": "MPx/s", "cores": CPU_THREADS, "kind": "port",
+                               "sample": f"the same [{B},{S},{S},1] batch, oracle/autoencoder_graph.py (PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}
+        out["rel_l2_vs_oracle"] = float(f"{np.linalg.norm(got - ref) / np.linalg.norm(ref):.3e}")
+    return out
+
+
 def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     """BASELINE configs[4]: one iteration of the in-filling GAN's training loop (misc_py/gan-infilling-100.py:1650-1790)
     on `--gan-batch` 512x512 images per GPU: generator towers through the discriminator (feature matching), generator
@@ -522,7 +558,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["K", "D", "X", "T", "G", "A", "both", "all"], default="all",
+    ap.add_argument("--workload", choices=["K", "D", "X", "T", "G", "A", "S", "both", "all"], default="all",
                     help="K and D: see the module docstring; X: misc_py/modified_Xception.py; all (default) = K primary, D and X alongside")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
@@ -599,6 +635,15 @@ def main():
                 raise
             res_G = {"error": f"{type(e).__name__}: {e}"}
 
+    res_S = None
+    if a.workload == "S" or (a.workload == "all" and not multi):
+        try:
+            res_S = bench_S(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
+        except Exception as e:
+            if a.workload == "S":
+                raise
+            res_S = {"error": f"{type(e).__name__}: {e}"}
+
     res_A = None
     if a.workload == "A" or (a.workload == "all" and not multi):
         try:
@@ -617,6 +662,11 @@ def main():
         prim["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel", "achieved": prim["tflops_algorithmic"],
                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(prim["tflops_algorithmic"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
+    if prim is None and a.workload == "S":
+        prim, res_S = dict(res_S), None
+        prim["dtype"] = "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)"
+        prim["roofline"] = {"bound": "hbm", "kernel": "whole forward (launch-bound at 160 px: per-image statistics launches)",
+                            "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
     if prim is None and a.workload == "T":
         prim, res_T = res_T, None
     if prim is None:  # --workload X alone
@@ -627,7 +677,7 @@ def main():
                                      "frac": round((prim.get("tflops_algorithmic") or 0.0) / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None})
         res_X = None
     out = {
-        "metric": {"T": "megapixels/sec trained (512x512x1 LQ/HQ pairs)", "G": "megapixels/sec in-filled (512x512x1 bs=32)",
+        "metric": {"T": "megapixels/sec trained (512x512x1 LQ/HQ pairs)", "G": "megapixels/sec in-filled (512x512x1 bs=32)", "S": "megapixels/sec restored (160x160x1 crops, bs=32)",
                    "A": "megapixels/sec trained (in-filling GAN, 512x512x1)"}.get(
             a.workload, "megapixels/sec restored (512x512x1 bs=32)"),
         "value": round(prim["value"], 1),
@@ -661,6 +711,8 @@ def main():
         out["workload_G"] = res_G
     if res_A is not None:
         out["workload_A"] = res_A
+    if res_S is not None:
+        out["workload_S"] = res_S
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
