@@ -212,6 +212,27 @@ def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
                      "avg_launch_us": round(launch_us, 3),
                      "how": f"HIP events around a hipGraph of {n_burst} back-to-back launches (includes the ~1.5 us kernel boundary)"},
     }
+    # the same kernel on a batch that is not launch-bound and does not fit the 256 MiB Infinity Cache (SURVEY.md 8d:
+    # "the kernel is launch/latency-limited at this size, so also report B=256"): 8x the images, one launch
+    if (B, H, W) == (32, 512, 512) and rank == 0:
+        try:
+            xb = x.repeat(8, 1, 1, 1).contiguous()
+            yb = torch.empty_like(xb)
+            for _ in range(3):
+                emdenoise.kernel_denoise(xb, pd, 3, 2, params.symmetric, out=yb)
+            eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            eb0.record()
+            for _ in range(20):
+                emdenoise.kernel_denoise(xb, pd, 3, 2, params.symmetric, out=yb)
+            eb1.record()
+            torch.cuda.synchronize()
+            us256 = eb0.elapsed_time(eb1) * 1e3 / 20
+            out["roofline"]["batch256"] = {"avg_launch_us": round(us256, 2), "achieved": round(8 * alg_bytes / (us256 * 1e-6) / 1e9, 1),
+                                           "frac": round(8 * alg_bytes / (us256 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                                           "note": "[256,512,512,1]: 537 MB per launch, HIP events around 20 launches"}
+            del xb, yb
+        except Exception as e:  # out of memory on a shared card: the primary figure stands on its own
+            out["roofline"]["batch256"] = {"error": f"{type(e).__name__}: {e}"}
     if want_cpu:
         cb, y_cpu = cpu_baseline_K(x_host, params.wmaps, params.bmaps, params.s)
         out["cpu_baseline"] = cb
