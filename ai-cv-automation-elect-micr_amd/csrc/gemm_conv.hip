@@ -258,40 +258,55 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
     __syncthreads();
     constexpr int C4 = BN / 4;            // float4 chunks per staged row
     constexpr int ROWS_PER_PASS = 256 / C4;
+    constexpr int NROWS = BM / ROWS_PER_PASS;
     const int ec = (tid % C4) * 4, er = tid / C4;
     const int n = n0 + ec;
     if (n < p.N) {                        // N % 4 == 0: a chunk is all inside or all outside
-        const float4 s1 = *reinterpret_cast<const float4*>(p.scale1 + n);
-        const float4 t1 = *reinterpret_cast<const float4*>(p.shift1 + n);
-        float4 s2 = make_float4(1.f, 1.f, 1.f, 1.f), t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
+        f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
         if (p.scale2) {
-            s2 = *reinterpret_cast<const float4*>(p.scale2 + n);
-            t2 = *reinterpret_cast<const float4*>(p.shift2 + n);
+            s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
+            t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
         }
-        const float* __restrict__ resp = p.res;
         float* __restrict__ outp = p.C;
-        const float hi = p.act == 2 ? __builtin_inff() : 6.f;
+        // one clamp form for every activation code: v = min(max(max(v, lo), slope*v), hi) -- (lo, slope, hi) = none: (-inf, 1, inf); relu6: (0, 1, 6);
+        // relu: (0, 1, inf); leaky relu (graph G): (-inf, 0.2, inf); a clamped negative comes out as +0, as tf.nn.relu6 gives it
+        const float hi = p.act == 1 ? 6.f : __builtin_inff();
+        const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
+        const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+        const bool two = p.scale2 != nullptr;
+        auto finish = [&](f32x4 v) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float u = fmaf(v[c], s1[c], t1[c]);
+                u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                if (two) u = fminf(fmaxf(fmaf(u, s2[c], t2[c]), 0.f), hi2);
+                v[c] = u;
+            }
+            return v;
+        };
+        if (p.res) {
+            // all residual values of this thread's rows are requested before the first one is used
+            f32x4 rv[NROWS];
+#pragma unroll
+            for (int k = 0; k < NROWS; ++k) {
+                const long long pix = rowP[er + k * ROWS_PER_PASS];
+                rv[k] = pix >= 0 ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < NROWS; ++k) {
+                const int r = er + k * ROWS_PER_PASS;
+                const long long pix = rowP[r];
+                if (pix >= 0) *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec])) + rv[k];
+            }
+        } else {
 #pragma unroll 4
-        for (int r = er; r < BM; r += ROWS_PER_PASS) {
-            const long long pix = rowP[r];
-            if (pix < 0) continue;
-            float4 v = *reinterpret_cast<const float4*>(&stage[r][ec]);
-            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (resp) rv = *reinterpret_cast<const float4*>(resp + pix * p.ldres + n);
-            v.x = fmaf(v.x, s1.x, t1.x); v.y = fmaf(v.y, s1.y, t1.y); v.z = fmaf(v.z, s1.z, t1.z); v.w = fmaf(v.w, s1.w, t1.w);
-            if (p.act == 4) {  // tf.nn.leaky_relu, alpha 0.2 (graph G)
-                v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
-                v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
-            } else if (p.act) {  // hi = 6 (relu6) or +inf (relu)
-                v.x = fminf(fmaxf(v.x, 0.f), hi); v.y = fminf(fmaxf(v.y, 0.f), hi);
-                v.z = fminf(fmaxf(v.z, 0.f), hi); v.w = fminf(fmaxf(v.w, 0.f), hi);
+            for (int r = er; r < BM; r += ROWS_PER_PASS) {
+                const long long pix = rowP[r];
+                if (pix < 0) continue;
+                *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec]));
             }
-            if (p.scale2) {
-                v.x = fminf(fmaxf(fmaf(v.x, s2.x, t2.x), 0.f), hi); v.y = fminf(fmaxf(fmaf(v.y, s2.y, t2.y), 0.f), hi);
-                v.z = fminf(fmaxf(fmaf(v.z, s2.z, t2.z), 0.f), hi); v.w = fminf(fmaxf(fmaf(v.w, s2.w, t2.w), 0.f), hi);
-            }
-            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            *reinterpret_cast<float4*>(outp + pix * p.ldc + n) = v;
         }
     }
 }

@@ -241,8 +241,24 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
 
     // ---- epilogue (as gemm_conv.hip): accumulators -> fp32 LDS tile -> per-channel affine(s), activation, residual,
     // 16-byte loads and stores along the channel axis.  C/D layout of mfma_32x32: col = lane&31,
-    // row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    // row = (e&3) + 8*(e>>2) + 4*(lane>>5).  The residual values of this thread's rows are requested BEFORE the
+    // accumulators go through LDS: their latency hides behind the staging pass and its barrier (a residual epilogue took
+    // 20-27 k cycles per tile with the loads inside the store loop, 7 k without a residual).
     float(*stage)[EPI_LD] = reinterpret_cast<float(*)[EPI_LD]>(smem);
+    constexpr int C4 = SBN / 4;             // 32 float4 chunks per staged row
+    constexpr int ROWS_PER_PASS = NT / C4;
+    constexpr int NROWS = BM / ROWS_PER_PASS;   // 16 rows per thread
+    const int ec = (tid % C4) * 4, er = tid / C4;
+    const int n = n0 + ec;
+    const bool ncol = n < p.N;              // N % 4 == 0: a chunk is all inside or all outside
+    f32x4 rv[NROWS];
+    if (p.res) {
+#pragma unroll
+        for (int k = 0; k < NROWS; ++k) {
+            const long pix = m0 + er + k * ROWS_PER_PASS;
+            rv[k] = (ncol && pix < p.M) ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -254,42 +270,45 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
             }
     __syncthreads();
     if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
-    constexpr int C4 = SBN / 4;             // 32 float4 chunks per staged row
-    constexpr int ROWS_PER_PASS = NT / C4;
-    const int ec = (tid % C4) * 4, er = tid / C4;
-    const int n = n0 + ec;
-    if (n < p.N) {                          // N % 4 == 0: a chunk is all inside or all outside
-        const float4 s1 = *reinterpret_cast<const float4*>(p.scale1 + n);
-        const float4 t1 = *reinterpret_cast<const float4*>(p.shift1 + n);
-        float4 s2 = make_float4(1.f, 1.f, 1.f, 1.f), t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ncol) {
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
+        f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
         if (p.scale2) {
-            s2 = *reinterpret_cast<const float4*>(p.scale2 + n);
-            t2 = *reinterpret_cast<const float4*>(p.shift2 + n);
+            s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
+            t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
         }
-        const float* __restrict__ resp = p.res;
         float* __restrict__ outp = p.C;
-        const float hi = p.act == 2 ? __builtin_inff() : 6.f;
+        // one clamp form for every activation code: v = min(max(max(v, lo), slope*v), hi) -- (lo, slope, hi) = none: (-inf, 1, inf); relu6: (0, 1, 6);
+        // relu: (0, 1, inf); leaky relu (graph G): (-inf, 0.2, inf); a clamped negative comes out as +0, as tf.nn.relu6 gives it
+        const float hi = p.act == 1 ? 6.f : __builtin_inff();
+        const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
+        const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+        const bool two = p.scale2 != nullptr;
+        auto finish = [&](f32x4 v) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float u = fmaf(v[c], s1[c], t1[c]);
+                u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                if (two) u = fminf(fmaxf(fmaf(u, s2[c], t2[c]), 0.f), hi2);
+                v[c] = u;
+            }
+            return v;
+        };
+        if (p.res) {
+#pragma unroll
+            for (int k = 0; k < NROWS; ++k) {
+                const int r = er + k * ROWS_PER_PASS;
+                const long pix = m0 + r;
+                if (pix < p.M) *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec])) + rv[k];
+            }
+        } else {
 #pragma unroll 4
-        for (int r = er; r < BM; r += ROWS_PER_PASS) {
-            const long pix = m0 + r;
-            if (pix >= p.M) break;
-            float4 v = *reinterpret_cast<const float4*>(&stage[r][ec]);
-            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (resp) rv = *reinterpret_cast<const float4*>(resp + pix * p.ldres + n);
-            v.x = fmaf(v.x, s1.x, t1.x); v.y = fmaf(v.y, s1.y, t1.y); v.z = fmaf(v.z, s1.z, t1.z); v.w = fmaf(v.w, s1.w, t1.w);
-            if (p.act == 4) {  // tf.nn.leaky_relu, alpha 0.2 (graph G)
-                v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
-                v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
-            } else if (p.act) {  // hi = 6 (relu6) or +inf (relu)
-                v.x = fminf(fmaxf(v.x, 0.f), hi); v.y = fminf(fmaxf(v.y, 0.f), hi);
-                v.z = fminf(fmaxf(v.z, 0.f), hi); v.w = fminf(fmaxf(v.w, 0.f), hi);
+            for (int r = er; r < BM; r += ROWS_PER_PASS) {
+                const long pix = m0 + r;
+                if (pix >= p.M) break;
+                *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec]));
             }
-            if (p.scale2) {
-                v.x = fminf(fmaxf(fmaf(v.x, s2.x, t2.x), 0.f), hi); v.y = fminf(fmaxf(fmaf(v.y, s2.y, t2.y), 0.f), hi);
-                v.z = fminf(fmaxf(fmaf(v.z, s2.z, t2.z), 0.f), hi); v.w = fminf(fmaxf(fmaf(v.w, s2.w, t2.w), 0.f), hi);
-            }
-            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            *reinterpret_cast<float4*>(outp + pix * p.ldc + n) = v;
         }
     }
     if (p.stamps && tid == 0) {
@@ -569,7 +588,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
         }
         const float* __restrict__ resp = real ? p.res : nullptr;
         const float hi = p.act == 1 ? 6.f : __builtin_inff();
-        const float slope = p.act == 0 ? 1.f : (p.act == 4 ? 0.2f : 0.f);   // v = min(max(v, slope*v), hi): every act code
+        const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
+        const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();   // v = min(max(max(v, lo), slope*v), hi): every act code
 #pragma unroll 4
         for (int r = er; r < BM; r += ROWS_PER_PASS) {
             const long long pix = rowP[r];
@@ -578,11 +598,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
             float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (resp) rv = *reinterpret_cast<const float4*>(resp + pix * p.ldres + n);
             v.x = fmaf(v.x, s1.x, t1.x); v.y = fmaf(v.y, s1.y, t1.y); v.z = fmaf(v.z, s1.z, t1.z); v.w = fmaf(v.w, s1.w, t1.w);
-            v.x = fminf(fmaxf(v.x, slope * v.x), hi); v.y = fminf(fmaxf(v.y, slope * v.y), hi);
-            v.z = fminf(fmaxf(v.z, slope * v.z), hi); v.w = fminf(fmaxf(v.w, slope * v.w), hi);
+            v.x = fminf(fmaxf(fmaxf(v.x, lo), slope * v.x), hi); v.y = fminf(fmaxf(fmaxf(v.y, lo), slope * v.y), hi);
+            v.z = fminf(fmaxf(fmaxf(v.z, lo), slope * v.z), hi); v.w = fminf(fmaxf(fmaxf(v.w, lo), slope * v.w), hi);
             if (p.scale2) {
-                v.x = fminf(fmaxf(fmaf(v.x, s2.x, t2.x), 0.f), hi); v.y = fminf(fmaxf(fmaf(v.y, s2.y, t2.y), 0.f), hi);
-                v.z = fminf(fmaxf(fmaf(v.z, s2.z, t2.z), 0.f), hi); v.w = fminf(fmaxf(fmaf(v.w, s2.w, t2.w), 0.f), hi);
+                v.x = fminf(fmaxf(fmaf(v.x, s2.x, t2.x), 0.f), hi2); v.y = fminf(fmaxf(fmaf(v.y, s2.y, t2.y), 0.f), hi2);
+                v.z = fminf(fmaxf(fmaf(v.z, s2.z, t2.z), 0.f), hi2); v.w = fminf(fmaxf(fmaf(v.w, s2.w, t2.w), 0.f), hi2);
             }
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             if (!real) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -831,10 +851,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_persist_kernel(const SplitG
         if (p.stamps && !have_prev) t3 = __builtin_amdgcn_s_memtime();
 
         // the finished tile: affine(s) + activation in registers.  One clamp form for every activation code:
-        // v = min(max(v, slope*v), hi) -- none: slope 1, hi inf; relu6: 0, 6; relu: 0, inf; leaky relu: 0.2, inf
+        // v = min(max(max(v, lo), slope*v), hi) -- (lo, slope, hi) = none: (-inf, 1, inf); relu6: (0, 1, 6); relu: 0, inf; leaky relu: 0.2, inf
         {
             const float hi = p.act == 1 ? 6.f : __builtin_inff();
-            const float slope = p.act == 0 ? 1.f : (p.act == 4 ? 0.2f : 0.f);
+        const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
+            const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 64 + j * 32 + fr;
@@ -847,8 +868,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_persist_kernel(const SplitG
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             float v = fmaf(acc[i][j][e], s1v, t1v);
-                            v = fminf(fmaxf(v, slope * v), hi);
-                            o[i * 32 + j * 16 + e] = fminf(fmaxf(fmaf(v, s2v, t2v), 0.f), hi);
+                            v = fminf(fmaxf(fmaxf(v, lo), slope * v), hi);
+                            o[i * 32 + j * 16 + e] = fminf(fmaxf(fmaf(v, s2v, t2v), 0.f), hi2);
                         }
                 } else {
 #pragma unroll
@@ -856,7 +877,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_persist_kernel(const SplitG
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             const float v = fmaf(acc[i][j][e], s1v, t1v);
-                            o[i * 32 + j * 16 + e] = fminf(fmaxf(v, slope * v), hi);
+                            o[i * 32 + j * 16 + e] = fminf(fmaxf(fmaxf(v, lo), slope * v), hi);
                         }
                 }
             }

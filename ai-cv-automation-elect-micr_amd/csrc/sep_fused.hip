@@ -222,25 +222,45 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
             t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
         }
-        const float* __restrict__ resp = p.res;
         float* __restrict__ outp = p.y;
-        const float hi = p.act == 2 ? __builtin_inff() : 6.f;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, six = {hi, hi, hi, hi};
-#pragma unroll 4
-        for (int r = er; r < BM; r += ROWS_PER_PASS) {
-            const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
-            f32x4 v = *reinterpret_cast<const f32x4*>(&stage[r][n]);
-            f32x4 rv = zero;
-            if (resp) rv = *reinterpret_cast<const f32x4*>(resp + pix * p.ldres + n);
-            v = v * s1 + t1;
-            if (p.act == 4) {  // tf.nn.leaky_relu, alpha 0.2 (graph G)
-                const f32x4 neg = v * 0.2f;
-                v = __builtin_elementwise_max(v, neg);
-            } else if (p.act) {
-                v = __builtin_elementwise_min(__builtin_elementwise_max(v, zero), six);
+        // one clamp form for every activation code: v = min(max(max(v, lo), slope*v), hi) -- (lo, slope, hi) = none: (-inf, 1, inf); relu6: (0, 1, 6);
+        // relu: (0, 1, inf); leaky relu (graph G): (-inf, 0.2, inf); a clamped negative comes out as +0, as tf.nn.relu6 gives it
+        const float hi = p.act == 1 ? 6.f : __builtin_inff();
+        const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
+        const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+        const bool two = p.scale2 != nullptr;
+        auto finish = [&](f32x4 v) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float u = fmaf(v[c], s1[c], t1[c]);
+                u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                if (two) u = fminf(fmaxf(fmaf(u, s2[c], t2[c]), 0.f), hi2);
+                v[c] = u;
             }
-            if (p.scale2) v = __builtin_elementwise_min(__builtin_elementwise_max(v * s2 + t2, zero), six);
-            *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = v + rv;
+            return v;
+        };
+        constexpr int NROWS = BM / ROWS_PER_PASS;
+        if (p.res) {
+            // all residual values of this thread's rows are requested before the first one is used
+            f32x4 rv[NROWS];
+#pragma unroll
+            for (int k = 0; k < NROWS; ++k) {
+                const int r = er + k * ROWS_PER_PASS;
+                const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
+                rv[k] = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n);
+            }
+#pragma unroll
+            for (int k = 0; k < NROWS; ++k) {
+                const int r = er + k * ROWS_PER_PASS;
+                const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
+                *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n])) + rv[k];
+            }
+        } else {
+#pragma unroll 4
+            for (int r = er; r < BM; r += ROWS_PER_PASS) {
+                const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
+                *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n]));
+            }
         }
     }
 }
