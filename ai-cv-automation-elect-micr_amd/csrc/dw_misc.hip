@@ -8,6 +8,8 @@
 // Layout rule for all of them: channels are innermost, a lane owns 4 consecutive channels (one 16-B
 // access) and consecutive lanes own consecutive channel groups, then consecutive pixels along W, so
 // a wavefront's access is one contiguous run of NHWC memory whenever C >= 4*64/pixels-per-wave.
+#include <cstdlib>
+
 #include "mfma_common.hpp"
 
 namespace {
@@ -36,17 +38,26 @@ template <int TH, bool SPLIT = false>
 __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x, int ldx,
                                                      const float* __restrict__ w, float* __restrict__ y,
                                                      int ldy, int H, int W, int C4, long nthreads, int nstrip, int C4t) {
-    // C4t = channel quads per pixel that have a thread: C4, or ceil32(C)/4 when the split32 padding is written too
-    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (tid >= nthreads) return;
-    const int c4o = (int)(tid % C4t);
+    // C4t = channel quads per pixel that have a thread: C4, or ceil32(C)/4 when the split32 padding is written too.
+    // A workgroup = 16 adjacent pixel columns x 16 channel quads (64 channels, 256 contiguous bytes per pixel): the left /
+    // right neighbours of a pixel are loaded by the SAME workgroup (L1 hits).  With one thread per (pixel, quad) in
+    // channel-major order a 728-channel pixel filled 0.7 of a workgroup, its neighbours sat in adjacent workgroups -- which
+    // the dispatcher deals to different XCDs -- and every input line crossed the fabric three times (53 us for the
+    // 32 x 32 x 728 maps; a copy of the same bytes takes 30).
+    (void)nthreads;
+    const int ncb = (C4t + 15) >> 4, npb = (W + 15) >> 4;
+    int bidx = blockIdx.x;
+    const int cblk = bidx % ncb;
+    bidx /= ncb;
+    const int pblk = bidx % npb;
+    bidx /= npb;
+    const int strip = bidx % nstrip;
+    const long b = bidx / nstrip;
+    const int c4o = cblk * 16 + (threadIdx.x & 15);
+    const int ox = pblk * 16 + (threadIdx.x >> 4);
+    if (c4o >= C4t || ox >= W) return;
     const bool padq = SPLIT && c4o >= C4;
     const int c4 = padq ? C4 - 1 : c4o;
-    long t = tid / C4t;
-    const int ox = (int)(t % W);
-    t /= W;
-    const int strip = (int)(t % nstrip);
-    const long b = t / nstrip;
     const int C = C4 * 4;
 
     float4 wk[9];
@@ -57,20 +68,42 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
     const int oy0 = strip * TH;
     const bool hasl = ox > 0, hasr = ox + 1 < W;
 
+    // Every load is unconditional (row and column indices clamped into the image, the value replaced by zero afterwards
+    // where TF SAME pads) and the loads of input row t+3 are issued before row t is used: the first version branched
+    // around each of a row's three loads and waited for them at the end of every row -- ten dependent memory round
+    // trips per thread, 53 us for the 32 x 32 x 728 maps that a plain copy moves in 30.
+    constexpr int PF = 3, NR = TH + 2;
+    const long xl = hasl ? -(long)ldx : 0, xr = hasr ? (long)ldx : 0;
+    auto row_ptr = [&](int tt) {
+        int iy = oy0 - 1 + tt;
+        iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+        return xb + ((long)iy * W + ox) * ldx;
+    };
+    float4 rc[PF], rl[PF], rr[PF];
+#pragma unroll
+    for (int t0 = 0; t0 < PF && t0 < NR; ++t0) {
+        const float* row = row_ptr(t0);
+        rc[t0] = *reinterpret_cast<const float4*>(row);
+        rl[t0] = *reinterpret_cast<const float4*>(row + xl);
+        rr[t0] = *reinterpret_cast<const float4*>(row + xr);
+    }
     float4 s0 = f4zero(), s1 = f4zero();  // s0: top+mid of output (t-2); s1: top of output (t-1)
 #pragma unroll
-    for (int tt = 0; tt < TH + 2; ++tt) {
+    for (int tt = 0; tt < NR; ++tt) {
         const int iy = oy0 - 1 + tt;
-        float4 h0 = f4zero(), h1 = f4zero(), h2 = f4zero();
-        if (iy >= 0 && iy < H) {
-            const float* row = xb + ((long)iy * W + ox) * ldx;
-            const float4 c = *reinterpret_cast<const float4*>(row);
-            const float4 l = hasl ? *reinterpret_cast<const float4*>(row - ldx) : f4zero();
-            const float4 r = hasr ? *reinterpret_cast<const float4*>(row + ldx) : f4zero();
-            h0 = fma4(wk[0], l, fma4(wk[1], c, fma4(wk[2], r, h0)));
-            h1 = fma4(wk[3], l, fma4(wk[4], c, fma4(wk[5], r, h1)));
-            h2 = fma4(wk[6], l, fma4(wk[7], c, fma4(wk[8], r, h2)));
+        const bool ok = iy >= 0 && iy < H;
+        const float4 c = ok ? rc[tt % PF] : f4zero();
+        const float4 l = ok && hasl ? rl[tt % PF] : f4zero();
+        const float4 r = ok && hasr ? rr[tt % PF] : f4zero();
+        if (tt + PF < NR) {
+            const float* row = row_ptr(tt + PF);
+            rc[tt % PF] = *reinterpret_cast<const float4*>(row);
+            rl[tt % PF] = *reinterpret_cast<const float4*>(row + xl);
+            rr[tt % PF] = *reinterpret_cast<const float4*>(row + xr);
         }
+        const float4 h0 = fma4(wk[0], l, fma4(wk[1], c, fma4(wk[2], r, f4zero())));
+        const float4 h1 = fma4(wk[3], l, fma4(wk[4], c, fma4(wk[5], r, f4zero())));
+        const float4 h2 = fma4(wk[6], l, fma4(wk[7], c, fma4(wk[8], r, f4zero())));
         if (tt >= 2) {
             const int oy = oy0 + tt - 2;
             if (oy < H) emd::dw_store<SPLIT>(y, (b * H + oy) * (long)W + ox, ldy, c4o, padq ? f4zero() : add4(s0, h2));
@@ -501,7 +534,8 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
         // short images keep 8 so that small maps still spread over the chip
         const int TH = H >= 64 ? 16 : 8;
         const int nstrip = (H + TH - 1) / TH;
-        const long nthreads = (long)B * nstrip * W * C4t;
+        const long nblocks = (long)B * nstrip * ((W + 15) / 16) * ((C4t + 15) / 16);
+        const long nthreads = nblocks * 256;
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
         if (TH == 16)
