@@ -119,16 +119,22 @@ __global__ __launch_bounds__(256) void dw3x3_generic(const float* __restrict__ x
                                                      const float* __restrict__ w, float* __restrict__ y,
                                                      int ldy, int H, int W, int C4, int Ho, int Wo,
                                                      int stride, int rate, int pt, int pl, long nthreads, int C4t) {
-    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (tid >= nthreads) return;
-    const int c4o = (int)(tid % C4t);
+    // a workgroup = 4 x 4 output pixels x 16 channel quads: the overlapping windows of neighbouring outputs are served by
+    // the workgroup's L1 instead of by neighbouring workgroups on other XCDs (see dw3x3_s1_roll)
+    (void)nthreads;
+    const int ncb = (C4t + 15) >> 4, npx = (Wo + 3) >> 2, npy = (Ho + 3) >> 2;
+    int bidx = blockIdx.x;
+    const int cblk = bidx % ncb;
+    bidx /= ncb;
+    const int bx = bidx % npx;
+    bidx /= npx;
+    const int by = bidx % npy;
+    const long b = bidx / npy;
+    const int c4o = cblk * 16 + (threadIdx.x & 15);
+    const int ox = bx * 4 + ((threadIdx.x >> 4) & 3), oy = by * 4 + (threadIdx.x >> 6);
+    if (c4o >= C4t || ox >= Wo || oy >= Ho) return;
     const bool padq = SPLIT && c4o >= C4;
     const int c4 = padq ? C4 - 1 : c4o;
-    long t = tid / C4t;
-    const int ox = (int)(t % Wo);
-    t /= Wo;
-    const int oy = (int)(t % Ho);
-    const long b = t / Ho;
     const int C = C4 * 4;
     const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
     float4 acc = f4zero();
@@ -544,7 +550,7 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
             hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t);
         return emd::check_launch("dw3x3_s1_roll");
     }
-    const long nthreads = (long)B * Ho * Wo * C4t;
+    const long nthreads = (long)B * ((Ho + 3) / 4) * ((Wo + 3) / 4) * ((C4t + 15) / 16) * 256;
     int rc = grid_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL((dw3x3_generic<SPLIT>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, Ho, Wo, stride, rate, pt,

@@ -24,17 +24,22 @@ template <bool SPLIT = false>
 __global__ __launch_bounds__(256) void dw3x3_reflect_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                             float* __restrict__ y, int ldy, int H, int W, int C4, int Ho,
                                                             int Wo, int stride, long nthreads, int C4t) {
-    // C4t = channel quads per pixel that have a thread: C4, or ceil32(C)/4 when the split32 padding is written too
-    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (tid >= nthreads) return;
-    const int c4o = (int)(tid % C4t);
+    // C4t = channel quads per pixel that have a thread: C4, or ceil32(C)/4 when the split32 padding is written too.
+    // A workgroup = 4 x 4 output pixels x 16 channel quads: overlapping windows are served by the workgroup's L1.
+    (void)nthreads;
+    const int ncb = (C4t + 15) >> 4, npx = (Wo + 3) >> 2, npy = (Ho + 3) >> 2;
+    int bidx = blockIdx.x;
+    const int cblk = bidx % ncb;
+    bidx /= ncb;
+    const int bx = bidx % npx;
+    bidx /= npx;
+    const int by = bidx % npy;
+    const long b = bidx / npy;
+    const int c4o = cblk * 16 + (threadIdx.x & 15);
+    const int ox = bx * 4 + ((threadIdx.x >> 4) & 3), oy = by * 4 + (threadIdx.x >> 6);
+    if (c4o >= C4t || ox >= Wo || oy >= Ho) return;
     const bool padq = SPLIT && c4o >= C4;
     const int c4 = padq ? C4 - 1 : c4o;
-    long t = tid / C4t;
-    const int ox = (int)(t % Wo);
-    t /= Wo;
-    const int oy = (int)(t % Ho);
-    const long b = t / Ho;
     const int C = C4 * 4;
     const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
     float4 acc = f4zero();
@@ -178,7 +183,7 @@ static int dw3x3_reflect_launch(const float* x, int ldx, const float* w, float* 
     if (B == 0) return EMD_OK;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;  // VALID on the (H+2) x (W+2) padded input
     const int C4t = SPLIT ? Cp / 4 : C / 4;
-    const long nthreads = (long)B * Ho * Wo * C4t;
+    const long nthreads = (long)B * ((Ho + 3) / 4) * ((Wo + 3) / 4) * ((C4t + 15) / 16) * 256;
     unsigned nb;
     int rc = blocks_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
