@@ -34,7 +34,7 @@ __device__ __forceinline__ float cout1_out(float s, float pre_bias, int pre_relu
 // down a strip of TH output rows with the three live input rows' horizontal partial sums in registers:
 // an input row is read once per strip (3 shifted 16-B loads) and turned into its contribution as the
 // top / middle / bottom row of a window.  TF SAME: pad 1 on every side.
-template <int TH, bool SPLIT = false>
+template <int TH, bool SPLIT = false, bool REFLECT = false>
 __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x, int ldx,
                                                      const float* __restrict__ w, float* __restrict__ y,
                                                      int ldy, int H, int W, int C4, long nthreads, int nstrip, int C4t) {
@@ -73,9 +73,11 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
     // around each of a row's three loads and waited for them at the end of every row -- ten dependent memory round
     // trips per thread, 53 us for the 32 x 32 x 728 maps that a plain copy moves in 30.
     constexpr int PF = 3, NR = TH + 2;
-    const long xl = hasl ? -(long)ldx : 0, xr = hasr ? (long)ldx : 0;
+    // REFLECT (graph G: tf.pad(REFLECT, 1) + VALID): index -1 -> 1, H -> H-2, in both directions; nothing is zeroed
+    const long xl = hasl ? -(long)ldx : (REFLECT ? (long)ldx : 0), xr = hasr ? (long)ldx : (REFLECT ? -(long)ldx : 0);
     auto row_ptr = [&](int tt) {
         int iy = oy0 - 1 + tt;
+        if (REFLECT) iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
         iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
         return xb + ((long)iy * W + ox) * ldx;
     };
@@ -91,10 +93,10 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
 #pragma unroll
     for (int tt = 0; tt < NR; ++tt) {
         const int iy = oy0 - 1 + tt;
-        const bool ok = iy >= 0 && iy < H;
+        const bool ok = REFLECT || (iy >= 0 && iy < H);
         const float4 c = ok ? rc[tt % PF] : f4zero();
-        const float4 l = ok && hasl ? rl[tt % PF] : f4zero();
-        const float4 r = ok && hasr ? rr[tt % PF] : f4zero();
+        const float4 l = ok && (REFLECT || hasl) ? rl[tt % PF] : f4zero();
+        const float4 r = ok && (REFLECT || hasr) ? rr[tt % PF] : f4zero();
         if (tt + PF < NR) {
             const float* row = row_ptr(tt + PF);
             rc[tt % PF] = *reinterpret_cast<const float4*>(row);
@@ -559,6 +561,27 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
 }
 
 }  // namespace
+
+// stride-1 depthwise over the REFLECT-padded input on the rolling kernel (called by emd_dw3x3_reflect*_f32, gan_ops.hip;
+// arguments already validated there)
+int emd::launch_dw3x3_reflect_roll(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
+                                   bool split, hipStream_t st) {
+    const int C4 = C / 4, C4t = split ? (C + 31) / 32 * 8 : C4;
+    const int TH = H >= 64 ? 16 : 8;
+    const int nstrip = (H + TH - 1) / TH;
+    const long nthreads = (long)B * nstrip * ((W + 15) / 16) * ((C4t + 15) / 16) * 256;
+    unsigned nb;
+    int rc = grid_for(nthreads, &nb);
+    if (rc != EMD_OK) return rc;
+    if (TH == 16) {
+        if (split) hipLaunchKernelGGL((dw3x3_s1_roll<16, true, true>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t);
+        else hipLaunchKernelGGL((dw3x3_s1_roll<16, false, true>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t);
+    } else {
+        if (split) hipLaunchKernelGGL((dw3x3_s1_roll<8, true, true>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t);
+        else hipLaunchKernelGGL((dw3x3_s1_roll<8, false, true>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t);
+    }
+    return emd::check_launch("dw3x3_s1_roll (reflect)");
+}
 
 extern "C" int emd_dw3x3_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W,
                              int C, int stride, int rate, emd_stream_t stream) {

@@ -29,6 +29,10 @@ inline int check_launch(const char* kernel) {
     return EMD_OK;
 }
 
+// dw_misc.hip: the rolling depthwise kernel with REFLECT borders (graph G), used by gan_ops.hip
+int launch_dw3x3_reflect_roll(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C, bool split,
+                              hipStream_t st);
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr int kWave = 64;  // CDNA4 wavefront

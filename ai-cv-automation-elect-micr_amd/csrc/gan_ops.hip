@@ -181,6 +181,8 @@ static int dw3x3_reflect_launch(const float* x, int ldx, const float* w, float* 
         EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && emd::aligned16(x) &&
                         emd::aligned16(y) && emd::aligned16(w), EMD_E_ALIGN, "emd_dw3x3_reflect_f32: alignment");
     if (B == 0) return EMD_OK;
+    if (stride == 1)   // the rolling kernel (each input row read once per strip): 70 -> 40 us on the 32 x 32 x 768 maps
+        return emd::launch_dw3x3_reflect_roll(x, ldx, w, y, ldy, B, H, W, C, SPLIT, static_cast<hipStream_t>(stream));
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;  // VALID on the (H+2) x (W+2) padded input
     const int C4t = SPLIT ? Cp / 4 : C / 4;
     const long nthreads = (long)B * ((Ho + 3) / 4) * ((Wo + 3) / 4) * ((C4t + 15) / 16) * 256;
