@@ -16,6 +16,8 @@
 //      outputs), accumulates the 9 taps in fp32, splits to bf16 hi/lo and writes the A planes;
 //   3. v_mfma_f32_32x32x16_bf16, split-bf16 (3 passes) as in gemm_conv.hip; W tile staged like there.
 // Epilogue identical to gemm_conv.hip (fp32 LDS staging, 16-byte stores / residual loads).
+#include <cstdlib>
+
 #include "mfma_common.hpp"
 
 using namespace emd;
@@ -36,6 +38,7 @@ struct SepParams {
     int H, W, Cin, Cpad, N;
     int ldx, ldy, ldres, act;
     int reflect;          // 1: the patch border is tf.pad(REFLECT) of the image (graph G), 0: zero (TF SAME)
+    int tpw;              // output tiles per workgroup, side by side along W
 };
 
 template <int BN, int PASSES>
@@ -64,26 +67,31 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int xbase = blockIdx.x * p.tpw * TW, y0 = blockIdx.y * TH;
+    int x0 = xbase;       // tile whose chunks are being computed (the epilogue's tile)
     const long img = (long)blockIdx.z * p.H * p.W;  // pixel index of this image's (0,0)
 
     // ---- patch loader role: float4 #idx of the patch = (patch pixel idx/8, channel group idx%8)
     long long poff[P_PASSES];  // element offset of the source pixel + channel group, or -1 (zero padding / unused)
+    auto set_tile = [&](int xt) {
 #pragma unroll
-    for (int q = 0; q < P_PASSES; ++q) {
-        const int idx = tid + q * 256;
-        long long o = -1;
-        if (idx < NPX * 8) {
-            const int ppx = idx >> 3, py = ppx / PW, px = ppx - py * PW;
-            int gy = y0 - 1 + py, gx = x0 - 1 + px;
-            if (p.reflect) {  // index -1 -> 1, H -> H-2
-                gy = gy < 0 ? -gy : (gy >= p.H ? 2 * p.H - 2 - gy : gy);
-                gx = gx < 0 ? -gx : (gx >= p.W ? 2 * p.W - 2 - gx : gx);
+        for (int q = 0; q < P_PASSES; ++q) {
+            const int idx = tid + q * 256;
+            long long o = -1;
+            if (idx < NPX * 8) {
+                const int ppx = idx >> 3, py = ppx / PW, px = ppx - py * PW;
+                int gy = y0 - 1 + py, gx = xt - 1 + px;
+                if (p.reflect) {  // index -1 -> 1, H -> H-2
+                    gy = gy < 0 ? -gy : (gy >= p.H ? 2 * p.H - 2 - gy : gy);
+                    gx = gx < 0 ? -gx : (gx >= p.W ? 2 * p.W - 2 - gx : gx);
+                }
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) o = (img + (long)gy * p.W + gx) * p.ldx + (idx & 7) * 4;
             }
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) o = (img + (long)gy * p.W + gx) * p.ldx + (idx & 7) * 4;
+            poff[q] = o;
         }
-        poff[q] = o;
-    }
+    };
+    set_tile(xbase);
+    int ptile = 0;             // tile the patch offsets belong to
     // ---- W loader role
     const int w_col = (tid & 3) * 8, w_row = tid >> 2;  // + 64 rows per pass
     const uint16_t* __restrict__ whi = p.Whi + (long)w_row * p.Cpad + w_col;
@@ -106,9 +114,11 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nchunks = p.Cin / BK;
+    const int total = p.tpw * nchunks;   // (tile, chunk) steps of this workgroup: the staging pipeline runs on across tiles, so
+                                         // a tile's epilogue overlaps the loads of the next tile's first chunk
     const int fr = lane & 31, fh = lane >> 5;
 
-    for (int it = -1; it < nchunks; ++it) {
+    for (int it = -1; it < total; ++it) {
         if (it >= 0) {
             // staged registers (chunk `it`) -> LDS
 #pragma unroll
@@ -126,8 +136,13 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
         }
         // stage chunk it+1 (the last iteration re-loads its own chunk: branch-free).  Issued BEFORE the
         // depthwise work below so the loads have the depthwise + MFMA phases (not just the MFMAs) to land.
-        const int nx = it + 1 < nchunks ? it + 1 : it;
-        const int c0n = nx * BK;
+        const int nx = it + 1 < total ? it + 1 : it;
+        const int ntile = nx / nchunks;
+        const int c0n = (nx - ntile * nchunks) * BK;
+        if (ntile != ptile) {   // block-uniform: the next step belongs to the next tile
+            ptile = ntile;
+            set_tile(xbase + ntile * TW);
+        }
 #pragma unroll
         for (int q = 0; q < P_PASSES; ++q) {
             const bool ok = poff[q] >= 0;
@@ -198,80 +213,101 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                 }
         }
         __syncthreads();  // (3) fragment reads done before the next chunk overwrites patch / A / B
-    }
+        if ((it + 1) % nchunks != 0) continue;   // more chunks of this tile to come
 
-    // ---- epilogue (see gemm_conv.hip): accumulators -> fp32 LDS tile -> 16-byte stores along the channel axis
+        // ---- epilogue (see gemm_conv.hip): accumulators -> fp32 LDS tile -> 16-byte stores along the channel axis
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int r = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                stage[r][wn * (BN / WN) + j * 32 + fr] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e) {
+                    const int r = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    stage[r][wn * (BN / WN) + j * 32 + fr] = acc[i][j][e];
+                }
+        __syncthreads();
+        constexpr int C4 = BN / 4;
+        constexpr int ROWS_PER_PASS = 256 / C4;
+        const int n = (tid % C4) * 4, er = tid / C4;
+        if (n < p.N) {
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
+            f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+            if (p.scale2) {
+                s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
+                t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
             }
-    __syncthreads();
-    constexpr int C4 = BN / 4;
-    constexpr int ROWS_PER_PASS = 256 / C4;
-    const int n = (tid % C4) * 4, er = tid / C4;
-    if (n < p.N) {
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
-        f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale2) {
-            s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
-            t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
-        }
-        float* __restrict__ outp = p.y;
-        // one clamp form for every activation code: v = min(max(max(v, lo), slope*v), hi) -- (lo, slope, hi) = none: (-inf, 1, inf); relu6: (0, 1, 6);
-        // relu: (0, 1, inf); leaky relu (graph G): (-inf, 0.2, inf); a clamped negative comes out as +0, as tf.nn.relu6 gives it
-        const float hi = p.act == 1 ? 6.f : __builtin_inff();
-        const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
-        const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
-        const bool two = p.scale2 != nullptr;
-        auto finish = [&](f32x4 v) {
+            float* __restrict__ outp = p.y;
+            // one clamp form for every activation code: v = min(max(max(v, lo), slope*v), hi) -- (lo, slope, hi) = none: (-inf, 1, inf); relu6: (0, 1, 6);
+            // relu: (0, 1, inf); leaky relu (graph G): (-inf, 0.2, inf); a clamped negative comes out as +0, as tf.nn.relu6 gives it
+            const float hi = p.act == 1 ? 6.f : __builtin_inff();
+            const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
+            const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+            const bool two = p.scale2 != nullptr;
+            auto finish = [&](f32x4 v) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float u = fmaf(v[c], s1[c], t1[c]);
-                u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
-                if (two) u = fminf(fmaxf(fmaf(u, s2[c], t2[c]), 0.f), hi2);
-                v[c] = u;
-            }
-            return v;
-        };
-        constexpr int NROWS = BM / ROWS_PER_PASS;
-        if (p.res) {
-            // all residual values of this thread's rows are requested before the first one is used
-            f32x4 rv[NROWS];
+                for (int c = 0; c < 4; ++c) {
+                    float u = fmaf(v[c], s1[c], t1[c]);
+                    u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                    if (two) u = fminf(fmaxf(fmaf(u, s2[c], t2[c]), 0.f), hi2);
+                    v[c] = u;
+                }
+                return v;
+            };
+            constexpr int NROWS = BM / ROWS_PER_PASS;
+            if (p.res) {
+                // residual values are requested four rows at a time, before the first of them is used (the registers of the
+                // next chunk's prefetch are live here: no room for all NROWS at once)
 #pragma unroll
-            for (int k = 0; k < NROWS; ++k) {
-                const int r = er + k * ROWS_PER_PASS;
-                const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
-                rv[k] = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n);
-            }
+                for (int k0 = 0; k0 < NROWS; k0 += 4) {
+                    f32x4 rv[4];
 #pragma unroll
-            for (int k = 0; k < NROWS; ++k) {
-                const int r = er + k * ROWS_PER_PASS;
-                const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
-                *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n])) + rv[k];
-            }
-        } else {
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = er + (k0 + k) * ROWS_PER_PASS;
+                        const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
+                        rv[k] = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = er + (k0 + k) * ROWS_PER_PASS;
+                        const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
+                        *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n])) + rv[k];
+                    }
+                }
+            } else {
 #pragma unroll 4
-            for (int r = er; r < BM; r += ROWS_PER_PASS) {
-                const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
-                *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n]));
+                for (int r = er; r < BM; r += ROWS_PER_PASS) {
+                    const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
+                    *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n]));
+                }
             }
         }
+        __syncthreads();  // the staging tile is read out before the next tile's patch overwrites it
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        x0 += TW;
     }
 }
 
 template <int BN>
 int launch(const SepParams& p, int B, int passes, hipStream_t st) {
-    const dim3 grid(p.W / 16, p.H / 8, B);
+    SepParams q = p;
+    const int tiles_w = p.W / 16;
+    const long wgs1 = (long)tiles_w * (p.H / 8) * B;
+    static const int force = [] { const char* e = getenv("EMD_SEP_TPW"); return e ? atoi(e) : 0; }();
+    q.tpw = 1;
+    for (int t = 8; t >= 2; t >>= 1)   // several tiles per workgroup where that still leaves >= 8 workgroups per CU
+        if (tiles_w % t == 0 && wgs1 / t >= 2048) { q.tpw = t; break; }
+    if (force > 0 && tiles_w % force == 0) q.tpw = force;
+    const dim3 grid(tiles_w / q.tpw, p.H / 8, B);
     if (passes == 3)
-        hipLaunchKernelGGL((sep_fused_kernel<BN, 3>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((sep_fused_kernel<BN, 3>), grid, dim3(256), 0, st, q);
     else
-        hipLaunchKernelGGL((sep_fused_kernel<BN, 1>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((sep_fused_kernel<BN, 1>), grid, dim3(256), 0, st, q);
     return emd::check_launch("sep_fused_kernel");
 }
 
