@@ -622,14 +622,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
 
 // Persistent form of the same GEMM: one workgroup per CU walks over its tiles (vb = blockIdx.x, + gridDim.x, ...) and the
 // three-stage DMA / fragment pipeline simply runs on across tile boundaries: during a tile's last two K steps the first
-// two K steps of the NEXT tile are already being fetched, so only the first tile of a workgroup pays a prologue.  The
-// epilogue never goes through LDS and is not a phase of its own: when a tile's K loop ends, its accumulators get the
-// per-channel affine(s) + activation in registers (o[64]) and are stored -- straight from the MFMA C/D layout, 32 lanes x 4 B
-// = one 128-byte run of one pixel per half wave -- in 8 blocks of 8 dwords per lane during the next tile's K loop: block s
-// leaves at the first K step of the s-th eighth of the loop, the residual values of block s+1 are requested there.  The
-// non-persistent kernel spends 8 % of a workgroup's life in the prologue and 16 % in an exposed epilogue (all CUs reach it at
-// once, in lockstep rounds: 7.7 TB/s of store demand), a third more with a residual; here only the last tile's is exposed.
-// Needs Cin >= 256 (8 K steps), M % 256 == 0, and the lo weight plane within 2 GB behind the hi plane.
+// two K steps of the NEXT tile are already being fetched, and they land while this tile's epilogue runs -- only the first
+// tile of a workgroup pays a prologue.  The epilogue does not go through LDS (the stages hold the next tile): the
+// accumulators get the per-channel affine(s) + activation and leave straight from the MFMA C/D layout, 32 lanes x 4 B = one
+// 128-byte run of one pixel per half wave, in 8 blocks of 8 dwords per lane; the residual values of block s+1 are requested
+// while block s is stored.  Needs Cin >= 64 (two K steps), M % 256 == 0, and the lo weight plane within 2 GB behind the hi plane.
 __global__ __launch_bounds__(512, 2) void gemm_split_persist_kernel(const SplitGemmParams p) {
     constexpr int BM = 256, NS = 3, WQ = 2;
     constexpr int A_STAGE = BM * 128, W_STAGE = SBN * 128, STAGE = A_STAGE + W_STAGE;
@@ -651,55 +648,6 @@ __global__ __launch_bounds__(512, 2) void gemm_split_persist_kernel(const SplitG
     if (p.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
     f32x16 acc[2][2];
-    float o[64];      // the previous tile's finished values, block s = o[8s .. 8s+8)
-    float rres[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) rres[c] = 0.f;
-    long pm0 = 0;
-    int pn0 = 0;
-
-    // block s = (i, j, h) = (s>>2, (s>>1)&1, s&1) of the finished tile: accumulator elements e = 8h .. 8h+7 of MFMA tile
-    // (i, j): rows (e&3) + 8*(e>>2) + 4*(lane>>5) of the 32x32 tile, column lane & 31.  Address = uniform base (scalar
-    // unit) + one per-lane 32-bit offset.
-    const unsigned lrow = wm * 64 + 4 * fh, lcol = wn * 64 + fr;
-    const unsigned loff_c = lrow * (unsigned)p.ldc + lcol, loff_r = lrow * (unsigned)p.ldres + lcol;
-    auto load_res = [&](int sblk) {
-        if (!p.res) return;
-        const int rb = (sblk >> 2) * 32 + (sblk & 1) * 16, cb = ((sblk >> 1) & 1) * 32;
-        const bool nv = (int)(pn0 + cb + lcol) < p.N;
-        const float* ub = p.res + (pm0 + rb) * p.ldres + pn0 + cb;
-        if (nv) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) rres[c] = (ub + ((c & 3) + 8 * (c >> 2)) * p.ldres)[loff_r];
-        }
-    };
-    // all eight sums first (one wait for the residual values), then eight stores back to back
-#define EMD_STORE8(S)                                                                                   \
-    {                                                                                                   \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) rres[c] += o[8 * (S) + c];                        \
-        if (nv) {                                                                                       \
-            _Pragma("unroll") for (int c = 0; c < 8; ++c)(ub + ((c & 3) + 8 * (c >> 2)) * p.ldc)[loff_c] = rres[c]; \
-        }                                                                                               \
-    }
-    auto store8 = [&](int sblk) {
-        const int rb = (sblk >> 2) * 32 + (sblk & 1) * 16, cb = ((sblk >> 1) & 1) * 32;
-        const bool nv = (int)(pn0 + cb + lcol) < p.N;
-        float* ub = p.C + (pm0 + rb) * p.ldc + pn0 + cb;
-        switch (sblk) {   // uniform; static register indices inside each case
-            case 0: EMD_STORE8(0) break;
-            case 1: EMD_STORE8(1) break;
-            case 2: EMD_STORE8(2) break;
-            case 3: EMD_STORE8(3) break;
-            case 4: EMD_STORE8(4) break;
-            case 5: EMD_STORE8(5) break;
-            case 6: EMD_STORE8(6) break;
-            default: EMD_STORE8(7) break;
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) rres[c] = 0.f;
-    };
-#undef EMD_STORE8
-
     struct Frags { bf16x8 ah[2], al[2], bh[2], bl[2]; };
     auto load_frags = [&](Frags& f, const unsigned char* sb, int ks) {
         const int ch = ((ks * 2 + fh) ^ sw) << 4;
@@ -738,16 +686,15 @@ __global__ __launch_bounds__(512, 2) void gemm_split_persist_kernel(const SplitG
         const int wc = dchunk ^ ((wrow >> 1) & 7);
         woff[q] = (unsigned)wrow * (unsigned)p.Ktot * 2u + (wc & 3) * 16 + ((wc & 4) ? p.wlo_delta : 0u);
     }
-    auto issue = [&](int stage, const unsigned char* abase, const unsigned char* wbase, int kt) {
+    auto issue = [&](int stage, const unsigned char* abase, const unsigned char* wbase) {
         unsigned char* sb = smem + stage * STAGE;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(abase + (long)kt * 128 + (long)(q >> 1) * 16 * p.lda_bytes + aoff[q & 1]),
+            __builtin_amdgcn_global_load_lds((gptr_t)(abase + (long)(q >> 1) * 16 * p.lda_bytes + aoff[q & 1]),
                                              (lptr_t)(sb + (wv * 32 + q * 8) * 128), 16, 0, 0);
 #pragma unroll
         for (int q = 0; q < WQ; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (long)kt * 64 + woff[q]),
-                                             (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wbase + woff[q]), (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
     };
     auto tile_origin = [&](int vb, long& m0, int& n0) {   // XCD-aware tile mapping (bijective for any grid size)
         const int q = nblk >> 3, r = nblk & 7, xcd = vb & 7, loc = vb >> 3;
@@ -762,20 +709,24 @@ __global__ __launch_bounds__(512, 2) void gemm_split_persist_kernel(const SplitG
     tile_origin(vb, m0, n0);
     const unsigned char* abase = p.A + m0 * p.lda_bytes;
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.Whi + (long)n0 * p.Ktot);
-    issue(0, abase, wbase, 0);
-    issue(1, abase, wbase, 1);     // nk >= 8
+    issue(0, abase, wbase);
+    issue(1, abase + 128, wbase + 64);     // nk >= 2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
     Frags f0, f1;
     load_frags(f0, smem, 0);
     int s0 = 0, s1 = 1, s2 = 2;    // stage of K step kt / kt+1 / the one being refilled
-    bool have_prev = false, first_step = true;
-    // the DMA of the coming step, prepared one step ahead so that the scalar arithmetic sits between MFMAs, not between
-    // the barrier and the first instruction that matters
+    bool first_tile = true;
+    // the DMA of the coming step, prepared one step ahead so that the scalar arithmetic sits between MFMAs
     const unsigned char* dma_a = abase + 2 * 128;
     const unsigned char* dma_w = wbase + 2 * 64;
-    int pend = 0;                  // vector-memory operations issued after the last DMA group (stores, residual loads)
+
+    const unsigned lrow = wm * 64 + 4 * fh, lcol = wn * 64 + fr;
+    const unsigned loff_c = lrow * (unsigned)p.ldc + lcol, loff_r = lrow * (unsigned)p.ldres + lcol;
+    const float hi = p.act == 1 ? 6.f : __builtin_inff();
+    const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;
+    const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
 
     while (true) {
         // the tile after this one (its first two K steps are fetched during this tile's last two)
@@ -793,29 +744,20 @@ __global__ __launch_bounds__(512, 2) void gemm_split_persist_kernel(const SplitG
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        int sblk = 0;
-        int seg_k = __builtin_amdgcn_readfirstlane(have_prev ? 0 : -1);   // K step at whose end block sblk of the previous tile leaves
 
         for (int kt = 0; kt < nk; ++kt) {
-            if (!first_step) {
-                // K step kt+1 has landed for every wave (the stores / residual loads issued behind its DMA may stay in
-                // flight), and every wave is done reading the stage about to be refilled
-                if (pend == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (pend == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            first_step = false;
-            issue(s2, dma_a, dma_w, 0);
+            issue(s2, dma_a, dma_w);
             load_frags(f1, smem + s0 * STAGE, 1);
             mfma12(f0);
             load_frags(f0, smem + s1 * STAGE, 0);
             mfma12(f1);
-            {
-                const int nx = kt + 3;         // the step after this one fetches K step kt+3: beyond this tile's end that is the
-                const bool cur = nx < nk;      // next tile's first K steps (for the last tile: its own again, into a stage nobody computes on)
-                dma_a = (cur ? abase : abase_n) + (long)(cur ? nx : nx - nk) * 128;
-                dma_w = (cur ? wbase : wbase_n) + (long)(cur ? nx : nx - nk) * 64;
+            // the step after this one fetches K step kt+3: beyond this tile's end that is the next tile's first K steps (for the
+            // last tile: its own again, into a stage nobody computes on)
+            dma_a += 128;
+            dma_w += 64;
+            if (kt + 3 == nk) {
+                dma_a = abase_n;
+                dma_w = wbase_n;
             }
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
@@ -835,70 +777,64 @@ __global__ __launch_bounds__(512, 2) void gemm_split_persist_kernel(const SplitG
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             const int t = s0; s0 = s1; s1 = s2; s2 = t;
-            __builtin_amdgcn_sched_barrier(0);
-            pend = 0;
-            if (kt == seg_k) {   // uniform: block sblk of the previous tile leaves behind this step's DMA
-                store8(sblk);
-                ++sblk;
-                seg_k = sblk < 8 ? (sblk * nk) >> 3 : -1;
-                pend = 8;
-                if (sblk < 8 && p.res) {
-                    load_res(sblk);
-                    pend = 16;
-                }
-            }
+            // the step ENDS with the wait + barrier that certify the next one: K step kt+2 has landed for every wave (the
+            // previous tile's stores are older than this step's DMA, so they are covered too), and every wave is done
+            // reading the stage the next step refills
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
-        if (p.stamps && !have_prev) t3 = __builtin_amdgcn_s_memtime();
+        if (p.stamps && first_tile) t3 = __builtin_amdgcn_s_memtime();
+        first_tile = false;
 
-        // the finished tile: affine(s) + activation in registers.  One clamp form for every activation code:
-        // v = min(max(max(v, lo), slope*v), hi) -- (lo, slope, hi) = none: (-inf, 1, inf); relu6: (0, 1, 6); relu: 0, inf; leaky relu: 0.2, inf
+        // ---- epilogue of this tile, straight from the accumulators.  Block s = (i, j, h) = (s>>2, (s>>1)&1, s&1): elements
+        // e = 8h .. 8h+7 of MFMA tile (i, j): rows (e&3) + 8*(e>>2) + 4*(lane>>5), column lane & 31.  Address = uniform
+        // base (scalar unit) + one per-lane 32-bit offset.  One clamp form for every activation code (see gemm_split_kernel).
         {
-            const float hi = p.act == 1 ? 6.f : __builtin_inff();
-        const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
-            const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+            float s1v[2], t1v[2], s2v[2], t2v[2];
+            bool nv[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 64 + j * 32 + fr;
-                const bool nv = n < p.N;
-                const float s1v = nv ? p.scale1[n] : 0.f, t1v = nv ? p.shift1[n] : 0.f;
-                if (p.scale2) {
-                    const float s2v = nv ? p.scale2[n] : 1.f, t2v = nv ? p.shift2[n] : 0.f;
+                nv[j] = n < p.N;
+                s1v[j] = nv[j] ? p.scale1[n] : 0.f;
+                t1v[j] = nv[j] ? p.shift1[n] : 0.f;
+                s2v[j] = (p.scale2 && nv[j]) ? p.scale2[n] : 1.f;
+                t2v[j] = (p.scale2 && nv[j]) ? p.shift2[n] : 0.f;
+            }
+            float rres[8];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+            for (int c = 0; c < 8; ++c) rres[c] = 0.f;
+            auto load_res = [&](int i, int j, int h) {
+                const float* ub = p.res + (m0 + i * 32 + h * 16) * p.ldres + n0 + j * 32;
+                if (nv[j]) {
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            float v = fmaf(acc[i][j][e], s1v, t1v);
-                            v = fminf(fmaxf(fmaxf(v, lo), slope * v), hi);
-                            o[i * 32 + j * 16 + e] = fminf(fmaxf(fmaf(v, s2v, t2v), 0.f), hi2);
-                        }
-                } else {
+                    for (int c = 0; c < 8; ++c) rres[c] = (ub + ((c & 3) + 8 * (c >> 2)) * p.ldres)[loff_r];
+                }
+            };
+            if (p.res) load_res(0, 0, 0);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+            for (int s = 0; s < 8; ++s) {
+                const int i = s >> 2, j = (s >> 1) & 1, h = s & 1;
+                float v[8];
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const float v = fmaf(acc[i][j][e], s1v, t1v);
-                            o[i * 32 + j * 16 + e] = fminf(fmaxf(fmaxf(v, lo), slope * v), hi);
-                        }
+                for (int c = 0; c < 8; ++c) {
+                    float u = fmaf(acc[i][j][8 * h + c], s1v[j], t1v[j]);
+                    u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                    if (p.scale2) u = fminf(fmaxf(fmaf(u, s2v[j], t2v[j]), 0.f), hi2);
+                    v[c] = u + rres[c];
+                }
+                if (p.res && s < 7) load_res((s + 1) >> 2, ((s + 1) >> 1) & 1, (s + 1) & 1);
+                float* ub = p.C + (m0 + i * 32 + h * 16) * p.ldc + n0 + j * 32;
+                if (nv[j]) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) (ub + ((c & 3) + 8 * (c >> 2)) * p.ldc)[loff_c] = v[c];
                 }
             }
-        }
-        pm0 = m0;
-        pn0 = n0;
-        have_prev = true;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scale / shift loads above were waited for: nothing is in flight
-        pend = 0;
-        if (p.res) {
-            load_res(0);
-            pend = 8;
         }
         if (!has_next) break;
         vb = vbn; m0 = m0n; n0 = n0n; abase = abase_n; wbase = wbase_n;
     }
     if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
-    for (int sblk = 0; sblk < 8; ++sblk) {
-        if (sblk > 0) load_res(sblk);
-        store8(sblk);
-    }
     if (p.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long* o8 = p.stamps + (long)blockIdx.x * 8;
@@ -996,7 +932,7 @@ extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (v == 1) hipLaunchKernelGGL((gemm_split_kernel<256, 3>), dim3((unsigned)nblk), dim3(512), 0, st, p);
     else if (v == 0) hipLaunchKernelGGL((gemm_split_kernel<256, 2>), dim3((unsigned)nblk), dim3(512), 0, st, p);
-    else if (v == 4 && Cin >= 256 && M % 256 == 0 && wlo > whi &&
+    else if (v == 4 && Cin >= 64 && M % 256 == 0 && wlo > whi &&
              (reinterpret_cast<uintptr_t>(wlo) - reinterpret_cast<uintptr_t>(whi)) < 0x7fffffffu && (long)256 * p.lda_bytes < 0x7fffffffL) {
         p.wlo_delta = (unsigned)(reinterpret_cast<uintptr_t>(wlo) - reinterpret_cast<uintptr_t>(whi));
         int ncu = 256;
