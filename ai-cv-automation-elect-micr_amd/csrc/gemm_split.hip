@@ -321,6 +321,212 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
     }
 }
 
+// The pipelined kernel on v_mfma_f32_16x16x32_bf16 (dev variant 5): a lane's 16-byte fragment read covers a whole 32-wide K
+// step of one row (row = lane & 15, chunk = lane >> 4), so a K step is 16 fragment reads + 48 MFMAs of 16 cycles instead of
+// 2 x (8 + 12 x 32 cycles); MI355X_MICROARCH.md reports the 16x16x32 shape holding a ~1.15x higher clock under load.
+// Two whole fragment sets alternate between K steps.  The hardware sums a K step in a different order than 32x32x16 does,
+// so results are not bit-identical to emd_conv1x1_f32 (same error class, checked against the oracle).
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+__global__ __launch_bounds__(512, 2) void gemm_split16_kernel(const SplitGemmParams p) {
+    constexpr int BM = 256, NS = 3, WQ = 2, NT = 512;
+    constexpr int A_STAGE = BM * 128, W_STAGE = SBN * 128, STAGE = A_STAGE + W_STAGE;
+    constexpr int EPI_LD = SBN + 4;
+    constexpr int EPI_BYTES = BM * EPI_LD * 4;
+    constexpr int SMEM_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int nblk = p.n_mtiles * p.n_ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.n_ntiles, nt = bid % p.n_ntiles;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * SBN;
+
+    const int drow = lane >> 3, dchunk = lane & 7;
+    const unsigned char* asrc[4];
+    const unsigned char* wsrc[WQ];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wv * 32 + q * 8 + drow;
+        const int c = dchunk ^ ((row >> 1) & 7);
+        long m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        asrc[q] = p.A + m * p.lda_bytes + c * 16;
+    }
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+        const int row = wv * (WQ * 8) + q * 8 + drow;
+        const int c = dchunk ^ ((row >> 1) & 7);
+        const uint16_t* plane = (c & 4) ? p.Wlo : p.Whi;
+        wsrc[q] = reinterpret_cast<const unsigned char*>(plane + (long)(n0 + row) * p.Ktot + (c & 3) * 8);
+    }
+    auto issue = [&](int stage, int kt) {
+        unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (long)kt * 128), (lptr_t)(sb + (wv * 32 + q * 8) * 128), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[q] + (long)kt * 64),
+                                             (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
+    };
+
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing: lane reads row r16 = lane & 15 of a 16-row block, logical chunk plane*4 + (lane >> 4)
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int sw = (r16 >> 1) & 7;
+    const int ch_hi = ((q4 ^ sw) & 7) << 4, ch_lo = (((4 + q4) ^ sw) & 7) << 4;
+    const int a_off = (wm * 64 + r16) * 128;              // + i*16*128
+    const int w_off = A_STAGE + (wn * 64 + r16) * 128;    // + j*16*128
+    struct Frags { bf16x8 ah[4], al[4], bh[4], bl[4]; };
+    auto load_frags = [&](Frags& f, const unsigned char* sb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 2048 + ch_hi);
+            f.al[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 2048 + ch_lo);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 2048 + ch_hi);
+            f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 2048 + ch_lo);
+        }
+    };
+    auto mfma48 = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    const int nk = (p.Cin + SBK - 1) / SBK;
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, r0 = 0;
+    if (p.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    issue(0, 0);
+    issue(1, 1 < nk ? 1 : nk - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
+    Frags f0, f1;
+    load_frags(f0, smem);
+    int s0 = 0, s1 = 1, s2 = 2;
+    auto step = [&](Frags& cur, Frags& nxt, int kt) {
+        if (kt > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        issue(s2, kt + 2 < nk ? kt + 2 : nk - 1);
+        load_frags(nxt, smem + s1 * STAGE);      // tile kt+1: certified by this step's barrier
+        mfma48(cur);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        const int t = s0; s0 = s1; s1 = s2; s2 = t;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(f0, f1, kt);
+        if (kt + 1 < nk) step(f1, f0, kt + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue: C/D layout of mfma_16x16: col = lane & 15, rows 4*(lane >> 4) + e
+    float(*stage)[EPI_LD] = reinterpret_cast<float(*)[EPI_LD]>(smem);
+    constexpr int C4 = SBN / 4;
+    constexpr int ROWS_PER_PASS = NT / C4;
+    constexpr int NROWS = BM / ROWS_PER_PASS;
+    const int ec = (tid % C4) * 4, er = tid / C4;
+    const int n = n0 + ec;
+    const bool ncol = n < p.N;
+    f32x4 rv[NROWS];
+    if (p.res) {
+#pragma unroll
+        for (int k = 0; k < NROWS; ++k) {
+            const long pix = m0 + er + k * ROWS_PER_PASS;
+            rv[k] = (ncol && pix < p.M) ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stage[wm * 64 + i * 16 + 4 * q4 + e][wn * 64 + j * 16 + r16] = acc[i][j][e];
+    __syncthreads();
+    if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
+    if (ncol) {
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
+        f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale2) {
+            s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
+            t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
+        }
+        float* __restrict__ outp = p.C;
+        const float hi = p.act == 1 ? 6.f : __builtin_inff();
+        const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;
+        const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+        const bool two = p.scale2 != nullptr;
+        auto finish = [&](f32x4 v) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float u = fmaf(v[c], s1[c], t1[c]);
+                u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                if (two) u = fminf(fmaxf(fmaf(u, s2[c], t2[c]), 0.f), hi2);
+                v[c] = u;
+            }
+            return v;
+        };
+        if (p.res) {
+#pragma unroll
+            for (int k = 0; k < NROWS; ++k) {
+                const int r = er + k * ROWS_PER_PASS;
+                const long pix = m0 + r;
+                if (pix < p.M) *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec])) + rv[k];
+            }
+        } else {
+#pragma unroll 4
+            for (int r = er; r < BM; r += ROWS_PER_PASS) {
+                const long pix = m0 + r;
+                if (pix >= p.M) break;
+                *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec]));
+            }
+        }
+    }
+    if (p.stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* o = p.stamps + (long)blockIdx.x * 8;
+        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = __builtin_amdgcn_s_memtime();
+        o[5] = ((long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) << 32) |
+               (unsigned)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);
+        o[6] = r0; o[7] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolutions from split32 activations: dense 3x3 (stride 1/2, dilation), the four output phases of the
 // 3x3 stride-2 transposed convolution, strided 1x1 -- the row map and tap list of gemm_conv.hip on the pipelined LDS-DMA
@@ -917,12 +1123,15 @@ extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* 
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.M = M; p.lda_bytes = (long)ldx * 4; p.N = Cout; p.Cin = Cin; p.Ktot = (Cin + kBK - 1) / kBK * kBK;
     p.ldc = ldy; p.ldres = ldres; p.act = act;
-    // kernel variant: 3 = 256-row tiles, 3 stages, pipelined K loop (the default: fastest on every shape measured);
+    // kernel variant: 3 = 256-row tiles, 3 stages, pipelined K loop, 32x32x16 MFMAs; 5 = the same on 16x16x32 MFMAs;
     // dev knobs for A/B runs: EMD_SPLIT_VARIANT / emd_debug_split_variant = 0 (256 rows, 2 stages), 1 (256, 3, plain loop),
     // 2 (128 rows, 2 stages, two workgroups per CU), 4 (persistent, epilogue stores inside the next tile's K loop)
-    static const int variant = [] { const char* e = getenv("EMD_SPLIT_VARIANT"); return e ? atoi(e) : 3; }();
+    static const int variant = [] { const char* e = getenv("EMD_SPLIT_VARIANT"); return e ? atoi(e) : -1; }();
     int v = variant;
     if (g_variant_override >= 0) v = g_variant_override;
+    if (v < 0) v = 3;   // default: the pipelined 32x32x16 kernel -- bit-identical to emd_conv1x1_f32, so a result does not depend on
+                        // which of the two a batch size selects.  Variant 5 (16x16x32 MFMAs: same cycles, the chip holds 1.86
+                        // instead of 1.73 GHz, 97.9 vs 103.7 us on 32768 x 728 x 728) sums a K step in another order (2e-7).
     p.stamps = g_stamps;
     const int bm = v == 2 ? 128 : 256;
     p.n_mtiles = (int)((M + bm - 1) / bm);
@@ -942,6 +1151,7 @@ extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* 
         hipLaunchKernelGGL(gemm_split_persist_kernel, dim3(grid), dim3(512), 0, st, p);
     }
     else if (v == 2) hipLaunchKernelGGL((gemm_split_kernel<128, 2>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else if (v == 5) hipLaunchKernelGGL(gemm_split16_kernel, dim3((unsigned)nblk), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((gemm_split_kernel<256, 3, true>), dim3((unsigned)nblk), dim3(512), 0, st, p);
     return emd::check_launch("gemm_split_kernel");
 }

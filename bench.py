@@ -334,6 +334,38 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
                       "frac_of_2500": round(pw_flops_box[0] / (max(fam_ms.get("conv1x1_split32", 0.0), 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
         "kernel_family_ms": {k: round(v, 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])},
     }
+    # the headline pointwise GEMM on its own (32768 x 728 x 728 at B = 32: 40 of D's layers), interleaved rounds in this
+    # process: the default kernel, and the same pipeline on 16x16x32 MFMAs (opt-in: it sums a K step in another order)
+    if (B, H, W) == (32, 512, 512) and rank == 0 and a.precision == "bf16x3":
+        try:
+            from emdenoise import _lib as _L
+            lib = _L.load()
+            xa = ops.Act(torch.rand(B, 32, 32, 728, device=dev) * 2)
+            xs = ops.to_split32(xa)
+            wpk = ops.PackedWeights((np.random.default_rng(0).standard_normal((1, 728, 728)) * 0.05).astype(np.float32), False, dev)
+            one, zero = torch.ones(728, device=dev), torch.zeros(728, device=dev)
+            o = ops.Act.empty(B, 32, 32, 728, dev)
+            tms = {-1: [], 5: []}
+            for _ in range(3):
+                for v in (-1, 5):
+                    lib.emd_debug_split_variant(v)
+                    ops.conv1x1_split32(xs, wpk, one, zero, o)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        ops.conv1x1_split32(xs, wpk, one, zero, o)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    tms[v].append(e0.elapsed_time(e1) * 1e3 / 20)
+            lib.emd_debug_split_variant(-1)
+            fl = 6.0 * B * 1024 * 728 * 728
+            iso = {}
+            for v, nm in ((-1, "default_32x32x16"), (5, "variant_16x16x32")):
+                us = float(np.median(tms[v]))
+                iso[nm] = {"us": round(us, 1), "issued_tflops": round(fl / us / 1e6, 1), "frac_of_2500": round(fl / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4)}
+            out["pointwise"]["isolated_32768x728x728"] = iso
+        except Exception as e:
+            out["pointwise"]["isolated_32768x728x728"] = {"error": f"{type(e).__name__}: {e}"}
     if want_cpu:
         cb, y_cpu = cpu_baseline_D(x_host, weights)
         out["cpu_baseline"] = cb

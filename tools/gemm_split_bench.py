@@ -51,7 +51,8 @@ for nm in names:
     fns["v2"]()
     for v in VARIANTS:
         o2.buf.zero_(); fns[f"v3.{v}"](); torch.cuda.synchronize()
-        same.append(bool(torch.equal(o1.buf, o2.buf)))
+        eq = bool(torch.equal(o1.buf, o2.buf))
+        same.append(eq if eq else f"rel {float((o1.buf - o2.buf).norm() / o1.buf.norm()):.1e}")
     for f in fns.values(): f(); f()
     torch.cuda.synchronize()
     T = {k: [] for k in fns}
