@@ -80,6 +80,12 @@ SIGNATURES = {
     # x ldx scale shift res ldres y ldy npix C act stream
     "emd_affine_act_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p,
                                      C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    # x ldx B npix_img C mean var workspace stream
+    "emd_bn_stats_images_f32": (C.c_int, [_c_float_p, C.c_int, C.c_int, C.c_long, C.c_int, _c_float_p, _c_float_p, C.c_void_p,
+                                          C.c_void_p]),
+    # x ldx scale shift res ldres y ldy B npix_img C act stream
+    "emd_affine_act_images_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p,
+                                            C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "emd_bn_stats_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int]),
     "emd_bn_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_long, C.c_int, _c_float_p, _c_float_p, C.c_void_p,
                                    C.c_void_p]),

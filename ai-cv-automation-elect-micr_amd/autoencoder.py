@@ -11,9 +11,9 @@ Replaces (reference file:line):
 
 Every batch norm of this graph runs on BATCH statistics at inference too (``is_training=True`` is hard-coded, :105-116) and
 the reference feeds one 160x160 crop per ``sess.run`` (:331), so the statistics are PER IMAGE: a batch of crops here gets
-per-image statistics (``emd_bn_stats_f32`` on each image), the two norms of a separable block collapse into one per-channel
-affine on the device (``emd_bn_train_fold_f32``, the double-norm algebra of csrc/bn_train.hip), applied with the relu by
-``emd_affine_act_f32``.  The convolutions are the graph-D kernels: depthwise 3x3 stride 1/2, pointwise and transposed
+per-image statistics (``emd_bn_stats_images_f32``: every image reduced exactly as it would be alone), the two norms of a
+separable block collapse into one per-channel affine on the device (``emd_bn_train_fold_f32``, the double-norm algebra of csrc/bn_train.hip), applied with the relu by
+``emd_affine_act_images_f32``.  The convolutions are the graph-D kernels: depthwise 3x3 stride 1/2, pointwise and transposed
 convolutions on the matrix cores (split-bf16), the final 3x3 -> 1 conv.  The one-channel input travels as a 4-channel tensor
 (3 zero channels) and ``encoding_features`` < 4 is zero-padded to 4 channels -- zeros in, zeros out, nothing else changes.
 """
@@ -176,14 +176,12 @@ class AutoencoderEngine:
         del names
 
     def _norm_relu(self, r: ops.Act, gamma2, beta2, gamma1=None, beta1=None):
-        """Per-image batch-statistics norm(s) + relu, in place: statistics of image b -> one affine -> relu."""
-        npix = r.H * r.W
-        for b in range(r.B):
-            rb = ops.Act(r.buf[b:b + 1], r.C, r.c0)
-            mean, var = ops.bn_batch_stats(rb)
-            f = train_ops.bn_train_fold(mean, var, gamma2, beta2, npix, gamma1=gamma1, beta1=beta1, eps=BN_EPS)
-            ops.affine_act(rb, f["scale"], f["shift"], rb, act=ops.ACT_RELU)
-        return r
+        """Per-image batch-statistics norm(s) + relu, in place: the statistics of every image in one pair of launches
+        ([B][C]), one fold over the B*C (image, channel) pairs with the norm parameters repeated per image, one affine + relu."""
+        rep = lambda v: None if v is None else v.repeat(r.B)
+        mean, var = ops.bn_batch_stats_images(r)
+        f = train_ops.bn_train_fold(mean, var, rep(gamma2), rep(beta2), r.H * r.W, gamma1=rep(gamma1), beta1=rep(beta1), eps=BN_EPS)
+        return ops.affine_act_images(r, f["scale"], f["shift"], r, act=ops.ACT_RELU)
 
     def forward(self, x, trace=None):
         """x: torch CUDA float32 [B,S,S,1] contiguous, S a multiple of 8 -> [B,S,S,1] (no activation on the output, :176-184)."""

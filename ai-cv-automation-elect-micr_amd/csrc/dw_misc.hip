@@ -338,14 +338,17 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
 // y = act(x*scale + shift) [+ res]; x and y may be the same buffer (elementwise, same index).
 __global__ __launch_bounds__(256) void affine_relu6_kernel(const float* x, int ldx, const float* __restrict__ sc,
                                                            const float* __restrict__ sh, const float* res, int ldres,
-                                                           float* y, int ldy, int C4, long nthreads, int act) {
+                                                           float* y, int ldy, int C4, long nthreads, int act,
+                                                           long npix_img) {
+    // npix_img != 0: scale / shift are [image][C] (per-image statistics: instance norms, graph S), image = pix / npix_img
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;
     const int c4 = (int)(tid % C4);
     const long pix = tid / C4;
+    const long so = npix_img ? (pix / npix_img) * C4 * 4 : 0;
     const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c4 * 4);
-    const float4 s = *reinterpret_cast<const float4*>(sc + c4 * 4);
-    const float4 t = *reinterpret_cast<const float4*>(sh + c4 * 4);
+    const float4 s = *reinterpret_cast<const float4*>(sc + so + c4 * 4);
+    const float4 t = *reinterpret_cast<const float4*>(sh + so + c4 * 4);
     float4 o = make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
     if (act == 4) {  // tf.nn.leaky_relu, alpha 0.2
         o = make_float4(o.x > 0.f ? o.x : 0.2f * o.x, o.y > 0.f ? o.y : 0.2f * o.y, o.z > 0.f ? o.z : 0.2f * o.z,
@@ -367,6 +370,8 @@ __global__ __launch_bounds__(256) void affine_relu6_kernel(const float* x, int l
 __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int ldx, long npix, int C,
                                                         long rows_per_slab, double* __restrict__ part) {
     __shared__ double sm[2][4][64];
+    x += (long)blockIdx.z * npix * ldx;                    // blockIdx.z = image (per-image statistics); 0 for batch statistics
+    part += (long)blockIdx.z * gridDim.y * 2 * C;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rsub = threadIdx.x >> 6;  // 4 row phases
     const long r0 = (long)blockIdx.y * rows_per_slab;
@@ -392,6 +397,8 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
 __global__ __launch_bounds__(256) void bn_stats_partial_v4(const float* __restrict__ x, int ldx, long npix, int C,
                                                            long rows_per_slab, double* __restrict__ part) {
     __shared__ double sm[2][16][64 + 1];
+    x += (long)blockIdx.z * npix * ldx;                    // blockIdx.z = image (per-image statistics); 0 for batch statistics
+    part += (long)blockIdx.z * gridDim.y * 2 * C;
     const int cl = (threadIdx.x & 15) * 4;
     const int c = blockIdx.x * 64 + cl;
     const int rl = threadIdx.x >> 4;
@@ -430,6 +437,9 @@ __global__ __launch_bounds__(256) void bn_stats_final(const double* __restrict__
                                                       float* __restrict__ mean, float* __restrict__ var) {
     // 16 channels x 16 slab lanes per workgroup: the <= 512 slabs of a channel are summed by 16 lanes
     __shared__ double sm[2][16][16 + 1];
+    part += (long)blockIdx.y * nslab * 2 * C;              // blockIdx.y = image
+    mean += (long)blockIdx.y * C;
+    var += (long)blockIdx.y * C;
     const int l = threadIdx.x & 15, k0 = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + l;
     double s = 0.0, q = 0.0;
@@ -677,7 +687,7 @@ extern "C" int emd_affine_act_f32(const float* x, int ldx, const float* scale, c
     int rc = grid_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL(affine_relu6_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, scale,
-                       shift, res, ldres, y, ldy, C / 4, nthreads, act);
+                       shift, res, ldres, y, ldy, C / 4, nthreads, act, 0L);
     return emd::check_launch("affine_relu6_kernel");
 }
 
@@ -708,6 +718,48 @@ extern "C" int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float
     hipLaunchKernelGGL(bn_stats_final, dim3((C + 15) / 16), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
                        npix, mean, var);
     return emd::check_launch("bn_stats");
+}
+
+// Per-image statistics of a batch [B][npix_img][C] in one pair of launches (instance norms; the batch-statistics norms of
+// misc_py/apply_autoencoders.py:105-116, which the reference evaluates one crop per sess.run): mean / var are [B][C]; every
+// image is reduced exactly as emd_bn_stats_f32 reduces it alone (same slabs, same order: identical bits).
+extern "C" int emd_bn_stats_images_f32(const float* x, int ldx, int B, long npix_img, int C, float* mean, float* var,
+                                       void* workspace, emd_stream_t stream) {
+    EMD_REQUIRE(x && mean && var && workspace, EMD_E_INVALID, "emd_bn_stats_images_f32: null pointer");
+    EMD_REQUIRE(B >= 1 && B <= 65535 && npix_img >= 1 && C >= 1 && ldx >= C, EMD_E_INVALID, "emd_bn_stats_images_f32: bad shape");
+    EMD_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EMD_E_ALIGN, "emd_bn_stats_images_f32: workspace alignment");
+    const long nslab = emd::reduce_slabs(npix_img), rows_per_slab = emd::reduce_rows_per_slab(npix_img);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    if (C % 4 == 0 && ldx % 4 == 0 && emd::aligned16(x))
+        hipLaunchKernelGGL(bn_stats_partial_v4, dim3((C + 63) / 64, (unsigned)nslab, B), dim3(256), 0, st, x, ldx, npix_img, C,
+                           rows_per_slab, ws);
+    else
+        hipLaunchKernelGGL(bn_stats_partial, dim3((C + 63) / 64, (unsigned)nslab, B), dim3(256), 0, st, x, ldx, npix_img, C,
+                           rows_per_slab, ws);
+    hipLaunchKernelGGL(bn_stats_final, dim3((C + 15) / 16, B), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
+                       npix_img, mean, var);
+    return emd::check_launch("bn_stats (images)");
+}
+
+// y = act(x*scale[image] + shift[image]) [+ res]: emd_affine_act_f32 with per-image scale / shift vectors [B][C].
+extern "C" int emd_affine_act_images_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res,
+                                         int ldres, float* y, int ldy, int B, long npix_img, int C, int act,
+                                         emd_stream_t stream) {
+    EMD_REQUIRE(x && y && scale && shift, EMD_E_INVALID, "emd_affine_act_images_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && npix_img >= 1 && C >= 4 && act >= 0 && act <= 4, EMD_E_INVALID, "emd_affine_act_images_f32: bad argument");
+    EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && emd::aligned16(x) &&
+                    emd::aligned16(y) && emd::aligned16(scale) && emd::aligned16(shift) &&
+                    (!res || (ldres % 4 == 0 && ldres >= C && emd::aligned16(res))), EMD_E_ALIGN,
+                "emd_affine_act_images_f32: alignment");
+    if (B == 0) return EMD_OK;
+    const long nthreads = (long)B * npix_img * (C / 4);
+    unsigned nb;
+    int rc = grid_for(nthreads, &nb);
+    if (rc != EMD_OK) return rc;
+    hipLaunchKernelGGL(affine_relu6_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, scale,
+                       shift, res, ldres, y, ldy, C / 4, nthreads, act, npix_img);
+    return emd::check_launch("affine_relu6_kernel (images)");
 }
 
 extern "C" int emd_bn_fold_f32(const float* mean, const float* var, const float* gamma, const float* beta, float eps,

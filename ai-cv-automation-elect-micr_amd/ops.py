@@ -353,6 +353,31 @@ def bn_batch_stats(x: Act, stream=None):
     return mean, var
 
 
+def bn_batch_stats_images(x: Act, stream=None):
+    """Per-image, per-channel mean and biased variance of x [B,H,W,C]: two float32 CUDA vectors of B*C entries ([B][C])."""
+    import torch
+
+    lib = _lib.load()
+    npix = x.H * x.W
+    mean = torch.empty(x.B * x.C, dtype=torch.float32, device=x.buf.device)
+    var = torch.empty_like(mean)
+    ws = torch.empty(x.B * (lib.emd_bn_stats_workspace_bytes(npix, x.C) // 8), dtype=torch.float64, device=x.buf.device)
+    _lib.check(lib.emd_bn_stats_images_f32(x.ptr, x.ld, x.B, C.c_long(npix), x.C, _p(mean), _p(var), _p(ws),
+                                           _lib.stream_ptr(stream)), "emd_bn_stats_images_f32")
+    return mean, var
+
+
+def affine_act_images(x: Act, scale_dev, shift_dev, out: Act, act=ACT_RELU, res: Act | None = None, stream=None):
+    """out = act(x*scale[b] + shift[b]) [+ res] with per-image scale / shift ([B][C]); out may be x."""
+    lib = _lib.load()
+    assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, x.C) and scale_dev.numel() == x.B * x.C
+    rc = lib.emd_affine_act_images_f32(x.ptr, x.ld, _p(scale_dev), _p(shift_dev), res.ptr if res is not None else C.c_void_p(0),
+                                       res.ld if res is not None else 0, out.ptr, out.ld, x.B, C.c_long(x.H * x.W), x.C,
+                                       _act(act), _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_affine_act_images_f32")
+    return out
+
+
 def bn_fold(mean, var, gamma, beta, eps=1e-3, stream=None):
     """(mean, var, gamma|None, beta|None) -> (scale, shift) device vectors of the equivalent affine."""
     import torch

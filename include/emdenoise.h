@@ -234,6 +234,13 @@ int emd_affine_act_f32(const float* x, int ldx, const float* scale, const float*
  * variance of x [npix, C] (pixel stride ldx), accumulated in double.  workspace: device buffer of
  * emd_bn_stats_workspace_bytes(npix, C) bytes, 8-byte aligned.  emd_bn_fold_f32 turns (mean, var, gamma|NULL,
  * beta|NULL, eps) into the (scale, shift) of one affine, on the device (no host round trip). */
+/* Per-image forms (instance norms; the batch-statistics norms of misc_py/apply_autoencoders.py:105-116, which the reference
+ * evaluates one crop per sess.run): x is [B][npix_img][C]; mean / var / scale / shift are [B][C]; workspace:
+ * B x emd_bn_stats_workspace_bytes(npix_img, C) bytes.  Image b gets exactly the bits emd_bn_stats_f32 gives it alone. */
+int emd_bn_stats_images_f32(const float* x, int ldx, int B, long npix_img, int C, float* mean, float* var, void* workspace,
+                            emd_stream_t stream);
+int emd_affine_act_images_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
+                              float* y, int ldy, int B, long npix_img, int C, int act, emd_stream_t stream);
 size_t emd_bn_stats_workspace_bytes(long npix, int C);
 int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float* mean, float* var, void* workspace,
                      emd_stream_t stream);
