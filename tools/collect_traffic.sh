@@ -20,8 +20,13 @@ for wl in ("K", "D"):
                 nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
                 if "rocclr" in nm: continue
                 if wl == "K" and int(r["Grid_Size"]) < 100000: continue
-                per[nm][c].append(float(r["Counter_Value"]))
+                per[nm][c].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     for nm, d in per.items():
+        if wl == "K":  # the [32,512,512,1] launches only: bench K also times one [256,512,512,1] burst (the largest grid)
+            g0 = min(g for v in d.values() for g, _ in v)
+            d = {c: [x for g, x in v if g == g0] for c, v in d.items()}
+        else:
+            d = {c: [x for _, x in v] for c, v in d.items()}
         n = max(len(v) for v in d.values())
         f_kib = sum(d.get("FETCH_SIZE", [0])) / max(len(d.get("FETCH_SIZE", [1])), 1)
         w_kib = sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [1])), 1)
