@@ -1199,6 +1199,8 @@ int launch_conv(SplitConvParams& c, hipStream_t st) {
     p.stamps = nullptr;
     const long nblk = (long)p.n_mtiles * p.n_ntiles;
     if (nblk <= 0 || nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "split32 conv: grid too large");
+    if (p.M > 0x7fffffffL || (!c.flat && (long)(p.M / ((long)c.Hg * c.Wg)) * c.Ha * c.Wa > 0x7fffffffL))
+        return emd::fail(EMD_E_UNSUPPORTED, "split32 conv: more than 2^31 pixels");   // the kernel keeps pixel indices in 32 bits
     if (bn == 64) hipLaunchKernelGGL(gemm_split_conv_kernel<64>, dim3((unsigned)nblk), dim3(512), 0, st, c);
     else hipLaunchKernelGGL(gemm_split_conv_kernel<128>, dim3((unsigned)nblk), dim3(512), 0, st, c);
     return emd::check_launch("gemm_split_conv_kernel");

@@ -254,3 +254,38 @@ def test_deconv3x3s2_split32_equals_deconv(B, H, W, ci, co, out_split):
         got = ops.deconv3x3s2_split32(xs, phases, s1, t1, ops.Act.empty(B, 2 * H, 2 * W, co, dev()))
         torch.cuda.synchronize()
         assert torch.equal(got.buf, want.buf)
+
+
+def test_split32_convs_random_shapes_match_register_staged_kernels():
+    """Seeded sweep over ragged shapes (M, N and K tails, 1..3 M tiles, strides, dilations): every split32 GEMM form gives
+    the bits of its register-staged twin -- the DMA source addressing (per-tap rows, zero line, swizzle) has no shape it gets wrong."""
+    from emdenoise import ops
+
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        B = int(rng.integers(1, 3))
+        H, W = int(rng.integers(5, 29)), int(rng.integers(5, 29))
+        ci = int(rng.choice([4, 8, 20, 32, 36, 64, 96, 100, 160]))
+        co = int(rng.choice([4, 36, 64, 68, 128, 132, 200]))
+        kind = case % 3
+        x = rnd((B, H, W, ci), 100 + case)
+        xa = ops.Act(up(x))
+        xs = ops.to_split32(xa)
+        s1, t1 = up(rnd((co,), 200 + case, 0.3) + 1.0), up(rnd((co,), 300 + case, 0.5))
+        if kind == 0:      # dense 3x3, stride 1 (optionally dilated) or 2
+            stride = int(rng.integers(1, 3))
+            rate = int(rng.integers(1, 4)) if stride == 1 else 1
+            pw = ops.PackedWeights(rnd((9, ci, co), 400 + case, 0.05), False, dev())
+            Ho, Wo = -(-H // stride), -(-W // stride)
+            want = ops.conv3x3(xa, pw, s1, t1, ops.Act.empty(B, Ho, Wo, co, dev()), stride=stride, rate=rate)
+            got = ops.conv3x3_split32(xs, pw, s1, t1, ops.Act.empty(B, Ho, Wo, co, dev()), stride=stride, rate=rate)
+        elif kind == 1:    # transposed 3x3 stride 2
+            ph = ops.pack_deconv(rnd((3, 3, co, ci), 400 + case, 0.05), dev())
+            want = ops.deconv3x3s2(xa, ph, s1, t1, ops.Act.empty(B, 2 * H, 2 * W, co, dev()))
+            got = ops.deconv3x3s2_split32(xs, ph, s1, t1, ops.Act.empty(B, 2 * H, 2 * W, co, dev()))
+        else:              # pointwise
+            pw = ops.PackedWeights(rnd((1, ci, co), 400 + case, 0.05), False, dev())
+            want = ops.conv1x1(xa, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()))
+            got = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()))
+        torch.cuda.synchronize()
+        assert torch.equal(got.buf, want.buf), (case, kind, B, H, W, ci, co)
