@@ -49,6 +49,11 @@ SIGNATURES = {
     # x ldx w y ldy B H W C stride rate stream
     "emd_dw3x3_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # x ldx pre_scale pre_shift w y ldy B H W C stride rate stream
+    "emd_dw3x3_pre_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "emd_dw3x3_pre_split32_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_void_p, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "emd_split32_ld": (C.c_int, [C.c_int]),
     # x ldx y ldy npix C stream
     "emd_to_split32_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),

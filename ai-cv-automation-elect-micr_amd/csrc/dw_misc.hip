@@ -20,6 +20,7 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+__device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
 // act code of the Cout=1 kernels: 0 none, 1 relu6, 2 relu6 followed by tf.clip_by_value(0,1) = clamp to [0,1]
 __device__ __forceinline__ float act_out(float v, int act) { return act == 0 ? v : fminf(fmaxf(v, 0.f), act == 2 ? 1.f : 6.f); }
 // the Cout=1 kernels' output stage: optional "+pre_bias, relu" first (tf.layers.conv2d(activation=relu) before the
@@ -34,10 +35,14 @@ __device__ __forceinline__ float cout1_out(float s, float pre_bias, int pre_relu
 // down a strip of TH output rows with the three live input rows' horizontal partial sums in registers:
 // an input row is read once per strip (3 shifted 16-B loads) and turned into its contribution as the
 // top / middle / bottom row of a window.  TF SAME: pad 1 on every side.
-template <int TH, bool SPLIT = false, bool REFLECT = false>
+template <int TH, bool SPLIT = false, bool REFLECT = false, bool PRE = false>
 __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x, int ldx,
                                                      const float* __restrict__ w, float* __restrict__ y,
-                                                     int ldy, int H, int W, int C4, long nthreads, int nstrip, int C4t) {
+                                                     int ldy, int H, int W, int C4, long nthreads, int nstrip, int C4t,
+                                                     const float* __restrict__ pre_s = nullptr,
+                                                     const float* __restrict__ pre_t = nullptr) {
+    // PRE: the input is relu(x * pre_s + pre_t) per channel -- the batch-statistics norm + relu of the previous separable
+    // block (misc_py/modified_Xception.py:302-323) applied on the fly instead of in a pass of its own
     // C4t = channel quads per pixel that have a thread: C4, or ceil32(C)/4 when the split32 padding is written too.
     // A workgroup = 16 adjacent pixel columns x 16 channel quads (64 channels, 256 contiguous bytes per pixel): the left /
     // right neighbours of a pixel are loaded by the SAME workgroup (L1 hits).  With one thread per (pixel, quad) in
@@ -63,6 +68,11 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(w + k * C + c4 * 4);
+    float4 ps4 = f4zero(), pt4 = f4zero();
+    if (PRE) {
+        ps4 = *reinterpret_cast<const float4*>(pre_s + c4 * 4);
+        pt4 = *reinterpret_cast<const float4*>(pre_t + c4 * 4);
+    }
 
     const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
     const int oy0 = strip * TH;
@@ -94,9 +104,15 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
     for (int tt = 0; tt < NR; ++tt) {
         const int iy = oy0 - 1 + tt;
         const bool ok = REFLECT || (iy >= 0 && iy < H);
-        const float4 c = ok ? rc[tt % PF] : f4zero();
-        const float4 l = ok && (REFLECT || hasl) ? rl[tt % PF] : f4zero();
-        const float4 r = ok && (REFLECT || hasr) ? rr[tt % PF] : f4zero();
+        float4 c = rc[tt % PF], l = rl[tt % PF], r = rr[tt % PF];
+        if (PRE) {
+            c = relu4(fma4(c, ps4, pt4));
+            l = relu4(fma4(l, ps4, pt4));
+            r = relu4(fma4(r, ps4, pt4));
+        }
+        c = ok ? c : f4zero();
+        l = ok && (REFLECT || hasl) ? l : f4zero();
+        r = ok && (REFLECT || hasr) ? r : f4zero();
         if (tt + PF < NR) {
             const float* row = row_ptr(tt + PF);
             rc[tt % PF] = *reinterpret_cast<const float4*>(row);
@@ -116,11 +132,13 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
 }
 
 // Depthwise 3x3, any stride / rate: one output pixel x 4 channels per thread (9 loads).
-template <bool SPLIT = false>
+template <bool SPLIT = false, bool PRE = false>
 __global__ __launch_bounds__(256) void dw3x3_generic(const float* __restrict__ x, int ldx,
                                                      const float* __restrict__ w, float* __restrict__ y,
                                                      int ldy, int H, int W, int C4, int Ho, int Wo,
-                                                     int stride, int rate, int pt, int pl, long nthreads, int C4t) {
+                                                     int stride, int rate, int pt, int pl, long nthreads, int C4t,
+                                                     const float* __restrict__ pre_s = nullptr,
+                                                     const float* __restrict__ pre_t = nullptr) {
     // a workgroup = 4 x 4 output pixels x 16 channel quads: the overlapping windows of neighbouring outputs are served by
     // the workgroup's L1 instead of by neighbouring workgroups on other XCDs (see dw3x3_s1_roll)
     (void)nthreads;
@@ -148,7 +166,8 @@ __global__ __launch_bounds__(256) void dw3x3_generic(const float* __restrict__ x
         for (int j = 0; j < 3; ++j) {
             const int ix = ox * stride - pl + j * rate;
             if (ix < 0 || ix >= W) continue;
-            const float4 v = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx);
+            float4 v = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx);
+            if (PRE) v = relu4(fma4(v, *reinterpret_cast<const float4*>(pre_s + c4 * 4), *reinterpret_cast<const float4*>(pre_t + c4 * 4)));
             const float4 wk = *reinterpret_cast<const float4*>(w + (i * 3 + j) * C + c4 * 4);
             acc = fma4(wk, v, acc);
         }
@@ -520,10 +539,12 @@ inline int grid_for(long nthreads, unsigned* blocks) {
     return EMD_OK;
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool PRE = false>
 int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
-                 int stride, int rate, emd_stream_t stream) {
+                 int stride, int rate, emd_stream_t stream, const float* pre_s = nullptr, const float* pre_t = nullptr) {
     (void)who;
+    if (PRE) EMD_REQUIRE(pre_s && pre_t && emd::aligned16(pre_s) && emd::aligned16(pre_t), EMD_E_INVALID,
+                         "emd_dw3x3_pre: pre_scale / pre_shift must be non-null and 16-byte aligned");
     EMD_REQUIRE(x && w && y, EMD_E_INVALID, "emd_dw3x3: null pointer");
     EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1 && C >= 4, EMD_E_INVALID, "emd_dw3x3: bad shape");
     EMD_REQUIRE(stride == 1 || stride == 2, EMD_E_UNSUPPORTED, "emd_dw3x3: stride must be 1 or 2");
@@ -557,16 +578,16 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
         if (TH == 16)
-            hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t);
+            hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t);
         else
-            hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t);
+            hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t);
         return emd::check_launch("dw3x3_s1_roll");
     }
     const long nthreads = (long)B * ((Ho + 3) / 4) * ((Wo + 3) / 4) * ((C4t + 15) / 16) * 256;
     int rc = grid_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
-    hipLaunchKernelGGL((dw3x3_generic<SPLIT>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, Ho, Wo, stride, rate, pt,
-                       pl, nthreads, C4t);
+    hipLaunchKernelGGL((dw3x3_generic<SPLIT, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, Ho, Wo, stride, rate, pt,
+                       pl, nthreads, C4t, pre_s, pre_t);
     return emd::check_launch("dw3x3_generic");
 }
 
@@ -601,6 +622,18 @@ extern "C" int emd_dw3x3_f32(const float* x, int ldx, const float* w, float* y, 
 extern "C" int emd_dw3x3_split32_f32(const float* x, int ldx, const float* w, void* y, int ldy, int B, int H, int W,
                                      int C, int stride, int rate, emd_stream_t stream) {
     return dw3x3_launch<true>("emd_dw3x3_split32_f32", x, ldx, w, static_cast<float*>(y), ldy, B, H, W, C, stride, rate, stream);
+}
+
+// y = depthwise3x3( relu(x * pre_scale + pre_shift) ): the previous block's batch-statistics norm + relu applied on the fly
+extern "C" int emd_dw3x3_pre_f32(const float* x, int ldx, const float* pre_scale, const float* pre_shift, const float* w, float* y,
+                                 int ldy, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream) {
+    return dw3x3_launch<false, true>("emd_dw3x3_pre_f32", x, ldx, w, y, ldy, B, H, W, C, stride, rate, stream, pre_scale, pre_shift);
+}
+
+extern "C" int emd_dw3x3_pre_split32_f32(const float* x, int ldx, const float* pre_scale, const float* pre_shift, const float* w,
+                                         void* y, int ldy, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream) {
+    return dw3x3_launch<true, true>("emd_dw3x3_pre_split32_f32", x, ldx, w, static_cast<float*>(y), ldy, B, H, W, C, stride, rate,
+                                    stream, pre_scale, pre_shift);
 }
 
 extern "C" int emd_cin1_f32(const float* x, const float* w9, const float* a, const float* shift, float* y, int ldy,

@@ -172,11 +172,16 @@ def pack_deconv(w_tf: np.ndarray, device):
     return out
 
 
-def dw3x3(x: Act, w_dev, out: Act, stride=1, rate=1, stream=None):
+def dw3x3(x: Act, w_dev, out: Act, stride=1, rate=1, stream=None, pre=None):
+    """pre = (scale, shift): the depthwise conv runs on relu(x*scale + shift) (emd_dw3x3_pre_f32)."""
     lib = _lib.load()
     assert out.C == x.C and out.B == x.B and (out.H, out.W) == (-(-x.H // stride), -(-x.W // stride))
-    rc = lib.emd_dw3x3_f32(x.ptr, x.ld, _p(w_dev), out.ptr, out.ld, x.B, x.H, x.W, x.C, stride, rate,
-                           _lib.stream_ptr(stream))
+    if pre is not None:
+        rc = lib.emd_dw3x3_pre_f32(x.ptr, x.ld, _p(pre[0]), _p(pre[1]), _p(w_dev), out.ptr, out.ld, x.B, x.H, x.W, x.C, stride,
+                                   rate, _lib.stream_ptr(stream))
+    else:
+        rc = lib.emd_dw3x3_f32(x.ptr, x.ld, _p(w_dev), out.ptr, out.ld, x.B, x.H, x.W, x.C, stride, rate,
+                               _lib.stream_ptr(stream))
     _lib.check(rc, "emd_dw3x3_f32")
     return out
 
@@ -217,11 +222,16 @@ def to_split32(x: Act, out: SplitAct | None = None, stream=None):
     return out
 
 
-def dw3x3_split32(x: Act, w_dev, out: SplitAct, stride=1, rate=1, stream=None):
+def dw3x3_split32(x: Act, w_dev, out: SplitAct, stride=1, rate=1, stream=None, pre=None):
     lib = _lib.load()
     assert out.C == x.C and out.B == x.B and (out.H, out.W) == (-(-x.H // stride), -(-x.W // stride))
-    _lib.check(lib.emd_dw3x3_split32_f32(x.ptr, x.ld, _p(w_dev), out.ptr, out.ld, x.B, x.H, x.W, x.C, stride, rate,
-                                         _lib.stream_ptr(stream)), "emd_dw3x3_split32_f32")
+    if pre is not None:
+        rc = lib.emd_dw3x3_pre_split32_f32(x.ptr, x.ld, _p(pre[0]), _p(pre[1]), _p(w_dev), out.ptr, out.ld, x.B, x.H, x.W, x.C,
+                                           stride, rate, _lib.stream_ptr(stream))
+    else:
+        rc = lib.emd_dw3x3_split32_f32(x.ptr, x.ld, _p(w_dev), out.ptr, out.ld, x.B, x.H, x.W, x.C, stride, rate,
+                                       _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_dw3x3_split32_f32")
     return out
 
 
@@ -234,13 +244,14 @@ def dw3x3_reflect_split32(x: Act, w_dev, out: SplitAct, stride=1, stream=None):
 
 
 def sep_split32(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, stride=1, rate=1, act=True, scale2=None,
-                shift2=None, res: Act | None = None, reflect=False, stream=None):
+                shift2=None, res: Act | None = None, reflect=False, stream=None, pre=None):
     """Separable conv as depthwise (split32 output) -> LDS-DMA pointwise GEMM; the intermediate exists only in split form."""
     d = SplitAct(out.B, out.H, out.W, x.C, x.buf.device)
     if reflect:
+        assert pre is None
         dw3x3_reflect_split32(x, dw_dev, d, stride=stride, stream=stream)
     else:
-        dw3x3_split32(x, dw_dev, d, stride=stride, rate=rate, stream=stream)
+        dw3x3_split32(x, dw_dev, d, stride=stride, rate=rate, stream=stream, pre=pre)
     return conv1x1_split32(d, w, scale1, shift1, out, act=act, scale2=scale2, shift2=shift2, res=res, stream=stream)
 
 

@@ -274,20 +274,27 @@ class XceptionEngine:
                 trace.append(host(r))
             return r
 
-        def sep(a, res=None):
-            """depthwise -> pointwise (raw) -> batch-statistics BN (beta only) -> relu [+ res] (:302-323)."""
+        def sep(a, res=None, defer=False):
+            """depthwise -> pointwise (raw) -> batch-statistics BN (beta only) -> relu [+ res] (:302-323).  defer=True (the
+            output feeds nothing but the next block's depthwise conv): the norm + relu are not applied here -- the raw
+            pointwise output travels with its (scale, shift) and the next depthwise kernel applies them while loading."""
             L, p = next(it)
+            pre = None
+            if isinstance(a, tuple):
+                a, pre = a[0], (a[1], a[2])
             Ho, Wo = -(-a.H // L.stride), -(-a.W // L.stride)
             if prec == ops.PREC_BF16X3 and ops.conv1x1_split32_supported(a.B * Ho * Wo, L.cin, L.cout):
                 y = ops.sep_split32(a, p["dw"], p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout), stride=L.stride,
-                                    act=ops.ACT_NONE)
+                                    act=ops.ACT_NONE, pre=pre)
             else:
-                tmp = ops.dw3x3(a, p["dw"], E(Ho, Wo, L.cin), stride=L.stride)
+                tmp = ops.dw3x3(a, p["dw"], E(Ho, Wo, L.cin), stride=L.stride, pre=pre)
                 y = ops.conv1x1(tmp, p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout), act=ops.ACT_NONE, precision=prec)
             mean, var = ops.bn_batch_stats(y)
             scale, shift = ops.bn_fold(mean, var, None, p["beta"], BN_EPS)
             if trace is not None:   # the oracle traces the SEP output before the residual add
                 trace.append(ops.affine_act(y, scale, shift, E(Ho, Wo, L.cout), act=RELU).torch().cpu().numpy())
+            if defer and res is None and trace is None:
+                return (y, scale, shift)
             return ops.affine_act(y, scale, shift, y, act=RELU, res=res)
 
         def deconv(a):
@@ -309,19 +316,19 @@ class XceptionEngine:
         e = conv_bn_relu(e)
         for _ in range(3):
             res = conv_bn_relu(e)
-            m = sep(e)
-            m = sep(m)
+            m = sep(e, defer=True)
+            m = sep(m, defer=True)
             e = sep(m, res=res)
         for _ in range(numMiddleXception):
-            m = sep(e)
-            m = sep(m)
+            m = sep(e, defer=True)
+            m = sep(m, defer=True)
             e = sep(m, res=e)
         res = conv_bn_relu(e)                                   # exit flow
-        m = sep(e)
-        m = sep(m)
+        m = sep(e, defer=True)
+        m = sep(m, defer=True)
         m = sep(m, res=res)
-        m = sep(m)
-        m = sep(m)
+        m = sep(m, defer=True)
+        m = sep(m, defer=True)
         m = sep(m)
         # ASPP: branches write into their slices of the 1280-channel concat
         af = aspp_filters

@@ -196,6 +196,15 @@ int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* whi, const 
                             const float* shift1, const float* scale2, const float* shift2, const float* res,
                             int ldres, float* y, int ldy, long M, int Cin, int Cout, int act, emd_stream_t stream);
 
+/* emd_dw3x3_f32 / emd_dw3x3_split32_f32 on relu(x * pre_scale + pre_shift) (per channel, device float[C]): the
+ * batch-statistics norm + relu that ends the previous separable block of misc_py/modified_Xception.py (:302-323) applied
+ * while the depthwise kernel loads its input, instead of in a pass of its own; padding is applied after it (TF pads the
+ * activated tensor). */
+int emd_dw3x3_pre_f32(const float* x, int ldx, const float* pre_scale, const float* pre_shift, const float* w, float* y,
+                      int ldy, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream);
+int emd_dw3x3_pre_split32_f32(const float* x, int ldx, const float* pre_scale, const float* pre_shift, const float* w,
+                              void* y, int ldy, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream);
+
 /* Layers fed by the 1-channel image: y[pix][n] = act( d[pix]*a[n] + shift[n] ).
  * w9 != NULL: d = 3x3 SAME depthwise of x with the 9 weights w9 (stride 1)  -- cnn0 (denoiser.py:252),
  *             a[n] = pointwise_weights[0][n] * folded BN scale;

@@ -289,3 +289,26 @@ def test_split32_convs_random_shapes_match_register_staged_kernels():
             got = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()))
         torch.cuda.synchronize()
         assert torch.equal(got.buf, want.buf), (case, kind, B, H, W, ci, co)
+
+
+@pytest.mark.parametrize("B,H,W,C,stride,rate,split", [(2, 16, 16, 728, 1, 1, True), (1, 70, 33, 64, 1, 1, False),
+                                                        (2, 17, 13, 40, 2, 1, True), (1, 32, 32, 96, 1, 6, False)])
+def test_dw3x3_pre_equals_affine_then_dw3x3(B, H, W, C, stride, rate, split):
+    """The depthwise kernels with the previous block's norm + relu applied on the fly (emd_dw3x3_pre*_f32) give the bits of
+    emd_affine_act_f32 followed by the plain kernel (padding is applied after the activation)."""
+    from emdenoise import ops
+
+    x = rnd((B, H, W, C), 71)
+    w = up(rnd((9, C), 72, 0.3))
+    sc, sh = up(rnd((C,), 73, 0.5) + 1.0), up(rnd((C,), 74, 0.5))
+    xa = ops.Act(up(x))
+    act = ops.affine_act(xa, sc, sh, ops.Act.empty(B, H, W, C, dev()), act=ops.ACT_RELU)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    if split:
+        want = ops.dw3x3_split32(act, w, ops.SplitAct(B, Ho, Wo, C, dev()), stride=stride, rate=rate)
+        got = ops.dw3x3_split32(xa, w, ops.SplitAct(B, Ho, Wo, C, dev()), stride=stride, rate=rate, pre=(sc, sh))
+    else:
+        want = ops.dw3x3(act, w, ops.Act.empty(B, Ho, Wo, C, dev()), stride=stride, rate=rate)
+        got = ops.dw3x3(xa, w, ops.Act.empty(B, Ho, Wo, C, dev()), stride=stride, rate=rate, pre=(sc, sh))
+    torch.cuda.synchronize()
+    assert torch.equal(got.buf.view(torch.int32), want.buf.view(torch.int32))

@@ -95,3 +95,16 @@ def test_bn_batch_stats_and_fold(npix_shape, Cc):
     ops.affine_act(a, scale, shift, out, act=ops.ACT_RELU, res=res)
     ref = np.maximum((x64 - x64.mean(0)) / np.sqrt(x64.var(0) + 1e-3) + beta.cpu().numpy(), 0).reshape(B, H, W, Cc) + res.torch().cpu().numpy()
     assert rel_l2(out.torch().cpu().numpy(), ref) < 1e-5   # float32 mean, var, rsqrt and fma on the device
+
+
+@pytest.mark.gpu
+def test_deferred_norm_relu_is_the_same_arithmetic():
+    """Without a trace the engine leaves a separable block's norm + relu to the next block's depthwise kernel wherever that
+    is the only consumer (emd_dw3x3_pre*_f32); with a trace every block output is materialised.  Same bits either way."""
+    from emdenoise import xception as X
+
+    eng = X.XceptionEngine(X.synthetic_weights(), torch.device("cuda", 0), "bf16x3")
+    x = torch.from_numpy(synthetic_lq(2, 128, 128, seed=77)).cuda()
+    fused = eng.forward(x).cpu().numpy()
+    plain = eng.forward(x, trace=[]).cpu().numpy()
+    assert np.array_equal(fused, plain)
