@@ -593,6 +593,13 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
 
 }  // namespace
 
+// second stage of the batch statistics (sum over `nslab` partials per channel, fixed order), for producers of partials
+// outside this file (the statistics epilogue of gemm_split.hip)
+int emd::launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st) {
+    hipLaunchKernelGGL(bn_stats_final, dim3((C + 15) / 16), dim3(256), 0, st, part, nslab, C, npix, mean, var);
+    return emd::check_launch("bn_stats_final");
+}
+
 // stride-1 depthwise over the REFLECT-padded input on the rolling kernel (called by emd_dw3x3_reflect*_f32, gan_ops.hip;
 // arguments already validated there)
 int emd::launch_dw3x3_reflect_roll(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,

@@ -43,6 +43,7 @@ struct SplitGemmParams {
     int N, Cin, Ktot;
     int ldc, ldres, act;
     int n_mtiles, n_ntiles;
+    double* stats_part;       // optional [n_mtiles][2][N]: per-channel sum / sum of squares of the STORED values of each M tile
     unsigned wlo_delta;       // persistent kernel: byte distance Wlo - Whi (one allocation)
     long long* stamps;        // dev builds only: 5 s_memtime stamps per workgroup (NULL otherwise)
 };
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
             }
     __syncthreads();
     if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
+    double ssum[4] = {0.0, 0.0, 0.0, 0.0}, ssq[4] = {0.0, 0.0, 0.0, 0.0};
     if (ncol) {
         const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
         const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
@@ -302,12 +304,48 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
                 const long pix = m0 + r;
                 if (pix < p.M) *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec])) + rv[k];
             }
+        } else if (p.stats_part) {
+            // batch statistics of the output (misc_py/modified_Xception.py:302-323: the norm that follows runs on batch
+            // statistics) gathered while the tile is in hand: per-thread double sums over its 16 rows here, 16 -> 1 below,
+            // one partial per (M tile, channel) for the fixed-order final reduction (bn_stats_final): no second pass over y
+#pragma unroll 4
+            for (int r = er; r < BM; r += ROWS_PER_PASS) {
+                const long pix = m0 + r;
+                if (pix >= p.M) break;
+                const f32x4 v = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec]));
+                *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double d = (double)v[c];
+                    ssum[c] += d;
+                    ssq[c] += d * d;
+                }
+            }
         } else {
 #pragma unroll 4
             for (int r = er; r < BM; r += ROWS_PER_PASS) {
                 const long pix = m0 + r;
                 if (pix >= p.M) break;
                 *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec]));
+            }
+        }
+    }
+    if (p.stats_part) {   // block-uniform
+        __syncthreads();  // the staging tile has been read out
+        double(*red)[SBN][2] = reinterpret_cast<double(*)[SBN][2]>(smem);   // [row groups][128 channels][sum, sum of squares]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[er][ec + c][0] = ssum[c];
+            red[er][ec + c][1] = ssq[c];
+        }
+        __syncthreads();
+        if (tid < 2 * SBN) {
+            const int which = tid / SBN, col = tid % SBN;
+            if (n0 + col < p.N) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < ROWS_PER_PASS; ++k) t += red[k][col][which];
+                p.stats_part[((long)mt * 2 + which) * p.N + n0 + col] = t;
             }
         }
     }
@@ -1102,10 +1140,10 @@ extern "C" int emd_conv1x1_split32_supported(long M, int Cin, int Cout) {
     return tiles >= 192 ? 1 : 0;
 }
 
-extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo,
-                                       const float* scale1, const float* shift1, const float* scale2,
-                                       const float* shift2, const float* res, int ldres, float* y, int ldy, long M,
-                                       int Cin, int Cout, int act, emd_stream_t stream) {
+static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo,
+                                const float* scale1, const float* shift1, const float* scale2,
+                                const float* shift2, const float* res, int ldres, float* y, int ldy, long M,
+                                int Cin, int Cout, int act, emd_stream_t stream, double* stats_part) {
     EMD_REQUIRE(xs && whi && wlo && scale1 && shift1 && y, EMD_E_INVALID, "emd_conv1x1_split32_f32: null pointer");
     EMD_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), EMD_E_INVALID, "emd_conv1x1_split32_f32: scale2/shift2 must come together");
     EMD_REQUIRE(M >= 0 && Cin >= 1 && Cout >= 4, EMD_E_INVALID, "emd_conv1x1_split32_f32: bad shape");
@@ -1122,13 +1160,14 @@ extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* 
     p.A = static_cast<const unsigned char*>(xs); p.Whi = whi; p.Wlo = wlo; p.C = y; p.res = res;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.M = M; p.lda_bytes = (long)ldx * 4; p.N = Cout; p.Cin = Cin; p.Ktot = (Cin + kBK - 1) / kBK * kBK;
-    p.ldc = ldy; p.ldres = ldres; p.act = act;
+    p.ldc = ldy; p.ldres = ldres; p.act = act; p.stats_part = stats_part;
     // kernel variant: 3 = 256-row tiles, 3 stages, pipelined K loop, 32x32x16 MFMAs; 5 = the same on 16x16x32 MFMAs;
     // dev knobs for A/B runs: EMD_SPLIT_VARIANT / emd_debug_split_variant = 0 (256 rows, 2 stages), 1 (256, 3, plain loop),
     // 2 (128 rows, 2 stages, two workgroups per CU), 4 (persistent, epilogue stores inside the next tile's K loop)
     static const int variant = [] { const char* e = getenv("EMD_SPLIT_VARIANT"); return e ? atoi(e) : -1; }();
     int v = variant;
     if (g_variant_override >= 0) v = g_variant_override;
+    if (stats_part) v = 3;   // the statistics epilogue lives in the default kernel
     if (v < 0) v = 3;   // default: the pipelined 32x32x16 kernel -- bit-identical to emd_conv1x1_f32, so a result does not depend on
                         // which of the two a batch size selects.  Variant 5 (16x16x32 MFMAs: same cycles, the chip holds 1.86
                         // instead of 1.73 GHz, 97.9 vs 103.7 us on 32768 x 728 x 728) sums a K step in another order (2e-7).
@@ -1275,6 +1314,34 @@ extern "C" int emd_deconv3x3s2_split32_f32(const void* xs, int ldx, const uint16
         if (rc != EMD_OK) return rc;
     }
     return EMD_OK;
+}
+
+extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo,
+                                       const float* scale1, const float* shift1, const float* scale2,
+                                       const float* shift2, const float* res, int ldres, float* y, int ldy, long M,
+                                       int Cin, int Cout, int act, emd_stream_t stream) {
+    return conv1x1_split32_impl(xs, ldx, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, M, Cin, Cout, act, stream, nullptr);
+}
+
+// The same GEMM that also delivers the per-channel batch mean and biased variance of its OUTPUT y (what emd_bn_stats_f32 would
+// compute in a second pass over y): the epilogue leaves one double partial per (256-row tile, channel), a fixed-order final
+// reduction follows (deterministic).  workspace: emd_conv1x1_split32_stats_workspace_bytes(M, Cout) bytes, 8-byte aligned.
+extern "C" size_t emd_conv1x1_split32_stats_workspace_bytes(long M, int Cout) {
+    if (M < 1 || Cout < 1) return 0;
+    return (size_t)((M + 255) / 256) * 2 * (size_t)Cout * sizeof(double);
+}
+
+extern "C" int emd_conv1x1_split32_stats_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo,
+                                             const float* scale1, const float* shift1, float* y, int ldy, long M, int Cin,
+                                             int Cout, int act, float* mean, float* var, void* workspace, emd_stream_t stream) {
+    EMD_REQUIRE(mean && var && workspace && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EMD_E_INVALID,
+                "emd_conv1x1_split32_stats_f32: mean, var and an 8-byte aligned workspace are required");
+    EMD_REQUIRE(M >= 1, EMD_E_INVALID, "emd_conv1x1_split32_stats_f32: M >= 1");
+    int rc = conv1x1_split32_impl(xs, ldx, whi, wlo, scale1, shift1, nullptr, nullptr, nullptr, 0, y, ldy, M, Cin, Cout, act, stream,
+                                  static_cast<double*>(workspace));
+    if (rc != EMD_OK) return rc;
+    return emd::launch_bn_stats_final(static_cast<const double*>(workspace), (int)((M + 255) / 256), Cout, M, mean, var,
+                                      static_cast<hipStream_t>(stream));
 }
 
 // dev hooks (not in the header): kernel variant and stamp buffer for tools/gemm_split_bench.py

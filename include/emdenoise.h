@@ -180,6 +180,15 @@ int emd_dw3x3_split32_f32(const float* x, int ldx, const float* w, void* y, int 
 int emd_dw3x3_reflect_split32_f32(const float* x, int ldx, const float* w, void* y, int ldy, int B, int H, int W, int C,
                                   int stride, emd_stream_t stream); /* emd_dw3x3_reflect_f32 (graph G) with split32 output */
 int emd_conv1x1_split32_supported(long M, int Cin, int Cout);
+/* emd_conv1x1_split32_f32 (no second affine, no residual) that also returns the per-channel batch mean and BIASED variance
+ * of its output y -- what emd_bn_stats_f32 computes in a second pass over y (the batch-statistics norms that follow the
+ * pointwise convs of misc_py/modified_Xception.py:302-323).  The GEMM epilogue leaves one double partial per (256-row tile,
+ * channel); a fixed-order final reduction follows (deterministic).  workspace: emd_conv1x1_split32_stats_workspace_bytes(M,
+ * Cout) bytes, 8-byte aligned. */
+size_t emd_conv1x1_split32_stats_workspace_bytes(long M, int Cout);
+int emd_conv1x1_split32_stats_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                                  const float* shift1, float* y, int ldy, long M, int Cin, int Cout, int act, float* mean,
+                                  float* var, void* workspace, emd_stream_t stream);
 /* Dense 3x3 convolution (emd_conv3x3_f32: TF SAME, stride 1/2, dilation) and the 3x3 stride-2 transposed convolution
  * (emd_deconv3x3s2_f32) on a split32 input, same packed weights, same arithmetic (bit-identical results); out_split != 0
  * writes y itself as a split32 tensor (pitch ldy 4-byte units, % 32; channels Cout..ceil32(Cout) zero) for a following

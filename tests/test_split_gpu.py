@@ -312,3 +312,28 @@ def test_dw3x3_pre_equals_affine_then_dw3x3(B, H, W, C, stride, rate, split):
         got = ops.dw3x3(xa, w, ops.Act.empty(B, Ho, Wo, C, dev()), stride=stride, rate=rate, pre=(sc, sh))
     torch.cuda.synchronize()
     assert torch.equal(got.buf.view(torch.int32), want.buf.view(torch.int32))
+
+
+@pytest.mark.parametrize("B,H,W,ci,co", [(32, 32, 32, 728, 728), (2, 19, 23, 96, 132), (1, 16, 16, 64, 36)])
+def test_conv1x1_split32_stats_epilogue(B, H, W, ci, co):
+    """The statistics epilogue (emd_conv1x1_split32_stats_f32): same output bits as the plain GEMM, and mean / biased variance
+    of that output equal to a second pass over it (emd_bn_stats_f32) to double-rounding noise; ragged M and N tails."""
+    from emdenoise import ops
+
+    x = rnd((B, H, W, ci), 81)
+    w = rnd((1, ci, co), 82, scale=0.1)
+    pw = ops.PackedWeights(w, False, dev())
+    s1, t1 = up(rnd((co,), 83, 0.3) + 1.0), up(rnd((co,), 84, 0.5))
+    xs = ops.to_split32(ops.Act(up(x)))
+    plain = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()), act=ops.ACT_NONE)
+    y, mean, var = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()), act=ops.ACT_NONE, stats=True)
+    m2, v2 = ops.bn_batch_stats(plain)
+    torch.cuda.synchronize()
+    assert torch.equal(y.buf, plain.buf)
+    ref = plain.buf.double().reshape(-1, co)
+    assert torch.allclose(mean.double(), ref.mean(0), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(var.double(), ref.var(0, unbiased=False), rtol=1e-5, atol=1e-9)
+    assert torch.allclose(mean, m2, rtol=1e-6, atol=1e-7) and torch.allclose(var, v2, rtol=1e-5, atol=1e-9)
+    # deterministic: a second run gives the same bits
+    _, mean_b, var_b = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()), act=ops.ACT_NONE, stats=True)
+    assert torch.equal(mean, mean_b) and torch.equal(var, var_b)
