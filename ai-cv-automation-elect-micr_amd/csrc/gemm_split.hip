@@ -1102,9 +1102,13 @@ __global__ __launch_bounds__(256) void to_split32_kernel(const float* __restrict
     unsigned h0, l0, h1, l1;
     split2(v[0], v[1], h0, l0);
     split2(v[2], v[3], h1, l1);
-    unsigned char* o = y + pix * (long)ldy * 4 + (c4 >> 3) * 128 + (c4 & 7) * 8;
-    *reinterpret_cast<u32x2*>(o) = u32x2{h0, h1};
-    *reinterpret_cast<u32x2*>(o + 64) = u32x2{l0, l1};
+    // 16-byte stores through an exchange between the two lanes of a quad pair (see emd::dw_store); C4p is even, so a pair is
+    // never split by the bounds check above
+    const bool odd = c4 & 1;
+    const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1), r1 = __shfl_xor(odd ? h1 : l1, 1);
+    unsigned char* g = y + pix * (long)ldy * 4 + (c4 >> 3) * 128;
+    if (!odd) *reinterpret_cast<u32x4*>(g + (c4 & 7) * 8) = u32x4{h0, h1, r0, r1};
+    else *reinterpret_cast<u32x4*>(g + 64 + ((c4 - 1) & 7) * 8) = u32x4{r0, r1, l0, l1};
 }
 
 }  // namespace
@@ -1133,9 +1137,9 @@ extern "C" int emd_to_split32_f32(const float* x, int ldx, void* y, int ldy, lon
 extern "C" int emd_conv1x1_split32_supported(long M, int Cin, int Cout) {
     // Where the pair (depthwise with split32 output, this GEMM) beats (depthwise, emd_conv1x1_f32) on MI355X
     // (tools/gemm_split_bench.py): matrix-core bound shapes whose grid fills the chip with 256 x 128 tiles.  On the
-    // HBM-bound layers (K <= 256 at 128^2 and up) the 8-byte stores of the split depthwise output cost more than the GEMM gains.
+    // HBM-bound layers (N = 128 at 256^2, K <= 128) the register-staged kernel's 128 x 128 tiles at two workgroups per CU are as fast or faster.
     if (Cout < 128 || Cout % 4 || Cin % 4) return 0;
-    if (!(Cin >= 512 || (Cin >= 384 && Cout >= 256))) return 0;
+    if (!(Cin >= 512 || (Cin >= 256 && Cout >= 256))) return 0;
     const long tiles = ((M + 255) / 256) * ((Cout + SBN - 1) / SBN);
     return tiles >= 192 ? 1 : 0;
 }

@@ -191,7 +191,8 @@ def test_split32_argument_checks():
     assert b"multiple of 32" in lib.emd_last_error()
     assert lib.emd_conv1x1_split32_supported(32768, 728, 728) == 1
     assert lib.emd_conv1x1_split32_supported(524288, 384, 256) == 1
-    assert lib.emd_conv1x1_split32_supported(524288, 256, 256) == 0
+    assert lib.emd_conv1x1_split32_supported(524288, 256, 256) == 1
+    assert lib.emd_conv1x1_split32_supported(2097152, 384, 128) == 0
     assert lib.emd_conv1x1_split32_supported(32768, 64, 728) == 0
     assert lib.emd_conv1x1_split32_supported(1024, 728, 728) == 0
 
