@@ -851,12 +851,17 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             if (!real) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (cp.out_split) {
+                // 16-byte stores through an exchange between the two lanes of a channel-quad pair (see emd::dw_store): both
+                // lanes of a pair share the row and the n < Np test (Np is a multiple of 32)
                 unsigned h0, l0, h1, l1;
                 split2(v.x, v.y, h0, l0);
                 split2(v.z, v.w, h1, l1);
-                unsigned char* o = reinterpret_cast<unsigned char*>(p.C) + pix * (long)p.ldc * 4 + (n >> 5) * 128 + (n & 31) * 2;
-                *reinterpret_cast<u32x2*>(o) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(o + 64) = u32x2{l0, l1};
+                const int q = n >> 2;
+                const bool odd = q & 1;
+                const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1), r1 = __shfl_xor(odd ? h1 : l1, 1);
+                unsigned char* g = reinterpret_cast<unsigned char*>(p.C) + pix * (long)p.ldc * 4 + (n >> 5) * 128;
+                if (!odd) *reinterpret_cast<u32x4*>(g + (q & 7) * 8) = u32x4{h0, h1, r0, r1};
+                else *reinterpret_cast<u32x4*>(g + 64 + ((q - 1) & 7) * 8) = u32x4{r0, r1, l0, l1};
             } else {
                 *reinterpret_cast<float4*>(p.C + pix * p.ldc + n) = v;
             }
