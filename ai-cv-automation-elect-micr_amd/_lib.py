@@ -165,6 +165,10 @@ SIGNATURES = {
     "emd_sep3x3_fused_reflect_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
                                                _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int,
                                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # d ldd gen_a gen_t gen_act dw whi wlo scale1 shift1 scale2 shift2 res ldres y ldy B H W Cin Cout act precision reflect stream
+    "emd_sep3x3_fused_gen_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_void_p,
+                                           C.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, C.c_int,
+                                           _c_float_p, C.c_int] + [C.c_int] * 8 + [C.c_void_p]),
     # x ldx w bias y B K stream
     "emd_fc_rows_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_float, _c_float_p, C.c_int, C.c_int, C.c_void_p]),
     # a b c y n stream

@@ -24,6 +24,10 @@ using namespace emd;
 
 namespace {
 
+// source of the zero-padding pixels: the patch loads are unconditional (a select on the loaded value would make the wave wait for
+// the load where it is issued instead of a whole depthwise + MFMA phase later)
+__device__ __attribute__((aligned(16))) float g_zero_px[4096];
+
 struct SepParams {
     const float* x;       // [B,H,W,Cin] pixel stride ldx
     const float* dw;      // [9][Cin]
@@ -39,9 +43,15 @@ struct SepParams {
     int ldx, ldy, ldres, act;
     int reflect;          // 1: the patch border is tf.pad(REFLECT) of the image (graph G), 0: zero (TF SAME)
     int tpw;              // output tiles per workgroup, side by side along W
+    // generated input (layers fed by a 1-channel image): x is a one-value-per-pixel tensor d (pitch ldx) and the Cin-channel
+    // input the depthwise stage sees is act(d * gen_a[c] + gen_t[c]) -- never written to memory
+    const float* gen_a;
+    const float* gen_t;
+    int gen_act;
+    int dbg;              // dev knob EMD_SEP_DEBUG (timing experiments only): 1 no patch loads, 2 no depthwise stage, 4 no MFMAs
 };
 
-template <int BN, int PASSES>
+template <int BN, int PASSES, bool GEN>
 __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     constexpr int TH = 8, TW = 16, BM = TH * TW, BK = 32;
     constexpr int PH = TH + 2, PW = TW + 2, NPX = PH * PW;  // 10 x 18 = 180 patch pixels
@@ -72,12 +82,14 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     const long img = (long)blockIdx.z * p.H * p.W;  // pixel index of this image's (0,0)
 
     // ---- patch loader role: float4 #idx of the patch = (patch pixel idx/8, channel group idx%8)
-    long long poff[P_PASSES];  // element offset of the source pixel + channel group, or -1 (zero padding / unused)
+    const float* psrc[P_PASSES];  // source pixel + channel group of chunk 0, or the zero buffer (padding / unused slots)
+    bool pok[P_PASSES];           // generated input only: a real pixel (not padding)
     auto set_tile = [&](int xt) {
 #pragma unroll
         for (int q = 0; q < P_PASSES; ++q) {
             const int idx = tid + q * 256;
-            long long o = -1;
+            const float* o = GEN ? p.x : g_zero_px;
+            bool ok = false;
             if (idx < NPX * 8) {
                 const int ppx = idx >> 3, py = ppx / PW, px = ppx - py * PW;
                 int gy = y0 - 1 + py, gx = xt - 1 + px;
@@ -85,9 +97,13 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                     gy = gy < 0 ? -gy : (gy >= p.H ? 2 * p.H - 2 - gy : gy);
                     gx = gx < 0 ? -gx : (gx >= p.W ? 2 * p.W - 2 - gx : gx);
                 }
-                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) o = (img + (long)gy * p.W + gx) * p.ldx + (idx & 7) * 4;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                    o = p.x + (img + (long)gy * p.W + gx) * p.ldx + (GEN ? 0 : (idx & 7) * 4);
+                    ok = true;
+                }
             }
-            poff[q] = o;
+            psrc[q] = o;
+            pok[q] = ok;
         }
     };
     set_tile(xbase);
@@ -99,9 +115,9 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     // ---- depthwise role: 4 consecutive pixels of tile row ty, 4 channels
     const int c4 = tid & 7, pg = tid >> 3;
     const int ty = pg >> 2, tx0 = (pg & 3) * 4;
-    const float* __restrict__ dwp = p.dw + c4 * 4;
 
     f32x4 preg[P_PASSES];
+    f32x4 gga = {0.f, 0.f, 0.f, 0.f}, ggt = gga;   // generated input: the chunk's a / t vectors
     u32x4 wh0 = {0, 0, 0, 0}, wh1 = wh0, wl0 = wh0, wl1 = wh0;
     f32x4 wk[9];
 
@@ -121,6 +137,19 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     for (int it = -1; it < total; ++it) {
         if (it >= 0) {
             // staged registers (chunk `it`) -> LDS
+            if (GEN) {
+                const float ghi = p.gen_act == 1 ? 6.f : __builtin_inff();
+                const float gsl = p.gen_act == 4 ? 0.2f : 1.f, glo = (p.gen_act == 1 || p.gen_act == 2) ? 0.f : -__builtin_inff();
+#pragma unroll
+                for (int q = 0; q < P_PASSES; ++q) {
+                    const float dv = preg[q][0];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float u = fmaf(dv, gga[c], ggt[c]);
+                        preg[q][c] = pok[q] ? fminf(fmaxf(fmaxf(u, glo), gsl * u), ghi) : 0.f;
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < P_PASSES; ++q) {
                 const int idx = tid + q * 256;
@@ -139,15 +168,27 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
         const int nx = it + 1 < total ? it + 1 : it;
         const int ntile = nx / nchunks;
         const int c0n = (nx - ntile * nchunks) * BK;
-        if (ntile != ptile) {   // block-uniform: the next step belongs to the next tile
-            ptile = ntile;
-            set_tile(xbase + ntile * TW);
-        }
+        if (ntile != ptile) {   // block-uniform: the next step belongs to the next tile, 16 pixels to the right
+            const int xt = xbase + ntile * TW;
+            // between two tiles that both lie off the image's left and right edges only the x origin changes: every real source
+            // pixel moves 16 pixels on, the padding rows above / below the image stay padding
+            if (xt - TW > 0 && xt + TW < p.W) {
+                const long step = (long)TW * p.ldx;
 #pragma unroll
-        for (int q = 0; q < P_PASSES; ++q) {
-            const bool ok = poff[q] >= 0;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? p.x + poff[q] + c0n : p.x);
-            preg[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < P_PASSES; ++q) psrc[q] += pok[q] ? step : 0;
+            } else {
+                set_tile(xt);
+            }
+            ptile = ntile;
+        }
+        if (GEN) {   // the chunk is generated from the one-value-per-pixel tensor when it is written to LDS
+            gga = *reinterpret_cast<const f32x4*>(p.gen_a + c0n + (tid & 7) * 4);
+            ggt = *reinterpret_cast<const f32x4*>(p.gen_t + c0n + (tid & 7) * 4);
+#pragma unroll
+            for (int q = 0; q < P_PASSES; ++q) preg[q][0] = *psrc[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < P_PASSES; ++q) preg[q] = *reinterpret_cast<const f32x4*>(psrc[q] + c0n);
         }
         wh0 = *reinterpret_cast<const u32x4*>(whi + c0n);
         if (NPL == 2) wl0 = *reinterpret_cast<const u32x4*>(wlo + c0n);
@@ -155,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             wh1 = *reinterpret_cast<const u32x4*>(whi + 64L * p.Cpad + c0n);
             if (NPL == 2) wl1 = *reinterpret_cast<const u32x4*>(wlo + 64L * p.Cpad + c0n);
         }
-        if (it >= 0) {
+        if (it >= 0 && !(p.dbg & 2)) {
             // depthwise 3x3 from the LDS patch -> bf16 hi/lo A planes
             f32x4 o[4];
 #pragma unroll
@@ -183,9 +224,10 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
         }
         // the next chunk's depthwise weights (their registers are free only now)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const f32x4*>(dwp + (long)k * p.Cin + c0n);
+        for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const f32x4*>(p.dw + ((long)k * p.Cin + c0n) + c4 * 4);
         if (it < 0) continue;
         __syncthreads();  // (2) A planes of chunk `it` visible
+        if (!(p.dbg & 4))
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -255,6 +297,13 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                 return v;
             };
             constexpr int NROWS = BM / ROWS_PER_PASS;
+            // tile row origin as a 64-bit pointer, the pixel relative to it as a 32-bit offset (the host checks 9 rows fit in 2^31 floats)
+            // (x0 is folded into the 32-bit part on purpose: tile-invariant offsets would be hoisted out of the tile loop and pinned
+            // in registers for the whole kernel)
+            const long pix0 = img + (long)y0 * p.W;
+            float* __restrict__ ytile = outp + pix0 * p.ldy + n;
+            const float* __restrict__ rtile = p.res ? p.res + pix0 * p.ldres + n : nullptr;
+            auto tpix = [&](int r) { return (r >> 4) * p.W + (r & 15) + x0; };
             if (p.res) {
                 // residual values are requested four rows at a time, before the first of them is used (the registers of the
                 // next chunk's prefetch are live here: no room for all NROWS at once)
@@ -264,22 +313,18 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int r = er + (k0 + k) * ROWS_PER_PASS;
-                        const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
-                        rv[k] = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n);
+                        rv[k] = *reinterpret_cast<const f32x4*>(rtile + tpix(r) * p.ldres);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int r = er + (k0 + k) * ROWS_PER_PASS;
-                        const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
-                        *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n])) + rv[k];
+                        *reinterpret_cast<f32x4*>(ytile + tpix(r) * p.ldy) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n])) + rv[k];
                     }
                 }
             } else {
 #pragma unroll 4
-                for (int r = er; r < BM; r += ROWS_PER_PASS) {
-                    const long pix = img + (long)(y0 + (r >> 4)) * p.W + x0 + (r & 15);
-                    *reinterpret_cast<f32x4*>(outp + pix * p.ldy + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n]));
-                }
+                for (int r = er; r < BM; r += ROWS_PER_PASS)
+                    *reinterpret_cast<f32x4*>(ytile + tpix(r) * p.ldy) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n]));
             }
         }
         __syncthreads();  // the staging tile is read out before the next tile's patch overwrites it
@@ -303,25 +348,31 @@ int launch(const SepParams& p, int B, int passes, hipStream_t st) {
     for (int t = 8; t >= 2; t >>= 1)   // several tiles per workgroup where that still leaves >= 8 workgroups per CU
         if (tiles_w % t == 0 && wgs1 / t >= 2048) { q.tpw = t; break; }
     if (force > 0 && tiles_w % force == 0) q.tpw = force;
+    static const int dbg = [] { const char* e = getenv("EMD_SEP_DEBUG"); return e ? atoi(e) : 0; }();
+    q.dbg = dbg;
     const dim3 grid(tiles_w / q.tpw, p.H / 8, B);
-    if (passes == 3)
-        hipLaunchKernelGGL((sep_fused_kernel<BN, 3>), grid, dim3(256), 0, st, q);
+    if (p.gen_a) {   // generated input: the full-precision variant only
+        if (passes != 3) return emd::fail(EMD_E_UNSUPPORTED, "emd_sep3x3_fused_gen_f32: precision must be EMD_PREC_BF16X3");
+        hipLaunchKernelGGL((sep_fused_kernel<BN, 3, true>), grid, dim3(256), 0, st, q);
+    } else if (passes == 3)
+        hipLaunchKernelGGL((sep_fused_kernel<BN, 3, false>), grid, dim3(256), 0, st, q);
     else
-        hipLaunchKernelGGL((sep_fused_kernel<BN, 1>), grid, dim3(256), 0, st, q);
+        hipLaunchKernelGGL((sep_fused_kernel<BN, 1, false>), grid, dim3(256), 0, st, q);
     return emd::check_launch("sep_fused_kernel");
 }
 
 }  // namespace
 
 extern "C" int emd_sep3x3_fused_supported(int H, int W, int Cin, int Cout, int stride, int rate) {
-    return stride == 1 && rate == 1 && H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && Cin >= 32 && Cout % 4 == 0 &&
+    return stride == 1 && rate == 1 && H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && Cin >= 32 && Cin <= 4096 && Cout % 4 == 0 &&
            Cout >= 4 && Cout <= 128;
 }
 
 static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
                            const float* scale1, const float* shift1, const float* scale2, const float* shift2,
                            const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
-                           int precision, int reflect, emd_stream_t stream) {
+                           int precision, int reflect, emd_stream_t stream, const float* gen_a = nullptr,
+                           const float* gen_t = nullptr, int gen_act = 0) {
     EMD_REQUIRE(x && dw && whi && scale1 && shift1 && y, EMD_E_INVALID, "emd_sep3x3_fused_f32: null pointer");
     EMD_REQUIRE(precision == 1 || precision == 3, EMD_E_INVALID, "emd_sep3x3_fused_f32: bad precision");
     EMD_REQUIRE(precision == 1 || wlo, EMD_E_INVALID, "emd_sep3x3_fused_f32: the split-bf16 mode needs the lo plane");
@@ -330,8 +381,13 @@ static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint1
     EMD_REQUIRE(emd_sep3x3_fused_supported(H, W, Cin, Cout, 1, 1), EMD_E_UNSUPPORTED,
                 "emd_sep3x3_fused_f32: needs H%8==0, W%16==0, Cin%32==0, Cout%4==0, Cout<=128 (use emd_dw3x3_f32 + emd_conv1x1_f32)");
     EMD_REQUIRE(B <= 65535, EMD_E_UNSUPPORTED, "emd_sep3x3_fused_f32: B > 65535");
-    EMD_REQUIRE(ldx % 4 == 0 && ldx >= Cin && ldy % 4 == 0 && ldy >= Cout && (!res || (ldres % 4 == 0 && ldres >= Cout)),
+    EMD_REQUIRE(9L * W * (ldy > ldres ? ldy : ldres) < (1L << 31), EMD_E_UNSUPPORTED,
+                "emd_sep3x3_fused_f32: 9 image rows of the output must span fewer than 2^31 floats");
+    EMD_REQUIRE((gen_a ? ldx >= 1 : (ldx % 4 == 0 && ldx >= Cin)) && ldy % 4 == 0 && ldy >= Cout &&
+                    (!res || (ldres % 4 == 0 && ldres >= Cout)),
                 EMD_E_ALIGN, "emd_sep3x3_fused_f32: pixel strides must be multiples of 4 and >= the channel count");
+    EMD_REQUIRE(!gen_a || (gen_t && emd::aligned16(gen_a) && emd::aligned16(gen_t) && gen_act >= 0 && gen_act <= 4 && gen_act != 3),
+                EMD_E_INVALID, "emd_sep3x3_fused_gen_f32: gen_a / gen_t must be 16-byte aligned device vectors, gen_act an EMD_ACT_* code");
     EMD_REQUIRE(emd::aligned16(x) && emd::aligned16(dw) && emd::aligned16(whi) && (!wlo || emd::aligned16(wlo)) &&
                     emd::aligned16(y) && (!res || emd::aligned16(res)) && emd::aligned16(scale1) &&
                     emd::aligned16(shift1) && (!scale2 || (emd::aligned16(scale2) && emd::aligned16(shift2))),
@@ -342,6 +398,7 @@ static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint1
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
     p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act; p.reflect = reflect;
+    p.gen_a = gen_a; p.gen_t = gen_t; p.gen_act = gen_act;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return Cout <= 64 ? launch<64>(p, B, precision, st) : launch<128>(p, B, precision, st);
 }
@@ -364,4 +421,18 @@ extern "C" int emd_sep3x3_fused_reflect_f32(const float* x, int ldx, const float
                                             int precision, emd_stream_t stream) {
     return sep_fused_entry(x, ldx, dw, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, B, H, W, Cin, Cout, act,
                            precision, 1, stream);
+}
+
+// The fused separable conv on a GENERATED input: the layer's Cin-channel input is act(d[pixel] * gen_a[c] + gen_t[c]), d a
+// one-value-per-pixel tensor (pitch ldd floats) -- what emd_cin1_f32 / emd_cin1_k7_reflect_f32 would write out for the layer
+// that follows the one fed by the 1-channel image (cnn0 -> cnn0_last, machine_learning/denoiser.py:252-255; the generator's first
+// two layers, misc_py/gan-infilling-100.py:343-349).  The Cin-channel tensor never exists in memory.
+extern "C" int emd_sep3x3_fused_gen_f32(const float* d, int ldd, const float* gen_a, const float* gen_t, int gen_act,
+                                        const float* dw, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                                        const float* shift1, const float* scale2, const float* shift2, const float* res,
+                                        int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                                        int precision, int reflect, emd_stream_t stream) {
+    EMD_REQUIRE(gen_a && gen_t, EMD_E_INVALID, "emd_sep3x3_fused_gen_f32: null gen_a / gen_t");
+    return sep_fused_entry(d, ldd, dw, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, B, H, W, Cin, Cout, act,
+                           precision, reflect, stream, gen_a, gen_t, gen_act);
 }

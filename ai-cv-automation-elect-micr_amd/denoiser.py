@@ -275,6 +275,7 @@ class DenoiserEngine:
         self.layers = declare_layers(variant)
         self.P = {}
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        self._unit4, self._zero4 = d(np.array([1, 0, 0, 0])), d(np.zeros(4))
         for key, L in self.layers.items():
             p = {}
             if L.kind == "sep":
@@ -389,8 +390,18 @@ class DenoiserEngine:
         f0, f1, f2, f3 = features0, features1, features2, features3
 
         # encoder 0 (:252-264).  cnn0_strided lives in the channel slice of concat1 that :365 reads it from.
-        cnn0 = ops.cin1(x, P["cnn0"]["w9"], P["cnn0"]["a"], P["cnn0"]["shift"], E(S, f0))
-        cnn0_last = self._sep("cnn0_last", cnn0)
+        if (self.fuse_sep and os.environ.get("EMD_D_GEN", "1") != "0"
+                and bool(_lib.load().emd_sep3x3_fused_supported(S, S, f0, f0, 1, 1))):
+            # cnn0 = relu6(d * a + t) is an outer product of the 1-channel depthwise result d: cnn0_last's patch loader
+            # rebuilds it from d (4-channel scratch, d in channel 0) instead of reading a [B,S,S,64] tensor
+            pc, pl = P["cnn0"], P["cnn0_last"]
+            d4 = ops.cin1(x, pc["w9"], self._unit4, self._zero4, E(S, 4), act=False)
+            cnn0 = None
+            cnn0_last = ops.sep_fused_gen(d4, pc["a"], pc["shift"], pl["dw"], pl["pw"], pl["scale"], pl["shift"], E(S, f0),
+                                          scale2=pl.get("scale2"), shift2=pl.get("shift2"), precision=self.precision)
+        else:
+            cnn0 = ops.cin1(x, P["cnn0"]["w9"], P["cnn0"]["a"], P["cnn0"]["shift"], E(S, f0))
+            cnn0_last = self._sep("cnn0_last", cnn0)
         residual0 = ops.cin1(x, None, P["residual0"]["a"], P["residual0"]["shift"], E(S2, f1), stride=2)
         concat1 = E(S2, f2 + f1)
         cnn0_strided = self._sep("cnn0_strided", cnn0_last, out=concat1.slice(f2, f1), res=residual0)

@@ -143,6 +143,24 @@ def sep_fused(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, act=Tr
     return out
 
 
+def sep_fused_gen(d: Act, gen_a, gen_t, dw_dev, w: PackedWeights, scale1, shift1, out: Act, gen_act=True, act=True,
+                  scale2=None, shift2=None, res: Act | None = None, precision=PREC_BF16X3, stream=None, reflect=False):
+    """sep_fused on the generated input act(d[..., 0] * gen_a + gen_t) (emd_sep3x3_fused_gen_f32): d holds one value per
+    pixel in its channel 0, the w.cin-channel tensor is rebuilt in registers."""
+    lib = _lib.load()
+    assert (out.B, out.H, out.W, out.C) == (d.B, d.H, d.W, w.cout) and w.taps == 1
+    assert gen_a.numel() == w.cin and gen_t.numel() == w.cin
+    if res is not None:
+        assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
+    rc = lib.emd_sep3x3_fused_gen_f32(d.ptr, d.ld, _p(gen_a), _p(gen_t), _act(gen_act), _p(dw_dev), _p(w.hi), _p(w.lo),
+                                      _p(scale1), _p(shift1), _p(scale2), _p(shift2),
+                                      res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
+                                      out.ptr, out.ld, d.B, d.H, d.W, w.cin, w.cout, _act(act), precision,
+                                      1 if reflect else 0, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_sep3x3_fused_gen_f32")
+    return out
+
+
 def deconv3x3s2(x: Act, w_phases, scale1, shift1, out: Act, act=True, precision=PREC_BF16X3, stream=None):
     lib = _lib.load()
     assert len(w_phases) == 4 and (out.B, out.H, out.W) == (x.B, 2 * x.H, 2 * x.W) and out.C == w_phases[0].cout

@@ -390,6 +390,17 @@ int emd_sep3x3_fused_reflect_f32(const float* x, int ldx, const float* dw, const
                                  const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout,
                                  int act, int precision, emd_stream_t stream);
 
+/* emd_sep3x3_fused_f32 on a GENERATED input: the Cin-channel tensor the depthwise stage reads is
+ * act_gen(d[pixel] * gen_a[c] + gen_t[c]) with d a one-value-per-pixel tensor of pitch ldd floats (e.g. channel 0 of a
+ * 4-channel emd_cin1_f32 output with a = (1,0,0,0), no activation).  It is the layer after the one fed by the 1-channel
+ * micrograph (cnn0 -> cnn0_last, machine_learning/denoiser.py:252-255): cnn0 = relu6(BN(depthwise(img) (x) pointwise)) is
+ * rebuilt in registers and never written to memory.  gen_act is an EMD_ACT_* code (0 none, 1 relu6, 2 relu, 4 leaky 0.2);
+ * reflect as in emd_sep3x3_fused_reflect_f32.  Bit-identical to emd_cin1_f32 followed by emd_sep3x3_fused_f32. */
+int emd_sep3x3_fused_gen_f32(const float* d, int ldd, const float* gen_a, const float* gen_t, int gen_act, const float* dw,
+                             const uint16_t* whi, const uint16_t* wlo, const float* scale1, const float* shift1,
+                             const float* scale2, const float* shift2, const float* res, int ldres, float* y, int ldy, int B,
+                             int H, int W, int Cin, int Cout, int act, int precision, int reflect, emd_stream_t stream);
+
 /* Discriminator head (misc_py/gan-infilling-100.py:560-567, :708): a fully connected layer to ONE output per row,
  * y[b] = x[b,:K].w + bias (x row stride ldx), and output = sigmoid(max(small, medium, large)). */
 int emd_fc_rows_f32(const float* x, int ldx, const float* w, float bias, float* y, int B, int K, emd_stream_t stream);

@@ -265,6 +265,38 @@ def test_sep_fused(B, H, W, ci, co, res, extra, prec):
     assert np.isnan(full[..., :4]).all() and np.isnan(full[..., 4 + co:]).all()   # nothing written outside the slice
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,gen_act,reflect,extra", [
+    (2, 32, 48, 64, 64, 1, False, False),     # graph D's cnn0 -> cnn0_last
+    (1, 64, 64, 64, 64, 1, False, True),      # several tiles per workgroup
+    (2, 16, 32, 32, 128, 4, True, False),     # leaky relu, reflect border
+    (1, 8, 16, 128, 24, 0, False, False),
+])
+def test_sep_fused_generated_input(B, H, W, ci, co, gen_act, reflect, extra):
+    """emd_sep3x3_fused_gen_f32 == emd_cin1_f32 (written out) followed by emd_sep3x3_fused[_reflect]_f32, bit for bit."""
+    from emdenoise import ops
+
+    img = rnd((B, H, W, 1), 140)
+    w9, a, t = rnd((9,), 141, 0.4), rnd((ci,), 142, 0.8), rnd((ci,), 143, 0.5) + 0.5
+    dw = rnd((3, 3, ci), 144, 0.35)
+    pw = ops.PackedWeights(rnd((1, ci, co), 145, scale=(2.0 / (ci + co)) ** 0.5), False, dev())
+    d = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev())
+    s1, t1, s2, t2 = d(rnd((co,), 146, 0.2) + 1), d(rnd((co,), 147, 0.5)), d(rnd((co,), 148, 0.2) + 1), d(rnd((co,), 149, 0.5))
+    x = d(img)
+    # the written-out route; cin1 only knows relu6 / none, so the other activations are applied by torch on its raw output
+    full = ops.cin1(x, d(w9), d(a), d(t), out_act(B, H, W, ci, ld=ci, c0=0), act=(gen_act == 1))
+    if gen_act == 4:
+        v = full.buf
+        full.buf.copy_(torch.minimum(torch.maximum(v, 0.2 * v), torch.full_like(v, float("inf"))))
+    want = ops.sep_fused(full, d(dw), pw, s1, t1, out_act(B, H, W, co, ld=co, c0=0), scale2=s2 if extra else None,
+                         shift2=t2 if extra else None, reflect=reflect)
+    d4 = ops.cin1(x, d(w9), d(np.array([1, 0, 0, 0])), d(np.zeros(4)), out_act(B, H, W, 4, ld=4, c0=0), act=False)
+    got = ops.sep_fused_gen(d4, d(a), d(t), d(dw), pw, s1, t1, out_act(B, H, W, co, ld=co, c0=0), gen_act=gen_act,
+                            scale2=s2 if extra else None, shift2=t2 if extra else None, reflect=reflect)
+    torch.cuda.synchronize()
+    assert torch.equal(got.torch(), want.torch())
+    assert not torch.isnan(got.torch()).any()
+
+
 def test_sep_fused_falls_back_cleanly():
     from emdenoise import _lib, ops
 
