@@ -37,6 +37,8 @@ namespace {
 
 using namespace emd;
 
+__device__ __attribute__((aligned(16))) float g_zero16[4];   // what padding rows and channel tails load
+
 struct GemmParams {
     const float* A;       // source activations (NHWC), pixel stride lda
     const uint16_t* Whi;  // [Npad][taps*Cpad]
@@ -59,7 +61,7 @@ struct GemmParams {
 };
 
 // Block tile 128 x BN (BN = 128: 2x2 waves of 64x64; BN = 64: 4x1 waves of 32x64), K step 64.
-template <int BN, int PASSES>
+template <int BN, int PASSES, bool FLAT>
 __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
     constexpr int BM = 128, BK = 64;
     constexpr int LDK = BK + 8;                      // bf16 elements per LDS row: 144 B, conflict-free b128 reads
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
             const long m = m0 + tid;
             long long src = -1, dst = -1;
             if (m < p.M) {
-                if (p.flat) {
+                if (FLAT) {
                     src = dst = m;
                 } else {
                     const int j = (int)(m % p.Wg);
@@ -120,9 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
             if (with_dest) rowP[tid] = dst;
         }
     };
-    // block-uniform: every row of this tile has a source pixel for every tap (true for all interior tiles of
-    // the flat / strided 1x1 forms); then the loads need no per-row validity select
-    const bool rows_all_valid = p.flat ? (m0 + BM <= p.M) : false;
+    const bool rows_all_valid = m0 + BM <= p.M;   // block-uniform
 
     // global -> register staging, one K step ahead.  The loop starts at it = -1 (stage tile 0 only) so that
     // the load code and the LDS-store code each exist once, straight-line and fully unrolled.
@@ -181,23 +181,36 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
             // stage tile it+1 (the last iteration re-loads its own tile: keeps this path branch-free)
             const int nx = it + 1 < total ? it + 1 : it;
             const int tap = nx / ksteps, c0 = (nx - tap * ksteps) * BK;
-            if (c0 == 0 && !p.flat && nx != it && nx > 0) {  // tap change: new source rows (block-uniform)
+            if (c0 == 0 && !FLAT && nx != it && nx > 0) {  // tap change: new source rows (block-uniform)
                 map_rows(tap, false);
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < A_PASSES; ++q) aoff[q] = rowA[a_row + q * 16];
             }
-            if (rows_all_valid && c0 + BK <= p.Cin) {  // block-uniform fast path: plain loads
+            const bool kok = c0 + a_col < p.Cin;  // Cin % 4 == 0: a float4 is all inside or all outside
+            if (FLAT) {
+                // 1x1 forms: every tile but the last is all real rows; plain loads there (block-uniform)
+                if (rows_all_valid && c0 + BK <= p.Cin) {
 #pragma unroll
-                for (int q = 0; q < A_PASSES; ++q) areg[q] = *reinterpret_cast<const f32x4*>(Ab + aoff[q] + c0);
+                    for (int q = 0; q < A_PASSES; ++q) areg[q] = *reinterpret_cast<const f32x4*>(Ab + aoff[q] + c0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < A_PASSES; ++q) {
+                        // branch-free: an invalid row / K-tail chunk reads the tensor's first 16 bytes and is zeroed
+                        const bool ok = aoff[q] >= 0 && kok;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? Ab + aoff[q] + c0 : p.A);
+                        areg[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
             } else {
-                const bool kok = c0 + a_col < p.Cin;  // Cin % 4 == 0: a float4 is all inside or all outside
+                // forms with taps / strides: a row without a source pixel for this tap (padding) or a channel group beyond Cin
+                // reads 16 zero bytes.  The select is on the ADDRESS -- a select on the loaded value makes the wave wait for the
+                // load right here instead of a whole MFMA phase later (measured: the 3x3 / transposed-conv phases of graph D
+                // 6 - 12 % faster).
 #pragma unroll
                 for (int q = 0; q < A_PASSES; ++q) {
-                    // branch-free: an invalid row / K-tail chunk reads the tensor's first 16 bytes and is zeroed
-                    const bool ok = aoff[q] >= 0 && kok;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? Ab + aoff[q] + c0 : p.A);
-                    areg[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const float* src = (aoff[q] >= 0 && kok) ? Ab + aoff[q] + c0 : g_zero16;
+                    areg[q] = *reinterpret_cast<const f32x4*>(src);
                 }
             }
             const long kk = (long)tap * p.Cpad + c0;
@@ -319,9 +332,11 @@ int launch(const GemmParams& p0, int passes, hipStream_t st) {
     const long nblk = (long)p.n_mtiles * p.n_ntiles;
     if (nblk <= 0 || nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "gemm_conv: grid too large");
     if (passes == 3)
-        hipLaunchKernelGGL((gemm_conv_kernel<BN, 3>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+        if (p.flat) hipLaunchKernelGGL((gemm_conv_kernel<BN, 3, true>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_conv_kernel<BN, 3, false>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     else
-        hipLaunchKernelGGL((gemm_conv_kernel<BN, 1>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+        if (p.flat) hipLaunchKernelGGL((gemm_conv_kernel<BN, 1, true>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_conv_kernel<BN, 1, false>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     return emd::check_launch("gemm_conv_kernel");
 }
 

@@ -48,7 +48,7 @@ struct SepParams {
     const float* gen_a;
     const float* gen_t;
     int gen_act;
-    int dbg;              // dev knob EMD_SEP_DEBUG (timing experiments only): 1 no patch loads, 2 no depthwise stage, 4 no MFMAs
+    long long* stamps;    // dev hook: per-workgroup phase cycle sums (NULL otherwise)
 };
 
 template <int BN, int PASSES, bool GEN>
@@ -65,13 +65,16 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     constexpr int LDS_STAGE = BN + 4;
     constexpr int PATCH_BYTES = NPX * PLD * 4, A_BYTES = NPL * BM * LDK * 2, B_BYTES = NPL * BN * LDK * 2;
     constexpr int STAGE_BYTES = BM * LDS_STAGE * 4;
-    constexpr int TILE_BYTES = PATCH_BYTES + A_BYTES + B_BYTES > STAGE_BYTES ? PATCH_BYTES + A_BYTES + B_BYTES : STAGE_BYTES;
+    constexpr int DW_BYTES = 9 * BK * 4;                     // the chunk's depthwise weights [9][32]
+    constexpr int DW_OFF = PATCH_BYTES + A_BYTES + B_BYTES > STAGE_BYTES ? PATCH_BYTES + A_BYTES + B_BYTES : STAGE_BYTES;   // clear of the staging tile
+    constexpr int TILE_BYTES = DW_OFF + DW_BYTES;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES];
     float* patch = reinterpret_cast<float*>(smem);
     auto As = reinterpret_cast<uint16_t(*)[BM][LDK]>(smem + PATCH_BYTES);
     auto Bs = reinterpret_cast<uint16_t(*)[BN][LDK]>(smem + PATCH_BYTES + A_BYTES);
     float(*stage)[LDS_STAGE] = reinterpret_cast<float(*)[LDS_STAGE]>(smem);
+    float* wks = reinterpret_cast<float*>(smem + DW_OFF);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     f32x4 preg[P_PASSES];
     f32x4 gga = {0.f, 0.f, 0.f, 0.f}, ggt = gga;   // generated input: the chunk's a / t vectors
     u32x4 wh0 = {0, 0, 0, 0}, wh1 = wh0, wl0 = wh0, wl1 = wh0;
-    f32x4 wk[9];
+    f32x4 wkreg = {0.f, 0.f, 0.f, 0.f};
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -134,6 +137,9 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                                          // a tile's epilogue overlaps the loads of the next tile's first chunk
     const int fr = lane & 31, fh = lane >> 5;
 
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    if (p.stamps) tprev = __builtin_amdgcn_s_memtime();
+#define SEP_STAMP(i) if (p.stamps) { const long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tprev; tprev = t_; }
     for (int it = -1; it < total; ++it) {
         if (it >= 0) {
             // staged registers (chunk `it`) -> LDS
@@ -155,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                 const int idx = tid + q * 256;
                 if (idx < NPX * 8) *reinterpret_cast<f32x4*>(patch + (idx >> 3) * PLD + (idx & 7) * 4) = preg[q];
             }
+            if (tid < 72) *reinterpret_cast<f32x4*>(wks + tid * 4) = wkreg;
             *reinterpret_cast<u32x4*>(&Bs[0][w_row][w_col]) = wh0;
             if (NPL == 2) *reinterpret_cast<u32x4*>(&Bs[NPL - 1][w_row][w_col]) = wl0;
             if (W_PASSES == 2) {
@@ -163,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             }
             __syncthreads();  // (1) patch + W tile of chunk `it` visible
         }
+        SEP_STAMP(0)
         // stage chunk it+1 (the last iteration re-loads its own chunk: branch-free).  Issued BEFORE the
         // depthwise work below so the loads have the depthwise + MFMA phases (not just the MFMAs) to land.
         const int nx = it + 1 < total ? it + 1 : it;
@@ -190,14 +198,20 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
 #pragma unroll
             for (int q = 0; q < P_PASSES; ++q) preg[q] = *reinterpret_cast<const f32x4*>(psrc[q] + c0n);
         }
+        // the chunk's 9 x 32 depthwise weights travel through LDS too: one 16-byte load for 72 threads instead of nine for every thread
+        if (tid < 72) wkreg = *reinterpret_cast<const f32x4*>(p.dw + ((long)(tid >> 3) * p.Cin + c0n) + (tid & 7) * 4);
         wh0 = *reinterpret_cast<const u32x4*>(whi + c0n);
         if (NPL == 2) wl0 = *reinterpret_cast<const u32x4*>(wlo + c0n);
         if (W_PASSES == 2) {
             wh1 = *reinterpret_cast<const u32x4*>(whi + 64L * p.Cpad + c0n);
             if (NPL == 2) wl1 = *reinterpret_cast<const u32x4*>(wlo + 64L * p.Cpad + c0n);
         }
-        if (it >= 0 && !(p.dbg & 2)) {
+        SEP_STAMP(1)
+        if (it >= 0) {
             // depthwise 3x3 from the LDS patch -> bf16 hi/lo A planes
+            f32x4 wk[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const f32x4*>(wks + k * BK + c4 * 4);
             f32x4 o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -222,12 +236,10 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                 if (NPL == 2) *reinterpret_cast<u32x2*>(&As[NPL - 1][r][c4 * 4]) = u32x2{l0, l1};
             }
         }
-        // the next chunk's depthwise weights (their registers are free only now)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const f32x4*>(p.dw + ((long)k * p.Cin + c0n) + c4 * 4);
+        SEP_STAMP(2)
         if (it < 0) continue;
         __syncthreads();  // (2) A planes of chunk `it` visible
-        if (!(p.dbg & 4))
+        SEP_STAMP(3)
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -254,7 +266,9 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
+        SEP_STAMP(4)
         __syncthreads();  // (3) fragment reads done before the next chunk overwrites patch / A / B
+        SEP_STAMP(5)
         if ((it + 1) % nchunks != 0) continue;   // more chunks of this tile to come
 
         // ---- epilogue (see gemm_conv.hip): accumulators -> fp32 LDS tile -> 16-byte stores along the channel axis
@@ -328,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             }
         }
         __syncthreads();  // the staging tile is read out before the next tile's patch overwrites it
+        SEP_STAMP(6)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -336,7 +351,15 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         x0 += TW;
     }
+    if (p.stamps && tid == 0) {
+        long long* o = p.stamps + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = ph[i];
+    }
+#undef SEP_STAMP
 }
+
+long long* g_sep_stamps = nullptr;   // dev hook, see emd_debug_sep_stamps
 
 template <int BN>
 int launch(const SepParams& p, int B, int passes, hipStream_t st) {
@@ -348,12 +371,13 @@ int launch(const SepParams& p, int B, int passes, hipStream_t st) {
     for (int t = 8; t >= 2; t >>= 1)   // several tiles per workgroup where that still leaves >= 8 workgroups per CU
         if (tiles_w % t == 0 && wgs1 / t >= 2048) { q.tpw = t; break; }
     if (force > 0 && tiles_w % force == 0) q.tpw = force;
-    static const int dbg = [] { const char* e = getenv("EMD_SEP_DEBUG"); return e ? atoi(e) : 0; }();
-    q.dbg = dbg;
+    q.stamps = g_sep_stamps;
     const dim3 grid(tiles_w / q.tpw, p.H / 8, B);
-    if (p.gen_a) {   // generated input: the full-precision variant only
-        if (passes != 3) return emd::fail(EMD_E_UNSUPPORTED, "emd_sep3x3_fused_gen_f32: precision must be EMD_PREC_BF16X3");
-        hipLaunchKernelGGL((sep_fused_kernel<BN, 3, true>), grid, dim3(256), 0, st, q);
+    if (p.gen_a) {
+        if (passes == 3)
+            hipLaunchKernelGGL((sep_fused_kernel<BN, 3, true>), grid, dim3(256), 0, st, q);
+        else
+            hipLaunchKernelGGL((sep_fused_kernel<BN, 1, true>), grid, dim3(256), 0, st, q);
     } else if (passes == 3)
         hipLaunchKernelGGL((sep_fused_kernel<BN, 3, false>), grid, dim3(256), 0, st, q);
     else
@@ -436,3 +460,6 @@ extern "C" int emd_sep3x3_fused_gen_f32(const float* d, int ldd, const float* ge
     return sep_fused_entry(d, ldd, dw, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, B, H, W, Cin, Cout, act,
                            precision, reflect, stream, gen_a, gen_t, gen_act);
 }
+
+// dev hook (not in the header): per-workgroup phase cycle sums for tools/sep_bench.py
+extern "C" void emd_debug_sep_stamps(void* buf) { g_sep_stamps = static_cast<long long*>(buf); }
