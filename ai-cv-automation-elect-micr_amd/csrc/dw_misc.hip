@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restr
 // output rows keeping the vector partial sums of the three live input rows, so an input row is read once
 // per strip (3 shifted 16-B loads per lane) instead of 9 loads per output; the cross-lane reduction over the
 // LP channel groups happens once per output pixel.
-template <int TH>
+template <int TH, bool REFLECT>
 __global__ __launch_bounds__(256) void conv3x3_cout1_roll(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ w, float scale, float shift,
                                                           float* __restrict__ y, int H, int W, int LP, int nstrip,
@@ -294,28 +294,48 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_roll(const float* __restric
     float* yb = y + (b * H) * (long)W;
     const int oy0 = strip * TH;
     const bool hasl = ox > 0, hasr = ox + 1 < W;
+    // As in dw3x3_s1_roll: every load unconditional (indices clamped or reflected into the image, a padding value replaced by
+    // zero where it is USED) and issued PF rows ahead; the first version branched around each load and waited row by row
+    // (629 us for the 64-channel 512^2 x 32 maps of graph D, 2.1 GB).  REFLECT: tf.pad(REFLECT, 1) + VALID (graph G).
+    constexpr int PF = 3, NR = TH + 2;
+    const long xl = hasl ? -(long)ldx : (REFLECT ? (long)ldx : 0), xr = hasr ? (long)ldx : (REFLECT ? -(long)ldx : 0);
+    auto row_ptr = [&](int tt) {
+        int iy = oy0 - 1 + tt;
+        if (REFLECT) iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
+        iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+        return xb + ((long)iy * W + ox) * ldx;
+    };
+    float4 rc[PF], rl[PF], rr[PF];
+#pragma unroll
+    for (int t0 = 0; t0 < PF && t0 < NR; ++t0) {
+        const float* row = row_ptr(t0);
+        rc[t0] = *reinterpret_cast<const float4*>(row);
+        rl[t0] = *reinterpret_cast<const float4*>(row + xl);
+        rr[t0] = *reinterpret_cast<const float4*>(row + xr);
+    }
     float4 s0 = f4zero(), s1 = f4zero();
 #pragma unroll
-    for (int tt = 0; tt < TH + 2; ++tt) {
+    for (int tt = 0; tt < NR; ++tt) {
         const int iy = oy0 - 1 + tt;
-        float4 h0 = f4zero(), h1 = f4zero(), h2 = f4zero();
-        if (iy >= 0 && iy < H) {
-            const float* row = xb + ((long)iy * W + ox) * ldx;
-            const float4 c = *reinterpret_cast<const float4*>(row);
-            const float4 l = hasl ? *reinterpret_cast<const float4*>(row - ldx) : f4zero();
-            const float4 r = hasr ? *reinterpret_cast<const float4*>(row + ldx) : f4zero();
-            h0 = fma4(wk[0], l, fma4(wk[1], c, fma4(wk[2], r, h0)));
-            h1 = fma4(wk[3], l, fma4(wk[4], c, fma4(wk[5], r, h1)));
-            h2 = fma4(wk[6], l, fma4(wk[7], c, fma4(wk[8], r, h2)));
+        const bool ok = REFLECT || (iy >= 0 && iy < H);
+        const float4 c = ok ? rc[tt % PF] : f4zero();
+        const float4 l = ok && (REFLECT || hasl) ? rl[tt % PF] : f4zero();
+        const float4 r = ok && (REFLECT || hasr) ? rr[tt % PF] : f4zero();
+        if (tt + PF < NR) {
+            const float* row = row_ptr(tt + PF);
+            rc[tt % PF] = *reinterpret_cast<const float4*>(row);
+            rl[tt % PF] = *reinterpret_cast<const float4*>(row + xl);
+            rr[tt % PF] = *reinterpret_cast<const float4*>(row + xr);
         }
+        const float4 h0 = fma4(wk[0], l, fma4(wk[1], c, fma4(wk[2], r, f4zero())));
+        const float4 h1 = fma4(wk[3], l, fma4(wk[4], c, fma4(wk[5], r, f4zero())));
+        const float4 h2 = fma4(wk[6], l, fma4(wk[7], c, fma4(wk[8], r, f4zero())));
         if (tt >= 2) {
             const int oy = oy0 + tt - 2;
             const float4 a = add4(s0, h2);
             float s = (a.x + a.y) + (a.z + a.w);
             for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m);
-            if (c4 == 0 && oy < H) {
-                yb[(long)oy * W + ox] = cout1_out(s, pre_bias, pre_relu, scale, shift, act);
-            }
+            if (c4 == 0 && oy < H) yb[(long)oy * W + ox] = cout1_out(s, pre_bias, pre_relu, scale, shift, act);
         }
         s0 = add4(s1, h1);
         s1 = h0;
@@ -410,6 +430,35 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
         part[((long)blockIdx.y * 2 + 0) * C + c] = sm[0][0][l] + sm[0][1][l] + sm[0][2][l] + sm[0][3][l];
         part[((long)blockIdx.y * 2 + 1) * C + c] = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
     }
+}
+
+// The same for ONE dense channel (C == 1, ldx == 1: the instance norm of the generator's output image, misc_py/gan-infilling-100.py:367):
+// all 256 threads of the workgroup share the slab (the kernel above would leave 252 of them idle); fixed shuffle tree, so
+// the sum is reproducible run to run.
+__global__ __launch_bounds__(256) void bn_stats_partial_c1(const float* __restrict__ x, long npix, long rows_per_slab,
+                                                           double* __restrict__ part) {
+    __shared__ double sm[2][4];
+    x += (long)blockIdx.z * npix;
+    part += (long)blockIdx.z * gridDim.y * 2;
+    const long r0 = (long)blockIdx.y * rows_per_slab;
+    const long r1 = min(r0 + rows_per_slab, npix);
+    double s = 0.0, q = 0.0;
+    for (long r = r0 + threadIdx.x; r < r1; r += 256) {
+        const double v = (double)x[r];
+        s += v;
+        q += v * v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s += __shfl_down(s, d);
+        q += __shfl_down(q, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sm[0][threadIdx.x >> 6] = s;
+        sm[1][threadIdx.x >> 6] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) part[(long)blockIdx.y * 2 + threadIdx.x] = (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
 }
 
 // The same for C % 4 == 0: 16 channel quads x 16 row lanes per workgroup, 16-byte loads, 4 rows in flight per thread.
@@ -600,6 +649,20 @@ int emd::launch_bn_stats_final(const double* part, int nslab, int C, long npix, 
     return emd::check_launch("bn_stats_final");
 }
 
+// emd_conv3x3_cout1_reflect_f32 on the rolling kernel (gan_ops.hip calls it where a wave never straddles an image row)
+int emd::launch_conv3x3_cout1_reflect_roll(const float* x, int ldx, const float* w, float bias, float* y, int B, int H, int W,
+                                           int Cin, hipStream_t st) {
+    constexpr int TH = 8;
+    const int LP = Cin / 4, nstrip = (H + TH - 1) / TH;
+    const long nthreads = (long)B * nstrip * W * LP;
+    unsigned nb;
+    int rc = grid_for(nthreads, &nb);
+    if (rc != EMD_OK) return rc;
+    hipLaunchKernelGGL((conv3x3_cout1_roll<TH, true>), dim3(nb), dim3(256), 0, st, x, ldx, w, 1.f, bias, y, H, W, LP, nstrip,
+                       nthreads, 0, 0.f, 0);
+    return emd::check_launch("conv3x3_cout1_roll (reflect)");
+}
+
 // stride-1 depthwise over the REFLECT-padded input on the rolling kernel (called by emd_dw3x3_reflect*_f32, gan_ops.hip;
 // arguments already validated there)
 int emd::launch_dw3x3_reflect_roll(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
@@ -685,7 +748,7 @@ extern "C" int emd_conv3x3_cout1_f32(const float* x, int ldx, const float* w, fl
         const long nthreads = (long)B * nstrip * W * LP;
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
-        hipLaunchKernelGGL(conv3x3_cout1_roll<TH>, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w,
+        hipLaunchKernelGGL((conv3x3_cout1_roll<TH, false>), dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w,
                            scale, shift, y, H, W, LP, nstrip, nthreads, act, pre_bias, pre_relu);
         return emd::check_launch("conv3x3_cout1_roll");
     }
@@ -749,7 +812,9 @@ extern "C" int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float
     const long nslab = emd::reduce_slabs(npix), rows_per_slab = emd::reduce_rows_per_slab(npix);
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
-    if (C % 4 == 0 && ldx % 4 == 0 && emd::aligned16(x))
+    if (C == 1 && ldx == 1)
+        hipLaunchKernelGGL(bn_stats_partial_c1, dim3(1, (unsigned)nslab), dim3(256), 0, st, x, npix, rows_per_slab, ws);
+    else if (C % 4 == 0 && ldx % 4 == 0 && emd::aligned16(x))
         hipLaunchKernelGGL(bn_stats_partial_v4, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, npix, C,
                            rows_per_slab, ws);
     else
@@ -771,7 +836,9 @@ extern "C" int emd_bn_stats_images_f32(const float* x, int ldx, int B, long npix
     const long nslab = emd::reduce_slabs(npix_img), rows_per_slab = emd::reduce_rows_per_slab(npix_img);
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
-    if (C % 4 == 0 && ldx % 4 == 0 && emd::aligned16(x))
+    if (C == 1 && ldx == 1)
+        hipLaunchKernelGGL(bn_stats_partial_c1, dim3(1, (unsigned)nslab, B), dim3(256), 0, st, x, npix_img, rows_per_slab, ws);
+    else if (C % 4 == 0 && ldx % 4 == 0 && emd::aligned16(x))
         hipLaunchKernelGGL(bn_stats_partial_v4, dim3((C + 63) / 64, (unsigned)nslab, B), dim3(256), 0, st, x, ldx, npix_img, C,
                            rows_per_slab, ws);
     else

@@ -33,6 +33,10 @@ inline int check_launch(const char* kernel) {
 int launch_dw3x3_reflect_roll(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C, bool split,
                               hipStream_t st);
 
+// dw_misc.hip: the rolling 3x3 conv to one channel over the REFLECT-padded input, y = conv + bias (W % (256 / Cin) == 0)
+int launch_conv3x3_cout1_reflect_roll(const float* x, int ldx, const float* w, float bias, float* y, int B, int H, int W, int Cin,
+                                      hipStream_t st);
+
 int launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -235,6 +235,8 @@ extern "C" int emd_conv3x3_cout1_reflect_f32(const float* x, int ldx, const floa
     if (B == 0) return EMD_OK;
     const long npix = (long)B * H * W;
     const int ppw = 64 / LP;
+    if (W % ppw == 0)   // a wave never straddles an image row: rolling kernel (an input row is read once per 8-row strip)
+        return emd::launch_conv3x3_cout1_reflect_roll(x, ldx, w, bias, y, B, H, W, Cin, static_cast<hipStream_t>(stream));
     unsigned nb;
     int rc = blocks_for((npix + ppw - 1) / ppw * 64, &nb);
     if (rc != EMD_OK) return rc;

@@ -155,6 +155,24 @@ def test_first_and_last_layer_kernels():
 
 
 @gpu
+@pytest.mark.parametrize("B,H,W,ci", [(1, 16, 64, 32), (2, 9, 20, 32), (1, 8, 8, 64), (1, 33, 16, 16)])
+def test_conv3x3_cout1_reflect_shapes(B, H, W, ci):
+    """Both forms of emd_conv3x3_cout1_reflect_f32 (rolling strips where a wave stays inside an image row, per-pixel otherwise),
+    ragged strip heights included, against the float64 reflect-pad + VALID conv."""
+    from emdenoise import ops
+    from oracle import gan_graph as GG
+    from tests.test_ops_gpu import rnd, t64, to_act
+
+    xin, w = rnd((B, H, W, ci), 80), rnd((3, 3, ci, 1), 81, 0.2)
+    wt = t64(w).permute(3, 2, 0, 1).contiguous()
+    raw = torch.nn.functional.conv2d(GG.reflect_pad_t(t64(xin), 1).permute(0, 3, 1, 2), wt, t64(np.array([-0.2]))).permute(0, 2, 3, 1)
+    got = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev())
+    ops.conv3x3_cout1_reflect(to_act(xin, ld=ci + 8, c0=4), torch.from_numpy(np.ascontiguousarray(w[..., 0].reshape(9, ci))).to(dev()), -0.2, got)
+    torch.cuda.synchronize()
+    assert rel_l2(got.cpu().numpy(), raw.numpy()) < 2e-6
+
+
+@gpu
 def test_leaky_relu_epilogue():
     from emdenoise import ops
     from oracle import tf_ops as T

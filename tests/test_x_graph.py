@@ -73,6 +73,26 @@ def test_engine_matches_oracle(B, S):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(3, 64, 48), (2, 512, 512), (1, 7, 5)])
+def test_single_channel_image_statistics(B, H, W):
+    """The dense one-channel reduction (emd_bn_stats_images_f32 with C == 1, ldx == 1: the generator's output instance norm) and
+    the batch form over the same buffer, against numpy float64."""
+    from emdenoise import ops
+
+    rng = np.random.default_rng(H * W + B)
+    x = (rng.standard_normal((B, H, W, 1)) * np.array([0.5, 2.0, 1.0])[:B].reshape(B, 1, 1, 1) + 3.0).astype(np.float32)
+    a = ops.Act(torch.from_numpy(x).to(torch.device("cuda", 0)))
+    mean, var = ops.bn_batch_stats_images(a)
+    x64 = x.astype(np.float64).reshape(B, -1)
+    assert np.allclose(mean.cpu().numpy(), x64.mean(1), rtol=1e-6, atol=1e-6)
+    assert np.allclose(var.cpu().numpy(), x64.var(1), rtol=2e-6, atol=1e-7)
+    m1, v1 = ops.bn_batch_stats(a)
+    assert np.allclose(m1.cpu().numpy(), x64.mean(), rtol=1e-6) and np.allclose(v1.cpu().numpy(), x64.var(), rtol=2e-6)
+    m2, v2 = ops.bn_batch_stats_images(a)
+    assert torch.equal(mean, m2) and torch.equal(var, v2)          # reproducible run to run
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("npix_shape,Cc", [((2, 33, 17), 728), ((1, 64, 64), 64), ((3, 5, 7), 2048), ((1, 1, 1), 8)])
 def test_bn_batch_stats_and_fold(npix_shape, Cc):
     from emdenoise import ops
