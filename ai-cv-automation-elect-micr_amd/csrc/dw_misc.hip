@@ -191,10 +191,9 @@ __global__ __launch_bounds__(256) void cin1_kernel(const float* __restrict__ x, 
     const long pix = p0 + lane;
     float d = 0.f;
     if (pix < npix) {
-        const int ox = (int)(pix % Wo);
-        const long t = pix / Wo;
-        const int oy = (int)(t % Ho);
-        const long b = t / Ho;
+        int ox, oy;
+        const long t = emd::divmod(pix, Wo, ox);
+        const long b = emd::divmod(t, Ho, oy);
         const float* img = x + b * (long)H * W;
         if (use_dw) {  // 3x3, stride 1, SAME (pad 1)
 #pragma unroll
@@ -245,10 +244,9 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restr
     const long pix = wave * ppw + sub;
     float4 acc = f4zero();
     if (pix < npix) {
-        const int ox = (int)(pix % W);
-        const long t = pix / W;
-        const int oy = (int)(t % H);
-        const long b = t / H;
+        int ox, oy;
+        const long t = emd::divmod(pix, W, ox);
+        const long b = emd::divmod(t, H, oy);
         const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -280,12 +278,10 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_roll(const float* __restric
                                                           long nthreads, int act, float pre_bias, int pre_relu) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;  // nthreads is a multiple of 64: whole waves leave together
-    const int c4 = (int)(tid % LP);
-    long t = tid / LP;
-    const int ox = (int)(t % W);
-    t /= W;
-    const int strip = (int)(t % nstrip);
-    const long b = t / nstrip;
+    int c4, ox, strip;
+    long t = emd::divmod(tid, LP, c4);
+    t = emd::divmod(t, W, ox);
+    const long b = emd::divmod(t, nstrip, strip);
     const int C = LP * 4;
     float4 wk[9];
 #pragma unroll
@@ -350,12 +346,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
                                                               long nthreads) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;
-    const int c4 = (int)(tid % C4);
-    long t = tid / C4;
-    const int ox = (int)(t % Wo);
-    t /= Wo;
-    const int oy = (int)(t % Ho);
-    const long b = t / Ho;
+    int c4, ox, oy;
+    long t = emd::divmod(tid, C4, c4);
+    t = emd::divmod(t, Wo, ox);
+    const long b = emd::divmod(t, Ho, oy);
     const float fy = (float)oy * sy, fx = (float)ox * sx;
     const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
     const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
@@ -374,6 +368,41 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     *reinterpret_cast<float4*>(y + ((b * Ho + oy) * (long)Wo + ox) * ldy + c4 * 4) = o;
 }
 
+// The same for an exact 2x upsampling (Ho = 2 Hi, Wo = 2 Wi: every resize of graph G's generator): src = dst / 2, so the
+// weights are 0 or 1/2 and one SOURCE pixel feeds a 2 x 2 block of outputs.  A thread owns (source pixel, channel quad):
+// four loads and one index decomposition for four 16-byte stores (the kernel above: four loads and a decomposition per
+// store).  Same expression per output, so the same bits.
+__global__ __launch_bounds__(256) void resize_up2_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                         int Hi, int Wi, int C4, long nthreads) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nthreads) return;
+    int c4, sx, sy;
+    long t = emd::divmod(tid, C4, c4);
+    t = emd::divmod(t, Wi, sx);
+    const long b = emd::divmod(t, Hi, sy);
+    const int y1 = min(sy + 1, Hi - 1), x1 = min(sx + 1, Wi - 1);
+    const float* xb = x + (b * Hi) * (long)Wi * ldx + c4 * 4;
+    const float4 tl = *reinterpret_cast<const float4*>(xb + ((long)sy * Wi + sx) * ldx);
+    const float4 tr = *reinterpret_cast<const float4*>(xb + ((long)sy * Wi + x1) * ldx);
+    const float4 bl = *reinterpret_cast<const float4*>(xb + ((long)y1 * Wi + sx) * ldx);
+    const float4 br = *reinterpret_cast<const float4*>(xb + ((long)y1 * Wi + x1) * ldx);
+    auto lerp = [](float a, float b2, float l) { return a + (b2 - a) * l; };
+    const int Wo = 2 * Wi;
+    float* yb = y + ((b * 2 * Hi + 2 * sy) * (long)Wo + 2 * sx) * ldy + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float ly = 0.5f * (float)i, lx = 0.5f * (float)j;
+            float4 o;
+            o.x = lerp(lerp(tl.x, tr.x, lx), lerp(bl.x, br.x, lx), ly);
+            o.y = lerp(lerp(tl.y, tr.y, lx), lerp(bl.y, br.y, lx), ly);
+            o.z = lerp(lerp(tl.z, tr.z, lx), lerp(bl.z, br.z, lx), ly);
+            o.w = lerp(lerp(tl.w, tr.w, lx), lerp(bl.w, br.w, lx), ly);
+            *reinterpret_cast<float4*>(yb + ((long)i * Wo + j) * ldy) = o;
+        }
+}
+
 // y = act(x*scale + shift) [+ res]; x and y may be the same buffer (elementwise, same index).
 __global__ __launch_bounds__(256) void affine_relu6_kernel(const float* x, int ldx, const float* __restrict__ sc,
                                                            const float* __restrict__ sh, const float* res, int ldres,
@@ -382,9 +411,9 @@ __global__ __launch_bounds__(256) void affine_relu6_kernel(const float* x, int l
     // npix_img != 0: scale / shift are [image][C] (per-image statistics: instance norms, graph S), image = pix / npix_img
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;
-    const int c4 = (int)(tid % C4);
-    const long pix = tid / C4;
-    const long so = npix_img ? (pix / npix_img) * C4 * 4 : 0;
+    int c4;
+    const long pix = emd::divmod(tid, C4, c4);
+    const long so = npix_img ? (((unsigned long)pix >> 32) == 0 && npix_img <= 0x7fffffffL ? (long)((unsigned)pix / (unsigned)npix_img) : pix / npix_img) * C4 * 4 : 0;
     const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c4 * 4);
     const float4 s = *reinterpret_cast<const float4*>(sc + so + c4 * 4);
     const float4 t = *reinterpret_cast<const float4*>(sh + so + c4 * 4);
@@ -548,12 +577,10 @@ __global__ __launch_bounds__(256) void avgpool2x2_kernel(const float* __restrict
                                                          int ldy, int H, int W, int Ho, int Wo, int C4, long nthreads) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;
-    const int c4 = (int)(tid % C4);
-    long t = tid / C4;
-    const int ox = (int)(t % Wo);
-    t /= Wo;
-    const int oy = (int)(t % Ho);
-    const long b = t / Ho;
+    int c4, ox, oy;
+    long t = emd::divmod(tid, C4, c4);
+    t = emd::divmod(t, Wo, ox);
+    const long b = emd::divmod(t, Ho, oy);
     const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
     float4 acc = f4zero();
     int cnt = 0;
@@ -767,8 +794,16 @@ extern "C" int emd_resize_bilinear_f32(const float* x, int ldx, float* y, int ld
     EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && emd::aligned16(x) &&
                     emd::aligned16(y), EMD_E_ALIGN, "emd_resize_bilinear_f32: alignment");
     if (B == 0) return EMD_OK;
-    const long nthreads = (long)B * Ho * Wo * (C / 4);
     unsigned nb;
+    if (Ho == 2 * Hi && Wo == 2 * Wi) {
+        const long nsrc = (long)B * Hi * Wi * (C / 4);
+        int rc2 = grid_for(nsrc, &nb);
+        if (rc2 != EMD_OK) return rc2;
+        hipLaunchKernelGGL(resize_up2_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, y, ldy, Hi, Wi,
+                           C / 4, nsrc);
+        return emd::check_launch("resize_up2_kernel");
+    }
+    const long nthreads = (long)B * Ho * Wo * (C / 4);
     int rc = grid_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, y, ldy,

@@ -69,10 +69,9 @@ __global__ __launch_bounds__(256) void cin1_k7_reflect_kernel(const float* __res
     const long pix = p0 + lane;
     float d = 0.f;
     if (pix < npix) {
-        const int ox = (int)(pix % W);
-        const long t = pix / W;
-        const int oy = (int)(t % H);
-        const float* img = x + (t / H) * (long)H * W;
+        int ox, oy;
+        const long t = emd::divmod(pix, W, ox);
+        const float* img = x + emd::divmod(t, H, oy) * (long)H * W;
         for (int i = 0; i < 7; ++i) {
             const float* row = img + (long)reflect(oy - 3 + i, H) * W;
 #pragma unroll
@@ -107,10 +106,9 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_reflect_kernel(const float*
     const long pix = wave * ppw + sub;
     float4 acc = f4zero();
     if (pix < npix) {
-        const int ox = (int)(pix % W);
-        const long t = pix / W;
-        const int oy = (int)(t % H);
-        const float* xb = x + ((t / H) * H) * (long)W * ldx + c4 * 4;
+        int ox, oy;
+        const long t = emd::divmod(pix, W, ox);
+        const float* xb = x + (emd::divmod(t, H, oy) * H) * (long)W * ldx + c4 * 4;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int iy = reflect(oy - 1 + i, H);

@@ -1100,8 +1100,8 @@ __global__ __launch_bounds__(256) void to_split32_kernel(const float* __restrict
                                                          int ldy, long npix, int C4, int C4p) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= npix * C4p) return;
-    const int c4 = (int)(tid % C4p);
-    const long pix = tid / C4p;
+    int c4;
+    const long pix = emd::divmod(tid, C4p, c4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (c4 < C4) v = *reinterpret_cast<const f32x4*>(x + pix * ldx + c4 * 4);
     unsigned h0, l0, h1, l1;

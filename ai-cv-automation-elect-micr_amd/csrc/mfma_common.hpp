@@ -17,6 +17,20 @@ constexpr int kBK = 64;       // channel padding unit of the packed weights (and
 constexpr int kNPadTo = 128;  // packed weights are padded to a multiple of the widest BN
 
 // a = hi + lo (+ O(2^-17)): two packed bf16 words for two floats
+// q = v / d, rem = v % d for the index decompositions of the element-wise kernels.  A 64-bit integer division is a ~100
+// instruction emulation on this ISA and those kernels do three of them per 16-byte output (the bilinear resize of graph G
+// ran at 1.4 TB/s because of it); an index below 2^32 -- every shape of the reference's graphs -- takes the 32-bit form.
+__device__ __forceinline__ long divmod(long v, int d, int& rem) {
+    if (((unsigned long)v >> 32) == 0) {
+        const unsigned q = (unsigned)v / (unsigned)d;
+        rem = (int)((unsigned)v - q * (unsigned)d);
+        return (long)q;
+    }
+    const long q = v / d;
+    rem = (int)(v - q * d);
+    return q;
+}
+
 __device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigned& lo) {
     const f32x2 v = {a0, a1};
     const bf16x2 h = __builtin_convertvector(v, bf16x2);

@@ -193,7 +193,8 @@ def test_conv3x3_cout1(B, H, W, ci):
     assert rel_l2(out.cpu().numpy(), ref) < TOL_F32
 
 
-@pytest.mark.parametrize("Hi,Wi,Ho,Wo,Cc", [(4, 4, 16, 16, 256), (8, 8, 8, 8, 728), (3, 5, 12, 20, 64), (32, 32, 128, 128, 8)])
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo,Cc", [(4, 4, 16, 16, 256), (8, 8, 8, 8, 728), (3, 5, 12, 20, 64), (32, 32, 128, 128, 8),
+                                            (16, 12, 32, 24, 64), (1, 1, 2, 2, 8), (5, 7, 10, 14, 728)])   # exact 2x: the block form
 def test_resize_bilinear(Hi, Wi, Ho, Wo, Cc):
     from emdenoise import ops
     from oracle import tf_ops as T
