@@ -165,6 +165,9 @@ SIGNATURES = {
     "emd_sep3x3_fused_reflect_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
                                                _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int,
                                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # d ldd gen_a gen_t leaky_act w y ldy B H W C stride stream
+    "emd_dw3x3_reflect_gen_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, _c_float_p, _c_float_p] +
+                                  [C.c_int] * 6 + [C.c_void_p]),
     # d ldd gen_a gen_t gen_act dw whi wlo scale1 shift1 scale2 shift2 res ldres y ldy B H W Cin Cout act precision reflect stream
     "emd_sep3x3_fused_gen_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_void_p,
                                            C.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, C.c_int,

@@ -56,6 +56,49 @@ __global__ __launch_bounds__(256) void dw3x3_reflect_kernel(const float* __restr
     emd::dw_store<SPLIT>(y, (b * Ho + oy) * (long)Wo + ox, ldy, c4o, padq ? f4zero() : acc);
 }
 
+// dw3x3_reflect_kernel on a GENERATED input: the C-channel tensor it reads is act(d[pixel] * a[c] + t[c]) with d one value per
+// pixel (pitch ldd) -- the first layer's output (cin1_k7_reflect_kernel) rebuilt in registers for the layer that follows it
+// (enc0 -> enc1, misc_py/gan-infilling-100.py:343-349), so that [B,H,W,C] tensor is neither written nor read.  Same
+// arithmetic in the same order as the two kernels it replaces.
+__global__ __launch_bounds__(256) void dw3x3_reflect_gen_kernel(const float* __restrict__ d, int ldd, const float* __restrict__ a,
+                                                                const float* __restrict__ tsh, int gen_act,
+                                                                const float* __restrict__ w, float* __restrict__ y, int ldy,
+                                                                int H, int W, int C4, int Ho, int Wo, int stride, int qs) {
+    // a workgroup = 2^qs channel quads x (4 rows x 2^(6-qs) columns) of output pixels; qs = 3 for the 32-channel first layer,
+    // so that no lane idles on a channel quad that does not exist
+    const int QB = 1 << qs, tw = 64 >> qs;
+    const int ncb = (C4 + QB - 1) >> qs, npx = (Wo + tw - 1) / tw, npy = (Ho + 3) >> 2;
+    int bidx = blockIdx.x;
+    const int cblk = bidx % ncb;
+    bidx /= ncb;
+    const int bx = bidx % npx;
+    bidx /= npx;
+    const int by = bidx % npy;
+    const long b = bidx / npy;
+    const int c4 = cblk * QB + (threadIdx.x & (QB - 1));
+    const int pp = threadIdx.x >> qs;
+    const int ox = bx * tw + (pp & (tw - 1)), oy = by * 4 + pp / tw;
+    if (c4 >= C4 || ox >= Wo || oy >= Ho) return;
+    const int C = C4 * 4;
+    const float4 av = *reinterpret_cast<const float4*>(a + c4 * 4);
+    const float4 tv = *reinterpret_cast<const float4*>(tsh + c4 * 4);
+    const float* db = d + (b * H) * (long)W * ldd;
+    float4 acc = f4zero();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int iy = reflect(oy * stride - 1 + i, H);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ix = reflect(ox * stride - 1 + j, W);
+            const float dv = db[((long)iy * W + ix) * ldd];
+            float4 v = make_float4(fmaf(dv, av.x, tv.x), fmaf(dv, av.y, tv.y), fmaf(dv, av.z, tv.z), fmaf(dv, av.w, tv.w));
+            if (gen_act) v = make_float4(leaky(v.x), leaky(v.y), leaky(v.z), leaky(v.w));
+            acc = fma4(*reinterpret_cast<const float4*>(w + (i * 3 + j) * C + c4 * 4), v, acc);
+        }
+    }
+    *reinterpret_cast<float4*>(y + ((b * Ho + oy) * (long)Wo + ox) * ldy + c4 * 4) = acc;
+}
+
 // First layer: d = (7x7 depthwise of the reflect-padded 1-channel image), y[pix][n] = leaky(d*a[n] + shift[n]).
 // One pixel per lane for the stencil, then N4 lanes share a pixel for the 16-byte stores (as cin1_kernel).
 __global__ __launch_bounds__(256) void cin1_k7_reflect_kernel(const float* __restrict__ x, const float* __restrict__ w49,
@@ -190,6 +233,26 @@ static int dw3x3_reflect_launch(const float* x, int ldx, const float* w, float* 
     hipLaunchKernelGGL((dw3x3_reflect_kernel<SPLIT>), dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, w, y, ldy,
                        H, W, C / 4, Ho, Wo, stride, nthreads, C4t);
     return emd::check_launch("dw3x3_reflect_kernel");
+}
+
+extern "C" int emd_dw3x3_reflect_gen_f32(const float* d, int ldd, const float* gen_a, const float* gen_t, int leaky_act,
+                                         const float* w, float* y, int ldy, int B, int H, int W, int C, int stride,
+                                         emd_stream_t stream) {
+    EMD_REQUIRE(d && gen_a && gen_t && w && y, EMD_E_INVALID, "emd_dw3x3_reflect_gen_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && H >= 2 && W >= 2 && C >= 4 && ldd >= 1 && (stride == 1 || stride == 2), EMD_E_INVALID,
+                "emd_dw3x3_reflect_gen_f32: bad shape (reflect padding needs H, W >= 2)");
+    EMD_REQUIRE(C % 4 == 0 && ldy % 4 == 0 && ldy >= C && emd::aligned16(y) && emd::aligned16(w) && emd::aligned16(gen_a) &&
+                    emd::aligned16(gen_t), EMD_E_ALIGN, "emd_dw3x3_reflect_gen_f32: alignment");
+    if (B == 0) return EMD_OK;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int C4 = C / 4, qs = C4 >= 16 ? 4 : (C4 >= 8 ? 3 : 2), QB = 1 << qs, tw = 64 >> qs;
+    const long nthreads = (long)B * ((Ho + 3) / 4) * ((Wo + tw - 1) / tw) * ((C4 + QB - 1) / QB) * 256;
+    unsigned nb;
+    int rc = blocks_for(nthreads, &nb);
+    if (rc != EMD_OK) return rc;
+    hipLaunchKernelGGL(dw3x3_reflect_gen_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), d, ldd, gen_a, gen_t,
+                       leaky_act ? 1 : 0, w, y, ldy, H, W, C4, Ho, Wo, stride, qs);
+    return emd::check_launch("dw3x3_reflect_gen_kernel");
 }
 
 extern "C" int emd_dw3x3_reflect_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,

@@ -177,6 +177,7 @@ class GeneratorEngine:
             else:
                 self.P[key] = {"dw": d(dw.reshape(9, L.cin)), "pw": ops.PackedWeights(pw, False, device), "scale": d(s),
                                "shift": d(t)}
+        self._unit4, self._zero4 = d(np.array([1, 0, 0, 0])), d(np.zeros(4))
         self.w_last = d(weights[conv_scope + "/weights"][..., 0].reshape(9, gen_features3))
         self.b_last = float(weights[conv_scope + "/biases"][0])
         shift, scale = (float(weights[v][0]) for v in in_vars)
@@ -220,8 +221,20 @@ class GeneratorEngine:
         B, S = x.shape[0], x.shape[1]
         assert x.shape[2] == S and S % 16 == 0 and S >= 32
         p0 = self.P["enc0"]
-        enc = ops.cin1_k7_reflect(x, p0["w49"], p0["a"], p0["shift"], ops.Act.empty(B, S, S, gen_features0, self.device))
-        enc = self._sep("enc1", enc)
+        L1, p1 = self.layers["enc1"], self.P["enc1"]
+        So = (S - 1) // L1.stride + 1
+        if L1.reflect and L1.stride == 2 and not (self.precision == ops.PREC_BF16X3
+                                                  and ops.conv1x1_split32_supported(B * So * So, L1.cin, L1.cout)):
+            # enc0 = leaky(d7 * a + t) is an outer product of the 7x7 stencil of the 1-channel image: enc1's depthwise conv rebuilds
+            # it from d7 (a 4-channel scratch tensor, d7 in channel 0) instead of a [B,S,S,32] tensor going out and coming back
+            d4 = ops.cin1_k7_reflect(x, p0["w49"], self._unit4, self._zero4, ops.Act.empty(B, S, S, 4, self.device), act=False)
+            dd = ops.dw3x3_reflect_gen(d4, p0["a"], p0["shift"], p1["dw"], ops.Act.empty(B, So, So, L1.cin, self.device),
+                                       stride=L1.stride)
+            enc = ops.conv1x1(dd, p1["pw"], p1["scale"], p1["shift"], ops.Act.empty(B, So, So, L1.cout, self.device),
+                              act=ops.ACT_LEAKY, precision=self.precision)
+        else:
+            enc = ops.cin1_k7_reflect(x, p0["w49"], p0["a"], p0["shift"], ops.Act.empty(B, S, S, gen_features0, self.device))
+            enc = self._sep("enc1", enc)
         n = self._sep("nin_down0", enc)
         n = self._sep("nin_down1", n)
         n = self._sep("nin_down2", n)

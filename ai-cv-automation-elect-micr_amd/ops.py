@@ -454,6 +454,15 @@ def cin1_k7_reflect(x_img, w49_dev, a_dev, shift_dev, out: Act, act=True, stream
     return out
 
 
+def dw3x3_reflect_gen(d: Act, gen_a, gen_t, w_dev, out: Act, stride=1, leaky=True, stream=None):
+    """dw3x3_reflect over the generated input act(d[..., 0] * gen_a + gen_t) (emd_dw3x3_reflect_gen_f32)."""
+    lib = _lib.load()
+    assert (out.B, out.H, out.W) == (d.B, (d.H - 1) // stride + 1, (d.W - 1) // stride + 1) and gen_a.numel() == out.C
+    _lib.check(lib.emd_dw3x3_reflect_gen_f32(d.ptr, d.ld, _p(gen_a), _p(gen_t), 1 if leaky else 0, _p(w_dev), out.ptr, out.ld,
+                                             d.B, d.H, d.W, out.C, stride, _lib.stream_ptr(stream)), "emd_dw3x3_reflect_gen_f32")
+    return out
+
+
 def conv3x3_cout1_reflect(x: Act, w_dev, bias: float, out_img, stream=None):
     lib = _lib.load()
     assert out_img.is_contiguous() and out_img.numel() == x.B * x.H * x.W

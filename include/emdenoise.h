@@ -390,6 +390,13 @@ int emd_sep3x3_fused_reflect_f32(const float* x, int ldx, const float* dw, const
                                  const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout,
                                  int act, int precision, emd_stream_t stream);
 
+/* emd_dw3x3_reflect_f32 on a GENERATED input: the C-channel tensor the depthwise conv reads is act(d[pixel] * gen_a[c] + gen_t[c]),
+ * d one value per pixel with pitch ldd floats (channel 0 of a 4-channel emd_cin1_k7_reflect_f32 output with a = (1,0,0,0), no
+ * activation); leaky_act != 0: tf.nn.leaky_relu(alpha 0.2).  The generator's first layer feeding its second
+ * (misc_py/gan-infilling-100.py:343-349) without the [B,H,W,C] tensor in memory; bit-identical to the two calls it replaces. */
+int emd_dw3x3_reflect_gen_f32(const float* d, int ldd, const float* gen_a, const float* gen_t, int leaky_act, const float* w,
+                              float* y, int ldy, int B, int H, int W, int C, int stride, emd_stream_t stream);
+
 /* emd_sep3x3_fused_f32 on a GENERATED input: the Cin-channel tensor the depthwise stage reads is
  * act_gen(d[pixel] * gen_a[c] + gen_t[c]) with d a one-value-per-pixel tensor of pitch ldd floats (e.g. channel 0 of a
  * 4-channel emd_cin1_f32 output with a = (1,0,0,0), no activation).  It is the layer after the one fed by the 1-channel

@@ -173,6 +173,28 @@ def test_conv3x3_cout1_reflect_shapes(B, H, W, ci):
 
 
 @gpu
+@pytest.mark.parametrize("B,H,W,co,stride", [(2, 20, 24, 32, 2), (1, 16, 16, 64, 1), (1, 9, 7, 32, 2), (1, 12, 40, 16, 2), (1, 6, 6, 128, 2)])
+def test_dw_reflect_on_generated_input(B, H, W, co, stride):
+    """emd_dw3x3_reflect_gen_f32 == emd_cin1_k7_reflect_f32 (written out) followed by emd_dw3x3_reflect_f32 (bit for bit at stride 2)."""
+    from emdenoise import ops
+    from tests.test_ops_gpu import out_act, rnd
+
+    dd = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    x, w49, a, t, dw = dd(rnd((B, H, W, 1), 90)), dd(rnd((49,), 91, 0.2)), dd(rnd((co,), 92, 0.8)), dd(rnd((co,), 93, 0.3)), dd(rnd((9, co), 94, 0.3))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    full = ops.cin1_k7_reflect(x, w49, a, t, out_act(B, H, W, co, ld=co, c0=0))
+    want = ops.dw3x3_reflect(full, dw, out_act(B, Ho, Wo, co, ld=co, c0=0), stride=stride)
+    d4 = ops.cin1_k7_reflect(x, w49, dd(np.array([1, 0, 0, 0])), dd(np.zeros(4)), out_act(B, H, W, 4, ld=4, c0=0), act=False)
+    got = ops.dw3x3_reflect_gen(d4, a, t, dw, out_act(B, Ho, Wo, co, ld=co + 4, c0=4), stride=stride)
+    torch.cuda.synchronize()
+    if stride == 2:
+        assert torch.equal(got.torch(), want.torch())
+    else:   # the stride-1 reference runs on the rolling kernel, which sums the nine taps row by row
+        assert rel_l2(got.torch().cpu().numpy(), want.torch().cpu().numpy()) < 1e-6
+    assert not torch.isnan(got.torch()).any()
+
+
+@gpu
 def test_leaky_relu_epilogue():
     from emdenoise import ops
     from oracle import tf_ops as T
