@@ -1,7 +1,8 @@
 """Dev tool: the launches of the LAST repetition of a rocprofv3 --kernel-trace csv, in order: python tools/trace_seq.py DIR NREP"""
 import csv, glob, sys
 d, nrep = sys.argv[1], int(sys.argv[2])
-f = glob.glob(d + "/*/*kernel_trace.csv")[0]
+import os
+f = max(glob.glob(d + "/*/*kernel_trace.csv"), key=os.path.getmtime)   # the newest run (local gpurun_out/ keeps old ones)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in rows if "rocclr" not in r["Kernel_Name"] and "at::native" not in r["Kernel_Name"]]
 n = len(rows) // nrep

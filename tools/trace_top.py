@@ -2,7 +2,8 @@
 import csv, glob, sys, collections
 d, name = sys.argv[1], sys.argv[2]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 15
-f = glob.glob(d + "/*/*kernel_trace.csv")[0]
+import os
+f = max(glob.glob(d + "/*/*kernel_trace.csv"), key=os.path.getmtime)   # the newest run (local gpurun_out/ keeps old ones)
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(f)):
     if name not in r["Kernel_Name"]:
