@@ -241,6 +241,17 @@ def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     return out
 
 
+from importlib import import_module as _imp
+
+
+class _LazyGraphed:
+    def __call__(self, eng):
+        return _imp('emdenoise.graphed').GraphedForward(eng)
+
+
+GraphedForward = _LazyGraphed()
+
+
 def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     from emdenoise import ops
 
@@ -466,14 +477,18 @@ def bench_S(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     x = torch.from_numpy(x_host).to(dev)
     box = [None]
 
+    # 45 launches of a few microseconds each: captured once into a hipGraph and replayed (--no-graph: eager launches).  The big
+    # graphs (D, X, G) gain nothing from a replay -- their launch queue never drains -- and stay eager.
+    fwd = eng.forward if a.no_graph else GraphedForward(eng)
+
     def step():
-        box[0] = eng.forward(x)
+        box[0] = fwd(x)
 
     ms = timer.run(step, steps, warmup)
     out = {"value": round(B * S * S / 1e6 * world / (ms / 1e3), 1), "unit": "MPx/s", "ms_per_step": round(ms, 3),
            "steps": steps, "warmup": warmup,
            "config": {"workload": f"S: separable autoencoder (misc_py/apply_autoencoders.py), [{B},{S},{S},1] fp32 per GPU, "
-                                  "encoding_features 16, per-image batch-statistics norms", "precision": "bf16x3"}}
+                                  "encoding_features 16, per-image batch-statistics norms", "precision": "bf16x3", "hip_graph": not a.no_graph}}
     if want_cpu:
         from oracle import autoencoder_graph as AG
 
@@ -619,7 +634,7 @@ def main():
     ap.add_argument("--tower-batch", type=int, default=1, help="workload T: images per tower (batch-norm statistics are per tower)")
     ap.add_argument("--gan-batch", type=int, default=4, help="workload A: images per GPU per GAN iteration")
     ap.add_argument("--train-streams", type=int, default=8, help="workload T: HIP streams the towers are issued on")
-    ap.add_argument("--no-graph", action="store_true", help="workload T: launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying captured hipGraphs (training steps T / A, forward pass of S)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3",
                     help="workload D matrix-core mode: bf16x3 = split-bf16 parity mode (default), bf16 = fast mode")

@@ -131,3 +131,26 @@ def test_training_twin_forward_matches_oracle(B, S):
     r = rel_l2(got, ref)
     print(f"D' graph B={B} S={S}: rel L2 {r:.2e}")
     assert r < 3e-4 and got.min() >= 0.0 and got.max() <= 1.0
+
+
+@pytest.mark.gpu
+def test_graphed_forward_replays_the_same_bits():
+    """emdenoise.graphed.GraphedForward: engine.forward captured into a hipGraph and replayed == the eager launch sequence, for
+    new inputs of the captured shape, a second shape, and for graphs D, S and G (fixed launch sequences, no host read-back)."""
+    import emdenoise
+    from emdenoise import autoencoder, gan
+    from emdenoise.graphed import GraphedForward
+
+    dev = torch.device("cuda", 0)
+    cases = [(emdenoise.DenoiserEngine(emdenoise.synthetic_weights(), dev, "bf16x3"), [(2, 64), (1, 32)]),
+             (autoencoder.AutoencoderEngine(autoencoder.synthetic_weights(16), dev, 16), [(3, 160)]),
+             (gan.GeneratorEngine(gan.synthetic_weights(), dev), [(2, 64)])]
+    for eng, shapes in cases:
+        g = GraphedForward(eng)
+        for B, S in shapes:
+            for seed in (1, 2, 3):
+                x = torch.from_numpy(synthetic_lq(B, S, S, seed=seed)).to(dev)
+                want = eng.forward(x).clone()
+                got = g(x)
+                torch.cuda.synchronize()
+                assert torch.equal(got, want), (type(eng).__name__, B, S, seed)
