@@ -647,13 +647,16 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
     if (stride == 1 && rate == 1) {
         // strip height: 16 rows (input re-read factor 18/16) measured 1-4 % faster than 8 on the 256^2/512^2 layers;
         // short images keep 8 so that small maps still spread over the chip
-        const int TH = H >= 64 ? 16 : 8;
+        static const int th_force = [] { const char* e = getenv("EMD_DW_TH"); return e ? atoi(e) : 0; }();
+        const int TH = th_force == 8 || th_force == 16 || th_force == 32 ? th_force : (H >= 64 ? 16 : 8);
         const int nstrip = (H + TH - 1) / TH;
         const long nblocks = (long)B * nstrip * ((W + 15) / 16) * ((C4t + 15) / 16);
         const long nthreads = nblocks * 256;
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
-        if (TH == 16)
+        if (TH == 32)
+            hipLaunchKernelGGL((dw3x3_s1_roll<32, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t);
+        else if (TH == 16)
             hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t);
         else
             hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t);
