@@ -21,7 +21,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from . import _lib, ops
+from . import _lib, ops, streams
 
 # denoiser.py:38-52
 features0, features1, features2, features3, features4 = 64, 128, 256, 728, 728
@@ -273,6 +273,8 @@ class DenoiserEngine:
         self.variant = variant
         self.precision = {"bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[precision]
         self.layers = declare_layers(variant)
+        self.two_streams = os.environ.get("EMD_D_TWO_STREAMS", "1") != "0"   # see _middle_flow
+        self._halves = streams.TwoHalves(device)
         self.P = {}
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
         self._unit4, self._zero4 = d(np.array([1, 0, 0, 0])), d(np.zeros(4))
@@ -337,6 +339,29 @@ class DenoiserEngine:
         ops.dw3x3(x, p["dw"], tmp, stride=L.stride, rate=L.rate)
         ops.conv1x1(tmp, p["pw"], p["scale"], p["shift"], out, scale2=p.get("scale2"), shift2=p.get("shift2"),
                     res=res, precision=self.precision)
+        return out
+
+    def _middle_chain(self, x, out):
+        """Encoder 4 and the middle flow (:312-325) on one batch (or part of one): 9 residual blocks of 3 separable convs."""
+        t = self._sep("cnn4_a", x)
+        t = self._sep("cnn4_b", t)
+        cur = self._sep("cnn4_last", t, res=x, out=out if num_extra_blocks == 0 else None)
+        for i in range(num_extra_blocks):
+            t = self._sep(f"middle{i}_0", cur)
+            t = self._sep(f"middle{i}_1", t)
+            cur = self._sep(f"middle{i}_2", t, res=cur, out=out if i == num_extra_blocks - 1 else None)
+            yield   # one block issued: the caller alternates between the halves of the batch
+        return
+
+    def _middle_flow(self, x):
+        """The 27 separable convs at 1/16 resolution; with an even batch as two halves on two streams (streams.TwoHalves)."""
+        out = ops.Act.empty(x.B, x.H, x.W, self.layers["cnn4_last"].cout, self.device)
+        half = x.B // 2
+        if (self.two_streams and x.B % 2 == 0 and half >= 1 and self.precision == ops.PREC_BF16X3
+                and ops.conv1x1_split32_supported(half * x.H * x.W, x.C, out.C)):
+            return self._halves.run(x, out, self._middle_chain)
+        for _ in self._middle_chain(x, out):
+            pass
         return out
 
     def _split_gemm_ok(self, npix, cout, ktot):
@@ -407,33 +432,28 @@ class DenoiserEngine:
         cnn0_strided = self._sep("cnn0_strided", cnn0_last, out=concat1.slice(f2, f1), res=residual0)
         del cnn0, cnn0_last, residual0
         # encoder 1 (:267-279); cnn1_strided lives in concat2 (:353)
+        residual1 = self._conv1x1("residual1", cnn0_strided)
         cnn1 = self._sep("cnn1", cnn0_strided)
         cnn1_last = self._sep("cnn1_last", cnn1)
-        residual1 = self._conv1x1("residual1", cnn0_strided)
         concat2 = E(S4, aspp_output + f1)
         cnn1_strided = self._sep("cnn1_strided", cnn1_last, out=concat2.slice(aspp_output, f1), res=residual1)
         del cnn1, cnn1_last, residual1
         # encoder 2 (:282-294)
+        residual2 = self._conv1x1("residual2", cnn1_strided)
         cnn2 = self._sep("cnn2", cnn1_strided)
         cnn2_last = self._sep("cnn2_last", cnn2)
-        residual2 = self._conv1x1("residual2", cnn1_strided)
         cnn2_strided = self._sep("cnn2_strided", cnn2_last, res=residual2)
         del cnn2, cnn2_last, residual2
         # encoder 3 (:297-309)
+        residual3 = self._conv1x1("residual3", cnn2_strided)
         cnn3 = self._sep("cnn3", cnn2_strided)
         cnn3_last = self._sep("cnn3_last", cnn3)
-        residual3 = self._conv1x1("residual3", cnn2_strided)
         cnn3_strided = self._sep("cnn3_strided", cnn3_last, res=residual3)
         del cnn2_strided, cnn3, cnn3_last, residual3
         # encoder 4 (:312-322) and the middle flow (:324-325)
-        t = self._sep("cnn4_a", cnn3_strided)
-        t = self._sep("cnn4_b", t)
-        cur = self._sep("cnn4_last", t, res=cnn3_strided)
+        cur = self._middle_flow(cnn3_strided)
         del cnn3_strided
-        for i in range(num_extra_blocks):
-            t = self._sep(f"middle{i}_0", cur)
-            t = self._sep(f"middle{i}_1", t)
-            cur = self._sep(f"middle{i}_2", t, res=cur)
+        t = None
         # ASPP (:152-216): the five branches write straight into their slices of the 3640-channel concat
         af = aspp_filters
         cat = E(S16, 5 * af)
@@ -461,19 +481,19 @@ class DenoiserEngine:
         del cur, cat, t, curs
         # decoder (:350-384)
         ops.resize_bilinear(aspp, concat2.slice(0, aspp_output))            # deconv3 (:350)
-        t = self._sep("deconv2_a", concat2)
         residual2_d = self._conv1x1("residual2_d", concat2)
+        t = self._sep("deconv2_a", concat2)
         deconv2 = self._sep("deconv2_b", t, res=residual2_d)
         del aspp, concat2, cnn1_strided, residual2_d, t
         self._deconv("deconv2to1", deconv2, concat1.slice(0, f2))
-        t = self._sep("deconv1_a", concat1)
         residual1_d = self._conv1x1("residual1_d", concat1)
+        t = self._sep("deconv1_a", concat1)
         deconv1 = self._sep("deconv1_b", t, res=residual1_d)
         del deconv2, concat1, cnn0_strided, residual1_d, t
         deconv1to0 = self._deconv("deconv1to0", deconv1, E(S, f1))
         del deconv1
-        t = self._sep("deconv0_a", deconv1to0)
         residual0_d = self._conv1x1("residual0_d", deconv1to0)
+        t = self._sep("deconv0_a", deconv1to0)
         deconv0 = self._sep("deconv0_b", t, res=residual0_d)
         del deconv1to0, residual0_d, t
         out = torch.empty((B, S, S, 1), dtype=torch.float32, device=dev)

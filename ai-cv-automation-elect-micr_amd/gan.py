@@ -19,7 +19,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from . import _lib, ops
+from . import _lib, ops, streams
 
 # gan-infilling-100.py:40-62
 gen_features0, gen_features1, gen_features2, gen_features3 = 32, 64, 64, 32
@@ -178,6 +178,8 @@ class GeneratorEngine:
                 self.P[key] = {"dw": d(dw.reshape(9, L.cin)), "pw": ops.PackedWeights(pw, False, device), "scale": d(s),
                                "shift": d(t)}
         self._unit4, self._zero4 = d(np.array([1, 0, 0, 0])), d(np.zeros(4))
+        self.two_streams = os.environ.get("EMD_D_TWO_STREAMS", "1") != "0"   # streams.TwoHalves
+        self._halves = streams.TwoHalves(device)
         self.w_last = d(weights[conv_scope + "/weights"][..., 0].reshape(9, gen_features3))
         self.b_last = float(weights[conv_scope + "/biases"][0])
         shift, scale = (float(weights[v][0]) for v in in_vars)
@@ -209,6 +211,30 @@ class GeneratorEngine:
         t = self._sep(prefix + "_1", t)
         return self._sep(prefix + "_2", t, res=x)
 
+    def _enhancer_chain(self, x, out):
+        """The global enhancer's residual blocks (:351-352) on one batch or part of one; yields after every block."""
+        n = x
+        for i in range(num_global_enhancer_blocks):
+            t = self._sep(f"nin_mid{i}_0", n)
+            t = self._sep(f"nin_mid{i}_1", t)
+            last = self._sep(f"nin_mid{i}_2", t, res=n)
+            if i == num_global_enhancer_blocks - 1:
+                out.torch().copy_(last.torch())
+            n = last
+            yield
+
+    def _global_enhancer(self, x):
+        half = x.B // 2
+        L = self.layers[f"nin_mid{num_global_enhancer_blocks - 1}_2"]
+        if (self.two_streams and x.B % 2 == 0 and half >= 1 and self.precision == ops.PREC_BF16X3
+                and ops.conv1x1_split32_supported(half * x.H * x.W, L.cin, L.cout)):
+            out = ops.Act.empty(x.B, x.H, x.W, L.cout, self.device)
+            return self._halves.run(x, out, self._enhancer_chain)
+        n = x
+        for i in range(num_global_enhancer_blocks):
+            n = self._middle(f"nin_mid{i}", n)
+        return n
+
     def _up(self, key, x, size, res=None):
         up = ops.resize_bilinear(x, ops.Act.empty(x.B, size, size, x.C, self.device))
         return self._sep(key, up, res=res)
@@ -238,8 +264,7 @@ class GeneratorEngine:
         n = self._sep("nin_down0", enc)
         n = self._sep("nin_down1", n)
         n = self._sep("nin_down2", n)
-        for i in range(num_global_enhancer_blocks):
-            n = self._middle(f"nin_mid{i}", n)
+        n = self._global_enhancer(n)
         n = self._up("nin_up0", n, S // 8)
         n = self._up("nin_up1", n, S // 4)
         enc = self._up("nin_up2", n, S // 2, res=enc)          # enc += network_in_network(enc)  (:355)

@@ -44,6 +44,10 @@ class Act:
     def slice(self, c0, Cc):
         return Act(self.buf, Cc, self.c0 + c0)
 
+    def images(self, b0, b1):
+        """Images [b0, b1) of the batch (a view of the same memory)."""
+        return Act(self.buf[b0:b1], self.C, self.c0)
+
     @property
     def ptr(self):
         return C.c_void_p(self.buf.data_ptr() + 4 * self.c0)

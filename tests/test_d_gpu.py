@@ -154,3 +154,24 @@ def test_graphed_forward_replays_the_same_bits():
                 got = g(x)
                 torch.cuda.synchronize()
                 assert torch.equal(got, want), (type(eng).__name__, B, S, seed)
+
+
+@pytest.mark.gpu
+def test_two_stream_halves_are_the_same_bits(weights):
+    """streams.TwoHalves: the 1/16-resolution chains of graphs D and G run as two half batches on two HIP streams when the half
+    still fills the split32 GEMM's tiles (16 images at 512 x 512 here); same bits as the single-stream launch sequence, and
+    image b of the batch == the image run alone."""
+    import emdenoise
+    from emdenoise import gan
+
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(synthetic_lq(16, 512, 512, seed=11)).to(dev)
+    for make in (lambda: emdenoise.DenoiserEngine(weights, dev, "bf16x3"), lambda: gan.GeneratorEngine(gan.synthetic_weights(), dev)):
+        eng = make()
+        assert eng.two_streams
+        both = eng.forward(x).clone()
+        eng.two_streams = False
+        single = eng.forward(x)
+        one = eng.forward(x[5:6].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(both, single) and torch.equal(both[5], one[0])
