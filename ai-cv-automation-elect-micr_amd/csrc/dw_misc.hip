@@ -330,7 +330,17 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_roll(const float* __restric
             const int oy = oy0 + tt - 2;
             const float4 a = add4(s0, h2);
             float s = (a.x + a.y) + (a.z + a.w);
-            for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m);
+            if (LP == 16) {
+                // 16 lanes = one DPP row: quad butterflies, then the neighbouring quad and the other half by row rotation (data
+                // parallel primitives, no LDS crossbar).  Lane c4 == 0 -- the one that stores -- sums in the butterfly's order:
+                // ((q0 + q1) + (q2 + q3)).
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x124, 0xF, 0xF, true));
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xF, 0xF, true));
+            } else {
+                for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m);
+            }
             if (c4 == 0 && oy < H) yb[(long)oy * W + ox] = cout1_out(s, pre_bias, pre_relu, scale, shift, act);
         }
         s0 = add4(s1, h1);

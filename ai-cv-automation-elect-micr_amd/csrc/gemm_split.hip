@@ -858,7 +858,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
                 split2(v.z, v.w, h1, l1);
                 const int q = n >> 2;
                 const bool odd = q & 1;
-                const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1), r1 = __shfl_xor(odd ? h1 : l1, 1);
+                const unsigned r0 = emd::swap_pair(odd ? h0 : l0), r1 = emd::swap_pair(odd ? h1 : l1);
                 unsigned char* g = reinterpret_cast<unsigned char*>(p.C) + pix * (long)p.ldc * 4 + (n >> 5) * 128;
                 if (!odd) *reinterpret_cast<u32x4*>(g + (q & 7) * 8) = u32x4{h0, h1, r0, r1};
                 else *reinterpret_cast<u32x4*>(g + 64 + ((q - 1) & 7) * 8) = u32x4{r0, r1, l0, l1};
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(256) void to_split32_kernel(const float* __restrict
     // 16-byte stores through an exchange between the two lanes of a quad pair (see emd::dw_store); C4p is even, so a pair is
     // never split by the bounds check above
     const bool odd = c4 & 1;
-    const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1), r1 = __shfl_xor(odd ? h1 : l1, 1);
+    const unsigned r0 = emd::swap_pair(odd ? h0 : l0), r1 = emd::swap_pair(odd ? h1 : l1);
     unsigned char* g = y + pix * (long)ldy * 4 + (c4 >> 3) * 128;
     if (!odd) *reinterpret_cast<u32x4*>(g + (c4 & 7) * 8) = u32x4{h0, h1, r0, r1};
     else *reinterpret_cast<u32x4*>(g + 64 + ((c4 - 1) & 7) * 8) = u32x4{r0, r1, l0, l1};

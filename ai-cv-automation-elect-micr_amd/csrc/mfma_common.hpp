@@ -40,6 +40,12 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigne
     lo = __builtin_bit_cast(unsigned, l);
 }
 
+// The value of the other lane of an (even, odd) lane pair: a DPP quad permute [1,0,3,2] -- what __shfl_xor(v, 1) returns, without
+// the trip through the LDS crossbar (ds_bpermute) that the HIP shuffle compiles to.
+__device__ __forceinline__ unsigned swap_pair(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+
 // Output stage of the depthwise kernels.  SPLIT = false: 4 fp32 channels at y + pix*ldy + 4*c4.  SPLIT = true: the
 // split32 layout consumed by emd_conv1x1_split32_f32 (gemm_split.hip): the value is split into bf16 hi + lo here, once,
 // instead of in every N-tile of the GEMM; pixel pitch ldy 4-byte units, channel group g = c/32 at byte 128 g:
@@ -56,7 +62,7 @@ __device__ __forceinline__ void dw_store(float* __restrict__ y, long pix, int ld
         split2(v.x, v.y, h0, l0);
         split2(v.z, v.w, h1, l1);
         const bool odd = c4 & 1;
-        const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1), r1 = __shfl_xor(odd ? h1 : l1, 1);
+        const unsigned r0 = emd::swap_pair(odd ? h0 : l0), r1 = emd::swap_pair(odd ? h1 : l1);
         unsigned char* g = reinterpret_cast<unsigned char*>(y) + pix * (long)ldy * 4 + (c4 >> 3) * 128;
         if (!odd) *reinterpret_cast<u32x4*>(g + (c4 & 7) * 8) = u32x4{h0, h1, r0, r1};
         else *reinterpret_cast<u32x4*>(g + 64 + ((c4 - 1) & 7) * 8) = u32x4{r0, r1, l0, l1};
