@@ -298,10 +298,13 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
                  "affine_relu6", "affine_act", "bn_batch_stats", "avgpool2x2", "conv1x1_split32", "conv3x3_split32",
                  "deconv3x3s2_split32", "dw3x3_split32", "to_split32"):
         wrap(name)
-    try:
+    two = eng.two_streams
+    eng.two_streams = False   # attribution pass on the single-stream launch sequence: with the two half batches on two streams
+    try:                      # (streams.TwoHalves) a launch's event pair would also span the other half's kernels
         step()
         torch.cuda.synchronize()
     finally:
+        eng.two_streams = two
         for name, f in orig.items():
             setattr(ops, name, f)
     fam_ms = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) for k, v in fam.items()}
@@ -317,9 +320,9 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     dw_bytes = dw_bytes_box[0]  # only the STANDALONE depthwise launches (the fused layers never write the depthwise result)
     tr = pmc_traffic()
     traffic = None
-    if tr and (B, H, W) == (32, 512, 512):  # HBM bytes of all gemm_conv launches of one step
+    if tr and (B, H, W) == (32, 512, 512):  # HBM bytes of every matrix-core launch of one step
         traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_sampled"] / 4.0
-                            for k, v in tr.items() if k.startswith("D:gemm_conv_kernel") or k.startswith("D:gemm_split")))
+                            for k, v in tr.items() if k.startswith(("D:gemm_conv_kernel", "D:gemm_split", "D:sep_fused"))))
     out = {
         "value": B * H * W / 1e6 * world / (ms / 1e3), "ms_per_step": ms, "steps": steps, "warmup": warmup,
         "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)" if passes == 3 else "bf16",
@@ -333,7 +336,7 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
                      "algorithmic_flops_per_step": alg_flops, "mfma_passes": passes,
                      "issued_tflops": round(achieved * passes, 1),
                      "kernel_ms_per_step": round(gemm_ms, 3),
-                     "how": "HIP events around every launch of the family in one extra step"},
+                     "how": "HIP events around every launch of the family in one extra step (single-stream launch sequence)"},
         "depthwise": {"bound": "hbm", "kernel": "dw3x3_s1_roll / dw3x3_generic, fp32 or split32 output (standalone launches only)",
                       "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(dw_ms, 3),
                       "achieved_GBps": round(dw_bytes / (max(dw_ms, 1e-9) * 1e-3) / 1e9, 1),
