@@ -163,6 +163,7 @@ def test_two_stream_halves_are_the_same_bits(weights):
     image b of the batch == the image run alone."""
     import emdenoise
     from emdenoise import gan
+    from emdenoise.graphed import GraphedForward
 
     dev = torch.device("cuda", 0)
     x = torch.from_numpy(synthetic_lq(16, 512, 512, seed=11)).to(dev)
@@ -170,6 +171,8 @@ def test_two_stream_halves_are_the_same_bits(weights):
         eng = make()
         assert eng.two_streams
         both = eng.forward(x).clone()
+        replay = GraphedForward(eng)(x).clone()        # the fork / join of the two streams is capturable as well
+        assert torch.equal(replay, both)
         eng.two_streams = False
         single = eng.forward(x)
         one = eng.forward(x[5:6].contiguous())
