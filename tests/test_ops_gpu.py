@@ -344,3 +344,31 @@ def test_avgpool2x2(H, W, Cc):
     ops.avgpool2x2(to_act(x, ld=Cc + 4, c0=0), out)
     torch.cuda.synchronize()
     assert rel_l2(out.torch().cpu().numpy(), ref) < TOL_F32
+
+
+def test_generated_input_entry_points_validate_and_accept_empty_batches():
+    """emd_sep3x3_fused_gen_f32 / emd_dw3x3_reflect_gen_f32: B = 0 is a no-op; misaligned (a, t) vectors, reflect padding on a
+    one-row image and an unsupported shape come back as negative status codes with a message (nothing is launched)."""
+    import ctypes as C
+
+    from emdenoise import _lib, ops
+
+    lib = _lib.load()
+    d4 = out_act(1, 8, 16, 4, ld=4, c0=0)
+    a = torch.zeros(68, device=dev())
+    pw = ops.PackedWeights(rnd((1, 64, 64), 150), False, dev())
+    dw, s1 = torch.zeros(9 * 64, device=dev()), torch.ones(64, device=dev())
+    y = out_act(1, 8, 16, 64, ld=64, c0=0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    args = lambda ga, B=1, H=8: (d4.ptr, 4, ga, p(a), 1, p(dw), p(pw.hi), p(pw.lo), p(s1), p(s1), None, None, None, 0, y.ptr, 64,
+                                B, H, 16, 64, 64, 1, ops.PREC_BF16X3, 0, None)
+    assert lib.emd_sep3x3_fused_gen_f32(*args(p(a), B=0)) == 0                                   # empty batch
+    assert lib.emd_sep3x3_fused_gen_f32(*args(C.c_void_p(a.data_ptr() + 4))) < 0                 # gen_a not 16-byte aligned
+    assert b"gen_a" in lib.emd_last_error()
+    assert lib.emd_sep3x3_fused_gen_f32(*args(p(a), H=12)) < 0                                   # H % 8 != 0: not a fused shape
+    y2 = out_act(1, 4, 8, 64, ld=64, c0=0)
+    g = lambda B, H, ga: lib.emd_dw3x3_reflect_gen_f32(d4.ptr, 4, ga, p(a), 1, p(dw), y2.ptr, 64, B, H, 16, 64, 2, None)
+    assert g(0, 8, p(a)) == 0
+    assert g(1, 1, p(a)) < 0 and b"reflect" in lib.emd_last_error()
+    assert g(1, 8, C.c_void_p(a.data_ptr() + 4)) < 0
+    torch.cuda.synchronize()
