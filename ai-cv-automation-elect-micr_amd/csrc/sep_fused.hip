@@ -11,11 +11,14 @@
 // Block = 256 threads = 4 waves; output tile = 8 x 16 pixels (128 GEMM rows) x all Cout (BN = 64 or 128).
 // Per 32-channel chunk of Cin:
 //   1. the (8+2) x (16+2) pixel fp32 input patch of the chunk is staged global -> registers (one chunk
-//      ahead) -> LDS; pixel pitch 40 floats so the depthwise reads below are bank-conflict free;
+//      ahead; unconditional loads, padding pixels read a zero buffer) -> LDS; pixel pitch 40 floats so the
+//      depthwise reads below are bank-conflict free; the chunk's 9 x 32 depthwise weights take the same route;
+//      GEN instances rebuild the chunk from a one-value-per-pixel tensor instead (emd_sep3x3_fused_gen_f32);
 //   2. thread (pixel group of 4 along W, 4 channels) reads 3 x 6 patch vectors (18 ds_read_b128 for 16
 //      outputs), accumulates the 9 taps in fp32, splits to bf16 hi/lo and writes the A planes;
 //   3. v_mfma_f32_32x32x16_bf16, split-bf16 (3 passes) as in gemm_conv.hip; W tile staged like there.
-// Epilogue identical to gemm_conv.hip (fp32 LDS staging, 16-byte stores / residual loads).
+// Epilogue identical to gemm_conv.hip (fp32 LDS staging, 16-byte stores / residual loads).  A workgroup walks up to 8
+// tiles side by side with the staging pipeline running on across them; DESIGN.md 3.3 has the measurements.
 #include <cstdlib>
 
 #include "mfma_common.hpp"
