@@ -77,6 +77,10 @@ SIGNATURES = {
     "emd_conv1x1_split32_stats_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p,
                                                 C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, _c_float_p, _c_float_p, C.c_void_p,
                                                 C.c_void_p]),
+    # ... gamma beta eps scale shift stream
+    "emd_conv1x1_split32_stats_fold_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p,
+                                                     C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, _c_float_p, _c_float_p, C.c_void_p,
+                                                     _c_float_p, _c_float_p, C.c_float, _c_float_p, _c_float_p, C.c_void_p]),
     # xs ldx whi wlo scale1 shift1 scale2 shift2 res ldres y ldy M Cin Cout act stream
     "emd_conv1x1_split32_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p,
                                           _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_long, C.c_int, C.c_int,

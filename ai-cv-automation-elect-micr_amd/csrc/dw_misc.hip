@@ -540,8 +540,15 @@ __global__ __launch_bounds__(256) void bn_stats_partial_v4(const float* __restri
     }
 }
 
+// FOLD: the batch norm that uses these statistics is folded right here as well (scale = gamma / sqrt(var + eps), shift = beta -
+// mean * scale, from the float mean / var exactly as bn_fold_kernel computes them): one launch instead of two between a GEMM
+// and the kernel that applies the norm (graph X has 63 such pairs on its critical path).
+template <bool FOLD>
 __global__ __launch_bounds__(256) void bn_stats_final(const double* __restrict__ part, int nslab, int C, long npix,
-                                                      float* __restrict__ mean, float* __restrict__ var) {
+                                                      float* __restrict__ mean, float* __restrict__ var,
+                                                      const float* __restrict__ gamma = nullptr,
+                                                      const float* __restrict__ beta = nullptr, float eps = 0.f,
+                                                      float* __restrict__ scale = nullptr, float* __restrict__ shift = nullptr) {
     // 16 channels x 16 slab lanes per workgroup: the <= 512 slabs of a channel are summed by 16 lanes
     __shared__ double sm[2][16][16 + 1];
     part += (long)blockIdx.y * nslab * 2 * C;              // blockIdx.y = image
@@ -567,8 +574,14 @@ __global__ __launch_bounds__(256) void bn_stats_final(const double* __restrict__
     }
     const double m = s / (double)npix;
     double v = q / (double)npix - m * m;
-    mean[c] = (float)m;
-    var[c] = (float)(v > 0.0 ? v : 0.0);
+    const float mf = (float)m, vf = (float)(v > 0.0 ? v : 0.0);
+    mean[c] = mf;
+    var[c] = vf;
+    if (FOLD) {
+        const float g = (gamma ? gamma[c] : 1.0f) / sqrtf(vf + eps);
+        scale[c] = g;
+        shift[c] = (beta ? beta[c] : 0.0f) - mf * g;
+    }
 }
 
 // scale = gamma / sqrt(var + eps) (gamma may be NULL = 1), shift = beta - mean*scale: a batch norm as one affine
@@ -684,8 +697,13 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
 
 // second stage of the batch statistics (sum over `nslab` partials per channel, fixed order), for producers of partials
 // outside this file (the statistics epilogue of gemm_split.hip)
-int emd::launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st) {
-    hipLaunchKernelGGL(bn_stats_final, dim3((C + 15) / 16), dim3(256), 0, st, part, nslab, C, npix, mean, var);
+int emd::launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st,
+                               const float* gamma, const float* beta, float eps, float* scale, float* shift) {
+    if (scale)
+        hipLaunchKernelGGL(bn_stats_final<true>, dim3((C + 15) / 16), dim3(256), 0, st, part, nslab, C, npix, mean, var, gamma, beta,
+                           eps, scale, shift);
+    else
+        hipLaunchKernelGGL(bn_stats_final<false>, dim3((C + 15) / 16), dim3(256), 0, st, part, nslab, C, npix, mean, var);
     return emd::check_launch("bn_stats_final");
 }
 
@@ -868,7 +886,7 @@ extern "C" int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float
     else
         hipLaunchKernelGGL(bn_stats_partial, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, npix, C,
                            rows_per_slab, ws);
-    hipLaunchKernelGGL(bn_stats_final, dim3((C + 15) / 16), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
+    hipLaunchKernelGGL(bn_stats_final<false>, dim3((C + 15) / 16), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
                        npix, mean, var);
     return emd::check_launch("bn_stats");
 }
@@ -892,7 +910,7 @@ extern "C" int emd_bn_stats_images_f32(const float* x, int ldx, int B, long npix
     else
         hipLaunchKernelGGL(bn_stats_partial, dim3((C + 63) / 64, (unsigned)nslab, B), dim3(256), 0, st, x, ldx, npix_img, C,
                            rows_per_slab, ws);
-    hipLaunchKernelGGL(bn_stats_final, dim3((C + 15) / 16, B), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
+    hipLaunchKernelGGL(bn_stats_final<false>, dim3((C + 15) / 16, B), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
                        npix_img, mean, var);
     return emd::check_launch("bn_stats (images)");
 }

@@ -37,7 +37,9 @@ int launch_dw3x3_reflect_roll(const float* x, int ldx, const float* w, float* y,
 int launch_conv3x3_cout1_reflect_roll(const float* x, int ldx, const float* w, float bias, float* y, int B, int H, int W, int Cin,
                                       hipStream_t st);
 
-int launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st);
+int launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st,
+                          const float* gamma = nullptr, const float* beta = nullptr, float eps = 0.f, float* scale = nullptr,
+                          float* shift = nullptr);   // scale != NULL: the norm is folded in the same launch
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -1353,6 +1353,22 @@ extern "C" int emd_conv1x1_split32_stats_f32(const void* xs, int ldx, const uint
                                       static_cast<hipStream_t>(stream));
 }
 
+// ... and folds the batch norm that uses those statistics in the same final-reduction launch: scale = gamma / sqrt(var + eps)
+// (gamma NULL = 1), shift = beta - mean * scale (beta NULL = 0) -- emd_bn_fold_f32's arithmetic on the same float mean / var.
+extern "C" int emd_conv1x1_split32_stats_fold_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo,
+                                                  const float* scale1, const float* shift1, float* y, int ldy, long M, int Cin,
+                                                  int Cout, int act, float* mean, float* var, void* workspace, const float* gamma,
+                                                  const float* beta, float eps, float* scale, float* shift, emd_stream_t stream) {
+    EMD_REQUIRE(mean && var && scale && shift && workspace && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EMD_E_INVALID,
+                "emd_conv1x1_split32_stats_fold_f32: mean, var, scale, shift and an 8-byte aligned workspace are required");
+    EMD_REQUIRE(M >= 1, EMD_E_INVALID, "emd_conv1x1_split32_stats_fold_f32: M >= 1");
+    int rc = conv1x1_split32_impl(xs, ldx, whi, wlo, scale1, shift1, nullptr, nullptr, nullptr, 0, y, ldy, M, Cin, Cout, act, stream,
+                                  static_cast<double*>(workspace));
+    if (rc != EMD_OK) return rc;
+    return emd::launch_bn_stats_final(static_cast<const double*>(workspace), (int)((M + 255) / 256), Cout, M, mean, var,
+                                      static_cast<hipStream_t>(stream), gamma, beta, eps, scale, shift);
+}
+
 // dev hooks (not in the header): kernel variant and stamp buffer for tools/gemm_split_bench.py
 extern "C" void emd_debug_split_variant(int v) { g_variant_override = v; }
 extern "C" void emd_debug_split_stamps(void* buf) { g_stamps = static_cast<long long*>(buf); }

@@ -266,7 +266,7 @@ def dw3x3_reflect_split32(x: Act, w_dev, out: SplitAct, stride=1, stream=None):
 
 
 def sep_split32(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, stride=1, rate=1, act=True, scale2=None,
-                shift2=None, res: Act | None = None, reflect=False, stream=None, pre=None, stats=False):
+                shift2=None, res: Act | None = None, reflect=False, stream=None, pre=None, stats=False, fold=None):
     """Separable conv as depthwise (split32 output) -> LDS-DMA pointwise GEMM; the intermediate exists only in split form.
     stats=True: (out, mean, var) with the batch statistics of the output from the GEMM epilogue."""
     d = SplitAct(out.B, out.H, out.W, x.C, x.buf.device)
@@ -275,7 +275,8 @@ def sep_split32(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, stri
         dw3x3_reflect_split32(x, dw_dev, d, stride=stride, stream=stream)
     else:
         dw3x3_split32(x, dw_dev, d, stride=stride, rate=rate, stream=stream, pre=pre)
-    return conv1x1_split32(d, w, scale1, shift1, out, act=act, scale2=scale2, shift2=shift2, res=res, stream=stream, stats=stats)
+    return conv1x1_split32(d, w, scale1, shift1, out, act=act, scale2=scale2, shift2=shift2, res=res, stream=stream, stats=stats,
+                           fold=fold)
 
 
 def conv3x3_split32(x: SplitAct, w: PackedWeights, scale1, shift1, out, stride=1, rate=1, act=True, scale2=None, shift2=None,
@@ -308,9 +309,10 @@ def conv1x1_split32_supported(npix: int, cin: int, cout: int) -> bool:
 
 
 def conv1x1_split32(x: SplitAct, w: PackedWeights, scale1, shift1, out: Act, act=True, scale2=None, shift2=None,
-                    res: Act | None = None, stream=None, stats=False):
+                    res: Act | None = None, stream=None, stats=False, fold=None):
     """Pointwise conv on a split32 input (split-bf16 precision; bit-identical to conv1x1 on the fp32 twin).
-    stats=True: returns (out, mean, var), the batch statistics of the output gathered in the GEMM epilogue."""
+    stats=True: returns (out, mean, var), the batch statistics of the output gathered in the GEMM epilogue; with
+    fold=(gamma or None, beta or None, eps) also the folded norm: (out, mean, var, scale, shift), same launch count."""
     lib = _lib.load()
     assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, w.cout) and w.cin == x.C and w.taps == 1
     if stats:
@@ -322,6 +324,14 @@ def conv1x1_split32(x: SplitAct, w: PackedWeights, scale1, shift1, out: Act, act
         var = torch.empty_like(mean)
         ws = torch.empty(lib.emd_conv1x1_split32_stats_workspace_bytes(C.c_long(M), w.cout) // 8, dtype=torch.float64,
                          device=x.buf.device)
+        if fold is not None:
+            scale, shift = torch.empty_like(mean), torch.empty_like(mean)
+            rc = lib.emd_conv1x1_split32_stats_fold_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), out.ptr, out.ld,
+                                                        C.c_long(M), x.C, w.cout, _act(act), _p(mean), _p(var), _p(ws),
+                                                        _p(fold[0]), _p(fold[1]), C.c_float(fold[2]), _p(scale), _p(shift),
+                                                        _lib.stream_ptr(stream))
+            _lib.check(rc, "emd_conv1x1_split32_stats_fold_f32")
+            return out, mean, var, scale, shift
         rc = lib.emd_conv1x1_split32_stats_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), out.ptr, out.ld,
                                                C.c_long(M), x.C, w.cout, _act(act), _p(mean), _p(var), _p(ws),
                                                _lib.stream_ptr(stream))

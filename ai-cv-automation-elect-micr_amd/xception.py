@@ -285,13 +285,15 @@ class XceptionEngine:
             Ho, Wo = -(-a.H // L.stride), -(-a.W // L.stride)
             if prec == ops.PREC_BF16X3 and ops.conv1x1_split32_supported(a.B * Ho * Wo, L.cin, L.cout):
                 # the batch statistics of the output come out of the GEMM epilogue: no second pass over y
-                y, mean, var = ops.sep_split32(a, p["dw"], p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout), stride=L.stride,
-                                               act=ops.ACT_NONE, pre=pre, stats=True)
+                # ... and the norm is folded in the statistics' final-reduction launch
+                y, mean, var, scale, shift = ops.sep_split32(a, p["dw"], p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout),
+                                                             stride=L.stride, act=ops.ACT_NONE, pre=pre, stats=True,
+                                                             fold=(None, p["beta"], BN_EPS))
             else:
                 tmp = ops.dw3x3(a, p["dw"], E(Ho, Wo, L.cin), stride=L.stride, pre=pre)
                 y = ops.conv1x1(tmp, p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout), act=ops.ACT_NONE, precision=prec)
                 mean, var = ops.bn_batch_stats(y)
-            scale, shift = ops.bn_fold(mean, var, None, p["beta"], BN_EPS)
+                scale, shift = ops.bn_fold(mean, var, None, p["beta"], BN_EPS)
             if trace is not None:   # the oracle traces the SEP output before the residual add
                 trace.append(ops.affine_act(y, scale, shift, E(Ho, Wo, L.cout), act=RELU).torch().cpu().numpy())
             if defer and res is None and trace is None:

@@ -189,6 +189,13 @@ size_t emd_conv1x1_split32_stats_workspace_bytes(long M, int Cout);
 int emd_conv1x1_split32_stats_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
                                   const float* shift1, float* y, int ldy, long M, int Cin, int Cout, int act, float* mean,
                                   float* var, void* workspace, emd_stream_t stream);
+/* ... and folds the batch norm that uses those statistics in the same final-reduction launch (emd_bn_fold_f32's arithmetic on
+ * the same float mean / var: scale = gamma / sqrt(var + eps), gamma NULL = 1; shift = beta - mean * scale, beta NULL = 0): one
+ * launch instead of two between the GEMM and the kernel that applies the norm. */
+int emd_conv1x1_split32_stats_fold_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                                       const float* shift1, float* y, int ldy, long M, int Cin, int Cout, int act, float* mean,
+                                       float* var, void* workspace, const float* gamma, const float* beta, float eps,
+                                       float* scale, float* shift, emd_stream_t stream);
 /* Dense 3x3 convolution (emd_conv3x3_f32: TF SAME, stride 1/2, dilation) and the 3x3 stride-2 transposed convolution
  * (emd_deconv3x3s2_f32) on a split32 input, same packed weights, same arithmetic (bit-identical results); out_split != 0
  * writes y itself as a split32 tensor (pitch ldy 4-byte units, % 32; channels Cout..ceil32(Cout) zero) for a following

@@ -338,3 +338,12 @@ def test_conv1x1_split32_stats_epilogue(B, H, W, ci, co):
     # deterministic: a second run gives the same bits
     _, mean_b, var_b = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()), act=ops.ACT_NONE, stats=True)
     assert torch.equal(mean, mean_b) and torch.equal(var, var_b)
+    # the norm folded in the same final-reduction launch == emd_bn_fold_f32 on those statistics, bit for bit (with and without gamma)
+    beta, gamma = up(rnd((co,), 85, 0.4)), up(rnd((co,), 86, 0.2) + 1.0)
+    for g in (None, gamma):
+        y3, m3, v3, sc, sh = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()), act=ops.ACT_NONE, stats=True,
+                                                 fold=(g, beta, 1e-3))
+        sc2, sh2 = ops.bn_fold(mean, var, g, beta, 1e-3)
+        torch.cuda.synchronize()
+        assert torch.equal(y3.buf, plain.buf) and torch.equal(m3, mean) and torch.equal(v3, var)
+        assert torch.equal(sc, sc2) and torch.equal(sh, sh2)
