@@ -285,10 +285,15 @@ class XceptionEngine:
             Ho, Wo = -(-a.H // L.stride), -(-a.W // L.stride)
             if prec == ops.PREC_BF16X3 and ops.conv1x1_split32_supported(a.B * Ho * Wo, L.cin, L.cout):
                 # the batch statistics of the output come out of the GEMM epilogue: no second pass over y
-                # ... and the norm is folded in the statistics' final-reduction launch
-                y, mean, var, scale, shift = ops.sep_split32(a, p["dw"], p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout),
-                                                             stride=L.stride, act=ops.ACT_NONE, pre=pre, stats=True,
-                                                             fold=(None, p["beta"], BN_EPS))
+                # ... and the norm is folded in the statistics' final-reduction launch (dev knob EMD_X_FOLD=0: a launch of its own)
+                if os.environ.get("EMD_X_FOLD", "1") != "0":
+                    y, mean, var, scale, shift = ops.sep_split32(a, p["dw"], p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout),
+                                                                 stride=L.stride, act=ops.ACT_NONE, pre=pre, stats=True,
+                                                                 fold=(None, p["beta"], BN_EPS))
+                else:
+                    y, mean, var = ops.sep_split32(a, p["dw"], p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout), stride=L.stride,
+                                                   act=ops.ACT_NONE, pre=pre, stats=True)
+                    scale, shift = ops.bn_fold(mean, var, None, p["beta"], BN_EPS)
             else:
                 tmp = ops.dw3x3(a, p["dw"], E(Ho, Wo, L.cin), stride=L.stride, pre=pre)
                 y = ops.conv1x1(tmp, p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout), act=ops.ACT_NONE, precision=prec)
