@@ -215,6 +215,13 @@ SIGNATURES = {
     "emd_bn_infer_grads_f32": (C.c_int, [_c_float_p] * 4 + [C.c_int] + [_c_float_p] * 4 + [C.c_void_p]),
 }
 
+# development hooks (include/emdenoise_dev.h): not part of the drop-in boundary, bound for tools/ and bench.py's A/B legs
+DEV_SIGNATURES = {
+    "emd_debug_split_variant": (None, [C.c_int]),
+    "emd_debug_split_stamps": (None, [C.c_void_p]),
+    "emd_debug_sep_stamps": (None, [C.c_void_p]),
+}
+
 _lib = None
 
 
@@ -238,7 +245,7 @@ def load():
     import torch  # noqa: F401
 
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEV_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

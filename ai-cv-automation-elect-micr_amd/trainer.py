@@ -311,9 +311,11 @@ class DenoiserTrainer:
         if not need_dx:
             return
         if L.stride == 1:
-            self._put(gslot, x, lambda dst: ops.dw3x3(dd, self.dw_flip[key], dst))
+            # SAME padding of a stride-1 dilated 3x3 is symmetric (rate, rate): the data gradient is the forward kernel
+            # with the taps reversed at the same dilation
+            self._put(gslot, x, lambda dst: ops.dw3x3(dd, self.dw_flip[key], dst, rate=L.rate))
         else:
-            self._put(gslot, x, lambda dst: TO.dw3x3_bwd_data(dd, self._dw(key), dst, stride=L.stride))
+            self._put(gslot, x, lambda dst: TO.dw3x3_bwd_data(dd, self._dw(key), dst, stride=L.stride, rate=L.rate))
 
     def _conv_bwd(self, key, dy, ctx, gslot, need_dx=True):
         L = self.layers[key]

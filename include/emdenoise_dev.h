@@ -1,0 +1,30 @@
+/* emdenoise_dev.h -- DEVELOPMENT hooks of libemdenoise.so.  NOT part of the drop-in boundary (include/emdenoise.h).
+ *
+ * These are the only places where the library keeps process-global mutable state.  They default to "off", change
+ * speed only (kernel variant selection, in-kernel time stamps), never results beyond what DESIGN.md states for the
+ * variant, and exist for the A/B tools under tools/ and for bench.py's isolated-GEMM comparison.  A product host must
+ * not call them.  Every symbol the shared library exports with an emd_ prefix is declared either in emdenoise.h or
+ * here (tests/test_abi.py checks both directions).
+ *
+ * Environment knobs read once per process by the same translation units (same rule: speed only, default off):
+ *   EMD_SPLIT_VARIANT  csrc/gemm_split.hip  pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
+ *   EMD_SEP_TPW        csrc/sep_fused.hip   tiles per workgroup of the fused separable conv (0 = rule)
+ *   EMD_DW_TH          csrc/dw_misc.hip     strip height of the rolling depthwise kernel (0 = rule)
+ */
+#ifndef EMDENOISE_DEV_H
+#define EMDENOISE_DEV_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Force the pipeline variant of emd_conv1x1_split32_f32 (csrc/gemm_split.hip); -1 restores the dispatch rule. */
+void emd_debug_split_variant(int v);
+/* Device buffer that the split32 GEMM writes s_memtime phase stamps into (NULL = off). */
+void emd_debug_split_stamps(void* device_buf);
+/* Device buffer that the fused separable conv writes s_memtime phase stamps into (NULL = off). */
+void emd_debug_sep_stamps(void* device_buf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMDENOISE_DEV_H */

@@ -11,8 +11,8 @@ import emdenoise
 from emdenoise import _lib
 
 
-def declared_symbols(root):
-    text = open(os.path.join(root, "include", "emdenoise.h")).read()
+def declared_symbols(root, header="emdenoise.h"):
+    text = open(os.path.join(root, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(emd_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,6 +26,23 @@ def test_header_symbols_exported_and_bound(repo_root):
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
     for s in _lib.SIGNATURES:
         assert s in syms, f"{s} bound in _lib.py but not declared in emdenoise.h"
+
+
+def test_every_exported_emd_symbol_is_declared(repo_root):
+    """export -> header: the library exports no C symbol with the emd_ prefix that neither header declares (the product ABI is
+    include/emdenoise.h; the development hooks with process-global state are fenced off in include/emdenoise_dev.h)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("emd_")})
+    product = set(declared_symbols(repo_root))
+    dev = set(declared_symbols(repo_root, "emdenoise_dev.h"))
+    assert dev == set(_lib.DEV_SIGNATURES) and not (dev & product)
+    assert all(s.startswith("emd_debug_") for s in dev)
+    stray = [s for s in exported if s not in product and s not in dev]
+    assert not stray, f"exported but declared in no header: {stray}"
+    missing = [s for s in sorted(product | dev) if s not in exported]
+    assert not missing, f"declared but not exported: {missing}"
 
 
 def test_version_and_params_count():
