@@ -213,6 +213,18 @@ SIGNATURES = {
     "emd_adam_step_dev_f32": (C.c_int, [_c_float_p] * 4 + [C.c_long, _c_float_p] + [C.c_float] * 4 + [_c_float_p, C.c_float, C.c_void_p]),
     "emd_bn_infer_fold2_f32": (C.c_int, [_c_float_p] * 8 + [C.c_float, C.c_int] + [_c_float_p] * 6 + [C.c_void_p]),
     "emd_bn_infer_grads_f32": (C.c_int, [_c_float_p] * 4 + [C.c_int] + [_c_float_p] * 4 + [C.c_void_p]),
+    # ---- device-side training input functions (csrc/input_ops.hip)
+    "emd_philox4x32_u32": (C.c_int, [C.c_void_p, C.c_long, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),
+    "emd_get_scale_f32": (C.c_int, [_c_float_p, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),
+    "emd_d4_choices_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),
+    # x y B H W choice_dev fix_nonfinite stream
+    "emd_flip_rotate_f32": (C.c_int, [_c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "emd_input_workspace_bytes": (C.c_size_t, [C.c_int, C.c_long]),
+    "emd_minmax_images_f32": (C.c_int, [_c_float_p, C.c_int, C.c_long, _c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
+    "emd_scale0to1_images_f32": (C.c_int, [_c_float_p, _c_float_p, C.c_int, C.c_long, _c_float_p, _c_float_p, C.c_void_p]),
+    # img scale lq truth counts_out B npix seed first_image workspace stream
+    "emd_gen_lq_f32": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, C.c_void_p, C.c_int, C.c_long, C.c_ulonglong,
+                                 C.c_ulonglong, C.c_void_p, C.c_void_p]),
 }
 
 # development hooks (include/emdenoise_dev.h): not part of the drop-in boundary, bound for tools/ and bench.py's A/B legs

@@ -266,3 +266,101 @@ def write_tfrecord(path, images):
             example = field(1, field(1, entry))                     # Example{features{feature}}
             head = struct.pack("<Q", len(example))
             fh.write(head + struct.pack("<I", _masked_crc(head)) + example + struct.pack("<I", _masked_crc(example)))
+
+
+# ---- the same functions on the device (csrc/input_ops.hip) ---------------------------------------------------
+class DeviceRecordParser:
+    """record_parser (denoiser-multi-gpu.py:861-870) for a whole batch on the GPU: preprocess (NaN/Inf -> 0.5, a random element
+    of D4, min-max), get_scale, gen_lq (Poisson counts, min-max) and the truth rescale, as libemdenoise.so launches on torch's
+    current stream.  HQ images in, (lq, truth) out, all float32 CUDA tensors [B,S,S,1]; nothing returns to the host, so the
+    trainer is fed at device speed (the reference runs these in 8 tf.py_func threads, :78).
+
+    Randomness is counter-based (Philox4x32-10 keyed by `seed`, indexed by the image's position in the stream of images this
+    parser has served): image k of the stream gets the same scale, D4 element and Poisson draws however the stream is cut into
+    batches or spread over ranks (give each rank a disjoint `first_image` range)."""
+
+    def __init__(self, device, seed: int = 0, first_image: int = 0):
+        from . import _lib
+
+        self._lib = _lib
+        self.lib = _lib.load()
+        self.device = device
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.next_image = int(first_image)
+
+    def _ws(self, B, npix):
+        import torch
+
+        n = self.lib.emd_input_workspace_bytes(B, npix)
+        return torch.empty((n + 15) // 16 * 4, dtype=torch.float32, device=self.device)
+
+    def flip_rotate(self, x, choices=None, fix_nonfinite=False):
+        """x [B,S,S(,1)] -> the D4 element `choices[b]` (int32 CUDA tensor; None = draw them) of every image."""
+        import ctypes as C
+
+        import torch
+
+        B, S = x.shape[0], x.shape[1]
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[2] == S
+        st = self._lib.stream_ptr()
+        if choices is None:
+            choices = torch.empty(B, dtype=torch.int32, device=self.device)
+            self._lib.check(self.lib.emd_d4_choices_i32(C.c_void_p(choices.data_ptr()), B, self.seed, self.next_image, st), "emd_d4_choices_i32")
+        assert choices.dtype == torch.int32 and choices.numel() == B and choices.is_cuda
+        y = torch.empty_like(x)
+        self._lib.check(self.lib.emd_flip_rotate_f32(C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), B, S, S,
+                                                     C.c_void_p(choices.data_ptr()), 1 if fix_nonfinite else 0, st), "emd_flip_rotate_f32")
+        return y, choices
+
+    def scale0to1(self, x, out=None):
+        import ctypes as C
+
+        import torch
+
+        B = x.shape[0]
+        npix = x.numel() // B
+        st = self._lib.stream_ptr()
+        mn = torch.empty(B, dtype=torch.float32, device=self.device)
+        mx = torch.empty_like(mn)
+        ws = self._ws(B, npix)
+        out = torch.empty_like(x) if out is None else out
+        p = lambda t: C.c_void_p(t.data_ptr())
+        self._lib.check(self.lib.emd_minmax_images_f32(p(x), B, npix, p(mn), p(mx), p(ws), st), "emd_minmax_images_f32")
+        self._lib.check(self.lib.emd_scale0to1_images_f32(p(x), p(out), B, npix, p(mn), p(mx), st), "emd_scale0to1_images_f32")
+        return out
+
+    def get_scale(self, B):
+        import ctypes as C
+
+        import torch
+
+        s = torch.empty(B, dtype=torch.float32, device=self.device)
+        self._lib.check(self.lib.emd_get_scale_f32(C.c_void_p(s.data_ptr()), B, self.seed, self.next_image, self._lib.stream_ptr()),
+                        "emd_get_scale_f32")
+        return s
+
+    def gen_lq(self, img, scale, want_counts=False):
+        """img [B,...] in [0,1], scale [B] -> (lq, truth[, counts int32]) (:787-799, :868)."""
+        import ctypes as C
+
+        import torch
+
+        B = img.shape[0]
+        npix = img.numel() // B
+        assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and scale.numel() == B and scale.dtype == torch.float32
+        lq, truth = torch.empty_like(img), torch.empty_like(img)
+        counts = torch.empty(img.shape, dtype=torch.int32, device=self.device) if want_counts else None
+        ws = self._ws(B, npix)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        self._lib.check(self.lib.emd_gen_lq_f32(p(img), p(scale), p(lq), p(truth), p(counts), B, npix, self.seed, self.next_image, p(ws),
+                                                self._lib.stream_ptr()), "emd_gen_lq_f32")
+        return (lq, truth, counts) if want_counts else (lq, truth)
+
+    def __call__(self, hq):
+        """hq [B,S,S,1] float32 CUDA (raw HQ images) -> (lq, truth): record_parser over the batch; advances the image counter."""
+        B = hq.shape[0]
+        img, _ = self.flip_rotate(hq, fix_nonfinite=True)       # preprocess (:853-858) ...
+        img = self.scale0to1(img, out=img)                      # ... min-max in place
+        lq, truth = self.gen_lq(img, self.get_scale(B))         # :865-868
+        self.next_image += B
+        return lq, truth

@@ -486,6 +486,38 @@ int emd_bn_infer_grads_f32(const float* s1, const float* t1, const float* t2, co
                            float* dg2, float* db2, emd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training input functions on the device (csrc/input_ops.hip).  They replace the numpy bodies of
+ * misc_py/denoiser-multi-gpu.py:783-870 (get_scale, gen_lq, scale0to1, flip_rotate, preprocess, record_parser), which the
+ * reference runs in tf.py_func threads.  Images are dense float32 [B][npix] (or [B][H][W]); all pointers are device
+ * pointers.  Random numbers: Philox4x32-10 keyed by `seed`, indexed by (first_image + b, pixel, draw): results do not depend
+ * on the launch geometry or on how a data set is cut into batches.  The reference's own stream (numpy Mersenne-Twister
+ * re-seeded from itself, :791) is irreproducible by construction; distributions and deterministic formulas are kept. */
+/* Raw generator output, for known-answer tests: out[4*i..4*i+3] = Philox4x32-10(counter = (counter0 + i, 0, 0), key = seed). */
+int emd_philox4x32_u32(unsigned* out, long n4, unsigned long long seed, unsigned long long counter0, emd_stream_t stream);
+/* get_scale (:783-784): scale[b] = 25 + Exp(mean 75). */
+int emd_get_scale_f32(float* scale, int B, unsigned long long seed, unsigned long long first_image, emd_stream_t stream);
+/* The draw of flip_rotate (:833): choice[b] = int(8 * U[0,1)). */
+int emd_d4_choices_i32(int* choice, int B, unsigned long long seed, unsigned long long first_image, emd_stream_t stream);
+/* flip_rotate (:830-851) with the element of D4 given per image (choice_dev[b] in 0..7, device memory; NULL = identity):
+ * 0 identity, 1-3 np.rot90(img, k), 4 np.flip(img, 0), 5 np.flip(img, 1), 6 / 7 np.flip(np.rot90(img, 1), 0 / 1).
+ * Square images only (H == W).  fix_nonfinite != 0 also applies preprocess()'s NaN / Inf -> 0.5 (:855-856).  x != y. */
+int emd_flip_rotate_f32(const float* x, float* y, int B, int H, int W, const int* choice_dev, int fix_nonfinite,
+                        emd_stream_t stream);
+/* Bytes of scratch emd_gen_lq_f32 / emd_minmax_images_f32 need for a batch of B images of npix pixels (16-byte aligned). */
+size_t emd_input_workspace_bytes(int B, long npix);
+/* Per-image minimum and maximum (the reductions of scale0to1, :817-828); exact. */
+int emd_minmax_images_f32(const float* x, int B, long npix, float* mn, float* mx, void* workspace, emd_stream_t stream);
+/* scale0to1 (:817-828): y = (x - min) / (max - min) in float32, a constant image becomes 0.5; y may alias x. */
+int emd_scale0to1_images_f32(const float* x, float* y, int B, long npix, const float* mn, const float* mx,
+                             emd_stream_t stream);
+/* gen_lq + the truth rescale of record_parser (:787-799, :861-870): counts = Poisson(img * scale[b]) (exact samplers in
+ * double precision: CDF inversion below a rate of 10, Hoermann's PTRS rejection method above), lq = scale0to1(counts)
+ * evaluated in float64 and rounded to float32 as numpy does for integer counts, truth = float32(mean(lq) / mean(img)) * img
+ * (truth may be NULL).  counts_out (int32 [B][npix]) may be NULL; when given it receives the raw counts. */
+int emd_gen_lq_f32(const float* img, const float* scale, float* lq, float* truth, int* counts_out, int B, long npix,
+                   unsigned long long seed, unsigned long long first_image, void* workspace, emd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host utility (no GPU): CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start).
  * Used by the TFRecord reader (emdenoise.input_pipeline) for the container that
  * misc_py/TFRecord_creator.py:57-85 writes with tf.python_io.TFRecordWriter. */
