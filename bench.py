@@ -1,39 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- megapixels/s restored on synthetic 512x512x1 micrograph batches (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload K|D|X|T|both|all] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload D|K|X|T|G|A|S|all] [--batch B]
+                    [--scaling weak|strong] [--dry-run]
 
-A "step" is one pass of the hot path over one batch that is already resident in HBM.
-Workloads:
-  K  BASELINE configs[1]: the 3-layer 3x3 kernel denoiser (misc_py/noise-removal-kernels.py, depth 2,
-     width 3) on [32,512,512,1].  This is the configuration the metric line is quoted on.
-  D  BASELINE configs[2]: the modified-Xception encoder-decoder of machine_learning/denoiser.py on
-     [32,512,512,1] (matrix cores in split-bf16 parity mode unless --precision bf16).
+A "step" is one pass of the hot path over one batch that is already resident in HBM.  Workloads:
+  D  BASELINE configs[2], THE PRIMARY LINE: the modified-Xception encoder-decoder of machine_learning/denoiser.py on
+     [32,512,512,1] -- the conv stack north_star sets its depthwise / pointwise targets on (matrix cores in split-bf16
+     parity mode unless --precision bf16).
+  K  BASELINE configs[1]: the 3-layer 3x3 kernel denoiser (misc_py/noise-removal-kernels.py, depth 2, width 3).
   X  the other graph BASELINE configs[2] can mean: misc_py/modified_Xception.py at 512x512.
-  G  BASELINE configs[4], the part that is built: the in-filling GAN's generator forward pass
-     (misc_py/gan-infilling-100.py:133-374) on [32,512,512,1]; rides along as "workload_G".
-  A  BASELINE configs[4]: one iteration of the in-filling GAN's adversarial training loop (generator towers through
-     the discriminator + Adam, discriminator towers + Adam) on --gan-batch images per GPU; rides along as "workload_A".
-  T  BASELINE configs[3]: graph D' TRAINING (misc_py/denoiser-multi-gpu.py): --train-batch LQ/HQ pairs per GPU per
-     step (default 8 = bs 64 over 8 GPUs), towers of --tower-batch images (default 1, the reference), one RCCL
-     all-reduce of the flat gradient vector per step, Nesterov step.  Rides along as "workload_T"; --workload T
-     makes it the primary line (metric "megapixels/sec trained").
-Default ("all"): the JSON line's metric/value/roofline/cpu_baseline are workload K's; workload D's and X's
-figures ride along under "workload_D" / "workload_X".  --workload D makes D the primary line.
-For N > 1 the driver launches one rank per GPU (torch.distributed.run); inference shards whole images
-across ranks with no data-path collective (weak scaling: --batch images PER GPU).  Rank 0 prints ONE
-JSON line.
+  T  BASELINE configs[3]: graph D' TRAINING (misc_py/denoiser-multi-gpu.py): --train-batch LQ/HQ pairs per GPU per step,
+     one RCCL all-reduce of the flat gradient vector per step, Nesterov step.
+  G  BASELINE configs[4], forward part: the in-filling GAN's generator (misc_py/gan-infilling-100.py:133-374).
+  A  BASELINE configs[4]: one adversarial training iteration of the in-filling GAN.
+  S  SURVEY.md 8f rank 4: the small separable autoencoder (misc_py/apply_autoencoders.py) on 160-px crops.
+Default ("all"): the JSON line's metric/value/roofline/cpu_baseline are workload D's, measured with --steps/--warmup
+(default 20 / 5); K, X, T, G, S, A ride along under "workload_<letter>" with short fixed step counts.  A rider that throws
+is reported in the line AND makes the exit code non-zero (with more than one rank it re-raises at once, so that the
+launcher tears every rank down instead of leaving the others in a collective).
+
+Multi-GPU: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the ranks itself -- a parent
+that has touched neither torch nor the GPU runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
+process and relays rank 0's JSON line and the exit code.  Under an external launcher (the driver's torch.distributed.run)
+the ranks are used as given.  Inference shards whole images across ranks with no data-path collective:
+  --scaling weak   (default) --batch images PER GPU;
+  --scaling strong --batch images in total, cut contiguously (input_pipeline.shard_contiguous).
+--dry-run runs the whole launch / rendezvous / sharding / timing / reporting path over gloo on the CPU with a host stand-in
+for the step (no GPU, no kernels): what tests/test_bench_launch.py exercises with world_size 2.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
 import json
+import math
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -43,22 +48,82 @@ CPU_THREADS = min(16, os.cpu_count() or 1)  # a 1-GPU box owns a 16-CPU share; m
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 D_GMAC_MATRIX_B32_512 = 2218.3  # pointwise 1304.5 + dense 1x1 295.3 - final 4.8 + conv-T 618.5 ... per B=32 batch
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
 
 
+# ================================================================================================
+# launcher (no torch, no GPU): python bench.py --gpus N  ->  N ranks under torch.distributed.run
+# ================================================================================================
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["K", "D", "X", "T", "G", "A", "S", "both", "all"], default="all",
+                    help="all (default) = D primary with K, X, T, G, S, A alongside; a letter = that workload alone as the primary line")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (--scaling weak) or in total (--scaling strong)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch images per GPU; strong: --batch images in total, cut contiguously across the ranks")
+    ap.add_argument("--dry-run", action="store_true", help="gloo on the CPU, a host stand-in for the step: launch / sharding / timing path only")
+    ap.add_argument("--train-batch", type=int, default=8, help="workload T: LQ/HQ pairs per GPU per step (bs=64 over 8 GPUs)")
+    ap.add_argument("--tower-batch", type=int, default=1, help="workload T: images per tower (batch-norm statistics are per tower)")
+    ap.add_argument("--gan-batch", type=int, default=4, help="workload A: images per GPU per GAN iteration")
+    ap.add_argument("--train-streams", type=int, default=8, help="workload T: HIP streams the towers are issued on")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying captured hipGraphs (T / A / S)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-riders", action="store_true", help="with --workload all: the primary workload only")
+    ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3",
+                    help="matrix-core mode: bf16x3 = split-bf16 parity mode (default), bf16 = fast mode (never reported as parity)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a, argv):
+    """Parent of a self-launched multi-rank run.  It has imported neither torch nor the package and never touches the GPU
+    (a process that has initialised HIP must not exec or re-launch itself on this pool); it starts the ranks as a CHILD
+    process tree, relays the child's stdout (rank 0's JSON line) and returns its exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, CPU_THREADS // max(a.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    return proc.returncode
+
+
+# ================================================================================================
+# helpers shared by the workloads
+# ================================================================================================
 def pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC run (tools/collect_traffic.sh: FETCH_SIZE and
-    WRITE_SIZE in separate passes, gfx950 correction applied).  bench.py cannot profile itself, so `traffic`
-    is the figure of that run for the same kernels and shapes; None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        return json.load(open(path))["kernels"]
-    except Exception:
-        return None
+    """HBM bytes per launch from the committed rocprofv3 PMC run (tools/collect_traffic.sh: FETCH_SIZE and WRITE_SIZE in
+    separate passes, gfx950 correction applied).  bench.py cannot profile itself, so `traffic` is the figure of that run for
+    the same kernels and shapes; (None, None) if no file is there."""
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            return json.load(open(path))["kernels"], "profiles/" + name
+        except Exception:
+            continue
+    return None, None
 
 
 def synthetic_lq(B, H, W, seed=1234):
     """Synthetic low-quality crops of the reference's shape and statistics: smooth field ->
     Poisson counts (scale = 25 + Exp(75), denoiser-multi-gpu.py:783-799) -> min-max to [0,1]."""
+    import numpy as np
+
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
     base = []
@@ -75,12 +140,215 @@ def synthetic_lq(B, H, W, seed=1234):
     return np.clip(out, 0.0, 1.0)
 
 
+def d_graph_algorithmic_bytes(B, S):
+    """fp32 activation bytes a FULLY FUSED graph D has to move per step (SURVEY.md 8d / 8a' stage table): every layer reads its
+    input once and writes its output once, a residual add reads the residual, a separable conv's depthwise result never touches
+    HBM, concats are free (producers write into their slice).  B=32, S=512: 80.0 GB = SURVEY's 118 GB of unfused Sigma(in + out)
+    - 2 x 22.5 GB of depthwise intermediates + 6.5 GB of residual reads (which the survey's sum leaves out)."""
+    e = 0.0   # elements per image
+    P = lambda h: float(h) * float(h)
+    s1, s2, s4, s8, s16 = S, S // 2, S // 4, S // 8, S // 16
+    lay = lambda hin, cin, hout, cout, res=False: cin * P(hin) + cout * P(hout) * (2 if res else 1)
+    e += lay(s1, 1, s1, 64) + lay(s1, 64, s1, 64) + lay(s1, 64, s2, 128, True) + lay(s1, 1, s2, 128)
+    e += 2 * lay(s2, 128, s2, 128) + lay(s2, 128, s4, 128, True) + lay(s2, 128, s4, 128)
+    e += lay(s4, 128, s4, 256) + lay(s4, 256, s4, 256) + lay(s4, 256, s8, 256, True) + lay(s4, 128, s8, 256)
+    e += lay(s8, 256, s8, 728) + lay(s8, 728, s8, 728) + lay(s8, 728, s16, 728, True) + lay(s8, 256, s16, 728)
+    e += 24 * lay(s16, 728, s16, 728) + 12 * lay(s16, 728, s16, 728, True)
+    e += 5 * lay(s16, 728, s16, 728) + lay(s16, 3640, s16, 256) + lay(s16, 256, s4, 256)
+    e += lay(s4, 384, s4, 256) + lay(s4, 256, s4, 256, True) + lay(s4, 384, s4, 256) + lay(s4, 256, s2, 256)
+    e += lay(s2, 384, s2, 128) + lay(s2, 128, s2, 128, True) + lay(s2, 384, s2, 128) + lay(s2, 128, s1, 128)
+    e += lay(s1, 128, s1, 64) + lay(s1, 64, s1, 64, True) + lay(s1, 128, s1, 64) + lay(s1, 64, s1, 1)
+    return 4.0 * e * B
+
+
+def psnr_rel(y_gpu, y_ref):
+    import numpy as np
+
+    d = y_gpu.astype(np.float64) - y_ref.astype(np.float64)
+    mse = float(np.mean(d * d))
+    rel = float(np.linalg.norm(d) / max(np.linalg.norm(y_ref.astype(np.float64)), 1e-30))
+    return (float("inf") if mse == 0 else round(10.0 * math.log10(1.0 / mse), 2)), float(f"{rel:.3e}")
+
+
+class Timer:
+    """Barrier + synchronize on both sides, exactly `steps` steps, max over ranks (the bench contract); one HIP-event pair per
+    step on the launch stream gives the median device-side step time beside it."""
+
+    def __init__(self, torch, dist, dev):
+        self.torch, self.dist, self.dev = torch, dist, dev
+        self.gpu = dev is not None and dev.type == "cuda"
+
+    def sync(self):
+        if self.gpu:
+            self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.gpu:
+                self.torch.cuda.synchronize()
+
+    def run(self, step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        self.sync()
+        evs = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if self.gpu:
+                e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+                e0.record()
+                step()
+                e1.record()
+                evs.append((e0, e1))
+            else:
+                step()
+        self.sync()
+        wall = time.perf_counter() - t0
+        if self.dist is not None:
+            tt = self.torch.tensor([wall], dtype=self.torch.float64, device=self.dev if self.gpu else "cpu")
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            wall = float(tt.item())
+        self.median_event_ms = None
+        if evs:
+            ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+            self.median_event_ms = round(ts[len(ts) // 2], 4)
+        return wall * 1e3 / steps
+
+
+class FamilyTimer:
+    """Device time per kernel family of ONE extra step: HIP events around every launch that goes through a function of
+    emdenoise.ops, with the algorithmic flops / bytes of the launch taken from its arguments."""
+
+    MATRIX = ("conv1x1", "conv3x3", "deconv3x3s2", "sep_fused", "sep_fused_gen", "sep_dual", "conv1x1_split32", "conv3x3_split32",
+              "deconv3x3s2_split32", "deconv3x3s2_fused")
+    NAMES = MATRIX + ("dw3x3", "dw3x3_split32", "dw3x3_reflect", "dw3x3_reflect_split32", "dw3x3_reflect_gen", "cin1", "cin1_k7_reflect",
+                      "conv3x3_cout1", "conv3x3_cout1_reflect", "resize_bilinear", "affine_relu6", "affine_act", "affine_act_images",
+                      "bn_batch_stats", "bn_batch_stats_images", "avgpool2x2", "to_split32", "instnorm_tanh")
+
+    def __init__(self, torch, ops):
+        self.torch, self.ops = torch, ops
+        self.ev, self.flops, self.bytes_, self.orig = {}, {}, {}, {}
+
+    def _account(self, name, args, kw):
+        ops = self.ops
+        try:
+            if name in ("conv1x1", "conv1x1_split32"):
+                x, w, out = args[0], args[1], (args[4] if len(args) > 4 else kw["out"])
+                self.flops[name] = self.flops.get(name, 0.0) + 2.0 * out.B * out.H * out.W * w.cin * w.cout
+            elif name in ("conv3x3", "conv3x3_split32"):
+                w, out = args[1], (args[4] if len(args) > 4 else kw["out"])
+                self.flops[name] = self.flops.get(name, 0.0) + 2.0 * out.B * out.H * out.W * 9 * w.cin * w.cout
+            elif name in ("deconv3x3s2", "deconv3x3s2_split32", "deconv3x3s2_fused"):
+                x, wp = args[0], args[1]
+                self.flops[name] = self.flops.get(name, 0.0) + 2.0 * x.B * x.H * x.W * 9 * wp[0].cin * wp[0].cout
+            elif name == "sep_fused":
+                x, w = args[0], args[2]
+                self.flops[name] = self.flops.get(name, 0.0) + 2.0 * x.B * x.H * x.W * w.cin * w.cout
+            elif name == "sep_fused_gen":
+                d, w = args[0], args[4]
+                self.flops[name] = self.flops.get(name, 0.0) + 2.0 * d.B * d.H * d.W * w.cin * w.cout
+            elif name == "sep_dual":
+                x, w, w2 = args[0], args[2], args[3]
+                self.flops[name] = self.flops.get(name, 0.0) + 2.0 * x.B * x.H * x.W * w.cin * (w.cout + w2.cout)
+            elif name in ("dw3x3", "dw3x3_split32"):   # algorithmic bytes: fp32 in + out (a split32 output has the bytes of its fp32 twin)
+                xin, out = args[0], args[2]
+                self.bytes_[name] = self.bytes_.get(name, 0.0) + 4.0 * xin.C * (xin.B * xin.H * xin.W + out.B * out.H * out.W)
+        except Exception:   # accounting never breaks the measured step
+            pass
+
+    def __enter__(self):
+        torch = self.torch
+        for name in self.NAMES:
+            f = getattr(self.ops, name, None)
+            if f is None:
+                continue
+            self.orig[name] = f
+
+            def g(*args, _f=f, _n=name, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = _f(*args, **kw)
+                e1.record()
+                self.ev.setdefault(_n, []).append((e0, e1))
+                self._account(_n, args, kw)
+                return r
+
+            setattr(self.ops, name, g)
+        return self
+
+    def __exit__(self, *exc):
+        for name, f in self.orig.items():
+            setattr(self.ops, name, f)
+        self.torch.cuda.synchronize()
+        self.ms = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) for k, v in self.ev.items()}
+        self.launches = {k: len(v) for k, v in self.ev.items()}
+        return False
+
+    def matrix_ms(self):
+        return sum(self.ms.get(k, 0.0) for k in self.MATRIX)
+
+    def matrix_flops(self):
+        return sum(self.flops.get(k, 0.0) for k in self.MATRIX)
+
+    def table(self):
+        return {k: round(v, 3) for k, v in sorted(self.ms.items(), key=lambda kv: -kv[1])}
+
+
+def measured_peaks(torch, dev):
+    """On-box peaks: a read + write stream copy of 1 GiB (far beyond the 256 MiB Infinity Cache) and a
+    back-to-back bf16 MFMA loop on random operands, one wave per SIMD on every CU; HIP events, median of 5 bursts."""
+    from emdenoise import _lib
+
+    lib = _lib.load()
+    out = {}
+    try:
+        n = 1 << 28   # floats: 1 GiB each way
+        a = torch.rand(n, device=dev)
+        b = torch.empty_like(a)
+        st = _lib.stream_ptr()
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        ts = []
+        for r in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                _lib.check(lib.emd_debug_stream_copy_f32(p(a), p(b), n, st))
+            e1.record()
+            torch.cuda.synchronize()
+            if r:
+                ts.append(e0.elapsed_time(e1) / 4)
+        ms = sorted(ts)[len(ts) // 2]
+        out["stream_copy_GBps"] = round(2.0 * 4.0 * n / (ms * 1e-3) / 1e9, 1)
+        out["stream_copy_note"] = "emd_debug_stream_copy_f32, 1 GiB read + 1 GiB write per launch, float4 per lane, HIP events"
+        del a, b
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        opsb = (torch.randn(2048, device=dev)).to(torch.bfloat16).contiguous()
+        sink = torch.empty(cus * 256, device=dev)
+        iters = 1500
+        ts = []
+        for r in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.emd_debug_mfma_peak_bf16(p(opsb), p(sink), cus, iters, st))
+            e1.record()
+            torch.cuda.synchronize()
+            if r:
+                ts.append(e0.elapsed_time(e1))
+        ms = sorted(ts)[len(ts) // 2]
+        fl = float(cus) * 4 * iters * 32 * 32768.0
+        out["mfma_bf16_TFLOPs"] = round(fl / (ms * 1e-3) / 1e12, 1)
+        out["mfma_note"] = (f"emd_debug_mfma_peak_bf16: {cus} workgroups x 4 waves x {iters * 32} back-to-back v_mfma_f32_32x32x16_bf16 "
+                            "on random register operands (the clock the chip holds under this load is part of the figure)")
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # CPU baselines: the ORACLE timed on the host cores (reported next to the GPU number; never shipped)
 # ------------------------------------------------------------------------------------------------
 def cpu_baseline_K(x_host, W, Bm, s, budget_s=10.0):
     """oracle/k_oracle.c (plain-C port of graph K, OpenMP over rows)."""
-    import subprocess
+    import numpy as np
 
     so = os.path.join(ROOT, "oracle", "_build", "libk_oracle.so")
     if not os.path.exists(so):
@@ -132,40 +400,32 @@ def cpu_baseline_D(x_host, weights):
                       f"(PyTorch-CPU float32, {torch.get_num_threads()} threads), {el:.1f} s"}, y
 
 
-# ------------------------------------------------------------------------------------------------
-class Timer:
-    """Barrier + synchronize on both sides, exactly `steps` steps, max over ranks."""
+def local_batch(a, rank, world):
+    """(images on this rank, first global index, images in the whole job) under --scaling."""
+    if a.scaling == "strong":
+        from emdenoise import input_pipeline as ip
 
-    def __init__(self, torch, dist, dev):
-        self.torch, self.dist, self.dev = torch, dist, dev
-
-    def sync(self):
-        self.torch.cuda.synchronize()
-        if self.dist is not None:
-            self.dist.barrier()
-            self.torch.cuda.synchronize()
-
-    def run(self, step, steps, warmup):
-        for _ in range(warmup):
-            step()
-        self.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        self.sync()
-        wall = time.perf_counter() - t0
-        if self.dist is not None:
-            tt = self.torch.tensor([wall], dtype=self.torch.float64, device=self.dev)
-            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
-            wall = float(tt.item())
-        return wall * 1e3 / steps
+        lo, hi = ip.shard_contiguous(a.batch, world, rank)
+        return hi - lo, lo, a.batch
+    return a.batch, rank * a.batch, a.batch * world
 
 
-def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
-    B, H, W = a.batch, a.size, a.size
-    steps = a.steps if a.steps is not None else 200
-    warmup = a.warmup if a.warmup is not None else 20
-    x_host = synthetic_lq(B, H, W, seed=1234 + rank)
+def shard_note(a, world, Bl, total):
+    if a.scaling == "strong":
+        return f"strong scaling: {total} images in total cut contiguously over {world} ranks ({Bl} on rank 0), no collective"
+    return f"{world} x {Bl} whole images, no collective"
+
+
+# ================================================================================================
+# workloads
+# ================================================================================================
+def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
+    import numpy as np
+
+    (B, first, total), H, W = local_batch(a, rank, world), a.size, a.size
+    steps = a.steps if (primary and a.steps is not None) else 200
+    warmup = a.warmup if (primary and a.warmup is not None) else 20
+    x_host = synthetic_lq(max(B, 1), H, W, seed=1234 + first)[:max(B, 1)]
     x_host = (x_host / np.maximum(x_host.mean(axis=(1, 2, 3), keepdims=True), 1e-9)).astype(np.float32)  # noise-removal-kernels.py:525-527
     rng = np.random.default_rng(7)
     pairs = emdenoise.kernel_denoiser.sym_pairs(3)
@@ -173,11 +433,12 @@ def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     bsc = [np.zeros(len(pairs), np.float32), (rng.standard_normal(len(pairs)) * 0.5).astype(np.float32)]
     params = emdenoise.KernelParams.from_symmetric(wsc, bsc, [1.0, 1.3], 3)
     pd = torch.from_numpy(params.packed()).to(dev)
-    x = torch.from_numpy(x_host).to(dev)
+    x = torch.from_numpy(x_host[:B]).to(dev)
     y = torch.empty_like(x)
 
     def step():
-        emdenoise.kernel_denoise(x, pd, 3, 2, params.symmetric, out=y)
+        if B:
+            emdenoise.kernel_denoise(x, pd, 3, 2, params.symmetric, out=y)
 
     ms = timer.run(step, steps, warmup)
     # the dominant (only) kernel, timed live with HIP events on the launch stream: torch's current stream IS
@@ -197,20 +458,22 @@ def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     launch_us = e0.elapsed_time(e1) * 1e3 / n_burst
     alg_bytes = 8.0 * B * H * W  # 8 B per pixel (read 4 + write 4)
     achieved = alg_bytes / (launch_us * 1e-6) / 1e9
-    tr = pmc_traffic()
+    tr, src = pmc_traffic()
     traffic = None
     if tr and "K:k3_roll<8, 2>" in tr and (B, H, W) == (32, 512, 512):
         traffic = round(tr["K:k3_roll<8, 2>"]["hbm_bytes_per_launch_corrected"])
     out = {
-        "value": B * H * W / 1e6 * world / (ms / 1e3), "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": "f32",
+        "value": total * H * W / 1e6 / (ms / 1e3), "unit": "MPx/s", "ms_per_step": ms, "median_hipevent_ms": timer.median_event_ms,
+        "steps": steps, "warmup": warmup, "dtype": "f32",
         "config": {"workload": f"K: kernel denoiser depth 2 width 3 (noise-removal-kernels.py), [{B},{H},{W},1] fp32 per GPU",
-                   "global_batch": B * world, "image": f"{H}x{W}x1", "sharding": f"{world} x {B} whole images, no collective"},
+                   "global_batch": total, "image": f"{H}x{W}x1", "sharding": shard_note(a, world, B, total)},
         "roofline": {"bound": "hbm", "kernel": "k3_roll<8,2>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2x FETCH correction)",
+                     "traffic_source": f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2x FETCH correction)",
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_us": round(launch_us, 3),
-                     "how": f"HIP events around a hipGraph of {n_burst} back-to-back launches (includes the ~1.5 us kernel boundary)"},
+                     "how": f"HIP events around a hipGraph of {n_burst} back-to-back launches (includes the ~1.5 us kernel boundary); "
+                            "67 MB replayed back to back lives in the 256 MiB Infinity Cache -- batch256 below is the figure beyond it"},
     }
     # the same kernel on a batch that is not launch-bound and does not fit the 256 MiB Infinity Cache (SURVEY.md 8d:
     # "the kernel is launch/latency-limited at this size, so also report B=256"): 8x the images, one launch
@@ -233,120 +496,88 @@ def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
             del xb, yb
         except Exception as e:  # out of memory on a shared card: the primary figure stands on its own
             out["roofline"]["batch256"] = {"error": f"{type(e).__name__}: {e}"}
-    if want_cpu:
-        cb, y_cpu = cpu_baseline_K(x_host, params.wmaps, params.bmaps, params.s)
+    if want_cpu and B:
+        cb, y_cpu = cpu_baseline_K(x_host[:B], params.wmaps, params.bmaps, params.s)
         out["cpu_baseline"] = cb
-        y_gpu = y.cpu().numpy()[..., 0].astype(np.float64)
-        out["rel_l2_vs_oracle"] = float(f"{np.linalg.norm(y_gpu - y_cpu) / np.linalg.norm(y_cpu):.3e}")
+        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(y.cpu().numpy()[..., 0], y_cpu)
     return out
 
 
-from importlib import import_module as _imp
+def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
+    import numpy as np
 
-
-class _LazyGraphed:
-    def __call__(self, eng):
-        return _imp('emdenoise.graphed').GraphedForward(eng)
-
-
-GraphedForward = _LazyGraphed()
-
-
-def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     from emdenoise import ops
 
-    B, H, W = a.batch, a.size, a.size
-    steps = a.steps if (a.steps is not None and a.workload == "D") else 10
-    warmup = a.warmup if (a.warmup is not None and a.workload == "D") else 2
-    x_host = synthetic_lq(B, H, W, seed=1234 + rank)
+    (B, first, total), H, W = local_batch(a, rank, world), a.size, a.size
+    steps = a.steps if (primary and a.steps is not None) else (20 if primary else 10)
+    warmup = a.warmup if (primary and a.warmup is not None) else (5 if primary else 2)
+    x_host = synthetic_lq(max(B, 1), H, W, seed=1234 + first)
     weights = emdenoise.synthetic_weights()
     eng = emdenoise.DenoiserEngine(weights, dev, a.precision)
-    x = torch.from_numpy(x_host).to(dev)
+    x = torch.from_numpy(x_host[:B]).to(dev)
     box = [None]
 
     def step():
-        box[0] = eng.forward(x)
+        if B:
+            box[0] = eng.forward(x)
 
     ms = timer.run(step, steps, warmup)
-    # per-kernel-family device time of ONE more step, HIP events around every launch of the family
-    fam = {}
-    orig = {}
-    dw_bytes_box = [0.0]
-    pw_flops_box = [0.0]
-
-    def wrap(name):
-        f = getattr(ops, name)
-        orig[name] = f
-
-        def g(*args, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = f(*args, **kw)
-            e1.record()
-            fam.setdefault(name, []).append((e0, e1))
-            if name in ("dw3x3", "dw3x3_split32"):  # algorithmic bytes of THIS launch: fp32 in + out;
-                xin, out = args[0], args[2]          # a split32 output has the bytes of its fp32 twin
-                dw_bytes_box[0] += 4.0 * xin.C * (xin.B * xin.H * xin.W + out.B * out.H * out.W)
-            if name == "conv1x1_split32":            # issued flops of THIS pointwise launch (3 bf16 MFMA passes)
-                xin, wgt = args[0], args[1]
-                pw_flops_box[0] += 6.0 * xin.B * xin.H * xin.W * wgt.cin * wgt.cout
-            return r
-
-        setattr(ops, name, g)
-
-    for name in ("conv1x1", "conv3x3", "deconv3x3s2", "sep_fused", "dw3x3", "cin1", "conv3x3_cout1", "resize_bilinear",
-                 "affine_relu6", "affine_act", "bn_batch_stats", "avgpool2x2", "conv1x1_split32", "conv3x3_split32",
-                 "deconv3x3s2_split32", "dw3x3_split32", "to_split32"):
-        wrap(name)
+    med = timer.median_event_ms
+    # per-kernel-family device time of ONE more step on the single-stream launch sequence (with the two half batches on two
+    # streams -- streams.TwoHalves -- a launch's event pair would also span the other half's kernels)
     two = eng.two_streams
-    eng.two_streams = False   # attribution pass on the single-stream launch sequence: with the two half batches on two streams
-    try:                      # (streams.TwoHalves) a launch's event pair would also span the other half's kernels
-        step()
-        torch.cuda.synchronize()
+    eng.two_streams = False
+    try:
+        with FamilyTimer(torch, ops) as fam:
+            step()
     finally:
         eng.two_streams = two
-        for name, f in orig.items():
-            setattr(ops, name, f)
-    fam_ms = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) for k, v in fam.items()}
-    # matrix-core time: the implicit-GEMM launches plus the fused separable convs (whose pointwise halves carry
-    # part of the algorithmic flops)
-    gemm_ms = sum(fam_ms.get(k, 0.0) for k in ("conv1x1", "conv3x3", "deconv3x3s2", "sep_fused", "conv1x1_split32",
-                                               "conv3x3_split32", "deconv3x3s2_split32"))
-    dw_ms = fam_ms.get("dw3x3", 0.0) + fam_ms.get("dw3x3_split32", 0.0)
+    gemm_ms = fam.matrix_ms()
+    dw_ms = fam.ms.get("dw3x3", 0.0) + fam.ms.get("dw3x3_split32", 0.0)
+    dw_bytes = fam.bytes_.get("dw3x3", 0.0) + fam.bytes_.get("dw3x3_split32", 0.0)
+    pw_ms, pw_flops = fam.ms.get("conv1x1_split32", 0.0), 3.0 * fam.flops.get("conv1x1_split32", 0.0)
     scale = (B / 32.0) * (H * W) / (512.0 * 512.0)
     alg_flops = 2.0 * D_GMAC_MATRIX_B32_512 * 1e9 * scale
-    achieved = alg_flops / (gemm_ms * 1e-3) / 1e12
     passes = 3 if a.precision == "bf16x3" else 1
-    dw_bytes = dw_bytes_box[0]  # only the STANDALONE depthwise launches (the fused layers never write the depthwise result)
-    tr = pmc_traffic()
+    alg_bytes = d_graph_algorithmic_bytes(B, H)
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    tr, src = pmc_traffic()
     traffic = None
-    if tr and (B, H, W) == (32, 512, 512):  # HBM bytes of every matrix-core launch of one step
-        traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_sampled"] / 4.0
-                            for k, v in tr.items() if k.startswith(("D:gemm_conv_kernel", "D:gemm_split", "D:sep_fused"))))
+    if tr and (B, H, W) == (32, 512, 512):   # HBM bytes of every launch of one step (PMC run of `steps_sampled` forwards)
+        dk = {k: v for k, v in tr.items() if k.startswith("D:")}
+        if dk:
+            n = float(next(iter(dk.values())).get("steps_sampled", 4))
+            traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_sampled"] / n for v in dk.values()))
     out = {
-        "value": B * H * W / 1e6 * world / (ms / 1e3), "ms_per_step": ms, "steps": steps, "warmup": warmup,
+        "value": total * H * W / 1e6 / (ms / 1e3), "unit": "MPx/s", "ms_per_step": ms, "median_hipevent_ms": med, "steps": steps, "warmup": warmup,
         "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)" if passes == 3 else "bf16",
         "config": {"workload": f"D: modified-Xception encoder-decoder (machine_learning/denoiser.py), [{B},{H},{W},1] fp32 per GPU",
-                   "global_batch": B * world, "image": f"{H}x{W}x1", "precision": a.precision,
-                   "sharding": f"{world} x {B} whole images, no collective"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel + gemm_split*_kernel + sep_fused_kernel (every matrix-core launch of one step)",
-                     "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "traffic_note": "HBM bytes per step over the family (PMC run of 4 forwards, profiles/r01_pmc_traffic.json)",
-                     "algorithmic_flops_per_step": alg_flops, "mfma_passes": passes,
-                     "issued_tflops": round(achieved * passes, 1),
-                     "kernel_ms_per_step": round(gemm_ms, 3),
-                     "how": "HIP events around every launch of the family in one extra step (single-stream launch sequence)"},
+                   "global_batch": total, "image": f"{H}x{W}x1", "precision": a.precision, "sharding": shard_note(a, world, B, total)},
+        "roofline": {"bound": "hbm", "kernel": "whole step (every launch of one forward pass; the graph is HBM-bound end to end, SURVEY.md 8d)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "algorithmic_bytes_per_step": alg_bytes,
+                     "algorithmic_note": "fp32 activation bytes of a fully fused graph: in + out (+ residual) per layer, no depthwise intermediates "
+                                         "(bench.d_graph_algorithmic_bytes; 80.0 GB at B=32, 512^2: SURVEY 8d's 118 GB unfused - 45 GB depthwise intermediates + 6.5 GB residual reads)",
+                     "traffic": traffic, "traffic_source": src,
+                     "hbm_busy_frac": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+                     "hbm_busy_note": "PMC bytes per step / step time / 8 TB/s (traffic above the algorithmic bytes = re-reads and unfused intermediates)",
+                     "how": "step time = wall clock over the timed steps (barrier + synchronize on both sides); median of per-step HIP events beside it"},
+        "matrix_cores": {"bound": "mfma", "kernel": "gemm_conv + gemm_split* + sep_fused / sep_dual + deconv (every matrix-core launch of one step)",
+                         "algorithmic_flops_per_step": alg_flops, "mfma_passes": passes, "kernel_ms_per_step": round(gemm_ms, 3),
+                         "achieved_tflops": round(alg_flops / (max(gemm_ms, 1e-9) * 1e-3) / 1e12, 1),
+                         "issued_tflops": round(passes * alg_flops / (max(gemm_ms, 1e-9) * 1e-3) / 1e12, 1),
+                         "frac_of_2500_algorithmic": round(alg_flops / (max(gemm_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "how": "HIP events around every launch of the family in one extra step (single-stream launch sequence)"},
         "depthwise": {"bound": "hbm", "kernel": "dw3x3_s1_roll / dw3x3_generic, fp32 or split32 output (standalone launches only)",
+                      "launches": fam.launches.get("dw3x3", 0) + fam.launches.get("dw3x3_split32", 0),
                       "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(dw_ms, 3),
                       "achieved_GBps": round(dw_bytes / (max(dw_ms, 1e-9) * 1e-3) / 1e9, 1),
                       "frac_of_8TBps": round(dw_bytes / (max(dw_ms, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-        "pointwise": {"bound": "mfma", "kernel": "gemm_split_kernel<256,3,true> (the 1x1 halves of the 728-channel separable convs, LDS-DMA from split32)",
-                      "launches": len(fam.get("conv1x1_split32", [])), "issued_flops_per_step": pw_flops_box[0],
-                      "ms_per_step": round(fam_ms.get("conv1x1_split32", 0.0), 3),
-                      "issued_tflops": round(pw_flops_box[0] / (max(fam_ms.get("conv1x1_split32", 0.0), 1e-9) * 1e-3) / 1e12, 1),
-                      "frac_of_2500": round(pw_flops_box[0] / (max(fam_ms.get("conv1x1_split32", 0.0), 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
-        "kernel_family_ms": {k: round(v, 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])},
+        "pointwise": {"bound": "mfma", "kernel": "gemm_split_kernel (the 1x1 halves of the 728-channel separable convs, LDS-DMA from split32)",
+                      "launches": fam.launches.get("conv1x1_split32", 0), "issued_flops_per_step": pw_flops, "ms_per_step": round(pw_ms, 3),
+                      "issued_tflops": round(pw_flops / (max(pw_ms, 1e-9) * 1e-3) / 1e12, 1),
+                      "frac_of_2500": round(pw_flops / (max(pw_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
+        "kernel_family_ms": fam.table(),
     }
     # the headline pointwise GEMM on its own (32768 x 728 x 728 at B = 32: 40 of D's layers), interleaved rounds in this
     # process: the default kernel, and the same pipeline on 16x16x32 MFMAs (opt-in: it sums a K step in another order)
@@ -380,79 +611,131 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
             out["pointwise"]["isolated_32768x728x728"] = iso
         except Exception as e:
             out["pointwise"]["isolated_32768x728x728"] = {"error": f"{type(e).__name__}: {e}"}
-    if want_cpu:
-        cb, y_cpu = cpu_baseline_D(x_host, weights)
+    if primary and rank == 0 and B:
+        # end to end from pinned host memory: H2D copy + forward + D2H copy of the same batch
+        try:
+            xp = torch.from_numpy(x_host[:B]).pin_memory()
+            yp = torch.empty((B, H, W, 1), dtype=torch.float32).pin_memory()
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                xd = xp.to(dev, non_blocking=True)
+                yp.copy_(eng.forward(xd), non_blocking=True)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            out["from_pinned_host"] = {"ms_per_step": round(min(ts), 3), "MPx_per_s": round(B * H * W / 1e6 / (min(ts) / 1e3), 1),
+                                       "note": "pinned host -> HBM, forward, HBM -> pinned host, one batch, best of 3 (never the headline value)"}
+        except Exception as e:
+            out["from_pinned_host"] = {"error": f"{type(e).__name__}: {e}"}
+    if want_cpu and B:
+        cb, y_cpu = cpu_baseline_D(x_host[:B], weights)
         out["cpu_baseline"] = cb
-        y_gpu = box[0][:1].cpu().numpy().astype(np.float64)
-        out["rel_l2_vs_oracle"] = float(f"{np.linalg.norm(y_gpu - y_cpu) / np.linalg.norm(y_cpu):.3e}")
+        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(box[0][:1].cpu().numpy(), y_cpu)
     return out
 
 
-def bench_X(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
+def bench_X(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     """BASELINE configs[2], second graph of that name: misc_py/modified_Xception.py at 512x512."""
-    from emdenoise import xception as X
+    import numpy as np
 
-    B, H, W = a.batch, a.size, a.size
-    steps, warmup = 3, 1
-    x_host = synthetic_lq(B, H, W, seed=1234 + rank)
+    from emdenoise import ops, xception as X
+
+    (B, first, total), H, W = local_batch(a, rank, world), a.size, a.size
+    steps = a.steps if (primary and a.steps is not None) else 3
+    warmup = a.warmup if (primary and a.warmup is not None) else 1
+    x_host = synthetic_lq(max(B, 1), H, W, seed=1234 + first)
     weights = X.synthetic_weights()
     eng = X.XceptionEngine(weights, dev, a.precision)
-    x = torch.from_numpy(x_host).to(dev)
+    x = torch.from_numpy(x_host[:B]).to(dev)
     box = [None]
 
     def step():
-        box[0] = eng.forward(x)
+        if B:
+            box[0] = eng.forward(x)
 
     ms = timer.run(step, steps, warmup)
+    with FamilyTimer(torch, ops) as fam:
+        step()
     scale = (B / 32.0) * (H * W) / (512.0 * 512.0)
-    out = {"value": round(B * H * W / 1e6 * world / (ms / 1e3), 1), "unit": "MPx/s", "ms_per_step": round(ms, 3),
-           "steps": steps, "warmup": warmup,
+    dec = ("conv3x3", "conv3x3_split32", "deconv3x3s2", "deconv3x3s2_split32", "deconv3x3s2_fused")
+    dec_ms = sum(fam.ms.get(k, 0.0) for k in dec)
+    dec_fl = sum(fam.flops.get(k, 0.0) for k in dec)
+    out = {"value": round(total * H * W / 1e6 / (ms / 1e3), 1), "unit": "MPx/s", "ms_per_step": round(ms, 3), "median_hipevent_ms": timer.median_event_ms,
+           "steps": steps, "warmup": warmup, "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)",
            "config": {"workload": f"X: Xception autoencoder (misc_py/modified_Xception.py), [{B},{H},{W},1] fp32 per GPU",
-                      "precision": a.precision, "algorithmic_tflop_per_step": round(9.01 * scale, 3)},
-           "tflops_algorithmic": round(9.01 * scale / (ms / 1e3), 1)}
-    if want_cpu:
+                      "precision": a.precision, "algorithmic_tflop_per_step": round(9.01 * scale, 3), "sharding": shard_note(a, world, B, total)},
+           "tflops_algorithmic": round(9.01 * scale / (ms / 1e3), 1),
+           "roofline": {"bound": "mfma", "kernel": "decoder family: dense 3x3 convs + transposed convs (gemm_split_conv / gemm_conv), 60 % of X's flops",
+                        "achieved": round(dec_fl / (max(dec_ms, 1e-9) * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(dec_fl / (max(dec_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "issued_frac": round(3.0 * dec_fl / (max(dec_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "algorithmic_flops_per_step": dec_fl, "kernel_ms_per_step": round(dec_ms, 3),
+                        "how": "HIP events around every launch of the family in one extra step; flops from the launch arguments"},
+           "kernel_family_ms": fam.table()}
+    if want_cpu and B:
         from oracle import xception_graph as XG
 
         torch.set_num_threads(CPU_THREADS)
+        # X normalises with the statistics of the batch it is given, so parity is defined per batch: the GPU runs the SAME
+        # sub-batch the CPU leg runs (2 images: ~25 s of CPU work), and that pair is what rel_l2_vs_oracle compares
+        n = min(B, 2)
         t0 = time.perf_counter()
-        XG.architecture(x_host[:1], weights, H, dtype=torch.float32)
-        t1 = time.perf_counter() - t0
-        n = int(max(1, min(B, round(12.0 / max(t1, 1e-3)))))
-        t0 = time.perf_counter()
-        XG.architecture(x_host[:n], weights, H, dtype=torch.float32)
+        ref = XG.architecture(x_host[:n], weights, H, dtype=torch.float32).numpy()
         el = time.perf_counter() - t0
+        got = eng.forward(x[:n].contiguous()).cpu().numpy()
         out["cpu_baseline"] = {"value": round(n * H * W / 1e6 / el, 4), "unit": "MPx/s", "cores": CPU_THREADS, "kind": "port",
                                "sample": f"1 pass over the first {n} images ([{n},{H},{W},1]), oracle/xception_graph.py "
                                          f"(PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}
+        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(got, ref)
+        out["parity_note"] = f"GPU and oracle both on the sub-batch [{n},{H},{W},1] (batch-statistics norms: the output depends on the batch)"
     return out
 
 
-def bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
-    """BASELINE configs[4], the part that is built: the in-filling GAN's GENERATOR forward pass
-    (misc_py/gan-infilling-100.py:133-374) on 1/64-sampled 512x512 images (the discriminator and the adversarial
-    training step are not built yet)."""
-    from emdenoise import gan as GN
+def bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
+    """BASELINE configs[4], forward part: the in-filling GAN's GENERATOR (misc_py/gan-infilling-100.py:133-374) on
+    1/64-sampled 512x512 images."""
+    from emdenoise import gan as GN, ops
 
-    B, S = a.batch, a.size
-    steps, warmup = 5, 1
-    x_host = GN.gen_lq(2.0 * synthetic_lq(B, S, S, seed=77 + rank)[..., 0] - 1.0)[..., None]
+    (B, first, total), S = local_batch(a, rank, world), a.size
+    steps = a.steps if (primary and a.steps is not None) else 5
+    warmup = a.warmup if (primary and a.warmup is not None) else 1
+    x_host = GN.gen_lq(2.0 * synthetic_lq(max(B, 1), S, S, seed=77 + first)[..., 0] - 1.0)[..., None]
     weights = GN.synthetic_weights()
     eng = GN.GeneratorEngine(weights, dev, a.precision)
-    x = torch.from_numpy(x_host).to(dev)
+    x = torch.from_numpy(x_host[:B]).to(dev)
     box = [None]
 
     def step():
-        box[0] = eng.forward(x)
+        if B:
+            box[0] = eng.forward(x)
 
     ms = timer.run(step, steps, warmup)
+    two = getattr(eng, "two_streams", None)
+    if two is not None:
+        eng.two_streams = False
+    try:
+        with FamilyTimer(torch, ops) as fam:
+            step()
+    finally:
+        if two is not None:
+            eng.two_streams = two
     tflop = GN.algorithmic_flops(S) * B / 1e12
-    out = {"value": round(B * S * S / 1e6 * world / (ms / 1e3), 1), "unit": "MPx/s in-filled", "ms_per_step": round(ms, 3),
-           "steps": steps, "warmup": warmup,
+    mm, mf = fam.matrix_ms(), fam.matrix_flops()
+    out = {"value": round(total * S * S / 1e6 / (ms / 1e3), 1), "unit": "MPx/s in-filled", "ms_per_step": round(ms, 3),
+           "median_hipevent_ms": timer.median_event_ms, "steps": steps, "warmup": warmup,
+           "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)",
            "config": {"workload": f"G: in-filling generator forward (misc_py/gan-infilling-100.py), [{B},{S},{S},1] fp32 per GPU, "
                                   "1/64 of the pixels given", "precision": a.precision,
-                      "algorithmic_tflop_per_step": round(tflop, 3)},
-           "tflops_algorithmic": round(tflop / (ms / 1e3), 1)}
-    if want_cpu:
+                      "algorithmic_tflop_per_step": round(tflop, 3), "sharding": shard_note(a, world, B, total)},
+           "tflops_algorithmic": round(tflop / (ms / 1e3), 1),
+           "roofline": {"bound": "mfma", "kernel": "matrix-core family (sep_fused + gemm_split + gemm_conv launches of one step)",
+                        "achieved": round(mf / (max(mm, 1e-9) * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(mf / (max(mm, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "algorithmic_flops_per_step": mf, "kernel_ms_per_step": round(mm, 3),
+                        "note": "<= 128 channels at 256-512 px: the graph is HBM-bound, the matrix-core fraction is low by construction"},
+           "kernel_family_ms": fam.table()}
+    if want_cpu and B:
         from oracle import gan_graph as GG
 
         torch.set_num_threads(CPU_THREADS)
@@ -462,59 +745,66 @@ def bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
         got = box[0][:1].cpu().numpy()
         out["cpu_baseline"] = {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s in-filled", "cores": CPU_THREADS, "kind": "port",
                                "sample": f"1 image ([1,{S},{S},1]), oracle/gan_graph.py (PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}
-        out["rel_l2_vs_oracle"] = float(f"{np.linalg.norm(got - ref) / np.linalg.norm(ref):.3e}")
+        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(got, ref)
     return out
 
 
-def bench_S(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
+def bench_S(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     """the small separable autoencoder of misc_py/apply_autoencoders.py (:91-187), the reference's
     own size: 160x160 crops, encoding_features 16, a batch of `--batch` crops per GPU with per-image batch statistics."""
-    from emdenoise import autoencoder as AE
+    import numpy as np
 
-    B, S = a.batch, 160
-    steps, warmup = 10, 2
-    x_host = synthetic_lq(B, S, S, seed=160 + rank)
+    from emdenoise import autoencoder as AE, graphed
+
+    (B, first, total), S = local_batch(a, rank, world), 160
+    steps = a.steps if (primary and a.steps is not None) else 10
+    warmup = a.warmup if (primary and a.warmup is not None) else 2
+    x_host = synthetic_lq(max(B, 1), S, S, seed=160 + first)
     x_host = (x_host / x_host.mean(axis=(1, 2, 3), keepdims=True)).astype(np.float32)
     weights = AE.synthetic_weights(16)
     eng = AE.AutoencoderEngine(weights, dev, 16)
-    x = torch.from_numpy(x_host).to(dev)
+    x = torch.from_numpy(x_host[:B]).to(dev)
     box = [None]
-
     # 45 launches of a few microseconds each: captured once into a hipGraph and replayed (--no-graph: eager launches).  The big
     # graphs (D, X, G) gain nothing from a replay -- their launch queue never drains -- and stay eager.
-    fwd = eng.forward if a.no_graph else GraphedForward(eng)
+    fwd = eng.forward if a.no_graph else graphed.GraphedForward(eng)
 
     def step():
-        box[0] = fwd(x)
+        if B:
+            box[0] = fwd(x)
 
     ms = timer.run(step, steps, warmup)
-    out = {"value": round(B * S * S / 1e6 * world / (ms / 1e3), 1), "unit": "MPx/s", "ms_per_step": round(ms, 3),
-           "steps": steps, "warmup": warmup,
+    out = {"value": round(total * S * S / 1e6 / (ms / 1e3), 1), "unit": "MPx/s", "ms_per_step": round(ms, 3), "median_hipevent_ms": timer.median_event_ms,
+           "steps": steps, "warmup": warmup, "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)",
            "config": {"workload": f"S: separable autoencoder (misc_py/apply_autoencoders.py), [{B},{S},{S},1] fp32 per GPU, "
-                                  "encoding_features 16, per-image batch-statistics norms", "precision": "bf16x3", "hip_graph": not a.no_graph}}
-    if want_cpu:
+                                  "encoding_features 16, per-image batch-statistics norms", "precision": "bf16x3", "hip_graph": not a.no_graph},
+           "roofline": {"bound": "hbm", "kernel": "whole forward (45 short launches at 160 px: launch / latency bound)",
+                        "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}}
+    if want_cpu and B:
         from oracle import autoencoder_graph as AG
 
         torch.set_num_threads(CPU_THREADS)
         t0 = time.perf_counter()
-        ref = AG.architecture(x_host, weights, 16, dtype=torch.float32).numpy()
+        ref = AG.architecture(x_host[:B], weights, 16, dtype=torch.float32).numpy()
         el = time.perf_counter() - t0
         got = box[0].cpu().numpy()
         out["cpu_baseline"] = {"value": round(B * S * S / 1e6 / el, 4), "unit": "MPx/s", "cores": CPU_THREADS, "kind": "port",
                                "sample": f"the same [{B},{S},{S},1] batch, oracle/autoencoder_graph.py (PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}
-        out["rel_l2_vs_oracle"] = float(f"{np.linalg.norm(got - ref) / np.linalg.norm(ref):.3e}")
+        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(got, ref)
     return out
 
 
-def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
+def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     """BASELINE configs[4]: one iteration of the in-filling GAN's training loop (misc_py/gan-infilling-100.py:1650-1790)
     on `--gan-batch` 512x512 images per GPU: generator towers through the discriminator (feature matching), generator
     Adam step, then the discriminator trained on the generated and the natural images (2T towers) and its Adam step."""
+    import numpy as np
+
     from emdenoise import gan as GN, gan_trainer as GT
 
     T, S = a.gan_batch, a.size
-    steps = a.steps if (a.steps is not None and a.workload == "A") else 3
-    warmup = a.warmup if (a.warmup is not None and a.workload == "A") else 1
+    steps = a.steps if (primary and a.steps is not None) else 3
+    warmup = a.warmup if (primary and a.warmup is not None) else 1
     hq = (2.0 * synthetic_lq(T, S, S, seed=177 + rank) - 1.0).astype(np.float32)
     lq = GN.gen_lq(hq[..., 0])[..., None]
     D = GT.DiscriminatorTrainer(GN.discriminator_synthetic_weights(), dev, a.precision)
@@ -525,7 +815,6 @@ def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
                for _ in range(T)]
     x, t = torch.from_numpy(lq).to(dev), torch.from_numpy(hq).to(dev)
     box = [None]
-
     loop = GT.GanLoop(G, D, streams=a.train_streams) if (world == 1 and not a.no_graph) else None
 
     def step():
@@ -536,6 +825,7 @@ def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     ms = timer.run(step, steps, warmup)
     rg, rd = box[0]
     out = {"value": round(T * S * S / 1e6 * world / (ms / 1e3), 2), "unit": "MPx/s trained (GAN)", "ms_per_step": round(ms, 3),
+           "median_hipevent_ms": timer.median_event_ms,
            "steps": steps, "warmup": warmup, "dtype": "bf16x3 GEMMs (split-bf16 MFMA inputs, fp32 accumulate), fp32 elsewhere",
            "config": {"workload": f"A: in-filling GAN training iteration (misc_py/gan-infilling-100.py), [{T},{S},{S},1] fp32 per GPU: "
                                   f"{T} generator towers + Adam, {2 * T} discriminator towers + Adam",
@@ -558,16 +848,18 @@ def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu):
     return out
 
 
-def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
+def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     """BASELINE configs[3]: graph D' TRAINING (misc_py/denoiser-multi-gpu.py): data-parallel steps of `--train-batch`
     512x512 LQ/HQ pairs per GPU (bs=64 over 8 GPUs => 8 per GPU), towers of `--tower-batch` images (1 = the
     reference, :763), gradients averaged over all towers and ranks (one RCCL all-reduce of the flat gradient vector),
     Nesterov momentum step, weights re-packed on the device."""
+    import numpy as np
+
     from emdenoise import denoiser as D, trainer as TR
 
     B, S, tb = a.train_batch, a.size, a.tower_batch
-    steps = a.steps if (a.steps is not None and a.workload == "T") else 3
-    warmup = a.warmup if (a.warmup is not None and a.workload == "T") else 1
+    steps = a.steps if (primary and a.steps is not None) else 3
+    warmup = a.warmup if (primary and a.warmup is not None) else 1
     rng = np.random.default_rng(4321 + rank)
     hq = synthetic_lq(B, S, S, seed=99 + rank)          # smooth synthetic micrographs as the clean images
     lq = np.clip(hq + rng.normal(0.0, 0.1, hq.shape).astype(np.float32), 0.0, 1.0)
@@ -582,6 +874,7 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
     ms = timer.run(step, steps, warmup)
     tflop = 3 * 5.38 / 32.0 * B * (S * S) / (512.0 * 512.0)   # forward + data gradient + weight gradient
     out = {"value": round(B * S * S / 1e6 * world / (ms / 1e3), 2), "unit": "MPx/s trained", "ms_per_step": round(ms, 3),
+           "median_hipevent_ms": timer.median_event_ms,
            "steps": steps, "warmup": warmup, "dtype": "bf16x3 GEMMs (split-bf16 MFMA inputs, fp32 accumulate), fp32 elsewhere",
            "config": {"workload": f"T: graph D' training step (misc_py/denoiser-multi-gpu.py), [{B},{S},{S},1] fp32 LQ/HQ pairs per GPU, "
                                   f"towers of {tb}, Nesterov momentum 0.9, lr 1e-3",
@@ -590,7 +883,11 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
                       "algorithmic_tflop_per_step_per_gpu": round(tflop, 3)},
            "tflops_algorithmic": round(tflop / (ms / 1e3), 1),
            "loss_first_tower": float(box[0][0, 1].item())}
-    if world > 1:  # the step's only exchange, timed on its own (SURVEY.md 8d cfg 4): all-reduce of the flat gradient
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        # the step's only exchange, timed on its own (SURVEY.md 8d cfg 4): all-reduce of the flat gradient + broadcast of
+        # the moving statistics (with one rank the process group exists but there is nothing to exchange: RCCL init only)
         from emdenoise.trainer import sync_gradients
 
         for _ in range(2):
@@ -604,10 +901,10 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
         torch.cuda.synchronize()
         ar_ms = e0.elapsed_time(e1) / 5
         nbytes = tr.grads.numel() * 4
-        out["allreduce"] = {"ms": round(ar_ms, 3), "bytes": nbytes,
-                            "bus_GBps": round(2.0 * (world - 1) / world * nbytes / (ar_ms / 1e3) / 1e9, 1),
-                            "note": "RCCL all-reduce (sum) of the fp32 gradient vector + broadcast of the moving statistics"}
-    out["roofline"] = {"bound": "mfma", "kernel": "whole step (gemm_conv + conv_wgrad dominate)", "achieved": out["tflops_algorithmic"],
+        out["allreduce"] = {"ms": round(ar_ms, 3), "bytes": nbytes, "ranks": world,
+                            "bus_GBps": round(2.0 * (world - 1) / world * nbytes / (max(ar_ms, 1e-9) / 1e3) / 1e9, 1),
+                            "note": "RCCL all-reduce (sum) of the fp32 gradient vector + broadcast of the moving statistics, HIP events over 5 rounds"}
+    out["roofline"] = {"bound": "mfma", "kernel": "whole step (forward + data-gradient + weight-gradient GEMMs dominate)", "achieved": out["tflops_algorithmic"],
                        "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(out["tflops_algorithmic"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
     if want_cpu:
@@ -615,142 +912,108 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist):
 
         torch.set_num_threads(CPU_THREADS)
         t0 = time.perf_counter()
-        G.tower_gradients(lq[:1], hq[:1], weights, S, dtype=torch.float64)
+        G.tower_gradients(lq[:1], hq[:1], weights, S, dtype=torch.float32)
         el = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s trained", "cores": CPU_THREADS, "kind": "port",
                                "sample": f"forward + backward of ONE tower of 1 image ([1,{S},{S},1]), oracle/denoiser_graph.py "
-                                         f"tower_gradients (PyTorch-CPU autograd, float64, {CPU_THREADS} threads), {el:.1f} s; "
+                                         f"tower_gradients (PyTorch-CPU autograd, float32, {CPU_THREADS} threads), {el:.1f} s; "
                                          "optimizer step not included"}
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["K", "D", "X", "T", "G", "A", "S", "both", "all"], default="all",
-                    help="K and D: see the module docstring; X: misc_py/modified_Xception.py; all (default) = K primary, D and X alongside")
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
-    ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--train-batch", type=int, default=8, help="workload T: LQ/HQ pairs per GPU per step (bs=64 over 8 GPUs)")
-    ap.add_argument("--tower-batch", type=int, default=1, help="workload T: images per tower (batch-norm statistics are per tower)")
-    ap.add_argument("--gan-batch", type=int, default=4, help="workload A: images per GPU per GAN iteration")
-    ap.add_argument("--train-streams", type=int, default=8, help="workload T: HIP streams the towers are issued on")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying captured hipGraphs (training steps T / A, forward pass of S)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3",
-                    help="workload D matrix-core mode: bf16x3 = split-bf16 parity mode (default), bf16 = fast mode")
-    a = ap.parse_args()
+BENCHES = {"K": bench_K, "D": bench_D, "X": bench_X, "T": bench_T, "G": bench_G, "A": bench_A, "S": bench_S}
+METRIC = {"T": "megapixels/sec trained (512x512x1 LQ/HQ pairs)", "G": "megapixels/sec in-filled (512x512x1 bs=32)",
+          "S": "megapixels/sec restored (160x160x1 crops, bs=32)", "A": "megapixels/sec trained (in-filling GAN, 512x512x1)"}
+
+
+# ================================================================================================
+def dry_run(a, rank, world):
+    """The launch / rendezvous / sharding / timing / reporting path with a host stand-in for the step: no GPU, no kernels.
+    Exercised by tests/test_bench_launch.py with two ranks over gloo."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if "WORLD_SIZE" in os.environ:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    d = dist if dist.is_initialized() else None
+    timer = Timer(torch, d, torch.device("cpu"))
+    Bl, first, total = local_batch(a, rank, world)
+    S = min(a.size, 64)
+    x = synthetic_lq(max(Bl, 1), S, S, seed=1234 + first)[:Bl]
+    acc = [0.0]
+
+    def step():
+        acc[0] += float(np.square(x).sum())   # stand-in for one pass over this rank's shard
+
+    steps, warmup = a.steps or 3, a.warmup if a.warmup is not None else 1
+    ms = timer.run(step, steps, warmup)
+    shards = [None] * world
+    if d is not None:
+        dist.all_gather_object(shards, (first, first + Bl))
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        shards = [(first, first + Bl)]
+    if rank == 0:
+        print(json.dumps({"metric": "megapixels/sec restored (512x512x1 bs=32)", "value": round(total * S * S / 1e6 / (ms / 1e3), 3), "unit": "MPx/s",
+                          "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 5), "higher_is_better": True,
+                          "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": f"dry run: host stand-in for the step on [{Bl},{S},{S},1] per rank", "global_batch": total,
+                                     "shards": shards, "sharding": shard_note(a, world, Bl, total)},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    return 0
+
+
+def worker(a):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.dry_run:
+        return dry_run(a, rank, world)
 
     import torch
 
     import emdenoise
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and a.gpus != world:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:   # under a launcher, also with one rank: the RCCL process group is part of what is exercised
         import torch.distributed as dist_mod
 
-        dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        dist = dist_mod
     timer = Timer(torch, dist, dev)
-    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
-
-    primary_is_D = a.workload == "D"
-    res_K = res_D = None
-    res_X = None
-    # multi-GPU runs of the default line keep the riders to D and the training step T (the one workload with a
-    # collective): every extra rider is one more place where a rank-local failure would leave the others in a barrier
     multi = world > 1
-    if a.workload in ("K", "both", "all"):
-        res_K = bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
-    if a.workload == "X" or (a.workload == "all" and not multi):
-        try:
-            res_X = bench_X(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
-        except Exception as e:
-            res_X = {"error": f"{type(e).__name__}: {e}"}
-    if a.workload in ("D", "both", "all"):
-        try:
-            res_D = bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
-        except Exception as e:  # the primary (K) line must survive a failure of the rider
-            if primary_is_D:
-                raise
-            res_D = {"error": f"{type(e).__name__}: {e}"}
+    want_cpu = rank == 0 and not multi and not a.no_cpu_baseline
 
-    res_T = None
-    if a.workload in ("T", "all"):
-        try:
-            res_T = bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, dist)
-        except Exception as e:
-            if a.workload == "T":
-                raise
-            res_T = {"error": f"{type(e).__name__}: {e}"}
+    if a.workload in ("all", "both"):
+        primary = "D"
+        riders = [] if a.no_riders else (["K"] if a.workload == "both" else (["T"] if multi else ["K", "X", "T", "G", "S", "A"]))
+    else:
+        primary, riders = a.workload, []
 
-    res_G = None
-    if a.workload == "G" or (a.workload == "all" and not multi):
+    res = {primary: BENCHES[primary](a, torch, emdenoise, dev, timer, rank, world, want_cpu, True)}
+    failed = []
+    for w in riders:
         try:
-            res_G = bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
+            res[w] = BENCHES[w](a, torch, emdenoise, dev, timer, rank, world, want_cpu and w != "A", False)
         except Exception as e:
-            if a.workload == "G":
+            if multi:   # the other ranks sit in this workload's collectives: fail the job, the launcher tears every rank down
                 raise
-            res_G = {"error": f"{type(e).__name__}: {e}"}
+            import traceback
 
-    res_S = None
-    if a.workload == "S" or (a.workload == "all" and not multi):
-        try:
-            res_S = bench_S(a, torch, emdenoise, dev, timer, rank, world, want_cpu)
-        except Exception as e:
-            if a.workload == "S":
-                raise
-            res_S = {"error": f"{type(e).__name__}: {e}"}
+            traceback.print_exc()
+            res[w] = {"error": f"{type(e).__name__}: {e}"}
+            failed.append(w)
 
-    res_A = None
-    if a.workload == "A" or (a.workload == "all" and not multi):
-        try:
-            res_A = bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu and a.workload == "A")
-        except Exception as e:
-            if a.workload == "A":
-                raise
-            res_A = {"error": f"{type(e).__name__}: {e}"}
-
-    prim = res_D if primary_is_D else res_K
-    if prim is None and a.workload == "A":
-        prim, res_A = res_A, None
-    if prim is None and a.workload == "G":
-        prim, res_G = dict(res_G), None
-        prim["dtype"] = "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)"
-        prim["roofline"] = {"bound": "mfma", "kernel": "gemm_conv_kernel", "achieved": prim["tflops_algorithmic"],
-                            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(prim["tflops_algorithmic"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
-    if prim is None and a.workload == "S":
-        prim, res_S = dict(res_S), None
-        prim["dtype"] = "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)"
-        prim["roofline"] = {"bound": "hbm", "kernel": "whole forward (launch-bound at 160 px: per-image statistics launches)",
-                            "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
-    if prim is None and a.workload == "T":
-        prim, res_T = res_T, None
-    if prim is None:  # --workload X alone
-        prim = dict(res_X)
-        prim.setdefault("dtype", "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)")
-        prim.setdefault("roofline", {"bound": "mfma", "kernel": "gemm_conv_kernel", "achieved": prim.get("tflops_algorithmic"),
-                                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                     "frac": round((prim.get("tflops_algorithmic") or 0.0) / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None})
-        res_X = None
+    prim = res[primary]
     out = {
-        "metric": {"T": "megapixels/sec trained (512x512x1 LQ/HQ pairs)", "G": "megapixels/sec in-filled (512x512x1 bs=32)", "S": "megapixels/sec restored (160x160x1 crops, bs=32)",
-                   "A": "megapixels/sec trained (in-filling GAN, 512x512x1)"}.get(
-            a.workload, "megapixels/sec restored (512x512x1 bs=32)"),
+        "metric": METRIC.get(primary, "megapixels/sec restored (512x512x1 bs=32)"),
         "value": round(prim["value"], 1),
         "unit": prim.get("unit", "MPx/s"),
         "n_gpus": world,
@@ -758,38 +1021,42 @@ def main():
         "warmup": prim["warmup"],
         "ms_per_step": round(prim["ms_per_step"], 5),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": a.scaling if primary in ("D", "K", "X", "G", "S") else "weak",
         "vs_baseline": None,
         "dtype": prim["dtype"],
         "data": "synthetic",
         "config": prim["config"],
         "roofline": prim["roofline"],
     }
-    for k in ("cpu_baseline", "rel_l2_vs_oracle", "depthwise", "pointwise", "kernel_family_ms", "tflops_algorithmic", "loss_first_tower", "d_fake_first", "d_out_first"):
+    for k in ("median_hipevent_ms", "cpu_baseline", "rel_l2_vs_oracle", "psnr_vs_oracle_db", "parity_note", "matrix_cores", "depthwise", "pointwise",
+              "kernel_family_ms", "from_pinned_host", "tflops_algorithmic", "loss_first_tower", "allreduce", "d_fake_first", "d_out_first"):
         if k in prim:
             out[k] = prim[k]
-    if not primary_is_D and res_D is not None:
-        if "value" in res_D:
-            res_D["value"] = round(res_D["value"], 1)
-            res_D["ms_per_step"] = round(res_D["ms_per_step"], 4)
-            res_D["unit"] = "MPx/s"
-        out["workload_D"] = res_D
-    if res_X is not None:
-        out["workload_X"] = res_X
-    if res_T is not None:
-        out["workload_T"] = res_T
-    if res_G is not None:
-        out["workload_G"] = res_G
-    if res_A is not None:
-        out["workload_A"] = res_A
-    if res_S is not None:
-        out["workload_S"] = res_S
+    if rank == 0 and primary == "D" and not multi:
+        out["measured_peaks"] = measured_peaks(torch, dev)
+    for w in riders:
+        r = res[w]
+        if "value" in r:
+            r["value"] = round(r["value"], 2)
+            r["ms_per_step"] = round(r["ms_per_step"], 5)
+        out["workload_" + w] = r
+    if failed:
+        out["failed_riders"] = failed
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    return 1 if failed else 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a, argv)
+    return worker(a)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -24,6 +24,15 @@ void emd_debug_split_stamps(void* device_buf);
 /* Device buffer that the fused separable conv writes s_memtime phase stamps into (NULL = off). */
 void emd_debug_sep_stamps(void* device_buf);
 
+
+/* On-box peak micro-benchmarks (csrc/dev_bench.hip), timed by bench.py with HIP events (SURVEY.md 8d asks for the measured
+ * peaks next to the nominal ones).  emd_stream_t is hipStream_t; return codes as in emdenoise.h. */
+/* dst[i] = src[i], n floats (multiple of 4), 16-byte aligned: the read + write stream-copy roof. */
+int emd_debug_stream_copy_f32(const float* src, float* dst, long n, void* stream);
+/* `workgroups` x 4 waves each issue iters x 32 back-to-back v_mfma_f32_32x32x16_bf16 (32768 flop each) on the 4 KiB of
+ * bf16 operands at `ops`; `out` (workgroups x 256 floats) exists to keep the chain alive. */
+int emd_debug_mfma_peak_bf16(const void* ops, float* out, int workgroups, int iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
