@@ -51,20 +51,32 @@ struct SepParams {
     const float* gen_a;
     const float* gen_t;
     int gen_act;
+    // second output of the DUAL instances (emd_sep3x3_dual_f32): y2 = relu6(x * W2 * scale_b + shift_b), a 1x1 conv of the block's
+    // INPUT -- the decoder's residual projection (denoiser.py:359/:371/:383), which reads the same tensor as the separable conv
+    const uint16_t* W2hi;
+    const uint16_t* W2lo;
+    float* y2;
+    const float* scale_b;
+    const float* shift_b;
+    int N2, ldy2;
     long long* stamps;    // dev hook: per-workgroup phase cycle sums (NULL otherwise)
 };
 
-template <int BN, int PASSES, bool GEN>
+// BN = columns of the workgroup's GEMM tile: 64 / 128 (one output), or with DUAL the two outputs side by side: 128 = 64 | 64 on an
+// 8 x 16 pixel tile, 256 = 128 | 128 on a 4 x 16 pixel tile (TH = 4: the accumulators of both outputs fit the same registers).
+template <int BN, int PASSES, bool GEN, int TH = 8, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
-    constexpr int TH = 8, TW = 16, BM = TH * TW, BK = 32;
-    constexpr int PH = TH + 2, PW = TW + 2, NPX = PH * PW;  // 10 x 18 = 180 patch pixels
+    constexpr int TW = 16, BM = TH * TW, BK = 32;
+    constexpr int PH = TH + 2, PW = TW + 2, NPX = PH * PW;  // 10 x 18 = 180 patch pixels (6 x 18 = 108 for TH = 4)
     constexpr int PLD = 40;                                 // floats per patch pixel (32 + 8 pad)
     constexpr int LDK = BK + 8;                             // bf16 per A/B row (80 B)
-    constexpr int WM = BN == 128 ? 2 : 4, WN = 4 / WM;
+    constexpr int WN = BN / 64, WM = 4 / WN;                // every wave owns 64 columns: 4 x 1, 2 x 2 or 1 x 4 waves
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NPL = PASSES == 3 ? 2 : 1;
-    constexpr int P_PASSES = (NPX * 8 + 255) / 256;          // 1440 float4 -> 6 passes
+    constexpr int P_PASSES = (NPX * 8 + 255) / 256;          // 1440 float4 -> 6 passes (864 -> 4)
     constexpr int W_PASSES = BN / 64;                        // BN rows x 4 chunks of 16 B
+    constexpr int NPT = BM / 32;                             // pixels per thread along W in the depthwise role (4 or 2)
+    static_assert(TM >= 1 && TN == 2 && (!DUAL || (!GEN && PASSES == 3 && WN >= 2)), "tile shape");
     constexpr int LDS_STAGE = BN + 4;
     constexpr int PATCH_BYTES = NPX * PLD * 4, A_BYTES = NPL * BM * LDK * 2, B_BYTES = NPL * BN * LDK * 2;
     constexpr int STAGE_BYTES = BM * LDS_STAGE * 4;
@@ -118,13 +130,18 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     const int w_col = (tid & 3) * 8, w_row = tid >> 2;  // + 64 rows per pass
     const uint16_t* __restrict__ whi = p.Whi + (long)w_row * p.Cpad + w_col;
     const uint16_t* __restrict__ wlo = NPL == 2 ? p.Wlo + (long)w_row * p.Cpad + w_col : nullptr;
-    // ---- depthwise role: 4 consecutive pixels of tile row ty, 4 channels
+    // DUAL: the second half of the B tile's rows are the 1x1 projection's weights
+    const uint16_t* __restrict__ w2hi = DUAL ? p.W2hi + (long)w_row * p.Cpad + w_col : nullptr;
+    const uint16_t* __restrict__ w2lo = DUAL ? p.W2lo + (long)w_row * p.Cpad + w_col : nullptr;
+    // ---- depthwise role: NPT consecutive pixels of tile row ty, 4 channels
     const int c4 = tid & 7, pg = tid >> 3;
-    const int ty = pg >> 2, tx0 = (pg & 3) * 4;
+    const int ty = pg / (TW / NPT), tx0 = (pg % (TW / NPT)) * NPT;
 
     f32x4 preg[P_PASSES];
     f32x4 gga = {0.f, 0.f, 0.f, 0.f}, ggt = gga;   // generated input: the chunk's a / t vectors
-    u32x4 wh0 = {0, 0, 0, 0}, wh1 = wh0, wl0 = wh0, wl1 = wh0;
+    u32x4 wh[W_PASSES], wl[W_PASSES];
+#pragma unroll
+    for (int q = 0; q < W_PASSES; ++q) wh[q] = wl[q] = u32x4{0, 0, 0, 0};
     f32x4 wkreg = {0.f, 0.f, 0.f, 0.f};
 
     f32x16 acc[TM][TN];
@@ -165,11 +182,10 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                 if (idx < NPX * 8) *reinterpret_cast<f32x4*>(patch + (idx >> 3) * PLD + (idx & 7) * 4) = preg[q];
             }
             if (tid < 72) *reinterpret_cast<f32x4*>(wks + tid * 4) = wkreg;
-            *reinterpret_cast<u32x4*>(&Bs[0][w_row][w_col]) = wh0;
-            if (NPL == 2) *reinterpret_cast<u32x4*>(&Bs[NPL - 1][w_row][w_col]) = wl0;
-            if (W_PASSES == 2) {
-                *reinterpret_cast<u32x4*>(&Bs[0][w_row + 64][w_col]) = wh1;
-                if (NPL == 2) *reinterpret_cast<u32x4*>(&Bs[NPL - 1][w_row + 64][w_col]) = wl1;
+#pragma unroll
+            for (int q = 0; q < W_PASSES; ++q) {
+                *reinterpret_cast<u32x4*>(&Bs[0][w_row + 64 * q][w_col]) = wh[q];
+                if (NPL == 2) *reinterpret_cast<u32x4*>(&Bs[NPL - 1][w_row + 64 * q][w_col]) = wl[q];
             }
             __syncthreads();  // (1) patch + W tile of chunk `it` visible
         }
@@ -203,11 +219,16 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
         }
         // the chunk's 9 x 32 depthwise weights travel through LDS too: one 16-byte load for 72 threads instead of nine for every thread
         if (tid < 72) wkreg = *reinterpret_cast<const f32x4*>(p.dw + ((long)(tid >> 3) * p.Cin + c0n) + (tid & 7) * 4);
-        wh0 = *reinterpret_cast<const u32x4*>(whi + c0n);
-        if (NPL == 2) wl0 = *reinterpret_cast<const u32x4*>(wlo + c0n);
-        if (W_PASSES == 2) {
-            wh1 = *reinterpret_cast<const u32x4*>(whi + 64L * p.Cpad + c0n);
-            if (NPL == 2) wl1 = *reinterpret_cast<const u32x4*>(wlo + 64L * p.Cpad + c0n);
+#pragma unroll
+        for (int q = 0; q < W_PASSES; ++q) {
+            constexpr int HALF = W_PASSES / 2;
+            if (DUAL && q >= HALF) {
+                wh[q] = *reinterpret_cast<const u32x4*>(w2hi + (long)(q - HALF) * 64 * p.Cpad + c0n);
+                wl[q] = *reinterpret_cast<const u32x4*>(w2lo + (long)(q - HALF) * 64 * p.Cpad + c0n);
+            } else {
+                wh[q] = *reinterpret_cast<const u32x4*>(whi + (long)q * 64 * p.Cpad + c0n);
+                if (NPL == 2) wl[q] = *reinterpret_cast<const u32x4*>(wlo + (long)q * 64 * p.Cpad + c0n);
+            }
         }
         SEP_STAMP(1)
         if (it >= 0) {
@@ -215,22 +236,22 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             f32x4 wk[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const f32x4*>(wks + k * BK + c4 * 4);
-            f32x4 o[4];
+            f32x4 o[NPT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NPT; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                f32x4 pr[6];
+                f32x4 pr[NPT + 2];
 #pragma unroll
-                for (int d = 0; d < 6; ++d)
+                for (int d = 0; d < NPT + 2; ++d)
                     pr[d] = *reinterpret_cast<const f32x4*>(patch + ((ty + i) * PW + tx0 + d) * PLD + c4 * 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NPT; ++j)
 #pragma unroll
                     for (int d = 0; d < 3; ++d) o[j] += wk[i * 3 + d] * pr[j + d];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NPT; ++j) {
                 const int r = ty * TW + tx0 + j;
                 unsigned h0, l0, h1, l1;
                 split2(o[j][0], o[j][1], h0, l0);
@@ -246,11 +267,29 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+            if (DUAL && wn >= WN / 2) {
+                // the 1x1 projection's A operand = the block's INPUT at the tile's own pixels: the centre of the fp32 patch, split
+                // into bf16 hi / lo here (8 channels per lane) instead of going through a second pair of A planes
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r = wm * (BM / WM) + i * 32 + fr;
-                ah[i] = *reinterpret_cast<const bf16x8*>(&As[0][r][ks * 16 + fh * 8]);
-                if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(&As[NPL - 1][r][ks * 16 + fh * 8]);
+                for (int i = 0; i < TM; ++i) {
+                    const int r = wm * (BM / WM) + i * 32 + fr;
+                    const float* src = patch + (((r >> 4) + 1) * PW + (r & 15) + 1) * PLD + ks * 16 + fh * 8;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                    split2(v0[0], v0[1], h0, l0);
+                    split2(v0[2], v0[3], h1, l1);
+                    split2(v1[0], v1[1], h2, l2);
+                    split2(v1[2], v1[3], h3, l3);
+                    ah[i] = __builtin_bit_cast(bf16x8, (u32x4{h0, h1, h2, h3}));
+                    al[i] = __builtin_bit_cast(bf16x8, (u32x4{l0, l1, l2, l3}));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = wm * (BM / WM) + i * 32 + fr;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&As[0][r][ks * 16 + fh * 8]);
+                    if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(&As[NPL - 1][r][ks * 16 + fh * 8]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -287,22 +326,25 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
         __syncthreads();
         constexpr int C4 = BN / 4;
         constexpr int ROWS_PER_PASS = 256 / C4;
-        const int n = (tid % C4) * 4, er = tid / C4;
-        if (n < p.N) {
-            const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
-            const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
+        const int ncol = (tid % C4) * 4, er = tid / C4;      // column of the staging tile
+        const bool out2 = DUAL && ncol >= BN / 2;             // DUAL: the right half of the tile is the 1x1 projection
+        const int n = out2 ? ncol - BN / 2 : ncol;            // channel of the output it belongs to
+        if (n < (out2 ? p.N2 : p.N)) {
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>((out2 ? p.scale_b : p.scale1) + n);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>((out2 ? p.shift_b : p.shift1) + n);
             f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
-            if (p.scale2) {
+            if (p.scale2 && !out2) {
                 s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
                 t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
             }
-            float* __restrict__ outp = p.y;
+            float* __restrict__ outp = out2 ? p.y2 : p.y;
+            const int ldo = out2 ? p.ldy2 : p.ldy;
             // one clamp form for every activation code: v = min(max(max(v, lo), slope*v), hi) -- (lo, slope, hi) = none: (-inf, 1, inf); relu6: (0, 1, 6);
             // relu: (0, 1, inf); leaky relu (graph G): (-inf, 0.2, inf); a clamped negative comes out as +0, as tf.nn.relu6 gives it
             const float hi = p.act == 1 ? 6.f : __builtin_inff();
             const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
             const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
-            const bool two = p.scale2 != nullptr;
+            const bool two = p.scale2 != nullptr && !out2;
             auto finish = [&](f32x4 v) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -318,10 +360,10 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             // (x0 is folded into the 32-bit part on purpose: tile-invariant offsets would be hoisted out of the tile loop and pinned
             // in registers for the whole kernel)
             const long pix0 = img + (long)y0 * p.W;
-            float* __restrict__ ytile = outp + pix0 * p.ldy + n;
+            float* __restrict__ ytile = outp + pix0 * ldo + n;
             const float* __restrict__ rtile = p.res ? p.res + pix0 * p.ldres + n : nullptr;
             auto tpix = [&](int r) { return (r >> 4) * p.W + (r & 15) + x0; };
-            if (p.res) {
+            if (p.res && !DUAL) {
                 // residual values are requested four rows at a time, before the first of them is used (the registers of the
                 // next chunk's prefetch are live here: no room for all NROWS at once)
 #pragma unroll
@@ -335,13 +377,13 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int r = er + (k0 + k) * ROWS_PER_PASS;
-                        *reinterpret_cast<f32x4*>(ytile + tpix(r) * p.ldy) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n])) + rv[k];
+                        *reinterpret_cast<f32x4*>(ytile + tpix(r) * ldo) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ncol])) + rv[k];
                     }
                 }
             } else {
 #pragma unroll 4
                 for (int r = er; r < BM; r += ROWS_PER_PASS)
-                    *reinterpret_cast<f32x4*>(ytile + tpix(r) * p.ldy) = finish(*reinterpret_cast<const f32x4*>(&stage[r][n]));
+                    *reinterpret_cast<f32x4*>(ytile + tpix(r) * ldo) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ncol]));
             }
         }
         __syncthreads();  // the staging tile is read out before the next tile's patch overwrites it
@@ -364,16 +406,21 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
 
 long long* g_sep_stamps = nullptr;   // dev hook, see emd_debug_sep_stamps
 
+// several tiles per workgroup where that still leaves >= 8 workgroups per CU
+int tiles_per_workgroup(int tiles_w, long wgs1) {
+    static const int force = [] { const char* e = getenv("EMD_SEP_TPW"); return e ? atoi(e) : 0; }();
+    int tpw = 1;
+    for (int t = 8; t >= 2; t >>= 1)
+        if (tiles_w % t == 0 && wgs1 / t >= 2048) { tpw = t; break; }
+    if (force > 0 && tiles_w % force == 0) tpw = force;
+    return tpw;
+}
+
 template <int BN>
 int launch(const SepParams& p, int B, int passes, hipStream_t st) {
     SepParams q = p;
     const int tiles_w = p.W / 16;
-    const long wgs1 = (long)tiles_w * (p.H / 8) * B;
-    static const int force = [] { const char* e = getenv("EMD_SEP_TPW"); return e ? atoi(e) : 0; }();
-    q.tpw = 1;
-    for (int t = 8; t >= 2; t >>= 1)   // several tiles per workgroup where that still leaves >= 8 workgroups per CU
-        if (tiles_w % t == 0 && wgs1 / t >= 2048) { q.tpw = t; break; }
-    if (force > 0 && tiles_w % force == 0) q.tpw = force;
+    q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / 8) * B);
     q.stamps = g_sep_stamps;
     const dim3 grid(tiles_w / q.tpw, p.H / 8, B);
     if (p.gen_a) {
@@ -386,6 +433,22 @@ int launch(const SepParams& p, int B, int passes, hipStream_t st) {
     else
         hipLaunchKernelGGL((sep_fused_kernel<BN, 1, false>), grid, dim3(256), 0, st, q);
     return emd::check_launch("sep_fused_kernel");
+}
+
+// DUAL: 64 | 64 columns on 8 x 16 pixel tiles, or 128 | 128 columns on 4 x 16 pixel tiles
+int launch_dual(const SepParams& p, int B, hipStream_t st) {
+    SepParams q = p;
+    const int tiles_w = p.W / 16;
+    const bool wide = p.N > 64 || p.N2 > 64;
+    const int th = wide ? 4 : 8;
+    q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / th) * B);
+    q.stamps = g_sep_stamps;
+    const dim3 grid(tiles_w / q.tpw, p.H / th, B);
+    if (wide)
+        hipLaunchKernelGGL((sep_fused_kernel<256, 3, false, 4, true>), grid, dim3(256), 0, st, q);
+    else
+        hipLaunchKernelGGL((sep_fused_kernel<128, 3, false, 8, true>), grid, dim3(256), 0, st, q);
+    return emd::check_launch("sep_fused_kernel<dual>");
 }
 
 }  // namespace
@@ -466,3 +529,44 @@ extern "C" int emd_sep3x3_fused_gen_f32(const float* d, int ldd, const float* ge
 
 // dev hook (not in the header): per-workgroup phase cycle sums for tools/sep_bench.py
 extern "C" void emd_debug_sep_stamps(void* buf) { g_sep_stamps = static_cast<long long*>(buf); }
+
+// The decoder pair "separable conv + 1x1 residual projection of the same input" in ONE launch (machine_learning/denoiser.py:356-359,
+// :368-371, :380-383: deconv*_a = strided_conv_block(concat) and residual*_d = conv_block_not_sep(concat, kernel_size=1)):
+//   y  = relu6(BN2(BN1(pointwise(depthwise3x3(x)))))        the fused separable conv of emd_sep3x3_fused_f32 (scale1 / shift1)
+//   y2 = relu6(BN(x * W2 + bias))                           a 1x1 conv of x itself (scale_b / shift_b: bias and BN folded)
+// Both read the 384- or 128-channel input, the largest tensors of the decoder; fused, it comes from HBM once.  The input patch of
+// a tile is staged in LDS for the depthwise stage anyway; its centre pixels are the projection's A operand.
+extern "C" int emd_sep3x3_dual_supported(int H, int W, int Cin, int Cout, int Cout2) {
+    const bool wide = Cout > 64 || Cout2 > 64;
+    return H % (wide ? 4 : 8) == 0 && W % 16 == 0 && Cin % 32 == 0 && Cin >= 32 && Cin <= 4096 && Cout % 4 == 0 && Cout2 % 4 == 0 &&
+           Cout >= 4 && Cout2 >= 4 && Cout <= 128 && Cout2 <= 128;
+}
+
+extern "C" int emd_sep3x3_dual_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                                   const float* scale1, const float* shift1, float* y, int ldy, const uint16_t* w2hi,
+                                   const uint16_t* w2lo, const float* scale_b, const float* shift_b, float* y2, int ldy2, int B, int H,
+                                   int W, int Cin, int Cout, int Cout2, int act, emd_stream_t stream) {
+    EMD_REQUIRE(x && dw && whi && wlo && scale1 && shift1 && y && w2hi && w2lo && scale_b && shift_b && y2, EMD_E_INVALID,
+                "emd_sep3x3_dual_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_sep3x3_dual_f32: bad shape");
+    EMD_REQUIRE(emd_sep3x3_dual_supported(H, W, Cin, Cout, Cout2), EMD_E_UNSUPPORTED,
+                "emd_sep3x3_dual_f32: needs H%8==0 (H%4==0 above 64 output channels), W%16==0, Cin%32==0, Cout%4==0, Cout<=128 (both outputs)");
+    EMD_REQUIRE(B <= 65535, EMD_E_UNSUPPORTED, "emd_sep3x3_dual_f32: B > 65535");
+    EMD_REQUIRE(9L * W * (ldy > ldy2 ? ldy : ldy2) < (1L << 31), EMD_E_UNSUPPORTED,
+                "emd_sep3x3_dual_f32: 9 image rows of an output must span fewer than 2^31 floats");
+    EMD_REQUIRE(ldx % 4 == 0 && ldx >= Cin && ldy % 4 == 0 && ldy >= Cout && ldy2 % 4 == 0 && ldy2 >= Cout2, EMD_E_ALIGN,
+                "emd_sep3x3_dual_f32: pixel strides must be multiples of 4 and >= the channel count");
+    EMD_REQUIRE(emd::aligned16(x) && emd::aligned16(dw) && emd::aligned16(whi) && emd::aligned16(wlo) && emd::aligned16(w2hi) &&
+                    emd::aligned16(w2lo) && emd::aligned16(y) && emd::aligned16(y2) && emd::aligned16(scale1) && emd::aligned16(shift1) &&
+                    emd::aligned16(scale_b) && emd::aligned16(shift_b),
+                EMD_E_ALIGN, "emd_sep3x3_dual_f32: pointers must be 16-byte aligned");
+    EMD_REQUIRE(y != y2, EMD_E_INVALID, "emd_sep3x3_dual_f32: the two outputs alias");
+    if (B == 0) return EMD_OK;
+    SepParams p{};
+    p.x = x; p.dw = dw; p.Whi = whi; p.Wlo = wlo; p.y = y; p.res = nullptr;
+    p.scale1 = scale1; p.shift1 = shift1; p.scale2 = nullptr; p.shift2 = nullptr;
+    p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
+    p.ldx = ldx; p.ldy = ldy; p.ldres = 0; p.act = act; p.reflect = 0;
+    p.W2hi = w2hi; p.W2lo = w2lo; p.y2 = y2; p.scale_b = scale_b; p.shift_b = shift_b; p.N2 = Cout2; p.ldy2 = ldy2;
+    return launch_dual(p, B, static_cast<hipStream_t>(stream));
+}

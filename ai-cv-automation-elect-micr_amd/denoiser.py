@@ -341,6 +341,19 @@ class DenoiserEngine:
                     res=res, precision=self.precision)
         return out
 
+    def _sep_and_projection(self, sep_key, conv_key, x):
+        """A decoder pair that reads the same tensor (denoiser.py:356-359, :368-371, :380-383): the separable conv `sep_key`
+        and the 1x1 residual projection `conv_key` -> (sep output, projection), one launch where emd_sep3x3_dual_f32 covers the
+        shape (the input is then read from HBM once), two otherwise."""
+        Ls, ps, Lc, pc = self.layers[sep_key], self.P[sep_key], self.layers[conv_key], self.P[conv_key]
+        if (self.fuse_sep and self.precision == ops.PREC_BF16X3 and os.environ.get("EMD_D_DUAL", "1") != "0" and "scale2" not in ps
+                and Ls.stride == 1 and Ls.rate == 1 and Lc.stride == 1 and ops.sep_dual_supported(x, Ls.cout, Lc.cout)):
+            out = ops.Act.empty(x.B, x.H, x.W, Ls.cout, self.device)
+            out2 = ops.Act.empty(x.B, x.H, x.W, Lc.cout, self.device)
+            return ops.sep_dual(x, ps["dw"], ps["pw"], pc["pw"], ps["scale"], ps["shift"], out, pc["scale"], pc["shift"], out2)
+        proj = self._conv1x1(conv_key, x)
+        return self._sep(sep_key, x), proj
+
     def _middle_chain(self, x, out):
         """Encoder 4 and the middle flow (:312-325) on one batch (or part of one): 9 residual blocks of 3 separable convs."""
         t = self._sep("cnn4_a", x)
@@ -486,14 +499,12 @@ class DenoiserEngine:
         deconv2 = self._sep("deconv2_b", t, res=residual2_d)
         del aspp, concat2, cnn1_strided, residual2_d, t
         self._deconv("deconv2to1", deconv2, concat1.slice(0, f2))
-        residual1_d = self._conv1x1("residual1_d", concat1)
-        t = self._sep("deconv1_a", concat1)
+        t, residual1_d = self._sep_and_projection("deconv1_a", "residual1_d", concat1)
         deconv1 = self._sep("deconv1_b", t, res=residual1_d)
         del deconv2, concat1, cnn0_strided, residual1_d, t
         deconv1to0 = self._deconv("deconv1to0", deconv1, E(S, f1))
         del deconv1
-        residual0_d = self._conv1x1("residual0_d", deconv1to0)
-        t = self._sep("deconv0_a", deconv1to0)
+        t, residual0_d = self._sep_and_projection("deconv0_a", "residual0_d", deconv1to0)
         deconv0 = self._sep("deconv0_b", t, res=residual0_d)
         del deconv1to0, residual0_d, t
         out = torch.empty((B, S, S, 1), dtype=torch.float32, device=dev)

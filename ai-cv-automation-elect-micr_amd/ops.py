@@ -147,6 +147,24 @@ def sep_fused(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, act=Tr
     return out
 
 
+def sep_dual_supported(x: Act, cout: int, cout2: int) -> bool:
+    return bool(_lib.load().emd_sep3x3_dual_supported(x.H, x.W, x.C, cout, cout2))
+
+
+def sep_dual(x: Act, dw_dev, w: PackedWeights, w2: PackedWeights, scale1, shift1, out: Act, scale_b, shift_b, out2: Act, act=True,
+             stream=None):
+    """One launch for a decoder pair (emd_sep3x3_dual_f32): out = act(pw(dw3x3(x)) * scale1 + shift1) and
+    out2 = relu6((x . w2) * scale_b + shift_b), the 1x1 residual projection of the same input."""
+    lib = _lib.load()
+    assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, w.cout) and w.cin == x.C and w.taps == 1
+    assert (out2.B, out2.H, out2.W, out2.C) == (x.B, x.H, x.W, w2.cout) and w2.cin == x.C and w2.taps == 1
+    rc = lib.emd_sep3x3_dual_f32(x.ptr, x.ld, _p(dw_dev), _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), out.ptr, out.ld, _p(w2.hi), _p(w2.lo),
+                                 _p(scale_b), _p(shift_b), out2.ptr, out2.ld, x.B, x.H, x.W, x.C, w.cout, w2.cout, _act(act),
+                                 _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_sep3x3_dual_f32")
+    return out, out2
+
+
 def sep_fused_gen(d: Act, gen_a, gen_t, dw_dev, w: PackedWeights, scale1, shift1, out: Act, gen_act=True, act=True,
                   scale2=None, shift2=None, res: Act | None = None, precision=PREC_BF16X3, stream=None, reflect=False):
     """sep_fused on the generated input act(d[..., 0] * gen_a + gen_t) (emd_sep3x3_fused_gen_f32): d holds one value per

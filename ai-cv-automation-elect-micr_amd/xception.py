@@ -147,6 +147,14 @@ def synthetic_weights(seed: int = SYNTH_SEED, bn: str = "calibrated"):
             w[name] = np.ones(shape, np.float32)
         else:
             raise AssertionError(name)
+    # The single output channel: with gamma ~ U(0.8, 2), beta ~ U(-0.5, 1) the last norm + relu + clip (:639-641) turns the image
+    # into a nearly binary one (57 % zeros, 38 % ones at 512 px), whose relative L2 against any other implementation counts
+    # threshold crossings -- the oracle's own float32 run is 4.9e-3 from its float64 run there.  A gentle last affine
+    # (0.15 z + 0.5 on the calibrated z) keeps the output inside (0, 1) so that parity measures the arithmetic of the network.
+    last = [n for n, sh in variable_specs().items() if n.endswith("/gamma") and tuple(sh) == (1,)]
+    assert len(last) == 1
+    w[last[0]] = np.full((1,), 0.15, np.float32)
+    w[last[0][:-5] + "beta"] = np.full((1,), 0.5, np.float32)
     if bn == "calibrated":
         path = os.path.join(DATA_DIR, f"synth_bn_X_seed{seed}.npz")
         if not os.path.exists(path):
@@ -210,8 +218,11 @@ class XceptionEngine:
                 p["scale"], p["shift"] = d(g), d(h)
             self.P.append(p)
 
-    def forward(self, x, trace=None):
-        """x: torch CUDA float32 [B,S,S,1], S a multiple of 64 -> [B,S,S,1] in [0,1]."""
+    def forward(self, x, trace=None, teacher=None):
+        """x: torch CUDA float32 [B,S,S,1], S a multiple of 64 -> [B,S,S,1] in [0,1].
+        trace: a list that receives every block output as a host array (the oracle's trace order).  teacher (with trace): a list
+        of reference tensors in the same order; after block i has been traced its output is REPLACED by teacher[i], so every
+        block is measured on the reference's input and an error cannot hide behind, or be blamed on, its propagation."""
         import torch
 
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[3] == 1
@@ -246,6 +257,17 @@ class XceptionEngine:
         def host(a):
             return (a.to_float() if isinstance(a, ops.SplitAct) else a.torch()).cpu().numpy()
         E = lambda H, W, Cc: ops.Act.empty(B, H, W, Cc, dev)
+        assert teacher is None or trace is not None
+
+        def forced(r):
+            """Teacher forcing: the block output just traced is replaced by the reference's tensor (same storage where it is a view)."""
+            if teacher is None:
+                return r
+            t = torch.from_numpy(np.ascontiguousarray(teacher[len(trace) - 1], dtype=np.float32)).to(dev)
+            if isinstance(r, ops.SplitAct):
+                return ops.Act(t.contiguous())
+            r.torch().copy_(t)
+            return r
 
         def conv_bn_relu(a, out=None):
             """tf.layers.conv2d (+bias) -> batch_then_activ: one GEMM launch."""
@@ -258,6 +280,7 @@ class XceptionEngine:
                 r = ops.conv3x3(a, p["pw"], p["gs"], p["hs"], out, stride=L.stride, rate=L.rate, act=RELU, precision=prec)
             if trace is not None:
                 trace.append(r.torch().cpu().numpy())
+                r = forced(r)
             return r
 
         def conv_block(a):
@@ -272,6 +295,7 @@ class XceptionEngine:
                                 scale2=p["g"], shift2=p["h"])
             if trace is not None:
                 trace.append(host(r))
+                r = forced(r)
             return r
 
         def sep(a, res=None, defer=False):
@@ -300,7 +324,10 @@ class XceptionEngine:
                 mean, var = ops.bn_batch_stats(y)
                 scale, shift = ops.bn_fold(mean, var, None, p["beta"], BN_EPS)
             if trace is not None:   # the oracle traces the SEP output before the residual add
-                trace.append(ops.affine_act(y, scale, shift, E(Ho, Wo, L.cout), act=RELU).torch().cpu().numpy())
+                tr_out = ops.affine_act(y, scale, shift, E(Ho, Wo, L.cout), act=RELU)
+                trace.append(tr_out.torch().cpu().numpy())
+                if teacher is not None:   # the reference's block output (>= 0: the relu is a no-op on it) [+ res], same kernel
+                    return ops.affine_act(forced(tr_out), p["one"], p["zero"], y, act=RELU, res=res)
             if defer and res is None and trace is None:
                 return (y, scale, shift)
             return ops.affine_act(y, scale, shift, y, act=RELU, res=res)
@@ -315,6 +342,7 @@ class XceptionEngine:
                 r = ops.deconv3x3s2(a, p["phases"], p["scale"], p["shift"], E(2 * a.H, 2 * a.W, L.cout), act=RELU, precision=prec)
             if trace is not None:
                 trace.append(host(r))
+                r = forced(r)
             return r
 
         # entry flow: the 1-channel image as a 4-channel tensor (3 zero channels) feeds the 9-tap GEMM
@@ -350,6 +378,7 @@ class XceptionEngine:
         pool = ops.affine_act(large, p["scale"], p["shift"], cat.slice(4 * af, af), act=RELU)
         if trace is not None:
             trace.append(pool.torch().cpu().numpy())
+            pool = forced(pool)
         d_ = conv_bn_relu(cat)
         d_ = conv_bn_relu(d_)                                   # decoder
         for _ in range(3):

@@ -390,6 +390,20 @@ int emd_conv3x3_cout1_reflect_f32(const float* x, int ldx, const float* w, float
 int emd_instnorm_tanh_f32(const float* x, const float* mean, const float* var, float* y, int B, long npix_img, float eps,
                           emd_stream_t stream);
 
+/* The decoder pair "separable conv + 1x1 residual projection of the SAME input" in one launch
+ * (machine_learning/denoiser.py:356-359, :368-371, :380-383: deconv*_a = strided_conv_block(concat) and
+ * residual*_d = conv_block_not_sep(concat, kernel_size=1)):
+ *   y  = act(pointwise(depthwise3x3(x)) * scale1 + shift1)     as emd_sep3x3_fused_f32 (stride 1, TF SAME)
+ *   y2 = relu6((x . W2) * scale_b + shift_b)                    W2 packed as for emd_conv1x1_f32; bias and BN folded into scale_b / shift_b
+ * The 384- / 128-channel input -- the largest tensors of the decoder -- is read from HBM once instead of twice.
+ * Split-bf16 precision.  Supported (emd_sep3x3_dual_supported): W%16==0, Cin%32==0, both Cout%4==0 and <= 128,
+ * H%8==0 (H%4==0 when either output has more than 64 channels). */
+int emd_sep3x3_dual_supported(int H, int W, int Cin, int Cout, int Cout2);
+int emd_sep3x3_dual_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                        const float* scale1, const float* shift1, float* y, int ldy, const uint16_t* w2hi,
+                        const uint16_t* w2lo, const float* scale_b, const float* shift_b, float* y2, int ldy2, int B, int H,
+                        int W, int Cin, int Cout, int Cout2, int act, emd_stream_t stream);
+
 /* emd_sep3x3_fused_f32 with the depthwise stage reading the tf.pad(REFLECT, 1) border instead of zeros: the
  * stride-1 strided_conv_block(pad_size=(1,1)) of graph G (:205-243).  Same arguments and support rule. */
 int emd_sep3x3_fused_reflect_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,

@@ -114,6 +114,15 @@ def test_denoiser_class_surface(weights):
     assert full.shape == (600, 700) and np.isfinite(full).all()
     tl = den.denoise_crop(big[:512, :512], preprocess=False, postprocess=True)
     np.testing.assert_allclose(full[:80, :80], tl[:80, :80], atol=1e-5)   # region covered by one tile only
+    # tiles start at rows {0, 88} and columns {0, 188}: a region covered by exactly TWO tiles is the mean of the two
+    # denoise_crop results there, and the centre (all four tiles) the mean of four (the intent of denoiser.py:653-682)
+    raw = lambda y, x: den.denoise_crop(big[y:y + 512, x:x + 512], preprocess=False, postprocess=False).reshape(512, 512)
+    t00, t01, t10, t11 = raw(0, 0), raw(0, 188), raw(88, 0), raw(88, 188)
+    two = 0.5 * (t00[:88, 188:512] + t01[:88, 0:324])
+    np.testing.assert_allclose(full[:88, 188:512], two.clip(0, 1), atol=1e-5)
+    four = 0.25 * (t00[88:512, 188:512] + t01[88:512, 0:324] + t10[0:424, 188:512] + t11[0:424, 0:324])
+    np.testing.assert_allclose(full[88:512, 188:512], four.clip(0, 1), atol=1e-5)
+    np.testing.assert_allclose(full[512:, 512:], t11[424:, 324:].clip(0, 1), atol=1e-5)        # bottom-right corner: last tile only
 
 
 @pytest.mark.parametrize("B,S", [(2, 64), (1, 32)])

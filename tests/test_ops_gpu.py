@@ -298,6 +298,52 @@ def test_sep_fused_generated_input(B, H, W, ci, co, gen_act, reflect, extra):
     assert not torch.isnan(got.torch()).any()
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,co2", [
+    (2, 16, 32, 128, 64, 64),       # deconv0_a + residual0_d: 64 | 64 columns on 8 x 16 tiles
+    (1, 8, 16, 384, 128, 128),      # deconv1_a + residual1_d: 128 | 128 columns on 4 x 16 tiles, concat-slice input
+    (2, 12, 48, 96, 128, 32),       # H % 4 == 0 only (wide form), unequal widths
+    (1, 24, 16, 64, 36, 64),        # a channel tail in the separable output
+    (2, 64, 64, 32, 8, 4),          # several tiles per workgroup, one K chunk
+])
+def test_sep_dual(B, H, W, ci, co, co2):
+    """emd_sep3x3_dual_f32 (denoiser.py:356-359 / :368-371 / :380-383 in one launch): output 1 == the separable conv block,
+    output 2 == slim.conv2d(kernel 1) + bias + BN + relu6 of the same input, both against oracle/tf_ops.py (float64); and each
+    against the kernel it replaces (emd_sep3x3_fused_f32 / emd_conv1x1_f32)."""
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 240, positive=True)
+    dw = rnd((3, 3, ci, 1), 241, 0.35)
+    pw = rnd((1, 1, ci, co), 242, scale=(2.0 / (ci + co)) ** 0.5)
+    w2 = rnd((1, 1, ci, co2), 243, scale=(2.0 / (ci + co2)) ** 0.5)
+    bias2 = rnd((co2,), 244, 0.2)
+    s1, t1 = rnd((co,), 245, 0.2) + 1, rnd((co,), 246, 0.5)
+    sb, tb = rnd((co2,), 247, 0.2) + 1, rnd((co2,), 248, 0.5)
+    y1 = T.relu6_t(T.conv2d_t(T.depthwise_conv2d_t(t64(x), t64(dw)), t64(pw)) * t64(s1) + t64(t1)).numpy()
+    y2 = T.relu6_t(T.conv2d_t(t64(x), t64(w2), t64(bias2)) * t64(sb) + t64(tb)).numpy()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    xa = to_act(x, ld=ci + 64, c0=32)
+    assert ops.sep_dual_supported(xa, co, co2)
+    out, out2 = out_act(B, H, W, co, ld=co + 8, c0=4), out_act(B, H, W, co2, ld=co2 + 12, c0=8)
+    p1, p2 = ops.PackedWeights(pw[0], False, dev()), ops.PackedWeights(w2[0], False, dev())
+    shift_b = (bias2.astype(np.float64) * sb + tb).astype(np.float32)
+    ops.sep_dual(xa, d(dw[..., 0]), p1, p2, d(s1), d(t1), out, d(sb), d(shift_b), out2)
+    torch.cuda.synchronize()
+    g1, g2 = out.torch().cpu().numpy(), out2.torch().cpu().numpy()
+    assert not np.isnan(g1).any() and not np.isnan(g2).any()
+    assert rel_l2(g1, y1) < TOL_X3 and rel_l2(g2, y2) < TOL_X3
+    for o, c in ((out, co), (out2, co2)):   # nothing written outside the slices
+        full = o.buf.cpu().numpy()
+        assert np.isnan(full[..., :o.c0]).all() and np.isnan(full[..., o.c0 + c:]).all()
+    # the kernels it replaces: same products, same order along K
+    want1 = ops.sep_fused(xa, d(dw[..., 0]), p1, d(s1), d(t1), out_act(B, H, W, co)) if ops.sep_fused_supported(xa, co, 1, 1) else None
+    want2 = ops.conv1x1(xa, p2, d(sb), d(shift_b), out_act(B, H, W, co2))
+    torch.cuda.synchronize()
+    if want1 is not None:
+        assert rel_l2(g1, want1.torch().cpu().numpy()) < 1e-6
+    assert rel_l2(g2, want2.torch().cpu().numpy()) < 1e-6
+
+
 def test_sep_fused_falls_back_cleanly():
     from emdenoise import _lib, ops
 

@@ -257,6 +257,52 @@ def test_deconv3x3s2_split32_equals_deconv(B, H, W, ci, co, out_split):
         assert torch.equal(got.buf, want.buf)
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,stride,rate", [
+    (2, 16, 16, 64, 128, 1, 1), (1, 33, 21, 96, 132, 1, 1), (1, 32, 32, 728, 728, 1, 6), (2, 18, 14, 40, 128, 2, 1),
+    (2, 24, 24, 64, 64, 1, 1), (1, 17, 19, 32, 36, 1, 3)])
+def test_conv3x3_split32_against_the_oracle(B, H, W, ci, co, stride, rate):
+    """emd_conv3x3_split32_f32 directly against oracle/tf_ops.py (float64 tf.layers.conv2d, TF SAME, dilation): the
+    bit-identity tests above compare it with the register-staged kernel only, i.e. with a sibling."""
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 71)
+    w = rnd((3, 3, ci, co), 72, scale=(2.0 / (9 * ci + co)) ** 0.5)
+    bias, g, h = rnd((co,), 73, 0.2), rnd((co,), 74, 0.3) + 1.0, rnd((co,), 75, 0.4)
+    # X's conv_block (modified_Xception.py:215-229): conv + bias -> relu -> affine (BN on moving statistics) -> relu
+    ref = torch.relu(torch.relu(T.conv2d_t(t64(x), t64(w), t64(bias), stride=stride, rate=rate)) * t64(g) + t64(h)).numpy()
+    pw = ops.PackedWeights(w.reshape(9, ci, co), False, dev())
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    xs = ops.to_split32(ops.Act(up(x)))
+    one = up(np.ones(co, np.float32))
+    got = ops.conv3x3_split32(xs, pw, one, up(bias), ops.Act.empty(B, Ho, Wo, co, dev()), stride=stride, rate=rate, act=ops.ACT_RELU,
+                              scale2=up(g), shift2=up(h))
+    sp = ops.conv3x3_split32(xs, pw, one, up(bias), ops.SplitAct(B, Ho, Wo, co, dev()), stride=stride, rate=rate, act=ops.ACT_RELU,
+                             scale2=up(g), shift2=up(h))
+    torch.cuda.synchronize()
+    assert rel_l2(got.torch().cpu().numpy(), ref) < TOL_X3
+    assert rel_l2(sp.to_float().cpu().numpy(), ref) < TOL_X3 + 2.0 ** -16       # + the split32 output's own rounding
+
+
+@pytest.mark.parametrize("B,H,W,ci,co", [(2, 8, 8, 256, 256), (1, 13, 9, 64, 132), (2, 16, 16, 128, 64), (1, 32, 32, 128, 128)])
+def test_deconv3x3s2_split32_against_the_oracle(B, H, W, ci, co):
+    """emd_deconv3x3s2_split32_f32 directly against oracle/tf_ops.py conv2d_transpose_s2_t (float64: the gradient of the SAME
+    stride-2 conv, cropped at the end; denoiser.py:138-150) + bias + folded BN + relu6."""
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 81)
+    w = rnd((3, 3, co, ci), 82, scale=(2.0 / (9 * ci + co)) ** 0.5)
+    bias, g, h = rnd((co,), 83, 0.2), rnd((co,), 84, 0.3) + 1.0, rnd((co,), 85, 0.4)
+    ref = T.relu6_t(T.conv2d_transpose_s2_t(t64(x), t64(w), t64(bias)) * t64(g) + t64(h)).numpy()
+    phases = ops.pack_deconv(w, dev())
+    shift = (bias.astype(np.float64) * g + h).astype(np.float32)
+    xs = ops.to_split32(ops.Act(up(x)))
+    got = ops.deconv3x3s2_split32(xs, phases, up(g), up(shift), ops.Act.empty(B, 2 * H, 2 * W, co, dev()))
+    torch.cuda.synchronize()
+    assert rel_l2(got.torch().cpu().numpy(), ref) < TOL_X3
+
+
 def test_split32_convs_random_shapes_match_register_staged_kernels():
     """Seeded sweep over ragged shapes (M, N and K tails, 1..3 M tiles, strides, dilations): every split32 GEMM form gives
     the bits of its register-staged twin -- the DMA source addressing (per-tap rows, zero line, swizzle) has no shape it gets wrong."""

@@ -43,33 +43,112 @@ def test_oracle_batch_statistics_make_output_batch_dependent():
     assert rel_l2(alone[0], both[0]) > 1e-3
 
 
+_CALIB = {}
+
+
+def weights_calibrated_at(S):
+    """The package's seeded synthetic X weights with the moving statistics of every batch_then_activ norm calibrated by the
+    ORACLE (float64) at crop size S on a 2-image batch of another seed.  The shipped calibration (data/synth_bn_X_seed1234.npz)
+    is made at 512 px; at 128 / 256 px the deepest maps are 2x2 / 4x4, the statistics drift, two thirds of the decoder's units
+    die and the single output channel is 99.7 % zeros -- an output whose relative L2 measures a handful of kink crossings, not
+    the kernels (the oracle's own float32 run then differs from float64 by 1e-4 ... 4e-3).  Calibration (oracle/xception_graph.py,
+    calibrate mode) also centres the pre-relu activation of every decoder conv block: uncentred, the residual-free decoder
+    amplifies rounding noise 1.2-1.4x per block.  Calibrated at the tested size the oracle's own float32 run stays within
+    1.3e-5 (128 px) / 7.3e-5 (256 px) of float64 at the output (asserted <= 1e-4 below) and the plain 1e-3 bar applies."""
+    if S not in _CALIB:
+        from emdenoise import xception as X
+        from oracle import xception_graph as XG
+
+        w = X.synthetic_weights(bn="tf_init")
+        calib = {}
+        XG.architecture(synthetic_lq(2, S, S, seed=9000 + S), w, S, dtype=torch.float64, calibrate=calib)
+        w.update({k: v.astype(np.float32) for k, v in calib.items()})
+        _CALIB[S] = w
+    return _CALIB[S]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,S", [(2, 128), (1, 256)])
 def test_engine_matches_oracle(B, S):
-    """With random weights, batch-statistics norms and unbounded relu the synthetic X graph amplifies rounding
-    noise: the oracle's OWN float32 run differs from its float64 run by 1.6e-4 (128 px) to 4e-3 (256 px) at the
-    output, so no float32-class implementation can be held to 1e-3 end to end there.  Checked instead:
-      * layer by layer (free running), the encoder + ASPP (first 73 traced tensors) within 3e-4 of float64;
-      * end to end within max(1e-3, 25 x the oracle's own float32-vs-float64 error on this very input)
-        (split-bf16 carries ~10x the rounding noise of float32)."""
+    """Graph X end to end and layer by layer against the float64 oracle, with weights calibrated at the tested size:
+      * precondition: the oracle's own float32 run is within 1e-4 of its float64 run (the graph is well conditioned);
+      * end to end, free running: relative L2 <= 1e-3 (north_star's bar, no allowance term);
+      * free running, EVERY traced tensor (encoder, ASPP and decoder: 100 tensors) within the same 1e-3, the encoder + ASPP
+        (tensors 0..74) within 3e-4;
+      * teacher forced (every block fed the oracle's float64 output of the block before it, XceptionEngine.forward(teacher=)):
+        EVERY block within 5e-5 -- split-bf16 GEMM rounding, with nothing propagated that could mask or excuse a block."""
     from emdenoise import xception as X
     from oracle import xception_graph as XG
 
-    w = X.synthetic_weights()
+    w = weights_calibrated_at(S)
     eng = X.XceptionEngine(w, torch.device("cuda", 0), "bf16x3")
     x = synthetic_lq(B, S, S, seed=400 + S)
-    t64, tgpu = [], []
+    t64, tgpu, tforced = [], [], []
     ref = XG.architecture(x, w, S, dtype=torch.float64, trace=t64).numpy()
     ref32 = XG.architecture(x, w, S, dtype=torch.float32).numpy()
-    got = eng.forward(torch.from_numpy(x).cuda(), trace=tgpu).cpu().numpy()
+    noise32 = rel_l2(ref32, ref)
+    assert 0.02 < (ref > 0).mean() and ref.std() > 1e-3, "degenerate oracle output: the bar would measure nothing"
+    assert noise32 <= 1e-4, f"ill-conditioned synthetic weights: oracle float32 vs float64 {noise32:.2e}"
+    xd = torch.from_numpy(x).cuda()
+    got = eng.forward(xd, trace=tgpu).cpu().numpy()
     assert got.shape == ref.shape and got.min() >= 0.0 and got.max() <= 1.0
     assert len(tgpu) == len(t64) - 1            # the oracle also traces the final conv_block
     layer_err = [rel_l2(b, a.numpy()) for a, b in zip(t64, tgpu)]
-    noise32, r = rel_l2(ref32, ref), rel_l2(got, ref)
-    print(f"X graph B={B} S={S}: encoder+ASPP max layer rel L2 {max(layer_err[:73]):.2e}; end to end {r:.2e} "
-          f"(oracle float32 vs float64 on the same input: {noise32:.2e})")
-    assert max(layer_err[:73]) < 3e-4
-    assert r < max(1e-3, 25 * noise32)
+    r = rel_l2(got, ref)
+    got_t = eng.forward(xd, trace=tforced, teacher=[t.numpy() for t in t64[:-1]]).cpu().numpy()
+    forced_err = [rel_l2(b, a.numpy()) for a, b in zip(t64, tforced)]
+    r_t = rel_l2(got_t, ref)
+    worst = int(np.argmax(forced_err))
+    print(f"X graph B={B} S={S}: end to end {r:.2e} (oracle float32 vs float64: {noise32:.2e}); free-running max layer rel L2 "
+          f"{max(layer_err):.2e}; teacher-forced max {max(forced_err):.2e} at tensor {worst} {tuple(t64[worst].shape)}, decoder "
+          f"(tensors 75..99) max {max(forced_err[75:]):.2e}, last layer on the oracle's input {r_t:.2e}")
+    assert r < 1e-3
+    assert max(layer_err) < 1e-3 and max(layer_err[:75]) < 3e-4
+    assert max(forced_err) < 5e-5
+    assert r_t < 5e-5
+    plain = eng.forward(xd).cpu().numpy()        # and the untraced launch sequence (deferred norms, split32 chains): same result
+    assert rel_l2(plain, got) < 1e-6
+
+
+@pytest.mark.gpu
+def test_full_size_golden_probes_and_layers():
+    """BASELINE's size: [2,512,512,1] with the shipped weights against tests/golden/x_graph_512.json (float64 oracle run,
+    tests/golden/make_x_golden.py): 128 probe pixels and the mean of the output, and for every traced tensor -- decoder
+    included -- its L2 norm and 4 fixed values.  The oracle's own float32-vs-float64 error at this size is in the fixture
+    ("noise32"); the end-to-end bar is the plain 1e-3."""
+    import hashlib
+    import json
+    import os
+
+    from emdenoise import xception as X
+
+    meta = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "x_graph_512.json")))
+    x = synthetic_lq(meta["B"], meta["S"], meta["S"], seed=meta["seed"])
+    assert hashlib.sha256(x.tobytes()).hexdigest() == meta["x_sha256"], "synthetic input generator changed"
+    eng = X.XceptionEngine(X.synthetic_weights(), torch.device("cuda", 0), "bf16x3")
+    tg = []
+    y = eng.forward(torch.from_numpy(x).cuda(), trace=tg).cpu().numpy()
+    assert len(tg) == len(meta["layers"]) - 1
+    worst = 0.0
+    for i, (g, L) in enumerate(zip(tg, meta["layers"])):
+        assert list(g.shape) == L["shape"]
+        l2 = float(np.linalg.norm(g.astype(np.float64)))
+        Bn, H, W, Cc = g.shape
+        pos = [(0, 0, 0, 0), (Bn - 1, H - 1, W - 1, Cc - 1), (0, H // 2, W // 3, Cc // 2), (Bn - 1, H // 3, W // 2, Cc // 3)]
+        scale = L["l2"] / np.sqrt(g.size)                                   # rms of the reference tensor
+        worst = max(worst, abs(l2 - L["l2"]) / L["l2"], max(abs(float(g[p]) - v) for p, v in zip(pos, L["values"])) / scale / 30)
+        assert abs(l2 - L["l2"]) < 2e-4 * L["l2"], (i, l2, L["l2"])
+        assert abs(float(g.astype(np.float64).mean()) - L["mean"]) < 2e-4 * scale + 1e-9, i
+        for p, v in zip(pos, L["values"]):
+            assert abs(float(g[p]) - v) < 6e-3 * scale, (i, p, float(g[p]), v)   # a single value: 6e-3 of the tensor's rms
+    pr = np.array(meta["probes"])
+    refv = np.array(meta["values"], np.float64)
+    got = y[pr[:, 0], pr[:, 1], pr[:, 2], 0]
+    r = rel_l2(got, refv)
+    print(f"X [2,512,512,1] vs golden: probes rel L2 {r:.2e}, mean {y.mean():.6f} vs {meta['mean']:.6f}, worst layer figure {worst:.2e}; "
+          f"oracle float32 vs float64 at this size: {meta['noise32']:.2e}")
+    assert r < 1e-3
+    assert abs(float(y.mean()) - meta["mean"]) < 1e-3 * max(abs(meta["mean"]), 1e-3)
 
 
 @pytest.mark.gpu
