@@ -341,9 +341,10 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             const int ldo = out2 ? p.ldy2 : p.ldy;
             // one clamp form for every activation code: v = min(max(max(v, lo), slope*v), hi) -- (lo, slope, hi) = none: (-inf, 1, inf); relu6: (0, 1, 6);
             // relu: (0, 1, inf); leaky relu (graph G): (-inf, 0.2, inf); a clamped negative comes out as +0, as tf.nn.relu6 gives it
-            const float hi = p.act == 1 ? 6.f : __builtin_inff();
-            const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
-            const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+            const int actc = out2 ? 1 : p.act;   // the projection of a DUAL launch is conv + BN + relu6 (conv_block_not_sep)
+            const float hi = actc == 1 ? 6.f : __builtin_inff();
+            const float hi2 = actc == 2 ? __builtin_inff() : 6.f;   // second stage (extra BN): relu6, or relu with act code relu
+            const float slope = actc == 4 ? 0.2f : 1.f, lo = (actc == 1 || actc == 2) ? 0.f : -__builtin_inff();
             const bool two = p.scale2 != nullptr && !out2;
             auto finish = [&](f32x4 v) {
 #pragma unroll

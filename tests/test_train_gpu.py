@@ -152,9 +152,13 @@ def test_tower_at_512_against_the_committed_golden():
     cos = (na * na + meta["flat_l2"] ** 2 - float(np.mean(e * e))) / (2 * na * meta["flat_l2"])
     print(f"D' tower at 512^2 vs golden: |g| {na:.4f} vs {meta['flat_l2']:.4f}, estimated rel L2 {rel:.2e} cos {cos:.5f}, worst "
           f"per-variable norm ratio off by {worst_norm:.2e}; oracle float32 vs float64: {meta['oracle_f32_vs_f64']}")
-    assert abs(na / meta["flat_l2"] - 1.0) < 2e-2
-    assert rel < 6e-2 and cos > 0.998
-    assert worst_norm < 0.15
+    # At this size the oracle's OWN float32 run is 0.11 (cosine 0.9935) from its float64 run (fixture: oracle_f32_vs_f64): two
+    # thirds of a million relu6 / clip units sit within rounding distance of a kink.  The bar for the split-bf16 forward (about
+    # 10x float32's forward error => about 3x its mask flips) is therefore set relative to that figure, not to a constant.
+    o = meta["oracle_f32_vs_f64"]
+    assert abs(na / meta["flat_l2"] - 1.0) < max(2e-2, 0.5 * o["rel_l2"])
+    assert rel < max(6e-2, 4.0 * o["rel_l2"]) and cos > min(0.998, 1.0 - 10.0 * (1.0 - o["cosine"]))
+    assert worst_norm < max(0.15, 4.0 * o["rel_l2"])
 
 
 def test_tower_batch_and_accumulation():
