@@ -72,6 +72,9 @@ SIGNATURES = {
     "emd_deconv3x3s2_split32_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, C.c_void_p,
                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p]),
+    "emd_deconv3x3s2_fused_split32_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, C.c_void_p,
+                                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.c_void_p]),
     "emd_conv1x1_split32_stats_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int]),
     # xs ldx whi wlo scale1 shift1 y ldy M Cin Cout act mean var workspace stream
     "emd_conv1x1_split32_stats_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p,

@@ -408,6 +408,9 @@ class DenoiserEngine:
         L, p = self.layers[key], self.P[key]
         # measured (tools/conv_split_bench.py): converting the input (fp32 -> split32, one pass) + the LDS-DMA GEMM beats the
         # register-staged GEMM where K = taps x Cin >= 1024 per output phase (deconv2to1: 2.72 -> 0.18 + 2.17 ms)
+        if self.precision == ops.PREC_BF16X3 and os.environ.get("EMD_D_DECONV_FUSED", "1") != "0" and x.B * x.H * x.W >= 256 * 192:
+            # one launch, the four output phases per workgroup: the input is read from HBM once instead of four times
+            return ops.deconv3x3s2_fused(ops.to_split32(x), p["phases"], p["scale"], p["shift"], out)
         if L.cin >= 256 and self._split_gemm_ok(x.B * x.H * x.W, L.cout, 4 * L.cin):
             return ops.deconv3x3s2_split32(ops.to_split32(x), p["phases"], p["scale"], p["shift"], out)
         return ops.deconv3x3s2(x, p["phases"], p["scale"], p["shift"], out, precision=self.precision)

@@ -322,6 +322,19 @@ def deconv3x3s2_split32(x: SplitAct, w_phases, scale1, shift1, out, act=True, st
     return out
 
 
+def deconv3x3s2_fused(x: SplitAct, w_phases, scale1, shift1, out, act=True, stream=None):
+    """The transposed conv as one launch (emd_deconv3x3s2_fused_split32_f32): every workgroup runs the four output phases of its
+    input pixels back to back -- the input comes from HBM once; bit-identical to deconv3x3s2_split32."""
+    lib = _lib.load()
+    assert len(w_phases) == 4 and (out.B, out.H, out.W) == (x.B, 2 * x.H, 2 * x.W) and out.C == w_phases[0].cout
+    hi = (C.c_void_p * 4)(*[w.hi.data_ptr() for w in w_phases])
+    lo = (C.c_void_p * 4)(*[w.lo.data_ptr() for w in w_phases])
+    rc = lib.emd_deconv3x3s2_fused_split32_f32(x.ptr, x.ld, hi, lo, _p(scale1), _p(shift1), out.ptr, out.ld, x.B, x.H, x.W, x.C,
+                                               out.C, _act(act), 1 if isinstance(out, SplitAct) else 0, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_deconv3x3s2_fused_split32_f32")
+    return out
+
+
 def conv1x1_split32_supported(npix: int, cin: int, cout: int) -> bool:
     return bool(_lib.load().emd_conv1x1_split32_supported(C.c_long(npix), cin, cout))
 

@@ -211,6 +211,11 @@ int emd_deconv3x3s2_split32_f32(const void* xs, int ldx, const uint16_t* const w
 int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
                             const float* shift1, const float* scale2, const float* shift2, const float* res,
                             int ldres, float* y, int ldy, long M, int Cin, int Cout, int act, emd_stream_t stream);
+/* emd_deconv3x3s2_split32_f32 as ONE launch: a workgroup computes the four output phases of its 256 input pixels back to
+ * back, so the input is read from HBM once instead of once per phase launch.  Same arguments, bit-identical results. */
+int emd_deconv3x3s2_fused_split32_f32(const void* xs, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4],
+                                      const float* scale1, const float* shift1, void* y, int ldy, int B, int H, int W, int Cin,
+                                      int Cout, int act, int out_split, emd_stream_t stream);
 
 /* emd_dw3x3_f32 / emd_dw3x3_split32_f32 on relu(x * pre_scale + pre_shift) (per channel, device float[C]): the
  * batch-statistics norm + relu that ends the previous separable block of misc_py/modified_Xception.py (:302-323) applied

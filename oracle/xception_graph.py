@@ -77,17 +77,20 @@ class _X:
     def conv_block(self, x, filters):
         if self.calibrate is not None:
             # Calibration of the SYNTHETIC weights only (tests/golden/make_synth_bn.py; never the inference path): besides the
-            # moving statistics, the conv's bias is set so that the pre-relu activation of every channel has mean +0.5 sigma.
-            # With a random zero-mean kernel on post-relu (positive-mean) inputs each output channel gets a random DC offset of
-            # the size of its fluctuation; channels whose offset is strongly negative pass only a sparse tail through the relu,
-            # which the following norm blows back up to unit variance -- a noise amplifier of 1.2-1.4x per block: the oracle's
-            # own float32 run drifts from 8e-6 to 1.3e-3 of its float64 run through the 25 blocks of the decoder (no residual
-            # connections there).  Centred, the drift is additive (4e-6 -> 2e-5) and the graph is as well conditioned as D.
+            # moving statistics, the conv's bias is set so that the pre-relu activation of every channel has mean +1 sigma
+            # (and emdenoise.xception.synthetic_weights gives the decoder's norms beta = gamma, the same +1 sigma for the second
+            # relu).  Why: a relu turns part of its input's variance into a mean, which the next norm subtracts, while the
+            # rounding noise riding on the passing elements survives in full -- relu(N(0.5, 1)) keeps 55 % of the variance but
+            # 69 % of the noise energy, a 1.12x gain in noise-to-signal per relu, 1.2-1.4x per conv block with random
+            # zero-mean kernels whose output channels sit at random offsets.  The encoder's residual connections absorb that; the
+            # 25 blocks of the residual-free decoder (:538-621) compound it: the oracle's own float32 run drifts from 8e-6 to
+            # 1.3e-3 of its float64 run there, and a split-bf16 run (1e-4 entering the decoder) to several 1e-3.  At +1 sigma
+            # 16-23 % of the units still clip (the relus are exercised) and the noise-to-signal ratio stays flat (3e-6 -> 5e-6).
             scope = self.names.unique("conv2d")
             w = self.get(scope + "/kernel", (3, 3, x.shape[-1], filters))
             self.get(scope + "/bias", (filters,))
             y = T.conv2d_t(x, w, None)
-            b = (-y.mean(dim=(0, 1, 2)) + 0.5 * y.std(dim=(0, 1, 2), unbiased=False)).to(torch.float32)
+            b = (-y.mean(dim=(0, 1, 2)) + 1.0 * y.std(dim=(0, 1, 2), unbiased=False)).to(torch.float32)
             self.calibrate[scope + "/bias"] = b.numpy().copy()
             return self.batch_then_activ(torch.relu(y + b.to(self.dtype)))
         return self.batch_then_activ(torch.relu(self.conv(x, filters, 3)))

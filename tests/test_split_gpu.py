@@ -255,6 +255,19 @@ def test_deconv3x3s2_split32_equals_deconv(B, H, W, ci, co, out_split):
         got = ops.deconv3x3s2_split32(xs, phases, s1, t1, ops.Act.empty(B, 2 * H, 2 * W, co, dev()))
         torch.cuda.synchronize()
         assert torch.equal(got.buf, want.buf)
+    # the one-launch form (four phases per workgroup): the same bits, into a NaN-filled buffer (every output pixel is written)
+    if out_split:
+        one = ops.SplitAct(B, 2 * H, 2 * W, co, dev())
+        one.buf.fill_(float("nan"))
+        ops.deconv3x3s2_fused(xs, phases, s1, t1, one)
+        torch.cuda.synchronize()
+        assert torch.equal(one.buf.view(torch.int32), got.buf.view(torch.int32))
+    else:
+        wide = torch.full((B, 2 * H, 2 * W, co + 8), float("nan"), dtype=torch.float32, device=dev())
+        one = ops.deconv3x3s2_fused(xs, phases, s1, t1, ops.Act(wide, co, 4))
+        torch.cuda.synchronize()
+        assert torch.equal(one.torch(), got.torch())
+        assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
 
 
 @pytest.mark.parametrize("B,H,W,ci,co,stride,rate", [
@@ -299,8 +312,10 @@ def test_deconv3x3s2_split32_against_the_oracle(B, H, W, ci, co):
     shift = (bias.astype(np.float64) * g + h).astype(np.float32)
     xs = ops.to_split32(ops.Act(up(x)))
     got = ops.deconv3x3s2_split32(xs, phases, up(g), up(shift), ops.Act.empty(B, 2 * H, 2 * W, co, dev()))
+    one = ops.deconv3x3s2_fused(xs, phases, up(g), up(shift), ops.Act.empty(B, 2 * H, 2 * W, co, dev()))
     torch.cuda.synchronize()
     assert rel_l2(got.torch().cpu().numpy(), ref) < TOL_X3
+    assert rel_l2(one.torch().cpu().numpy(), ref) < TOL_X3
 
 
 def test_split32_convs_random_shapes_match_register_staged_kernels():

@@ -52,9 +52,9 @@ def weights_calibrated_at(S):
     is made at 512 px; at 128 / 256 px the deepest maps are 2x2 / 4x4, the statistics drift, two thirds of the decoder's units
     die and the single output channel is 99.7 % zeros -- an output whose relative L2 measures a handful of kink crossings, not
     the kernels (the oracle's own float32 run then differs from float64 by 1e-4 ... 4e-3).  Calibration (oracle/xception_graph.py,
-    calibrate mode) also centres the pre-relu activation of every decoder conv block: uncentred, the residual-free decoder
-    amplifies rounding noise 1.2-1.4x per block.  Calibrated at the tested size the oracle's own float32 run stays within
-    1.3e-5 (128 px) / 7.3e-5 (256 px) of float64 at the output (asserted <= 1e-4 below) and the plain 1e-3 bar applies."""
+    calibrate mode) also centres the pre-relu activation of every decoder conv block at +1 sigma: uncentred, the residual-free
+    decoder compounds rounding noise 1.2-1.4x per block.  Calibrated at the tested size the oracle's own float32 run stays
+    within 3e-6 of float64 at the output (asserted <= 2e-5 below) and the plain 1e-3 bar applies."""
     if S not in _CALIB:
         from emdenoise import xception as X
         from oracle import xception_graph as XG
@@ -71,10 +71,9 @@ def weights_calibrated_at(S):
 @pytest.mark.parametrize("B,S", [(2, 128), (1, 256)])
 def test_engine_matches_oracle(B, S):
     """Graph X end to end and layer by layer against the float64 oracle, with weights calibrated at the tested size:
-      * precondition: the oracle's own float32 run is within 1e-4 of its float64 run (the graph is well conditioned);
+      * precondition: the oracle's own float32 run is within 2e-5 of its float64 run (the graph is well conditioned);
       * end to end, free running: relative L2 <= 1e-3 (north_star's bar, no allowance term);
-      * free running, EVERY traced tensor (encoder, ASPP and decoder: 100 tensors) within the same 1e-3, the encoder + ASPP
-        (tensors 0..74) within 3e-4;
+      * free running, EVERY traced tensor (encoder, ASPP and decoder: 100 tensors) within 3e-4;
       * teacher forced (every block fed the oracle's float64 output of the block before it, XceptionEngine.forward(teacher=)):
         EVERY block within 5e-5 -- split-bf16 GEMM rounding, with nothing propagated that could mask or excuse a block."""
     from emdenoise import xception as X
@@ -88,7 +87,7 @@ def test_engine_matches_oracle(B, S):
     ref32 = XG.architecture(x, w, S, dtype=torch.float32).numpy()
     noise32 = rel_l2(ref32, ref)
     assert 0.02 < (ref > 0).mean() and ref.std() > 1e-3, "degenerate oracle output: the bar would measure nothing"
-    assert noise32 <= 1e-4, f"ill-conditioned synthetic weights: oracle float32 vs float64 {noise32:.2e}"
+    assert noise32 <= 2e-5, f"ill-conditioned synthetic weights: oracle float32 vs float64 {noise32:.2e}"
     xd = torch.from_numpy(x).cuda()
     got = eng.forward(xd, trace=tgpu).cpu().numpy()
     assert got.shape == ref.shape and got.min() >= 0.0 and got.max() <= 1.0
@@ -103,7 +102,7 @@ def test_engine_matches_oracle(B, S):
           f"{max(layer_err):.2e}; teacher-forced max {max(forced_err):.2e} at tensor {worst} {tuple(t64[worst].shape)}, decoder "
           f"(tensors 75..99) max {max(forced_err[75:]):.2e}, last layer on the oracle's input {r_t:.2e}")
     assert r < 1e-3
-    assert max(layer_err) < 1e-3 and max(layer_err[:75]) < 3e-4
+    assert max(layer_err) < 3e-4
     assert max(forced_err) < 5e-5
     assert r_t < 5e-5
     plain = eng.forward(xd).cpu().numpy()        # and the untraced launch sequence (deferred norms, split32 chains): same result
