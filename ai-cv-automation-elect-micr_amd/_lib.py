@@ -72,6 +72,13 @@ SIGNATURES = {
     "emd_deconv3x3s2_split32_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, C.c_void_p,
                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p]),
+    # xs ldx whi wlo scale1 shift1 scale2 shift2 res ldres y ldy M Cin Cout act stream
+    "emd_conv1x1_split32_out_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                              _c_float_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # x ldx dw whi wlo scale1 shift1 scale2 shift2 res ldres y ldy B H W Cin Cout act stream
+    "emd_sep3x3_fused_out_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
+                                           _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "emd_deconv3x3s2_fused_split32_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, C.c_void_p,
                                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                     C.c_void_p]),

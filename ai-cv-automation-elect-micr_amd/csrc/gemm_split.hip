@@ -46,6 +46,7 @@ struct SplitGemmParams {
     double* stats_part;       // optional [n_mtiles][2][N]: per-channel sum / sum of squares of the STORED values of each M tile
     unsigned wlo_delta;       // persistent kernel: byte distance Wlo - Whi (one allocation)
     long long* stamps;        // dev builds only: 5 s_memtime stamps per workgroup (NULL otherwise)
+    int out_split;            // pointwise kernel: C is a split32 tensor (pitch ldc 4-byte units), for a following split32 GEMM
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -251,13 +252,16 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
     constexpr int NROWS = BM / ROWS_PER_PASS;   // 16 rows per thread
     const int ec = (tid % C4) * 4, er = tid / C4;
     const int n = n0 + ec;
-    const bool ncol = n < p.N;              // N % 4 == 0: a chunk is all inside or all outside
+    const bool real = n < p.N;              // N % 4 == 0: a chunk is all inside or all outside
+    // split32 output: the padding channels up to a multiple of 32 are written too (zeros), and both lanes of a channel-quad pair
+    // take the same branches (ceil32(N) is a multiple of 8: a pair is all inside or all outside)
+    const bool ncol = p.out_split ? n < (p.N + 31) / 32 * 32 : real;
     f32x4 rv[NROWS];
     if (p.res) {
 #pragma unroll
         for (int k = 0; k < NROWS; ++k) {
             const long pix = m0 + er + k * ROWS_PER_PASS;
-            rv[k] = (ncol && pix < p.M) ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rv[k] = (real && pix < p.M) ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 #pragma unroll
@@ -273,14 +277,34 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
     if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
     double ssum[4] = {0.0, 0.0, 0.0, 0.0}, ssq[4] = {0.0, 0.0, 0.0, 0.0};
     if (ncol) {
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, t1 = s1;
         f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale2) {
-            s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
-            t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
+        if (real) {
+            s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
+            t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
+            if (p.scale2) {
+                s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
+                t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
+            }
         }
         float* __restrict__ outp = p.C;
+        // the output stage: fp32 NHWC, or the split32 layout (16-byte stores through the pair exchange of emd::dw_store)
+        auto put = [&](long pix, f32x4 v) {
+            if (!p.out_split) {
+                *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = v;
+                return;
+            }
+            if (!real) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            unsigned h0, l0, h1, l1;
+            split2(v[0], v[1], h0, l0);
+            split2(v[2], v[3], h1, l1);
+            const int q = n >> 2;
+            const bool odd = q & 1;
+            const unsigned r0 = emd::swap_pair(odd ? h0 : l0), r1 = emd::swap_pair(odd ? h1 : l1);
+            unsigned char* g = reinterpret_cast<unsigned char*>(outp) + pix * (long)p.ldc * 4 + (n >> 5) * 128;
+            if (!odd) *reinterpret_cast<u32x4*>(g + (q & 7) * 8) = u32x4{h0, h1, r0, r1};
+            else *reinterpret_cast<u32x4*>(g + 64 + ((q - 1) & 7) * 8) = u32x4{r0, r1, l0, l1};
+        };
         // one clamp form for every activation code: v = min(max(max(v, lo), slope*v), hi) -- (lo, slope, hi) = none: (-inf, 1, inf); relu6: (0, 1, 6);
         // relu: (0, 1, inf); leaky relu (graph G): (-inf, 0.2, inf); a clamped negative comes out as +0, as tf.nn.relu6 gives it
         const float hi = p.act == 1 ? 6.f : __builtin_inff();
@@ -302,7 +326,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
             for (int k = 0; k < NROWS; ++k) {
                 const int r = er + k * ROWS_PER_PASS;
                 const long pix = m0 + r;
-                if (pix < p.M) *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec])) + rv[k];
+                if (pix < p.M) put(pix, finish(*reinterpret_cast<const f32x4*>(&stage[r][ec])) + rv[k]);
             }
         } else if (p.stats_part) {
             // batch statistics of the output (misc_py/modified_Xception.py:302-323: the norm that follows runs on batch
@@ -313,7 +337,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
                 const long pix = m0 + r;
                 if (pix >= p.M) break;
                 const f32x4 v = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec]));
-                *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = v;
+                put(pix, v);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const double d = (double)v[c];
@@ -326,7 +350,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
             for (int r = er; r < BM; r += ROWS_PER_PASS) {
                 const long pix = m0 + r;
                 if (pix >= p.M) break;
-                *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec]));
+                put(pix, finish(*reinterpret_cast<const f32x4*>(&stage[r][ec])));
             }
         }
     }
@@ -1169,8 +1193,10 @@ extern "C" int emd_conv1x1_split32_supported(long M, int Cin, int Cout) {
 static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo,
                                 const float* scale1, const float* shift1, const float* scale2,
                                 const float* shift2, const float* res, int ldres, float* y, int ldy, long M,
-                                int Cin, int Cout, int act, emd_stream_t stream, double* stats_part) {
+                                int Cin, int Cout, int act, emd_stream_t stream, double* stats_part, int out_split = 0) {
     EMD_REQUIRE(xs && whi && wlo && scale1 && shift1 && y, EMD_E_INVALID, "emd_conv1x1_split32_f32: null pointer");
+    EMD_REQUIRE(!out_split || (!stats_part && ldy % 32 == 0 && ldy >= emd_split32_ld(Cout) && (reinterpret_cast<uintptr_t>(y) & 127u) == 0),
+                EMD_E_ALIGN, "emd_conv1x1_split32_out_f32: a split32 output needs y 128-byte aligned, ldy a multiple of 32, >= ceil32(Cout)");
     EMD_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), EMD_E_INVALID, "emd_conv1x1_split32_f32: scale2/shift2 must come together");
     EMD_REQUIRE(M >= 0 && Cin >= 1 && Cout >= 4, EMD_E_INVALID, "emd_conv1x1_split32_f32: bad shape");
     EMD_REQUIRE(ldx % 32 == 0 && ldx >= emd_split32_ld(Cin) && (reinterpret_cast<uintptr_t>(xs) & 127u) == 0, EMD_E_ALIGN,
@@ -1186,14 +1212,14 @@ static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, co
     p.A = static_cast<const unsigned char*>(xs); p.Whi = whi; p.Wlo = wlo; p.C = y; p.res = res;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.M = M; p.lda_bytes = (long)ldx * 4; p.N = Cout; p.Cin = Cin; p.Ktot = (Cin + kBK - 1) / kBK * kBK;
-    p.ldc = ldy; p.ldres = ldres; p.act = act; p.stats_part = stats_part;
+    p.ldc = ldy; p.ldres = ldres; p.act = act; p.stats_part = stats_part; p.out_split = out_split ? 1 : 0;
     // kernel variant: 3 = 256-row tiles, 3 stages, pipelined K loop, 32x32x16 MFMAs; 5 = the same on 16x16x32 MFMAs;
     // dev knobs for A/B runs: EMD_SPLIT_VARIANT / emd_debug_split_variant = 0 (256 rows, 2 stages), 1 (256, 3, plain loop),
     // 2 (128 rows, 2 stages, two workgroups per CU), 4 (persistent, epilogue stores inside the next tile's K loop)
     static const int variant = [] { const char* e = getenv("EMD_SPLIT_VARIANT"); return e ? atoi(e) : -1; }();
     int v = variant;
     if (g_variant_override >= 0) v = g_variant_override;
-    if (stats_part) v = 3;   // the statistics epilogue lives in the default kernel
+    if (stats_part || out_split) v = 3;   // the statistics epilogue and the split32 output live in the default kernel
     if (v < 0) v = 3;   // default: the pipelined 32x32x16 kernel -- bit-identical to emd_conv1x1_f32, so a result does not depend on
                         // which of the two a batch size selects.  Variant 5 (16x16x32 MFMAs: same cycles, the chip holds 1.86
                         // instead of 1.73 GHz, 97.9 vs 103.7 us on 32768 x 728 x 728) sums a K step in another order (2e-7).
@@ -1390,6 +1416,16 @@ extern "C" int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* 
 // The same GEMM that also delivers the per-channel batch mean and biased variance of its OUTPUT y (what emd_bn_stats_f32 would
 // compute in a second pass over y): the epilogue leaves one double partial per (256-row tile, channel), a fixed-order final
 // reduction follows (deterministic).  workspace: emd_conv1x1_split32_stats_workspace_bytes(M, Cout) bytes, 8-byte aligned.
+// The same GEMM writing y as a split32 tensor (pitch ldy 4-byte units, % 32; channels Cout..ceil32(Cout) zero): the producer
+// of a split32 convolution's input (graph D: deconv2_b -> deconv2to1) then writes no fp32 activation and needs no converter pass.
+extern "C" int emd_conv1x1_split32_out_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo,
+                                           const float* scale1, const float* shift1, const float* scale2,
+                                           const float* shift2, const float* res, int ldres, void* y, int ldy, long M,
+                                           int Cin, int Cout, int act, emd_stream_t stream) {
+    return conv1x1_split32_impl(xs, ldx, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, static_cast<float*>(y), ldy, M, Cin, Cout,
+                                act, stream, nullptr, 1);
+}
+
 extern "C" size_t emd_conv1x1_split32_stats_workspace_bytes(long M, int Cout) {
     if (M < 1 || Cout < 1) return 0;
     return (size_t)((M + 255) / 256) * 2 * (size_t)Cout * sizeof(double);

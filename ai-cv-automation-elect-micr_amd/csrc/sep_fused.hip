@@ -59,6 +59,7 @@ struct SepParams {
     const float* scale_b;
     const float* shift_b;
     int N2, ldy2;
+    int out_split;        // y is a split32 tensor (pitch ldy 4-byte units; N % 32 == 0): the consumer is a split32 GEMM
     long long* stamps;    // dev hook: per-workgroup phase cycle sums (NULL otherwise)
 };
 
@@ -364,6 +365,22 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             float* __restrict__ ytile = outp + pix0 * ldo + n;
             const float* __restrict__ rtile = p.res ? p.res + pix0 * p.ldres + n : nullptr;
             auto tpix = [&](int r) { return (r >> 4) * p.W + (r & 15) + x0; };
+            // output stage: fp32 NHWC, or (single-output instances) the split32 layout through the pair exchange of emd::dw_store
+            auto put = [&](int r, f32x4 v) {
+                if (DUAL || !p.out_split) {
+                    *reinterpret_cast<f32x4*>(ytile + tpix(r) * ldo) = v;
+                    return;
+                }
+                unsigned h0, l0, h1, l1;
+                split2(v[0], v[1], h0, l0);
+                split2(v[2], v[3], h1, l1);
+                const int q = n >> 2;
+                const bool odd = q & 1;
+                const unsigned r0 = emd::swap_pair(odd ? h0 : l0), r1 = emd::swap_pair(odd ? h1 : l1);
+                unsigned char* g = reinterpret_cast<unsigned char*>(outp) + (pix0 + tpix(r)) * (long)ldo * 4 + (n >> 5) * 128;
+                if (!odd) *reinterpret_cast<u32x4*>(g + (q & 7) * 8) = u32x4{h0, h1, r0, r1};
+                else *reinterpret_cast<u32x4*>(g + 64 + ((q - 1) & 7) * 8) = u32x4{r0, r1, l0, l1};
+            };
             if (p.res && !DUAL) {
                 // residual values are requested four rows at a time, before the first of them is used (the registers of the
                 // next chunk's prefetch are live here: no room for all NROWS at once)
@@ -378,13 +395,13 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int r = er + (k0 + k) * ROWS_PER_PASS;
-                        *reinterpret_cast<f32x4*>(ytile + tpix(r) * ldo) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ncol])) + rv[k];
+                        put(r, finish(*reinterpret_cast<const f32x4*>(&stage[r][ncol])) + rv[k]);
                     }
                 }
             } else {
 #pragma unroll 4
                 for (int r = er; r < BM; r += ROWS_PER_PASS)
-                    *reinterpret_cast<f32x4*>(ytile + tpix(r) * ldo) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ncol]));
+                    put(r, finish(*reinterpret_cast<const f32x4*>(&stage[r][ncol])));
             }
         }
         __syncthreads();  // the staging tile is read out before the next tile's patch overwrites it
@@ -463,7 +480,7 @@ static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint1
                            const float* scale1, const float* shift1, const float* scale2, const float* shift2,
                            const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
                            int precision, int reflect, emd_stream_t stream, const float* gen_a = nullptr,
-                           const float* gen_t = nullptr, int gen_act = 0) {
+                           const float* gen_t = nullptr, int gen_act = 0, int out_split = 0) {
     EMD_REQUIRE(x && dw && whi && scale1 && shift1 && y, EMD_E_INVALID, "emd_sep3x3_fused_f32: null pointer");
     EMD_REQUIRE(precision == 1 || precision == 3, EMD_E_INVALID, "emd_sep3x3_fused_f32: bad precision");
     EMD_REQUIRE(precision == 1 || wlo, EMD_E_INVALID, "emd_sep3x3_fused_f32: the split-bf16 mode needs the lo plane");
@@ -474,6 +491,8 @@ static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint1
     EMD_REQUIRE(B <= 65535, EMD_E_UNSUPPORTED, "emd_sep3x3_fused_f32: B > 65535");
     EMD_REQUIRE(9L * W * (ldy > ldres ? ldy : ldres) < (1L << 31), EMD_E_UNSUPPORTED,
                 "emd_sep3x3_fused_f32: 9 image rows of the output must span fewer than 2^31 floats");
+    EMD_REQUIRE(!out_split || (Cout % 32 == 0 && ldy % 32 == 0 && (reinterpret_cast<uintptr_t>(y) & 127u) == 0), EMD_E_ALIGN,
+                "emd_sep3x3_fused_out_f32: a split32 output needs Cout % 32 == 0, ldy % 32 == 0 and y 128-byte aligned");
     EMD_REQUIRE((gen_a ? ldx >= 1 : (ldx % 4 == 0 && ldx >= Cin)) && ldy % 4 == 0 && ldy >= Cout &&
                     (!res || (ldres % 4 == 0 && ldres >= Cout)),
                 EMD_E_ALIGN, "emd_sep3x3_fused_f32: pixel strides must be multiples of 4 and >= the channel count");
@@ -489,7 +508,7 @@ static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint1
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
     p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act; p.reflect = reflect;
-    p.gen_a = gen_a; p.gen_t = gen_t; p.gen_act = gen_act;
+    p.gen_a = gen_a; p.gen_t = gen_t; p.gen_act = gen_act; p.out_split = out_split ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return Cout <= 64 ? launch<64>(p, B, precision, st) : launch<128>(p, B, precision, st);
 }
@@ -501,6 +520,17 @@ extern "C" int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, co
                                     int precision, emd_stream_t stream) {
     return sep_fused_entry(x, ldx, dw, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, B, H, W, Cin, Cout, act,
                            precision, 0, stream);
+}
+
+// emd_sep3x3_fused_f32 writing y as a split32 tensor (Cout % 32 == 0; pitch ldy 4-byte units, % 32): the producer of a split32
+// convolution's input (graph D: deconv1_b -> deconv1to0) then writes no fp32 activation and needs no converter pass.
+extern "C" int emd_sep3x3_fused_out_f32(const float* x, int ldx, const float* dw, const uint16_t* whi,
+                                        const uint16_t* wlo, const float* scale1, const float* shift1,
+                                        const float* scale2, const float* shift2, const float* res, int ldres,
+                                        void* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                                        emd_stream_t stream) {
+    return sep_fused_entry(x, ldx, dw, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, static_cast<float*>(y), ldy, B, H, W, Cin,
+                           Cout, act, 3, 0, stream, nullptr, nullptr, 0, 1);
 }
 
 // The same with the depthwise stage reading the tf.pad(REFLECT, 1) border instead of zeros: graph G's

@@ -335,6 +335,7 @@ class DenoiserEngine:
             # bf16 hi/lo, the pointwise GEMM gets both operands by LDS-DMA (csrc/gemm_split.hip); same arithmetic
             return ops.sep_split32(x, p["dw"], p["pw"], p["scale"], p["shift"], out, stride=L.stride, rate=L.rate,
                                    scale2=p.get("scale2"), shift2=p.get("shift2"), res=res)
+        assert not isinstance(out, ops.SplitAct)
         tmp = ops.Act.empty(x.B, Ho, Wo, L.cin, self.device)
         ops.dw3x3(x, p["dw"], tmp, stride=L.stride, rate=L.rate)
         ops.conv1x1(tmp, p["pw"], p["scale"], p["shift"], out, scale2=p.get("scale2"), shift2=p.get("shift2"),
@@ -404,13 +405,26 @@ class DenoiserEngine:
             return ops.conv3x3_split32(xs, p["pw"], p["scale"], p["shift"], out, rate=L.rate)
         return ops.conv3x3(x, p["pw"], p["scale"], p["shift"], out, stride=L.stride, rate=L.rate, precision=self.precision)
 
+    def _deconv_fused_ok(self, npix):
+        return self.precision == ops.PREC_BF16X3 and os.environ.get("EMD_D_DECONV_FUSED", "1") != "0" and npix >= 256 * 192
+
+    def _split_out(self, B, H, W, Cc):
+        """Output tensor of the layer in front of a transposed conv: split32 when the fused transposed conv will read it (the
+        producer's epilogue splits; no fp32 tensor, no converter pass), fp32 otherwise."""
+        if (self.fuse_sep and self._deconv_fused_ok(B * H * W) and Cc % 32 == 0 and H % 8 == 0 and W % 16 == 0
+                and os.environ.get("EMD_D_SPLIT_OUT", "1") != "0"):
+            return ops.SplitAct(B, H, W, Cc, self.device)
+        return None
+
     def _deconv(self, key, x, out):
         L, p = self.layers[key], self.P[key]
         # measured (tools/conv_split_bench.py): converting the input (fp32 -> split32, one pass) + the LDS-DMA GEMM beats the
         # register-staged GEMM where K = taps x Cin >= 1024 per output phase (deconv2to1: 2.72 -> 0.18 + 2.17 ms)
-        if self.precision == ops.PREC_BF16X3 and os.environ.get("EMD_D_DECONV_FUSED", "1") != "0" and x.B * x.H * x.W >= 256 * 192:
+        if self._deconv_fused_ok(x.B * x.H * x.W):
             # one launch, the four output phases per workgroup: the input is read from HBM once instead of four times
-            return ops.deconv3x3s2_fused(ops.to_split32(x), p["phases"], p["scale"], p["shift"], out)
+            xs = x if isinstance(x, ops.SplitAct) else ops.to_split32(x)
+            return ops.deconv3x3s2_fused(xs, p["phases"], p["scale"], p["shift"], out)
+        assert not isinstance(x, ops.SplitAct)
         if L.cin >= 256 and self._split_gemm_ok(x.B * x.H * x.W, L.cout, 4 * L.cin):
             return ops.deconv3x3s2_split32(ops.to_split32(x), p["phases"], p["scale"], p["shift"], out)
         return ops.deconv3x3s2(x, p["phases"], p["scale"], p["shift"], out, precision=self.precision)
@@ -499,11 +513,11 @@ class DenoiserEngine:
         ops.resize_bilinear(aspp, concat2.slice(0, aspp_output))            # deconv3 (:350)
         residual2_d = self._conv1x1("residual2_d", concat2)
         t = self._sep("deconv2_a", concat2)
-        deconv2 = self._sep("deconv2_b", t, res=residual2_d)
+        deconv2 = self._sep("deconv2_b", t, res=residual2_d, out=self._split_out(B, S4, S4, f2))
         del aspp, concat2, cnn1_strided, residual2_d, t
         self._deconv("deconv2to1", deconv2, concat1.slice(0, f2))
         t, residual1_d = self._sep_and_projection("deconv1_a", "residual1_d", concat1)
-        deconv1 = self._sep("deconv1_b", t, res=residual1_d)
+        deconv1 = self._sep("deconv1_b", t, res=residual1_d, out=self._split_out(B, S2, S2, f1))
         del deconv2, concat1, cnn0_strided, residual1_d, t
         deconv1to0 = self._deconv("deconv1to0", deconv1, E(S, f1))
         del deconv1

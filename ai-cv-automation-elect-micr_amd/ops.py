@@ -138,6 +138,13 @@ def sep_fused(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, act=Tr
     assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, w.cout) and w.cin == x.C and w.taps == 1
     if res is not None:
         assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
+    if isinstance(out, SplitAct):   # split32 output for a following split32 GEMM (emd_sep3x3_fused_out_f32)
+        assert not reflect and precision == PREC_BF16X3
+        rc = lib.emd_sep3x3_fused_out_f32(x.ptr, x.ld, _p(dw_dev), _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
+                                          res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
+                                          out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, _act(act), _lib.stream_ptr(stream))
+        _lib.check(rc, "emd_sep3x3_fused_out_f32")
+        return out
     fn = lib.emd_sep3x3_fused_reflect_f32 if reflect else lib.emd_sep3x3_fused_f32
     rc = fn(x.ptr, x.ld, _p(dw_dev), _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2),
                                   _p(shift2), res.ptr if res is not None else C.c_void_p(0),
@@ -370,6 +377,13 @@ def conv1x1_split32(x: SplitAct, w: PackedWeights, scale1, shift1, out: Act, act
         return out, mean, var
     if res is not None:
         assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
+    if isinstance(out, SplitAct):   # split32 output for a following split32 GEMM (emd_conv1x1_split32_out_f32)
+        rc = lib.emd_conv1x1_split32_out_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
+                                             res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
+                                             out.ptr, out.ld, C.c_long(x.B * x.H * x.W), x.C, w.cout, _act(act),
+                                             _lib.stream_ptr(stream))
+        _lib.check(rc, "emd_conv1x1_split32_out_f32")
+        return out
     rc = lib.emd_conv1x1_split32_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
                                      res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
                                      out.ptr, out.ld, C.c_long(x.B * x.H * x.W), x.C, w.cout, _act(act),

@@ -912,11 +912,13 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
 
         torch.set_num_threads(CPU_THREADS)
         t0 = time.perf_counter()
-        G.tower_gradients(lq[:1], hq[:1], weights, S, dtype=torch.float32)
+        # float64: PyTorch-CPU's float32 conv backward has twice died of glibc heap corruption in a process that had also
+        # initialised the GPU runtime (never in a CPU-only process on the same host)
+        G.tower_gradients(lq[:1], hq[:1], weights, S, dtype=torch.float64)
         el = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s trained", "cores": CPU_THREADS, "kind": "port",
                                "sample": f"forward + backward of ONE tower of 1 image ([1,{S},{S},1]), oracle/denoiser_graph.py "
-                                         f"tower_gradients (PyTorch-CPU autograd, float32, {CPU_THREADS} threads), {el:.1f} s; "
+                                         f"tower_gradients (PyTorch-CPU autograd, float64, {CPU_THREADS} threads), {el:.1f} s; "
                                          "optimizer step not included"}
     return out
 
@@ -997,11 +999,19 @@ def worker(a):
     else:
         primary, riders = a.workload, []
 
+    def note(msg):   # progress on stderr: a run that dies mid-way says where (stdout carries the one JSON line only)
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"workload {primary} (primary) ...")
     res = {primary: BENCHES[primary](a, torch, emdenoise, dev, timer, rank, world, want_cpu, True)}
+    note(f"workload {primary}: {res[primary]['ms_per_step']:.3f} ms per step")
     failed = []
     for w in riders:
         try:
+            note(f"rider {w} ...")
             res[w] = BENCHES[w](a, torch, emdenoise, dev, timer, rank, world, want_cpu and w != "A", False)
+            note(f"rider {w}: {res[w]['ms_per_step']:.3f} ms per step")
         except Exception as e:
             if multi:   # the other ranks sit in this workload's collectives: fail the job, the launcher tears every rank down
                 raise
@@ -1033,6 +1043,7 @@ def worker(a):
         if k in prim:
             out[k] = prim[k]
     if rank == 0 and primary == "D" and not multi:
+        note("on-box peaks ...")
         out["measured_peaks"] = measured_peaks(torch, dev)
     for w in riders:
         r = res[w]

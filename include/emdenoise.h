@@ -211,6 +211,17 @@ int emd_deconv3x3s2_split32_f32(const void* xs, int ldx, const uint16_t* const w
 int emd_conv1x1_split32_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
                             const float* shift1, const float* scale2, const float* shift2, const float* res,
                             int ldres, float* y, int ldy, long M, int Cin, int Cout, int act, emd_stream_t stream);
+/* emd_conv1x1_split32_f32 / emd_sep3x3_fused_f32 writing y as a split32 tensor (pitch ldy in 4-byte units, a multiple of 32;
+ * y 128-byte aligned; channels Cout..ceil32(Cout) zero; the fused separable form needs Cout % 32 == 0): the producer of a
+ * split32 convolution's input writes no fp32 activation and needs no emd_to_split32_f32 pass (graph D: deconv2_b -> deconv2to1,
+ * deconv1_b -> deconv1to0, machine_learning/denoiser.py:357-362, :369-374).  Same values as the fp32 form, then split. */
+int emd_conv1x1_split32_out_f32(const void* xs, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                                const float* shift1, const float* scale2, const float* shift2, const float* res,
+                                int ldres, void* y, int ldy, long M, int Cin, int Cout, int act, emd_stream_t stream);
+int emd_sep3x3_fused_out_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                             const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                             const float* res, int ldres, void* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                             emd_stream_t stream);
 /* emd_deconv3x3s2_split32_f32 as ONE launch: a workgroup computes the four output phases of its 256 input pixels back to
  * back, so the input is read from HBM once instead of once per phase launch.  Same arguments, bit-identical results. */
 int emd_deconv3x3s2_fused_split32_f32(const void* xs, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4],

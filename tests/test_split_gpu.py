@@ -270,6 +270,43 @@ def test_deconv3x3s2_split32_equals_deconv(B, H, W, ci, co, out_split):
         assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,res", [(2, 16, 16, 256, 256, True), (1, 24, 20, 728, 132, False), (1, 8, 8, 64, 36, True)])
+def test_conv1x1_split32_with_split32_output(B, H, W, ci, co, res):
+    """emd_conv1x1_split32_out_f32: the split32 tensor it writes == emd_to_split32_f32 of what emd_conv1x1_split32_f32 writes
+    (padding channels zero), bit for bit."""
+    from emdenoise import ops
+
+    x = rnd((B, H, W, ci), 91, positive=True)
+    pw = ops.PackedWeights(rnd((1, ci, co), 92, scale=(2.0 / (ci + co)) ** 0.5), False, dev())
+    s1, t1 = up(rnd((co,), 93, 0.3) + 1.0), up(rnd((co,), 94, 0.5))
+    r = ops.Act(up(rnd((B, H, W, co), 95))) if res else None
+    xs = ops.to_split32(ops.Act(up(x)))
+    want = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()), res=r)
+    got = ops.SplitAct(B, H, W, co, dev())
+    got.buf.fill_(float("nan"))
+    ops.conv1x1_split32(xs, pw, s1, t1, got, res=r)
+    torch.cuda.synchronize()
+    assert torch.equal(got.buf.view(torch.int32), ops.to_split32(want).buf.view(torch.int32))
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,res", [(2, 16, 32, 128, 128, True), (1, 8, 16, 64, 64, False), (1, 24, 48, 384, 96, True)])
+def test_sep_fused_with_split32_output(B, H, W, ci, co, res):
+    """emd_sep3x3_fused_out_f32 == emd_to_split32_f32(emd_sep3x3_fused_f32), bit for bit."""
+    from emdenoise import ops
+
+    x = ops.Act(up(rnd((B, H, W, ci), 96, positive=True)))
+    dw = up(rnd((9, ci), 97, 0.35))
+    pw = ops.PackedWeights(rnd((1, ci, co), 98, scale=(2.0 / (ci + co)) ** 0.5), False, dev())
+    s1, t1 = up(rnd((co,), 99, 0.3) + 1.0), up(rnd((co,), 100, 0.5))
+    r = ops.Act(up(rnd((B, H, W, co), 101))) if res else None
+    want = ops.sep_fused(x, dw, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()), res=r)
+    got = ops.SplitAct(B, H, W, co, dev())
+    got.buf.fill_(float("nan"))
+    ops.sep_fused(x, dw, pw, s1, t1, got, res=r)
+    torch.cuda.synchronize()
+    assert torch.equal(got.buf.view(torch.int32), ops.to_split32(want).buf.view(torch.int32))
+
+
 @pytest.mark.parametrize("B,H,W,ci,co,stride,rate", [
     (2, 16, 16, 64, 128, 1, 1), (1, 33, 21, 96, 132, 1, 1), (1, 32, 32, 728, 728, 1, 6), (2, 18, 14, 40, 128, 2, 1),
     (2, 24, 24, 64, 64, 1, 1), (1, 17, 19, 32, 36, 1, 3)])
