@@ -223,6 +223,11 @@ SIGNATURES = {
     "emd_adam_step_dev_f32": (C.c_int, [_c_float_p] * 4 + [C.c_long, _c_float_p] + [C.c_float] * 4 + [_c_float_p, C.c_float, C.c_void_p]),
     "emd_bn_infer_fold2_f32": (C.c_int, [_c_float_p] * 8 + [C.c_float, C.c_int] + [_c_float_p] * 6 + [C.c_void_p]),
     "emd_bn_infer_grads_f32": (C.c_int, [_c_float_p] * 4 + [C.c_int] + [_c_float_p] * 4 + [C.c_void_p]),
+    "emd_sep3x3_gemm_supported": (C.c_int, [C.c_int] * 4),
+    # x ldx dw whi wlo scale1 shift1 scale2 shift2 res ldres y ldy B H W Cin Cout act stream
+    "emd_sep3x3_gemm_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                      _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
     "emd_sep3x3_dual_supported": (C.c_int, [C.c_int] * 5),
     # x ldx dw whi wlo scale1 shift1 y ldy w2hi w2lo scale_b shift_b y2 ldy2 B H W Cin Cout Cout2 act stream
     "emd_sep3x3_dual_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int,

@@ -330,6 +330,9 @@ class DenoiserEngine:
                                  shift2=p.get("shift2"), res=res, precision=self.precision)
         if out is None:
             out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
+        if self._sep_gemm_ok(x, L) and not isinstance(out, ops.SplitAct):
+            # the 728-channel flow: the depthwise stage is computed per K step inside the pointwise GEMM (csrc/sep_gemm.hip)
+            return ops.sep_gemm(x, p["dw"], p["pw"], p["scale"], p["shift"], out, scale2=p.get("scale2"), shift2=p.get("shift2"), res=res)
         if self.precision == ops.PREC_BF16X3 and ops.conv1x1_split32_supported(x.B * Ho * Wo, L.cin, L.cout):
             # matrix-core bound layers (the 728-channel flow): the depthwise kernel writes its result pre-split into
             # bf16 hi/lo, the pointwise GEMM gets both operands by LDS-DMA (csrc/gemm_split.hip); same arithmetic
@@ -341,6 +344,10 @@ class DenoiserEngine:
         ops.conv1x1(tmp, p["pw"], p["scale"], p["shift"], out, scale2=p.get("scale2"), shift2=p.get("shift2"),
                     res=res, precision=self.precision)
         return out
+
+    def _sep_gemm_ok(self, x, L):
+        return (self.fuse_sep and self.precision == ops.PREC_BF16X3 and os.environ.get("EMD_D_SEPGEMM", "1") != "0"
+                and ops.sep_gemm_supported(x, L.cout, L.stride, L.rate))
 
     def _sep_and_projection(self, sep_key, conv_key, x):
         """A decoder pair that reads the same tensor (denoiser.py:356-359, :368-371, :380-383): the separable conv `sep_key`
@@ -374,7 +381,9 @@ class DenoiserEngine:
         """The 27 separable convs at 1/16 resolution; with an even batch as two halves on two streams (streams.TwoHalves)."""
         out = ops.Act.empty(x.B, x.H, x.W, self.layers["cnn4_last"].cout, self.device)
         half = x.B // 2
-        if (self.two_streams and x.B % 2 == 0 and half >= 1 and self.precision == ops.PREC_BF16X3
+        # with the depthwise stage inside the GEMM there is no bandwidth-bound kernel left for the other half's GEMM to overlap with
+        fused = self._sep_gemm_ok(x, self.layers["cnn4_a"]) and os.environ.get("EMD_D_TWO_STREAMS_FUSED", "0") != "1"
+        if (self.two_streams and not fused and x.B % 2 == 0 and half >= 1 and self.precision == ops.PREC_BF16X3
                 and ops.conv1x1_split32_supported(half * x.H * x.W, x.C, out.C)):
             return self._halves.run(x, out, self._middle_chain)
         for _ in self._middle_chain(x, out):

@@ -154,6 +154,24 @@ def sep_fused(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, act=Tr
     return out
 
 
+def sep_gemm_supported(x: Act, cout: int, stride: int = 1, rate: int = 1) -> bool:
+    return stride == 1 and rate == 1 and bool(_lib.load().emd_sep3x3_gemm_supported(x.H, x.W, x.C, cout))
+
+
+def sep_gemm(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, act=True, scale2=None, shift2=None, res: Act | None = None,
+             stream=None):
+    """Separable conv with the depthwise stage computed inside the pointwise GEMM (emd_sep3x3_gemm_f32): the 728-channel flow."""
+    lib = _lib.load()
+    assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, w.cout) and w.cin == x.C and w.taps == 1
+    if res is not None:
+        assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
+    rc = lib.emd_sep3x3_gemm_f32(x.ptr, x.ld, _p(dw_dev), _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
+                                 res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0, out.ptr, out.ld,
+                                 x.B, x.H, x.W, x.C, w.cout, _act(act), _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_sep3x3_gemm_f32")
+    return out
+
+
 def sep_dual_supported(x: Act, cout: int, cout2: int) -> bool:
     return bool(_lib.load().emd_sep3x3_dual_supported(x.H, x.W, x.C, cout, cout2))
 

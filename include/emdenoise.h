@@ -420,6 +420,17 @@ int emd_sep3x3_dual_f32(const float* x, int ldx, const float* dw, const uint16_t
                         const uint16_t* w2lo, const float* scale_b, const float* shift_b, float* y2, int ldy2, int B, int H,
                         int W, int Cin, int Cout, int Cout2, int act, emd_stream_t stream);
 
+/* The separable conv of the 728-channel flow as ONE kernel (csrc/sep_gemm.hip): the depthwise 3x3 stage (stride 1, TF SAME) is
+ * computed per 32-channel K step inside the pointwise GEMM -- no depthwise launch, no intermediate tensor, 128-pixel x
+ * 384-channel workgroup tiles (machine_learning/denoiser.py:110-136 as used by :297-302, :312-325).  Arguments as
+ * emd_sep3x3_fused_f32 (split-bf16 precision only).  Supported (emd_sep3x3_gemm_supported): H%4==0, W%32==0,
+ * 256 <= Cin <= 4096, 384 < Cout <= 768, Cin%4==0, Cout%4==0. */
+int emd_sep3x3_gemm_supported(int H, int W, int Cin, int Cout);
+int emd_sep3x3_gemm_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                        const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                        const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                        emd_stream_t stream);
+
 /* emd_sep3x3_fused_f32 with the depthwise stage reading the tf.pad(REFLECT, 1) border instead of zeros: the
  * stride-1 strided_conv_block(pad_size=(1,1)) of graph G (:205-243).  Same arguments and support rule. */
 int emd_sep3x3_fused_reflect_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,

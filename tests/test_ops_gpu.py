@@ -344,6 +344,48 @@ def test_sep_dual(B, H, W, ci, co, co2):
     assert rel_l2(g2, want2.torch().cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,res,extra", [
+    (2, 32, 32, 728, 728, True, False),     # the middle flow's third block conv (residual add), graph D at 512 px
+    (1, 8, 32, 256, 728, False, False),     # cnn3-like: K = 8 steps
+    (1, 4, 64, 728, 728, True, True),       # two tiles side by side (the patch's left / right columns are real pixels), extra BN
+    (1, 12, 32, 260, 388, False, False),    # channel tail (260 = 8 x 32 + 4) and an N half with 4 real columns
+])
+def test_sep_gemm(B, H, W, ci, co, res, extra):
+    """emd_sep3x3_gemm_f32 (depthwise stage inside the pointwise GEMM) against oracle/tf_ops.py, float64: depthwise 3x3 (SAME) ->
+    pointwise -> affine -> relu6 [-> affine -> relu6] [+ res]; and against the two-kernel route it replaces."""
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 340, positive=True)
+    dw = rnd((3, 3, ci, 1), 341, 0.35)
+    pw = rnd((1, 1, ci, co), 342, scale=(2.0 / (ci + co)) ** 0.5)
+    s1, t1 = rnd((co,), 343, 0.2) + 1, rnd((co,), 344, 0.5)
+    s2, t2 = rnd((co,), 345, 0.2) + 1, rnd((co,), 346, 0.5)
+    r = rnd((B, H, W, co), 347, positive=True)
+    y = T.relu6_t(T.conv2d_t(T.depthwise_conv2d_t(t64(x), t64(dw)), t64(pw)) * t64(s1) + t64(t1))
+    if extra:
+        y = T.relu6_t(y * t64(s2) + t64(t2))
+    if res:
+        y = y + t64(r)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    xa = to_act(x, ld=ci + 64, c0=32)
+    assert ops.sep_gemm_supported(xa, co)
+    out = out_act(B, H, W, co, ld=co + 8, c0=4)
+    pk = ops.PackedWeights(pw[0], False, dev())
+    kw = dict(scale2=d(s2) if extra else None, shift2=d(t2) if extra else None, res=to_act(r, ld=co + 12, c0=8) if res else None)
+    ops.sep_gemm(xa, d(dw[..., 0]), pk, d(s1), d(t1), out, **kw)
+    torch.cuda.synchronize()
+    got = out.torch().cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_l2(got, y.numpy()) < TOL_X3
+    full = out.buf.cpu().numpy()
+    assert np.isnan(full[..., :4]).all() and np.isnan(full[..., 4 + co:]).all()   # nothing written outside the slice
+    if ops.conv1x1_split32_supported(B * H * W, ci, co):
+        want = ops.sep_split32(xa, d(dw[..., 0]), pk, d(s1), d(t1), out_act(B, H, W, co), **kw)
+        torch.cuda.synchronize()
+        assert rel_l2(got, want.torch().cpu().numpy()) < 2e-6
+
+
 def test_sep_fused_falls_back_cleanly():
     from emdenoise import _lib, ops
 
