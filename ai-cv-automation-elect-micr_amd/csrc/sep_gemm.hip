@@ -198,38 +198,47 @@ __global__ __launch_bounds__(256, 1) void sep_gemm_kernel(const SepGemmParams p)
             }
         }
         __builtin_amdgcn_s_barrier();   // (b) A slice visible; patch and depthwise weights are free
-        if (k + 1 < nk) issue(k + 1, bslot ^ 1);
-
-        // 2 sub-steps of 16 channels
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        // fragments of BOTH 16-channel sub-steps are requested up front (one wave per SIMD: nothing else hides an LDS read's
+        // latency; hipcc otherwise waits for every fragment right where it is first used, a dozen times per step), the next step's
+        // DMA is issued between them
+        bf16x8 ah[2][4], al[2][4], bh[2][3], bl[2][3];
+        auto load_frags = [&](int ks) {
             const unsigned char* bb = smem + OFF_B + (bslot * 2 + ks) * B16_BYTES;
-            bf16x8 ah[4], al[4], bh[3], bl[3];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = i * 32 + fr;
                 const int sw = (r >> 1) & 7;
                 const unsigned char* row = smem + OFF_A + r * 128;
-                ah[i] = *reinterpret_cast<const bf16x8*>(row + (((ks * 4 + fh) ^ sw) << 4));
-                al[i] = *reinterpret_cast<const bf16x8*>(row + (((ks * 4 + 2 + fh) ^ sw) << 4));
+                ah[ks][i] = *reinterpret_cast<const bf16x8*>(row + (((ks * 4 + fh) ^ sw) << 4));
+                al[ks][i] = *reinterpret_cast<const bf16x8*>(row + (((ks * 4 + 2 + fh) ^ sw) << 4));
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int n = wv * 96 + j * 32 + fr;
                 const int sw = (n >> 2) & 3;
                 const unsigned char* row = bb + n * 64;
-                bh[j] = *reinterpret_cast<const bf16x8*>(row + ((fh ^ sw) << 4));
-                bl[j] = *reinterpret_cast<const bf16x8*>(row + (((2 + fh) ^ sw) << 4));
+                bh[ks][j] = *reinterpret_cast<const bf16x8*>(row + ((fh ^ sw) << 4));
+                bl[ks][j] = *reinterpret_cast<const bf16x8*>(row + (((2 + fh) ^ sw) << 4));
             }
+        };
+        load_frags(0);
+        issue(k + 1 < nk ? k + 1 : k, bslot ^ 1);   // past the end: the last step again, into the slot nobody reads (no branch here)
+        load_frags(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {   // small terms first (as gemm_conv.hip / gemm_split.hip)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
                 }
-        }
+        // keep the issue order: 28 fragment reads (with the DMA pieces between the two sets), then the 72 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 20, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 72, 0);
     }
 
     // ---- epilogue straight from the C/D layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)

@@ -274,6 +274,8 @@ class DenoiserEngine:
         self.precision = {"bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[precision]
         self.layers = declare_layers(variant)
         self.two_streams = os.environ.get("EMD_D_TWO_STREAMS", "1") != "0"   # see _middle_flow
+        self.pipeline = os.environ.get("EMD_D_PIPELINE", "1") != "0"          # see forward
+        self._pipe_streams = None
         self._halves = streams.TwoHalves(device)
         self.P = {}
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
@@ -346,7 +348,7 @@ class DenoiserEngine:
         return out
 
     def _sep_gemm_ok(self, x, L):
-        return (self.fuse_sep and self.precision == ops.PREC_BF16X3 and os.environ.get("EMD_D_SEPGEMM", "1") != "0"
+        return (self.fuse_sep and self.precision == ops.PREC_BF16X3 and os.environ.get("EMD_D_SEPGEMM", "0") == "1"   # opt-in: measured slower than the two-kernel route
                 and ops.sep_gemm_supported(x, L.cout, L.stride, L.rate))
 
     def _sep_and_projection(self, sep_key, conv_key, x):
@@ -444,13 +446,52 @@ class DenoiserEngine:
     # ---- the graph
     def forward(self, x):
         """x: torch CUDA float32 [B,S,S,1] contiguous, S a multiple of 16 -> [B,S,S,1].
-        No output clip (denoiser.py:396; the clip is applied by Denoiser.denoise_crop, :649)."""
+        No output clip (denoiser.py:396; the clip is applied by Denoiser.denoise_crop, :649).
+
+        With an even batch of >= 8 images the two halves run as two staggered passes on two HIP streams (EMD_D_PIPELINE=0:
+        one pass): half B starts its encoder when half A has finished its own, and its 1/16-resolution flow when A has
+        finished that, so that the matrix-core bound middle of one half shares the chip with the HBM-bound encoder / decoder
+        of the other.  Images are independent and every kernel treats them so: same bits as the single pass."""
         import torch
 
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[3] == 1
+        B = x.shape[0]
+        if not (self.pipeline and B % 2 == 0 and B >= 8):
+            return self._forward_pass(x)
+        out = torch.empty_like(x)
+        half = B // 2
+        main = torch.cuda.current_stream(self.device)
+        if self._pipe_streams is None:
+            self._pipe_streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        sa, sb = self._pipe_streams
+        ev = {"enc": torch.cuda.Event(), "mid": torch.cuda.Event()}
+        two = self.two_streams
+        self.two_streams = False          # the halves already are the two streams
+        try:
+            sa.wait_stream(main)
+            sb.wait_stream(main)
+            with torch.cuda.stream(sa):
+                self._forward_pass(x[:half], out[:half], stage=lambda name: ev[name].record(sa))
+            with torch.cuda.stream(sb):
+                self._forward_pass(x[half:], out[half:], stage=lambda name: sb.wait_event(ev[name]), stage_first=True)
+            main.wait_stream(sa)
+            main.wait_stream(sb)
+        finally:
+            self.two_streams = two
+        return out
+
+    def _forward_pass(self, x, out=None, stage=None, stage_first=False):
+        """One pass over a batch (or half of one).  stage(name) is called at the encoder / middle-flow boundaries: after the
+        stage's launches (stage_first=False: the leading half records an event) or before the NEXT stage's launches of the
+        trailing half (stage_first=True: it waits for the leading half's event of the stage it is about to enter... the
+        encoder of the trailing half waits for "enc", its middle flow for "mid")."""
+        import torch
+
         B, S = x.shape[0], x.shape[1]
         assert x.shape[2] == S and S % 16 == 0 and S >= 16, "square crops with side a multiple of 16"
         dev = self.device
+        if stage is not None and stage_first:
+            stage("enc")
         E = lambda H, Cc: ops.Act.empty(B, H, H, Cc, dev)
         P = self.P
         S2, S4, S8, S16 = S // 2, S // 4, S // 8, S // 16
@@ -492,6 +533,8 @@ class DenoiserEngine:
         cnn3_last = self._sep("cnn3_last", cnn3)
         cnn3_strided = self._sep("cnn3_strided", cnn3_last, res=residual3)
         del cnn2_strided, cnn3, cnn3_last, residual3
+        if stage is not None:
+            stage("mid" if stage_first else "enc")
         # encoder 4 (:312-322) and the middle flow (:324-325)
         cur = self._middle_flow(cnn3_strided)
         del cnn3_strided
@@ -521,6 +564,8 @@ class DenoiserEngine:
             del pooled, img_lvl, up
         aspp = self._conv1x1("aspp_reduce", cat)
         del cur, cat, t, curs
+        if stage is not None and not stage_first:
+            stage("mid")
         # decoder (:350-384)
         ops.resize_bilinear(aspp, concat2.slice(0, aspp_output))            # deconv3 (:350)
         residual2_d = self._conv1x1("residual2_d", concat2)
@@ -536,7 +581,8 @@ class DenoiserEngine:
         t, residual0_d = self._sep_and_projection("deconv0_a", "residual0_d", deconv1to0)
         deconv0 = self._sep("deconv0_b", t, res=residual0_d)
         del deconv1to0, residual0_d, t
-        out = torch.empty((B, S, S, 1), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((B, S, S, 1), dtype=torch.float32, device=dev)
         pf = P["deconv_final"]
         # the twin clips in-graph (denoiser-multi-gpu.py:534-538); D does not (denoiser.py:396)
         ops.conv3x3_cout1(deconv0, pf["w"], pf["scale_f"], pf["shift_f"], out, act=2 if self.variant == "Dprime" else 1)

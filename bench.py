@@ -532,15 +532,15 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
 
     ms = timer.run(step, steps, warmup)
     med = timer.median_event_ms
-    # per-kernel-family device time of ONE more step on the single-stream launch sequence (with the two half batches on two
-    # streams -- streams.TwoHalves -- a launch's event pair would also span the other half's kernels)
-    two = eng.two_streams
-    eng.two_streams = False
+    # per-kernel-family device time of ONE more step on the single-stream launch sequence (with the two half batches staggered on
+    # two streams -- DenoiserEngine.forward -- a launch's event pair would also span the other half's kernels)
+    two, pipe = eng.two_streams, eng.pipeline
+    eng.two_streams = eng.pipeline = False
     try:
         with FamilyTimer(torch, ops) as fam:
             step()
     finally:
-        eng.two_streams = two
+        eng.two_streams, eng.pipeline = two, pipe
     gemm_ms = fam.matrix_ms()
     dw_ms = fam.ms.get("dw3x3", 0.0) + fam.ms.get("dw3x3_split32", 0.0)
     dw_bytes = fam.bytes_.get("dw3x3", 0.0) + fam.bytes_.get("dw3x3_split32", 0.0)

@@ -179,6 +179,11 @@ def test_two_stream_halves_are_the_same_bits(weights):
     for make in (lambda: emdenoise.DenoiserEngine(weights, dev, "bf16x3"), lambda: gan.GeneratorEngine(gan.synthetic_weights(), dev)):
         eng = make()
         assert eng.two_streams
+        if hasattr(eng, "pipeline"):
+            # graph D: the staggered two-half pipeline over the whole graph (DenoiserEngine.forward) == one pass, bit for bit
+            piped = eng.forward(x).clone()
+            eng.pipeline = False
+            assert torch.equal(piped, eng.forward(x))
         both = eng.forward(x).clone()
         replay = GraphedForward(eng)(x).clone()        # the fork / join of the two streams is capturable as well
         assert torch.equal(replay, both)
