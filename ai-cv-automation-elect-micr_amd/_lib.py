@@ -251,6 +251,7 @@ DEV_SIGNATURES = {
     "emd_debug_split_variant": (None, [C.c_int]),
     "emd_debug_split_stamps": (None, [C.c_void_p]),
     "emd_debug_sep_stamps": (None, [C.c_void_p]),
+    "emd_debug_sepgemm_stamps": (None, [C.c_void_p]),
     "emd_debug_stream_copy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
     "emd_debug_mfma_peak_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }

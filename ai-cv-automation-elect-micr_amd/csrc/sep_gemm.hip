@@ -51,6 +51,7 @@ struct SepGemmParams {
     int H, W, Cin, N, Npad, Ktot;
     int ldx, ldy, ldres, act;
     int tiles_x, tiles_y;   // tiles per image row / column
+    long long* stamps;      // dev hook (emd_debug_sepgemm_stamps): per-workgroup phase cycle sums, NULL otherwise
 };
 
 constexpr int TM = 128, NH = 384, TROWS = 4, TCOLS = 32;
@@ -160,11 +161,16 @@ __global__ __launch_bounds__(256, 1) void sep_gemm_kernel(const SepGemmParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    if (p.stamps) tprev = __builtin_amdgcn_s_memtime();
+#define SG_STAMP(i) if (p.stamps) { const long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tprev; tprev = t_; }
     issue(0, 0);
     for (int k = 0; k < nk; ++k) {
         const int bslot = k & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SG_STAMP(0)                     // own DMA landed
         __builtin_amdgcn_s_barrier();   // (a) patch, depthwise weights and W slice of step k have landed; every wave is done with step k-1
+        SG_STAMP(1)
 
         // depthwise 3x3 of the step's 32 channels -> bf16 hi / lo A slice
         {
@@ -197,7 +203,9 @@ __global__ __launch_bounds__(256, 1) void sep_gemm_kernel(const SepGemmParams p)
                 *reinterpret_cast<u32x2*>(row + (((a_lc + 2) ^ sw) << 4)) = u32x2{l0, l1};
             }
         }
+        SG_STAMP(2)                     // depthwise stage
         __builtin_amdgcn_s_barrier();   // (b) A slice visible; patch and depthwise weights are free
+        SG_STAMP(3)
         // fragments of BOTH 16-channel sub-steps are requested up front (one wave per SIMD: nothing else hides an LDS read's
         // latency; hipcc otherwise waits for every fragment right where it is first used, a dozen times per step), the next step's
         // DMA is issued between them
@@ -239,8 +247,19 @@ __global__ __launch_bounds__(256, 1) void sep_gemm_kernel(const SepGemmParams p)
         __builtin_amdgcn_sched_group_barrier(0x010, 20, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 72, 0);
+        if (p.stamps) {   // the MFMA results are needed for the stamp to mean "MFMAs done": touch one accumulator
+            asm volatile("" ::"v"(acc[3][2][15]));
+        }
+        SG_STAMP(4)
     }
 
+    if (p.stamps && tid == 0) {
+        long long* o = p.stamps + (long)blockIdx.x * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[i] = ph[i];
+        o[6] = __builtin_amdgcn_s_memtime();
+    }
+#undef SG_STAMP
     // ---- epilogue straight from the C/D layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     const float hi = p.act == 1 ? 6.f : __builtin_inff();
     const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;
@@ -276,7 +295,12 @@ __global__ __launch_bounds__(256, 1) void sep_gemm_kernel(const SepGemmParams p)
     }
 }
 
+long long* g_sg_stamps = nullptr;
+
 }  // namespace
+
+// dev hook (include/emdenoise_dev.h): device buffer (8 x int64 per workgroup) for per-phase s_memtime sums, NULL = off
+extern "C" void emd_debug_sepgemm_stamps(void* buf) { g_sg_stamps = static_cast<long long*>(buf); }
 
 extern "C" int emd_sep3x3_gemm_supported(int H, int W, int Cin, int Cout) {
     // matrix-core bound separable convs: stride 1, rate 1, whole 4 x 32 pixel tiles, the K loop long enough to amortise a tile
@@ -304,7 +328,7 @@ extern "C" int emd_sep3x3_gemm_f32(const float* x, int ldx, const float* dw, con
     p.Npad = (Cout + kNPadTo - 1) / kNPadTo * kNPadTo;
     p.Ktot = (Cin + kBK - 1) / kBK * kBK;
     p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act;
-    p.tiles_x = W / TCOLS; p.tiles_y = H / TROWS;
+    p.tiles_x = W / TCOLS; p.tiles_y = H / TROWS; p.stamps = g_sg_stamps;
     const long tiles = (long)B * p.tiles_x * p.tiles_y;
     EMD_REQUIRE(tiles * 2 <= 0x7fffffffL, EMD_E_UNSUPPORTED, "emd_sep3x3_gemm_f32: grid too large");
     hipLaunchKernelGGL(sep_gemm_kernel, dim3((unsigned)(tiles * 2)), dim3(256), 0, static_cast<hipStream_t>(stream), p);

@@ -274,7 +274,10 @@ class DenoiserEngine:
         self.precision = {"bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[precision]
         self.layers = declare_layers(variant)
         self.two_streams = os.environ.get("EMD_D_TWO_STREAMS", "1") != "0"   # see _middle_flow
-        self.pipeline = os.environ.get("EMD_D_PIPELINE", "1") != "0"          # see forward
+        # staggered two-half pipeline over the whole graph (see forward): opt-in -- measured 27.5 ms against 26.3 ms for the
+        # single pass with the two-stream middle flow (profiles/r02_experiments.txt): the halves' HBM-bound stages collide more
+        # than their matrix-core stages overlap
+        self.pipeline = os.environ.get("EMD_D_PIPELINE", "0") == "1"
         self._pipe_streams = None
         self._halves = streams.TwoHalves(device)
         self.P = {}
@@ -448,8 +451,8 @@ class DenoiserEngine:
         """x: torch CUDA float32 [B,S,S,1] contiguous, S a multiple of 16 -> [B,S,S,1].
         No output clip (denoiser.py:396; the clip is applied by Denoiser.denoise_crop, :649).
 
-        With an even batch of >= 8 images the two halves run as two staggered passes on two HIP streams (EMD_D_PIPELINE=0:
-        one pass): half B starts its encoder when half A has finished its own, and its 1/16-resolution flow when A has
+        EMD_D_PIPELINE=1 (opt-in, see __init__): an even batch of >= 8 images runs as two staggered passes on two HIP
+        streams: half B starts its encoder when half A has finished its own, and its 1/16-resolution flow when A has
         finished that, so that the matrix-core bound middle of one half shares the chip with the HBM-bound encoder / decoder
         of the other.  Images are independent and every kernel treats them so: same bits as the single pass."""
         import torch

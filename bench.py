@@ -236,6 +236,7 @@ class FamilyTimer:
     def __init__(self, torch, ops):
         self.torch, self.ops = torch, ops
         self.ev, self.flops, self.bytes_, self.orig = {}, {}, {}, {}
+        self.pw_shapes = []
 
     def _account(self, name, args, kw):
         ops = self.ops
@@ -243,6 +244,8 @@ class FamilyTimer:
             if name in ("conv1x1", "conv1x1_split32"):
                 x, w, out = args[0], args[1], (args[4] if len(args) > 4 else kw["out"])
                 self.flops[name] = self.flops.get(name, 0.0) + 2.0 * out.B * out.H * out.W * w.cin * w.cout
+                if name == "conv1x1_split32":   # the 728-channel flow on its own (north_star's pointwise path): remember which launches
+                    self.pw_shapes.append((w.cin, w.cout, out.B * out.H * out.W, 2.0 * out.B * out.H * out.W * w.cin * w.cout))
             elif name in ("conv3x3", "conv3x3_split32"):
                 w, out = args[1], (args[4] if len(args) > 4 else kw["out"])
                 self.flops[name] = self.flops.get(name, 0.0) + 2.0 * out.B * out.H * out.W * 9 * w.cin * w.cout
@@ -545,6 +548,11 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     dw_ms = fam.ms.get("dw3x3", 0.0) + fam.ms.get("dw3x3_split32", 0.0)
     dw_bytes = fam.bytes_.get("dw3x3", 0.0) + fam.bytes_.get("dw3x3_split32", 0.0)
     pw_ms, pw_flops = fam.ms.get("conv1x1_split32", 0.0), 3.0 * fam.flops.get("conv1x1_split32", 0.0)
+    # ... and the 728-channel launches among them (36 middle-flow blocks + block 4 + ASPP + cnn3*: K or N = 728), which are the
+    # matrix-core bound ones; the rest of the family (K, N <= 384 at 128^2) is HBM-bound
+    pw728_ms = sum(e0.elapsed_time(e1) for (e0, e1), sh in zip(fam.ev.get("conv1x1_split32", []), fam.pw_shapes) if 728 in sh[:2])
+    pw728_flops = 3.0 * sum(sh[3] for sh in fam.pw_shapes if 728 in sh[:2])
+    pw728_n = sum(1 for sh in fam.pw_shapes if 728 in sh[:2])
     scale = (B / 32.0) * (H * W) / (512.0 * 512.0)
     alg_flops = 2.0 * D_GMAC_MATRIX_B32_512 * 1e9 * scale
     passes = 3 if a.precision == "bf16x3" else 1
@@ -585,7 +593,11 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
         "pointwise": {"bound": "mfma", "kernel": "gemm_split_kernel (the 1x1 halves of the 728-channel separable convs, LDS-DMA from split32)",
                       "launches": fam.launches.get("conv1x1_split32", 0), "issued_flops_per_step": pw_flops, "ms_per_step": round(pw_ms, 3),
                       "issued_tflops": round(pw_flops / (max(pw_ms, 1e-9) * 1e-3) / 1e12, 1),
-                      "frac_of_2500": round(pw_flops / (max(pw_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
+                      "frac_of_2500": round(pw_flops / (max(pw_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                      "channels_728": {"launches": pw728_n, "issued_flops_per_step": pw728_flops, "ms_per_step": round(pw728_ms, 3),
+                                       "issued_tflops": round(pw728_flops / (max(pw728_ms, 1e-9) * 1e-3) / 1e12, 1),
+                                       "frac_of_2500": round(pw728_flops / (max(pw728_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                       "note": "the launches with K or N = 728 (the matrix-core bound ones); the other launches of the family are HBM-bound"}},
         "kernel_family_ms": fam.table(),
     }
     # the headline pointwise GEMM on its own (32768 x 728 x 728 at B = 32: 40 of D's layers), interleaved rounds in this
@@ -1053,7 +1065,18 @@ def worker(a):
             out[k] = prim[k]
     if rank == 0 and primary == "D" and not multi:
         note("on-box peaks ...")
-        out["measured_peaks"] = measured_peaks(torch, dev)
+        pk = out["measured_peaks"] = measured_peaks(torch, dev)
+        # the same fractions against what THIS device delivers (nominal and measured peaks, both stated)
+        if "stream_copy_GBps" in pk:
+            out["roofline"]["frac_of_measured_stream_copy"] = round(out["roofline"]["achieved"] / pk["stream_copy_GBps"], 4)
+            if out["roofline"].get("traffic"):
+                out["roofline"]["hbm_busy_frac_of_measured_stream_copy"] = round(
+                    out["roofline"]["traffic"] / (prim["ms_per_step"] * 1e-3) / 1e9 / pk["stream_copy_GBps"], 4)
+            out["depthwise"]["frac_of_measured_stream_copy"] = round(out["depthwise"]["achieved_GBps"] / pk["stream_copy_GBps"], 4)
+        if "mfma_bf16_TFLOPs" in pk:
+            out["pointwise"]["frac_of_measured_mfma_peak"] = round(out["pointwise"]["issued_tflops"] / pk["mfma_bf16_TFLOPs"], 4)
+            out["pointwise"]["channels_728"]["frac_of_measured_mfma_peak"] = round(
+                out["pointwise"]["channels_728"]["issued_tflops"] / pk["mfma_bf16_TFLOPs"], 4)
     for w in riders:
         r = res[w]
         if "value" in r:

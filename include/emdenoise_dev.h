@@ -23,6 +23,9 @@ void emd_debug_split_variant(int v);
 void emd_debug_split_stamps(void* device_buf);
 /* Device buffer that the fused separable conv writes s_memtime phase stamps into (NULL = off). */
 void emd_debug_sep_stamps(void* device_buf);
+/* The same for emd_sep3x3_gemm_f32 (csrc/sep_gemm.hip): 8 x int64 per workgroup = cycle sums of {own DMA wait, barrier a,
+ * depthwise stage, barrier b, fragment reads + DMA issue + MFMAs, -, end stamp, -}. */
+void emd_debug_sepgemm_stamps(void* device_buf);
 
 
 /* On-box peak micro-benchmarks (csrc/dev_bench.hip), timed by bench.py with HIP events (SURVEY.md 8d asks for the measured

@@ -1,5 +1,5 @@
 # Collects HBM traffic of the dominant kernels with rocprofv3 PMC counters, FETCH_SIZE and WRITE_SIZE in
-# SEPARATE passes (they do not fit one pass on gfx950), and writes profiles/r01_pmc_traffic.json.
+# SEPARATE passes (they do not fit one pass on gfx950), and writes gpurun_out/pmc_traffic.json (copied to profiles/r02_pmc_traffic.json).
 # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of wide coalesced
 # streaming reads -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  Both counters are in KiB.
 cd /tmp && export TMPDIR=/tmp
@@ -32,6 +32,7 @@ for wl in ("K", "D"):
         w_kib = sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [1])), 1)
         out[wl + ":" + nm] = {"launches_sampled": n, "FETCH_SIZE_KiB_avg": f_kib, "WRITE_SIZE_KiB_avg": w_kib,
                               "hbm_bytes_per_launch_corrected": (2.0 * f_kib + w_kib) * 1024.0}
+for v in out.values(): v["steps_sampled"] = 4   # tools/dprofile.py: 1 warm-up + 3 timed forwards; bench K: the [32,512,512,1] launches
 json.dump({"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B read requests as 64 B)", "kernels": out}, open("$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic.json", "w"), indent=1)
 for k, v in out.items(): print(f"{k:60s} n={v['launches_sampled']:4d} fetch {v['FETCH_SIZE_KiB_avg']/1024:10.1f} MiB(raw) write {v['WRITE_SIZE_KiB_avg']/1024:10.1f} MiB -> corrected {v['hbm_bytes_per_launch_corrected']/1e6:10.1f} MB/launch")
 PY
