@@ -145,6 +145,15 @@ SIGNATURES = {
     # dy ldd x ldx K m1 mean m2 mscale mshift mask dx ldo npix C stream
     "emd_bn_bwd_apply_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int] + [_c_float_p] * 6 +
                              [C.c_int, _c_float_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
+    # the per-image forms: ... npix B C ...
+    "emd_bn_train_fold_images_f32": (C.c_int, [_c_float_p] * 7 + [C.c_float, C.c_long, C.c_int, C.c_int] + [_c_float_p] * 8 +
+                                     [C.c_double, C.c_void_p]),
+    "emd_bn_bwd_reduce_images_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p,
+                                               _c_float_p, C.c_int, C.c_int, C.c_long, C.c_int, _c_float_p, _c_float_p,
+                                               C.c_void_p, C.c_void_p]),
+    "emd_bn_bwd_prep_images_f32": (C.c_int, [_c_float_p] * 6 + [C.c_float, C.c_long, C.c_int, C.c_int] + [_c_float_p] * 6 + [C.c_void_p]),
+    "emd_bn_bwd_apply_images_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int] + [_c_float_p] * 6 +
+                                    [C.c_int, _c_float_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     # x ldx dy ldd dw B H W C stride rate stream
     "emd_dw3x3_wgrad_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p] + [C.c_int] * 6 + [C.c_void_p]),
     # dy ldd w dx ldx B H W C stride rate stream

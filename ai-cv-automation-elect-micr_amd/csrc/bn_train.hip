@@ -31,6 +31,14 @@ __global__ __launch_bounds__(256) void chan_reduce_partial(const float* __restri
                                                            const float* __restrict__ mscale, const float* __restrict__ mshift,
                                                            int mask, long npix, int C, long rows_per_slab,
                                                            double* __restrict__ part) {
+    // per-image form (gridDim.z images of npix pixels each, per-image statistics vectors [B][C]): image b = blockIdx.z
+    {
+        const long b = blockIdx.z;
+        dy += b * npix * ldd;
+        if (x) { x += b * npix * ldx; mean += b * C; rstd += b * C; }
+        if (mask) { mscale += b * C; mshift += b * C; }
+        part += b * (long)gridDim.y * 2 * C;
+    }
     __shared__ double sm[2][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rsub = threadIdx.x >> 6;
@@ -64,6 +72,14 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
                                                               const float* __restrict__ mscale, const float* __restrict__ mshift,
                                                               int mask, long npix, int C, long rows_per_slab,
                                                               double* __restrict__ part) {
+    // per-image form (gridDim.z images of npix pixels each, per-image statistics vectors [B][C]): image b = blockIdx.z
+    {
+        const long b = blockIdx.z;
+        dy += b * npix * ldd;
+        if (x) { x += b * npix * ldx; mean += b * C; rstd += b * C; }
+        if (mask) { mscale += b * C; mshift += b * C; }
+        part += b * (long)gridDim.y * 2 * C;
+    }
     __shared__ double sm[2][16][64 + 1];
     const int cl = (threadIdx.x & 15) * 4;
     const int c = blockIdx.x * 64 + cl;
@@ -112,8 +128,14 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
 
 __global__ __launch_bounds__(256) void chan_reduce_final(const double* __restrict__ part, int nslab, int C,
                                                          float* __restrict__ s1, float* __restrict__ s2, int accumulate) {
-    // 16 channels x 16 slab lanes per workgroup
+    // 16 channels x 16 slab lanes per workgroup; per-image form: image b = blockIdx.y
     __shared__ double sm[2][16][16 + 1];
+    {
+        const long b = blockIdx.y;
+        part += b * (long)nslab * 2 * C;
+        s1 += b * C;
+        if (s2) s2 += b * C;
+    }
     const int l = threadIdx.x & 15, k0 = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + l;
     double s = 0.0, q = 0.0;
@@ -146,6 +168,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
                                                            const float* __restrict__ mscale, const float* __restrict__ mshift,
                                                            int mask, float* dx, int ldo, long npix, int CV) {
     constexpr int ROWS = V == 4 ? 8 : 1;
+    {   // per-image form: image b = blockIdx.y, npix pixels per image, per-image vectors [B][C]
+        const long b = blockIdx.y;
+        dy += b * npix * ldd; x += b * npix * ldx; dx += b * npix * ldo;
+        K += b * CV * V; m1 += b * CV * V; mean += b * CV * V; m2 += b * CV * V;
+        if (mask) { mscale += b * CV * V; mshift += b * CV * V; }
+    }
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     const long ngroups = (npix + ROWS - 1) / ROWS;
     if (tid >= ngroups * CV) return;
@@ -192,21 +220,25 @@ __global__ __launch_bounds__(256) void bn_train_fold_kernel(const float* __restr
                                                             const float* __restrict__ bias, float eps, float n, int C,
                                                             float* __restrict__ scale, float* __restrict__ shift,
                                                             float* __restrict__ rstd1, float* __restrict__ rstd2,
-                                                            float* mm1, float* mv1, float* mm2, float* mv2, float omd) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const float mu = mean[c], v = var[c];
+                                                            float* mm1, float* mv1, float* mm2, float* mv2, float omd, int period) {
+    // per-image form: C = B * period entries [B][period]; the parameters repeat with `period`, the moving statistics follow
+    // image 0 only (the first tower, misc_py/denoiser-multi-gpu.py:701-707)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C) return;
+    const int c = i % period;
+    if (i >= period) mm1 = mv1 = mm2 = mv2 = nullptr;
+    const float mu = mean[i], v = var[i];
     const float r1 = rsqrtf(v + eps);
     const float bessel = n > 1.f ? n / (n - 1.f) : 1.f;
-    rstd1[c] = r1;
+    rstd1[i] = r1;
     if (gamma1) {  // BN1 (gamma1, beta1) then BN2 (gamma2, beta2)
         const float g1 = gamma1[c];
         const float var2 = g1 * g1 * v * r1 * r1;
         const float r2 = rsqrtf(var2 + eps);
-        rstd2[c] = r2;
+        rstd2[i] = r2;
         const float sc = g1 * gamma2[c] * r1 * r2;
-        scale[c] = sc;
-        shift[c] = beta2[c] - mu * sc;
+        scale[i] = sc;
+        shift[i] = beta2[c] - mu * sc;
         if (mm1) {
             mm1[c] -= (mm1[c] - mu) * omd;
             mv1[c] -= (mv1[c] - v * bessel) * omd;
@@ -215,8 +247,8 @@ __global__ __launch_bounds__(256) void bn_train_fold_kernel(const float* __restr
         }
     } else {       // a single BN (gamma2, beta2) after conv + bias
         const float sc = gamma2[c] * r1;
-        scale[c] = sc;
-        shift[c] = beta2[c] - mu * sc;
+        scale[i] = sc;
+        shift[i] = beta2[c] - mu * sc;
         if (mm2) {
             mm2[c] -= (mm2[c] - (mu + (bias ? bias[c] : 0.f))) * omd;
             mv2[c] -= (mv2[c] - v * bessel) * omd;
@@ -231,23 +263,25 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const float* __restric
                                                           const float* __restrict__ rstd1, const float* __restrict__ rstd2,
                                                           float eps, float inv_n, int C, float* __restrict__ K,
                                                           float* __restrict__ m1, float* __restrict__ m2,
-                                                          float* dgamma1, float* dgamma2, float* dbeta2) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const float r1 = rstd1[c], tv = t[c], sv = s1[c];
-    m1[c] = sv * inv_n;
+                                                          float* dgamma1, float* dgamma2, float* dbeta2, int period) {
+    // per-image form: C = B * period entries; parameters and their gradients are indexed by the channel i % period
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C) return;
+    const int c = i % period;
+    const float r1 = rstd1[i], tv = t[i], sv = s1[i];
+    m1[i] = sv * inv_n;
     atomicAdd(dbeta2 + c, sv);  // parameter gradients: towers on different streams add concurrently
     if (gamma1) {
-        const float g1 = gamma1[c], g2 = gamma2[c], r2 = rstd2[c];
+        const float g1 = gamma1[c], g2 = gamma2[c], r2 = rstd2[i];
         const float a = g1 * r2;
         const float e2 = eps * r2 * r2;
-        K[c] = g1 * g2 * r1 * r2;
-        m2[c] = r1 * tv * inv_n * (a * a + e2);
+        K[i] = g1 * g2 * r1 * r2;
+        m2[i] = r1 * tv * inv_n * (a * a + e2);
         atomicAdd(dgamma2 + c, a * tv);
         atomicAdd(dgamma1 + c, g2 * r2 * e2 * tv);
     } else {
-        K[c] = gamma2[c] * r1;
-        m2[c] = r1 * tv * inv_n;
+        K[i] = gamma2[c] * r1;
+        m2[i] = r1 * tv * inv_n;
         atomicAdd(dgamma2 + c, tv);
     }
 }
@@ -259,72 +293,131 @@ extern "C" size_t emd_chan_reduce_workspace_bytes(long npix, int C) {
     return (size_t)emd::reduce_slabs(npix) * 2 * C * sizeof(double);
 }
 
-extern "C" int emd_bn_bwd_reduce_f32(const float* dy, int ldd, const float* x, int ldx, const float* mean,
-                                     const float* rstd, const float* mscale, const float* mshift, int mask, long npix,
-                                     int C, float* s1, float* s2, int accumulate_s1, void* workspace, emd_stream_t stream) {
+// B = 1: the batch forms (npix = all pixels of the tower).  B > 1: the per-image forms -- npix pixels PER IMAGE, statistics /
+// coefficient vectors [B][C]; image b is reduced exactly as it would be alone (same slabs, same order), so a batch of one-image
+// towers (misc_py/denoiser-multi-gpu.py:763) can run as one batched pass with identical arithmetic per image.
+static int bwd_reduce_impl(const float* dy, int ldd, const float* x, int ldx, const float* mean, const float* rstd,
+                           const float* mscale, const float* mshift, int mask, int B, long npix, int C, float* s1, float* s2,
+                           int accumulate_s1, void* workspace, emd_stream_t stream) {
     EMD_REQUIRE(dy && s1 && workspace, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: null pointer");
-    EMD_REQUIRE(npix >= 1 && C >= 1 && mask >= 0 && mask <= 3, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: bad argument");
+    EMD_REQUIRE(B >= 1 && B <= 65535 && npix >= 1 && C >= 1 && mask >= 0 && mask <= 3, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: bad argument");
     EMD_REQUIRE(!x || (mean && rstd && s2), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: x needs mean, rstd and s2");
     EMD_REQUIRE(!mask || (x && mscale && mshift), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: a mask needs x, mscale, mshift");
+    EMD_REQUIRE(B == 1 || !accumulate_s1, EMD_E_INVALID, "emd_bn_bwd_reduce_images_f32: accumulate_s1 is a batch-form option");
     const long ns = emd::reduce_slabs(npix), rps = emd::reduce_rows_per_slab(npix);
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
     if (C % 4 == 0 && ldd % 4 == 0 && (!x || ldx % 4 == 0) && emd::aligned16(dy) && (!x || emd::aligned16(x)))
-        hipLaunchKernelGGL(chan_reduce_partial_v4, dim3((C + 63) / 64, (unsigned)ns), dim3(256), 0, st, dy, ldd, x, ldx, mean,
+        hipLaunchKernelGGL(chan_reduce_partial_v4, dim3((C + 63) / 64, (unsigned)ns, (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, mean,
                            rstd, mscale, mshift, mask, npix, C, rps, ws);
     else
-        hipLaunchKernelGGL(chan_reduce_partial, dim3((C + 63) / 64, (unsigned)ns), dim3(256), 0, st, dy, ldd, x, ldx, mean,
+        hipLaunchKernelGGL(chan_reduce_partial, dim3((C + 63) / 64, (unsigned)ns, (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, mean,
                            rstd, mscale, mshift, mask, npix, C, rps, ws);
-    hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16), dim3(256), 0, st, static_cast<const double*>(ws), (int)ns, C, s1,
+    hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16, (unsigned)B), dim3(256), 0, st, static_cast<const double*>(ws), (int)ns, C, s1,
                        x ? s2 : nullptr, accumulate_s1);
     return emd::check_launch("chan_reduce");
 }
 
-extern "C" int emd_bn_bwd_apply_f32(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,
-                                    const float* mean, const float* m2, const float* mscale, const float* mshift,
-                                    int mask, float* dx, int ldo, long npix, int C, emd_stream_t stream) {
+extern "C" int emd_bn_bwd_reduce_f32(const float* dy, int ldd, const float* x, int ldx, const float* mean,
+                                     const float* rstd, const float* mscale, const float* mshift, int mask, long npix,
+                                     int C, float* s1, float* s2, int accumulate_s1, void* workspace, emd_stream_t stream) {
+    return bwd_reduce_impl(dy, ldd, x, ldx, mean, rstd, mscale, mshift, mask, 1, npix, C, s1, s2, accumulate_s1, workspace, stream);
+}
+
+extern "C" int emd_bn_bwd_reduce_images_f32(const float* dy, int ldd, const float* x, int ldx, const float* mean,
+                                            const float* rstd, const float* mscale, const float* mshift, int mask, int B,
+                                            long npix, int C, float* s1, float* s2, void* workspace, emd_stream_t stream) {
+    return bwd_reduce_impl(dy, ldd, x, ldx, mean, rstd, mscale, mshift, mask, B, npix, C, s1, s2, 0, workspace, stream);
+}
+
+static int bwd_apply_impl(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,
+                          const float* mean, const float* m2, const float* mscale, const float* mshift,
+                          int mask, float* dx, int ldo, int B, long npix, int C, emd_stream_t stream) {
     EMD_REQUIRE(dy && x && K && m1 && mean && m2 && dx, EMD_E_INVALID, "emd_bn_bwd_apply_f32: null pointer");
-    EMD_REQUIRE(npix >= 1 && C >= 1 && mask >= 0 && mask <= 3 && (!mask || (mscale && mshift)), EMD_E_INVALID,
+    EMD_REQUIRE(B >= 1 && B <= 65535 && npix >= 1 && C >= 1 && mask >= 0 && mask <= 3 && (!mask || (mscale && mshift)), EMD_E_INVALID,
                 "emd_bn_bwd_apply_f32: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (C % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && emd::aligned16(dy) && emd::aligned16(x) &&
         emd::aligned16(dx)) {
         const long n = ((npix + 7) / 8) * (C / 4);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, ldd, x, ldx, K,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, K,
                            m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C / 4);
     } else {
         const long n = npix * C;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, ldd, x, ldx, K,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, K,
                            m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C);
     }
     return emd::check_launch("bn_bwd_apply_kernel");
 }
 
-extern "C" int emd_bn_train_fold_f32(const float* mean, const float* var, const float* gamma1, const float* beta1,
-                                     const float* gamma2, const float* beta2, const float* bias, float eps, long npix,
-                                     int C, float* scale, float* shift, float* rstd1, float* rstd2, float* mm1, float* mv1,
-                                     float* mm2, float* mv2, double decay, emd_stream_t stream) {
+extern "C" int emd_bn_bwd_apply_f32(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,
+                                    const float* mean, const float* m2, const float* mscale, const float* mshift,
+                                    int mask, float* dx, int ldo, long npix, int C, emd_stream_t stream) {
+    return bwd_apply_impl(dy, ldd, x, ldx, K, m1, mean, m2, mscale, mshift, mask, dx, ldo, 1, npix, C, stream);
+}
+
+extern "C" int emd_bn_bwd_apply_images_f32(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,
+                                           const float* mean, const float* m2, const float* mscale, const float* mshift,
+                                           int mask, float* dx, int ldo, int B, long npix, int C, emd_stream_t stream) {
+    return bwd_apply_impl(dy, ldd, x, ldx, K, m1, mean, m2, mscale, mshift, mask, dx, ldo, B, npix, C, stream);
+}
+
+static int train_fold_impl(const float* mean, const float* var, const float* gamma1, const float* beta1,
+                           const float* gamma2, const float* beta2, const float* bias, float eps, long npix, int B,
+                           int C, float* scale, float* shift, float* rstd1, float* rstd2, float* mm1, float* mv1,
+                           float* mm2, float* mv2, double decay, emd_stream_t stream) {
     EMD_REQUIRE(mean && var && gamma2 && beta2 && scale && shift && rstd1, EMD_E_INVALID, "emd_bn_train_fold_f32: null pointer");
     EMD_REQUIRE((gamma1 == nullptr) == (beta1 == nullptr) && (!gamma1 || rstd2), EMD_E_INVALID,
                 "emd_bn_train_fold_f32: the double batch norm needs gamma1, beta1 and rstd2");
     EMD_REQUIRE(!mm2 || mv2, EMD_E_INVALID, "emd_bn_train_fold_f32: moving mean and variance come together");
     EMD_REQUIRE(!gamma1 || ((mm1 == nullptr) == (mm2 == nullptr) && (!mm1 || mv1)), EMD_E_INVALID,
                 "emd_bn_train_fold_f32: the double batch norm updates both sets of moving statistics or none");
-    EMD_REQUIRE(npix >= 1 && C >= 1, EMD_E_INVALID, "emd_bn_train_fold_f32: bad shape");
-    hipLaunchKernelGGL(bn_train_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), mean,
-                       var, gamma1, beta1, gamma2, beta2, bias, eps, (float)npix, C, scale, shift, rstd1, rstd2, mm1, mv1,
-                       mm2, mv2, (float)(1.0 - decay));
+    EMD_REQUIRE(npix >= 1 && C >= 1 && B >= 1 && (long)B * C <= 0x7fffffffL, EMD_E_INVALID, "emd_bn_train_fold_f32: bad shape");
+    const int n = B * C;
+    hipLaunchKernelGGL(bn_train_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), mean,
+                       var, gamma1, beta1, gamma2, beta2, bias, eps, (float)npix, n, scale, shift, rstd1, rstd2, mm1, mv1,
+                       mm2, mv2, (float)(1.0 - decay), C);
     return emd::check_launch("bn_train_fold_kernel");
+}
+
+extern "C" int emd_bn_train_fold_f32(const float* mean, const float* var, const float* gamma1, const float* beta1,
+                                     const float* gamma2, const float* beta2, const float* bias, float eps, long npix,
+                                     int C, float* scale, float* shift, float* rstd1, float* rstd2, float* mm1, float* mv1,
+                                     float* mm2, float* mv2, double decay, emd_stream_t stream) {
+    return train_fold_impl(mean, var, gamma1, beta1, gamma2, beta2, bias, eps, npix, 1, C, scale, shift, rstd1, rstd2, mm1, mv1, mm2, mv2,
+                           decay, stream);
+}
+
+extern "C" int emd_bn_train_fold_images_f32(const float* mean, const float* var, const float* gamma1, const float* beta1,
+                                            const float* gamma2, const float* beta2, const float* bias, float eps, long npix,
+                                            int B, int C, float* scale, float* shift, float* rstd1, float* rstd2, float* mm1,
+                                            float* mv1, float* mm2, float* mv2, double decay, emd_stream_t stream) {
+    return train_fold_impl(mean, var, gamma1, beta1, gamma2, beta2, bias, eps, npix, B, C, scale, shift, rstd1, rstd2, mm1, mv1, mm2, mv2,
+                           decay, stream);
+}
+
+static int bwd_prep_impl(const float* s1, const float* t, const float* gamma1, const float* gamma2,
+                         const float* rstd1, const float* rstd2, float eps, long npix, int B, int C, float* K,
+                         float* m1, float* m2, float* dgamma1, float* dgamma2, float* dbeta2, emd_stream_t stream) {
+    EMD_REQUIRE(s1 && t && gamma2 && rstd1 && K && m1 && m2 && dgamma2 && dbeta2, EMD_E_INVALID, "emd_bn_bwd_prep_f32: null pointer");
+    EMD_REQUIRE(!gamma1 || (rstd2 && dgamma1), EMD_E_INVALID, "emd_bn_bwd_prep_f32: the double batch norm needs rstd2 and dgamma1");
+    EMD_REQUIRE(npix >= 1 && C >= 1 && B >= 1 && (long)B * C <= 0x7fffffffL, EMD_E_INVALID, "emd_bn_bwd_prep_f32: bad shape");
+    const int n = B * C;
+    hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), s1, t,
+                       gamma1, gamma2, rstd1, rstd2, eps, 1.0f / (float)npix, n, K, m1, m2, dgamma1, dgamma2, dbeta2, C);
+    return emd::check_launch("bn_bwd_prep_kernel");
 }
 
 extern "C" int emd_bn_bwd_prep_f32(const float* s1, const float* t, const float* gamma1, const float* gamma2,
                                    const float* rstd1, const float* rstd2, float eps, long npix, int C, float* K,
                                    float* m1, float* m2, float* dgamma1, float* dgamma2, float* dbeta2,
                                    emd_stream_t stream) {
-    EMD_REQUIRE(s1 && t && gamma2 && rstd1 && K && m1 && m2 && dgamma2 && dbeta2, EMD_E_INVALID, "emd_bn_bwd_prep_f32: null pointer");
-    EMD_REQUIRE(!gamma1 || (rstd2 && dgamma1), EMD_E_INVALID, "emd_bn_bwd_prep_f32: the double batch norm needs rstd2 and dgamma1");
-    EMD_REQUIRE(npix >= 1 && C >= 1, EMD_E_INVALID, "emd_bn_bwd_prep_f32: bad shape");
-    hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), s1, t,
-                       gamma1, gamma2, rstd1, rstd2, eps, 1.0f / (float)npix, C, K, m1, m2, dgamma1, dgamma2, dbeta2);
-    return emd::check_launch("bn_bwd_prep_kernel");
+    return bwd_prep_impl(s1, t, gamma1, gamma2, rstd1, rstd2, eps, npix, 1, C, K, m1, m2, dgamma1, dgamma2, dbeta2, stream);
+}
+
+extern "C" int emd_bn_bwd_prep_images_f32(const float* s1, const float* t, const float* gamma1, const float* gamma2,
+                                          const float* rstd1, const float* rstd2, float eps, long npix, int B, int C, float* K,
+                                          float* m1, float* m2, float* dgamma1, float* dgamma2, float* dbeta2,
+                                          emd_stream_t stream) {
+    return bwd_prep_impl(s1, t, gamma1, gamma2, rstd1, rstd2, eps, npix, B, C, K, m1, m2, dgamma1, dgamma2, dbeta2, stream);
 }

@@ -80,10 +80,28 @@ def _reduce_ws(npix, Cc, device):
 
 
 def bn_train_fold(mean, var, gamma2, beta2, npix, gamma1=None, beta1=None, bias=None, moving=None, eps=BN_EPS,
-                  decay=BN_DECAY, stream=None):
-    """-> dict(scale, shift, rstd1, rstd2|None).  moving: None, (mm2, mv2) for a single BN, or (mm1, mv1, mm2, mv2)."""
+                  decay=BN_DECAY, stream=None, images=0):
+    """-> dict(scale, shift, rstd1, rstd2|None).  moving: None, (mm2, mv2) for a single BN, or (mm1, mv1, mm2, mv2).
+    images = B > 0: per-image statistics mean / var [B][C] (ops.bn_batch_stats_images), npix pixels per image; the result vectors
+    are [B][C] too and the dict carries "B" (the per-image forms of affine_act / bn_backward follow from it)."""
     import torch
 
+    if images:
+        Cc = mean.numel() // images
+        scale, shift, rstd1 = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+        rstd2 = torch.empty_like(mean) if gamma1 is not None else None
+        mm1 = mv1 = mm2 = mv2 = None
+        if moving is not None:
+            if gamma1 is not None:
+                mm1, mv1, mm2, mv2 = moving
+            else:
+                mm2, mv2 = moving
+        rc = _lib.load().emd_bn_train_fold_images_f32(_p(mean), _p(var), _p(gamma1), _p(beta1), _p(gamma2), _p(beta2), _p(bias),
+                                                      C.c_float(eps), C.c_long(npix), images, Cc, _p(scale), _p(shift), _p(rstd1),
+                                                      _p(rstd2), _p(mm1), _p(mv1), _p(mm2), _p(mv2), C.c_double(decay),
+                                                      _lib.stream_ptr(stream))
+        _lib.check(rc, "emd_bn_train_fold_images_f32")
+        return {"scale": scale, "shift": shift, "rstd1": rstd1, "rstd2": rstd2, "mean": mean, "B": images}
     Cc = mean.numel()
     scale, shift, rstd1 = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
     rstd2 = torch.empty_like(mean) if gamma1 is not None else None
@@ -118,10 +136,27 @@ def bn_backward(dy: Act, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MA
     import torch
 
     lib = _lib.load()
-    npix = dy.B * dy.H * dy.W
     Cc = dy.C
     assert (r.B, r.H, r.W, r.C) == (dy.B, dy.H, dy.W, Cc) and (dr.B, dr.H, dr.W, dr.C) == (dy.B, dy.H, dy.W, Cc)
     dev = dy.buf.device
+    if fold.get("B"):   # per-image statistics: B one-image towers as one batched pass
+        B, npix = dy.B, dy.H * dy.W
+        assert fold["B"] == B
+        s1, t = torch.empty(B * Cc, dtype=torch.float32, device=dev), torch.empty(B * Cc, dtype=torch.float32, device=dev)
+        ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
+        ws = torch.empty(max(B * (lib.emd_chan_reduce_workspace_bytes(npix, Cc) // 8), 1), dtype=torch.float64, device=dev)
+        _lib.check(lib.emd_bn_bwd_reduce_images_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(fold["mean"]), _p(fold["rstd1"]), _p(ms), _p(mh), mask,
+                                                    B, C.c_long(npix), Cc, _p(s1), _p(t), _p(ws), _lib.stream_ptr(stream)),
+                   "emd_bn_bwd_reduce_images_f32")
+        K, m1, m2 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
+        _lib.check(lib.emd_bn_bwd_prep_images_f32(_p(s1), _p(t), _p(gamma1), _p(gamma2), _p(fold["rstd1"]), _p(fold["rstd2"]),
+                                                  C.c_float(eps), C.c_long(npix), B, Cc, _p(K), _p(m1), _p(m2), _p(dgamma1), _p(dgamma2),
+                                                  _p(dbeta2), _lib.stream_ptr(stream)), "emd_bn_bwd_prep_images_f32")
+        _lib.check(lib.emd_bn_bwd_apply_images_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(K), _p(m1), _p(fold["mean"]), _p(m2), _p(ms), _p(mh),
+                                                   mask, dr.ptr, dr.ld, B, C.c_long(npix), Cc, _lib.stream_ptr(stream)),
+                   "emd_bn_bwd_apply_images_f32")
+        return dr
+    npix = dy.B * dy.H * dy.W
     s1, t = torch.empty(Cc, dtype=torch.float32, device=dev), torch.empty(Cc, dtype=torch.float32, device=dev)
     ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
     chan_reduce(dy, s1, r, fold["mean"], fold["rstd1"], t, ms, mh, mask, stream=stream)

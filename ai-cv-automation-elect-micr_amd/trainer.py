@@ -111,6 +111,7 @@ class DenoiserTrainer:
         self.pk_b["cnn0"] = TO.DevPackedWeights(1, features0, 4, device)   # d loss / d (depthwise output), 4 padded channels
         self.dw_flip = {}
         self._streams, self._graphs = [], {}
+        self._per_image = False
         self.repack()
         self.last = None
 
@@ -217,19 +218,31 @@ class DenoiserTrainer:
     def _bn(self, key, r, bias_name=None):
         """Batch statistics of r -> fold dict of the layer's BN chain (+ moving-average updates on the first tower)."""
         L = self.layers[key]
-        mean, var = ops.bn_batch_stats(r)
-        npix = r.B * r.H * r.W
+        img = r.B if self._per_image else 0    # per-image statistics: B one-image towers as one batched pass
+        if img:
+            mean, var = ops.bn_batch_stats_images(r)
+            npix = r.H * r.W
+        else:
+            mean, var = ops.bn_batch_stats(r)
+            npix = r.B * r.H * r.W
         upd = self._update_moving
         if len(L.bn) == 2:
             b1, b2 = L.bn
             mv = (self.m[b1 + "/moving_mean"], self.m[b1 + "/moving_variance"], self.m[b2 + "/moving_mean"],
                   self.m[b2 + "/moving_variance"]) if upd else None
             return TO.bn_train_fold(mean, var, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], npix, gamma1=self.v[b1 + "/gamma"],
-                                    beta1=self.v[b1 + "/beta"], moving=mv)
+                                    beta1=self.v[b1 + "/beta"], moving=mv, images=img)
         (b2,) = L.bn
         mv = (self.m[b2 + "/moving_mean"], self.m[b2 + "/moving_variance"]) if upd else None
         return TO.bn_train_fold(mean, var, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], npix,
-                                bias=self.v[bias_name] if bias_name else None, moving=mv)
+                                bias=self.v[bias_name] if bias_name else None, moving=mv, images=img)
+
+    @staticmethod
+    def _affine(r, fold, out, act, res=None):
+        """out = act(r * scale + shift) [+ res] with the fold of _bn: per-channel, or per (image, channel) for per-image statistics."""
+        if fold.get("B"):
+            return ops.affine_act_images(r, fold["scale"], fold["shift"], out, act=act, res=res)
+        return ops.affine_act(r, fold["scale"], fold["shift"], out, act=act, res=res)
 
     def _sep_fwd(self, key, x, out=None, res=None):
         L = self.layers[key]
@@ -240,7 +253,7 @@ class DenoiserTrainer:
         fold = self._bn(key, r)
         if out is None:
             out = self._E(x.B, Ho, Wo, L.cout)
-        ops.affine_act(r, fold["scale"], fold["shift"], out, act=ops.ACT_RELU6, res=res)
+        self._affine(r, fold, out, ops.ACT_RELU6, res)
         return out, {"x": x, "d": d, "r": r, "fold": fold}
 
     def _conv_fwd(self, key, x, out=None, act=True):
@@ -261,7 +274,7 @@ class DenoiserTrainer:
         fold = self._bn(key, tgt, L.scope + "/" + L.bname)
         if out is None:
             out = self._E(x.B, Ho, Wo, L.cout)
-        ops.affine_act(tgt, fold["scale"], fold["shift"], out, act=ops.ACT_RELU6 if act else ops.ACT_NONE)
+        self._affine(tgt, fold, out, ops.ACT_RELU6 if act else ops.ACT_NONE)
         return out, {"x": x, "r": tgt, "fold": fold}
 
     def _deconv_fwd(self, key, x, out):
@@ -269,7 +282,7 @@ class DenoiserTrainer:
         r = ops.deconv3x3s2(x, self.pk_f[key], self.ones, self.zeros, self._E(x.B, 2 * x.H, 2 * x.W, L.cout), act=False,
                             precision=self.precision)
         fold = self._bn(key, r, L.scope + "/" + L.bname)
-        ops.affine_act(r, fold["scale"], fold["shift"], out, act=ops.ACT_RELU6)
+        self._affine(r, fold, out, ops.ACT_RELU6)
         return out, {"x": x, "r": r, "fold": fold}
 
     # ---- backward building blocks ---------------------------------------------------------------------------
@@ -357,10 +370,15 @@ class DenoiserTrainer:
                   lambda dst: ops.conv3x3(dr, pk, self.ones, self.zeros, dst, stride=2, act=False, res=dst, precision=self.precision))
 
     # ---- one tower ---------------------------------------------------------------------------------------------
-    def tower(self, lq, truth, update_moving=True, grad_scale=1.0):
+    def tower(self, lq, truth, update_moving=True, grad_scale=1.0, per_image=False):
         """Forward (phase=True) + loss + backward for the images of one tower; parameter gradients are ADDED into
         self.grads.  lq, truth: CUDA float32 [B,S,S,1] contiguous, S a multiple of 32.  Returns (out, result3) with
-        result3 a device tensor (mse, loss, dloss/dout factor) -- no host synchronisation."""
+        result3 a device tensor (mse, loss, dloss/dout factor) -- no host synchronisation.
+        per_image=True: the B images are B TOWERS OF ONE IMAGE (the reference's towers, :763) run as one batched pass: every batch
+        norm takes per-image statistics (and its backward per-image reductions), every image has its own loss; convolutions,
+        depthwise convs, resampling and every parameter gradient are per-pixel or sums over pixels, so they need no change.
+        Same arithmetic per image as B separate towers (the moving statistics follow image 0), B times the GEMM M, B times
+        fewer launches.  result3 is then [B, 3]."""
         import torch
 
         assert lq.is_cuda and lq.dtype == torch.float32 and lq.is_contiguous() and lq.dim() == 4 and lq.shape[3] == 1
@@ -368,6 +386,7 @@ class DenoiserTrainer:
         B, S = lq.shape[0], lq.shape[1]
         assert lq.shape[2] == S and S % 32 == 0, "square crops with side a multiple of 32"
         self._update_moving = update_moving
+        self._per_image = bool(per_image)
         E = lambda H, Cc: self._E(B, H, H, Cc)
         S2, S4, S8, S16 = S // 2, S // 4, S // 8, S // 16
         f0, f1, f2, f3, f4, af = features0, features1, features2, features3, features4, aspp_filters
@@ -412,7 +431,7 @@ class DenoiserTrainer:
         up = ops.resize_bilinear(img_lvl, E(S16, af))
         Lp = self.layers["aspp_pooling_bn"]
         fold_p = self._bn("aspp_pooling_bn", up)
-        ops.affine_act(up, fold_p["scale"], fold_p["shift"], cat.slice(4 * af, af), act=ops.ACT_RELU6)
+        self._affine(up, fold_p, cat.slice(4 * af, af), ops.ACT_RELU6)
         C["aspp_pooling_bn"] = {"r": up, "fold": fold_p}
         aspp, C["aspp_reduce"] = self._conv_fwd("aspp_reduce", cat)
         ops.resize_bilinear(aspp, concat2.slice(0, aspp_output))
@@ -436,12 +455,20 @@ class DenoiserTrainer:
         fold_f = self._bn("deconv_final", rfa, Lf.scope + "/" + Lf.bname)
         out = torch.empty_like(rf)
         # one channel: run the per-channel affine over a [.., 4] view with the scalar replicated
-        sc4, sh4 = fold_f["scale"].expand(4).contiguous(), fold_f["shift"].expand(4).contiguous()
-        ops.affine_act(ops.Act(rf.view(B, S, S // 4, 4)), sc4, sh4, ops.Act(out.view(B, S, S // 4, 4)), act=ops.ACT_RELU6_CLIP01)
+        if per_image:
+            sc4 = fold_f["scale"].view(B, 1).expand(B, 4).contiguous().view(-1)
+            sh4 = fold_f["shift"].view(B, 1).expand(B, 4).contiguous().view(-1)
+            ops.affine_act_images(ops.Act(rf.view(B, S, S // 4, 4)), sc4, sh4, ops.Act(out.view(B, S, S // 4, 4)), act=ops.ACT_RELU6_CLIP01)
+        else:
+            sc4, sh4 = fold_f["scale"].expand(4).contiguous(), fold_f["shift"].expand(4).contiguous()
+            ops.affine_act(ops.Act(rf.view(B, S, S // 4, 4)), sc4, sh4, ops.Act(out.view(B, S, S // 4, 4)), act=ops.ACT_RELU6_CLIP01)
 
         # ---------------- loss (:768-775)
         dout = torch.empty_like(out)
-        result = TO.denoise_loss(out, truth, dout, grad_scale=grad_scale)
+        if per_image:   # every image is its own tower: its own mse, loss and dloss/dout (:763, :768-775)
+            result = torch.stack([TO.denoise_loss(out[b:b + 1], truth[b:b + 1], dout[b:b + 1], grad_scale=grad_scale) for b in range(B)])
+        else:
+            result = TO.denoise_loss(out, truth, dout, grad_scale=grad_scale)
 
         # ---------------- backward: reverse order; gslot holds the gradients that exist so far
         G = {}
@@ -526,7 +553,7 @@ class DenoiserTrainer:
             self._streams.append(torch.cuda.Stream(device=self.device))
         return self._streams[:n]
 
-    def local_gradients(self, lq, truth, tower_batch=1, streams=1):
+    def local_gradients(self, lq, truth, tower_batch=1, streams=1, batched=False):
         """zero_grad + every tower of this rank's images (forward, loss, backward) -> device tensor [n_towers, 3] of
         (mse, loss, factor); the gradient sets are summed into self.grads.  streams > 1: the towers are independent
         (they only meet in the atomically accumulated parameter gradients), so they are issued round-robin on that
@@ -538,6 +565,11 @@ class DenoiserTrainer:
         assert B % tower_batch == 0
         n_local = B // tower_batch
         self.zero_grad()
+        if batched and tower_batch == 1 and B > 1:
+            # the B one-image towers as ONE batched pass with per-image batch-norm statistics (see tower): same arithmetic per image
+            _, res = self.tower(lq, truth, update_moving=True, per_image=True)
+            self._unpad_grads()
+            return res
         results = []
         main = torch.cuda.current_stream()
         side = self._side_streams(min(streams, n_local)) if streams > 1 else []
@@ -575,7 +607,7 @@ class DenoiserTrainer:
             self.pad_g[k].copy_(t)
         torch.cuda.synchronize()
 
-    def _capture(self, lq, truth, tower_batch, streams, group):
+    def _capture(self, lq, truth, tower_batch, streams, group, batched=False):
         """Capture local_gradients for this input shape into a hipGraph.  Returns (graph, static lq, static truth,
         static results), or None if capture failed on ANY rank (all ranks then run eagerly: a rank that skipped the
         graph while the others replay it would still meet them at the all-reduce, but the decision must be common
@@ -590,7 +622,7 @@ class DenoiserTrainer:
             g = torch.cuda.CUDAGraph()
             # thread_local: other threads (e.g. the RCCL watchdog polling its events) may touch the runtime meanwhile
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                sres = self.local_gradients(slq, str_, tower_batch, streams)
+                sres = self.local_gradients(slq, str_, tower_batch, streams, batched)
             entry = (g, slq, str_, sres)
         except Exception as e:  # noqa: BLE001 -- fall back to eager launches
             err = e
@@ -605,7 +637,7 @@ class DenoiserTrainer:
             return None
         return entry
 
-    def train_step(self, lq, truth, tower_batch=1, learning_rate=None, group=None, streams=1, graph=False):
+    def train_step(self, lq, truth, tower_batch=1, learning_rate=None, group=None, streams=1, graph=False, batched=False):
         """One optimizer step on this rank's images (misc_py/denoiser-multi-gpu.py:1169-1206): every ``tower_batch``
         images form a tower (gradient set); all sets of all ranks are averaged (:1040) and applied with Nesterov
         momentum (:1064-1066).  Returns the device tensor [n_towers_local, 3] of (mse, loss, factor).
@@ -614,11 +646,11 @@ class DenoiserTrainer:
         import torch
 
         n_local = lq.shape[0] // tower_batch
-        key = (tuple(lq.shape), tower_batch, streams)
+        key = (tuple(lq.shape), tower_batch, streams, bool(batched))
         if graph and key not in self._graphs:
-            self._graphs[key] = self._capture(lq, truth, tower_batch, streams, group)
+            self._graphs[key] = self._capture(lq, truth, tower_batch, streams, group, batched)
         if not graph or self._graphs[key] is None:
-            results = self.local_gradients(lq, truth, tower_batch, streams)
+            results = self.local_gradients(lq, truth, tower_batch, streams, batched)
         else:
             g, slq, str_, sres = self._graphs[key]
             slq.copy_(lq)

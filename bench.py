@@ -70,6 +70,8 @@ def parse_args(argv=None):
     ap.add_argument("--tower-batch", type=int, default=1, help="workload T: images per tower (batch-norm statistics are per tower)")
     ap.add_argument("--gan-batch", type=int, default=4, help="workload A: images per GPU per GAN iteration")
     ap.add_argument("--train-streams", type=int, default=8, help="workload T: HIP streams the towers are issued on")
+    ap.add_argument("--tower-mode", choices=["streams", "batched"], default="streams",
+                    help="workload T, towers of 1: the towers on --train-streams HIP streams, or as ONE batched pass with per-image batch-norm statistics")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying captured hipGraphs (T / A / S)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-riders", action="store_true", help="with --workload all: the primary workload only")
@@ -890,7 +892,7 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     box = [None]
 
     def step():
-        box[0] = tr.train_step(x, t, tower_batch=tb, streams=a.train_streams, graph=not a.no_graph)
+        box[0] = tr.train_step(x, t, tower_batch=tb, streams=a.train_streams, graph=not a.no_graph, batched=a.tower_mode == "batched")
 
     ms = timer.run(step, steps, warmup)
     tflop = 3 * 5.38 / 32.0 * B * (S * S) / (512.0 * 512.0)   # forward + data gradient + weight gradient
@@ -899,7 +901,7 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
            "steps": steps, "warmup": warmup, "dtype": "bf16x3 GEMMs (split-bf16 MFMA inputs, fp32 accumulate), fp32 elsewhere",
            "config": {"workload": f"T: graph D' training step (misc_py/denoiser-multi-gpu.py), [{B},{S},{S},1] fp32 LQ/HQ pairs per GPU, "
                                   f"towers of {tb}, Nesterov momentum 0.9, lr 1e-3",
-                      "global_batch": B * world, "tower_batch": tb, "streams": a.train_streams, "hip_graph": not a.no_graph,
+                      "global_batch": B * world, "tower_batch": tb, "tower_mode": a.tower_mode, "streams": a.train_streams, "hip_graph": not a.no_graph,
                       "precision": a.precision, "parallelism": f"dp{world}",
                       "algorithmic_tflop_per_step_per_gpu": round(tflop, 3)},
            "tflops_algorithmic": round(tflop / (ms / 1e3), 1),

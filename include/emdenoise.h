@@ -344,6 +344,25 @@ int emd_bn_bwd_prep_f32(const float* s1, const float* t, const float* gamma1, co
 int emd_bn_bwd_apply_f32(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,
                          const float* mean, const float* m2, const float* mscale, const float* mshift, int mask, float* dx,
                          int ldo, long npix, int C, emd_stream_t stream);
+/* Per-image forms of the four (B images of npix pixels each; statistics / coefficient vectors [B][C]; the parameter
+ * vectors gamma / beta / bias and their gradients stay [C]; the moving statistics follow image 0, the first tower,
+ * misc_py/denoiser-multi-gpu.py:701-707).  Image b is reduced exactly as it would be alone, so the one-image towers of a
+ * rank (:763) run as ONE batched pass with per-image statistics from emd_bn_stats_images_f32 / emd_affine_act_images_f32:
+ * identical arithmetic per image, B times the GEMM M, B times fewer launches.  Workspace of the reduce: B x
+ * emd_chan_reduce_workspace_bytes(npix, C). */
+int emd_bn_train_fold_images_f32(const float* mean, const float* var, const float* gamma1, const float* beta1,
+                                 const float* gamma2, const float* beta2, const float* bias, float eps, long npix, int B, int C,
+                                 float* scale, float* shift, float* rstd1, float* rstd2, float* mm1, float* mv1, float* mm2,
+                                 float* mv2, double decay, emd_stream_t stream);
+int emd_bn_bwd_reduce_images_f32(const float* dy, int ldd, const float* x, int ldx, const float* mean, const float* rstd,
+                                 const float* mscale, const float* mshift, int mask, int B, long npix, int C, float* s1,
+                                 float* s2, void* workspace, emd_stream_t stream);
+int emd_bn_bwd_prep_images_f32(const float* s1, const float* t, const float* gamma1, const float* gamma2, const float* rstd1,
+                               const float* rstd2, float eps, long npix, int B, int C, float* K, float* m1, float* m2,
+                               float* dgamma1, float* dgamma2, float* dbeta2, emd_stream_t stream);
+int emd_bn_bwd_apply_images_f32(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,
+                                const float* mean, const float* m2, const float* mscale, const float* mshift, int mask,
+                                float* dx, int ldo, int B, long npix, int C, emd_stream_t stream);
 
 /* Depthwise 3x3 backward (the depthwise half of slim.separable_convolution2d, :253-273); shapes as emd_dw3x3_f32
  * (x, dx [B,H,W,C]; dy [B,ceil(H/s),ceil(W/s),C]); dw [3][3][C] +=. */

@@ -212,6 +212,44 @@ def test_gradient_accumulation_run_to_run_spread():
     assert spread < 1e-6
 
 
+def test_batched_per_image_towers_equal_towers_of_one():
+    """the one-image towers of a rank (misc_py/denoiser-multi-gpu.py:763) as ONE batched pass with per-image
+    batch-norm statistics (DenoiserTrainer.tower(per_image=True); emd_bn_stats_images_f32, emd_bn_*_images_f32) against the
+    same images as separate towers: outputs, per-image mse / loss and the moving statistics (image 0) bit for bit -- every
+    per-image reduction runs exactly as it would alone, every other kernel is batch-independent -- and the accumulated
+    gradient to the run-to-run spread of its float atomics (1e-6)."""
+    from emdenoise import trainer as TR
+
+    S, B = 64, 4
+    w = weights()
+    lq, hq = synthetic_pair(B, S, S, seed=17)
+    x, t = torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev())
+    a = TR.DenoiserTrainer(w, dev())
+    outs, ress = [], []
+    a.zero_grad()
+    for k in range(B):
+        o, r = a.tower(x[k:k + 1].contiguous(), t[k:k + 1].contiguous(), update_moving=(k == 0))
+        outs.append(o.clone())
+        ress.append(r.clone())
+    torch.cuda.synchronize()
+    b = TR.DenoiserTrainer(w, dev())
+    b.zero_grad()
+    ob, rb = b.tower(x, t, update_moving=True, per_image=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ob, torch.cat(outs)) and torch.equal(rb, torch.stack(ress))
+    assert torch.equal(a.moving, b.moving)
+    ga, gb = a.grads.detach().cpu().numpy().astype(np.float64), b.grads.detach().cpu().numpy().astype(np.float64)
+    spread = rel_l2(gb, ga)
+    print(f"batched per-image towers vs {B} towers of one at {S} px: outputs, losses, moving statistics identical; gradient rel L2 {spread:.2e}")
+    assert spread < 2e-6
+    # and through train_step: the same update from either form
+    pa, pb = TR.DenoiserTrainer(w, dev()), TR.DenoiserTrainer(w, dev())
+    pa.train_step(x, t, tower_batch=1, streams=2)
+    pb.train_step(x, t, tower_batch=1, batched=True)
+    torch.cuda.synchronize()
+    assert rel_l2(pb.params.cpu().numpy(), pa.params.cpu().numpy()) < 1e-7
+
+
 def test_train_steps_follow_the_oracle():
     """Free-running: three optimizer steps (2 towers of 1 image, averaged; Nesterov momentum 0.9, lr 1e-3; moving
     statistics from tower 0) against the oracle's float64 loop, in the regime where no unit sits on a kink."""
