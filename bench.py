@@ -70,7 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--tower-batch", type=int, default=1, help="workload T: images per tower (batch-norm statistics are per tower)")
     ap.add_argument("--gan-batch", type=int, default=4, help="workload A: images per GPU per GAN iteration")
     ap.add_argument("--train-streams", type=int, default=8, help="workload T: HIP streams the towers are issued on")
-    ap.add_argument("--tower-mode", choices=["streams", "batched"], default="streams",
+    ap.add_argument("--tower-mode", choices=["streams", "batched"], default="batched",
                     help="workload T, towers of 1: the towers on --train-streams HIP streams, or as ONE batched pass with per-image batch-norm statistics")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying captured hipGraphs (T / A / S)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
