@@ -241,6 +241,11 @@ SIGNATURES = {
     # x ldx dw whi wlo scale1 shift1 y ldy w2hi w2lo scale_b shift_b y2 ldy2 B H W Cin Cout Cout2 act stream
     "emd_sep3x3_dual_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int,
                                       C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 7 + [C.c_void_p]),
+    # ---- native graph executor (csrc/graph_exec.hip)
+    "emd_graph_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_long)]),
+    "emd_graph_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "emd_graph_run": (C.c_int, [C.c_void_p, _c_float_p, _c_float_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "emd_graph_destroy": (None, [C.c_void_p]),
     # ---- device-side training input functions (csrc/input_ops.hip)
     "emd_philox4x32_u32": (C.c_int, [C.c_void_p, C.c_long, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),
     "emd_get_scale_f32": (C.c_int, [_c_float_p, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),

@@ -1,0 +1,657 @@
+// graph_exec.hip -- graph D as a native executor behind the C ABI: emd_graph_create / _workspace_bytes / _run / _destroy
+// (last row).  Replaces architecture() of machine_learning/denoiser.py:58-398 for a host that is not Python: the
+// layer table in the reference's variable-creation order (so that every weight keeps its TensorFlow name), the folding of the
+// inference batch norms into per-channel affines (float64), the bf16 hi / lo weight packing, and the launch sequence of the
+// library's own entry points over a caller-provided device workspace.  Same kernel choices as the Python engine
+// (emdenoise.denoiser.DenoiserEngine), single stream: results are bit-identical to it (tests/test_graph_exec_gpu.py).
+//
+// Ownership: emd_graph_create uploads the prepared parameters into device memory it allocates and emd_graph_destroy frees (the
+// one explicit handle of the ABI); activations live in the caller's workspace (emd_graph_workspace_bytes), nothing else is
+// allocated, no global state.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "mfma_common.hpp"
+
+namespace {
+
+constexpr int F0 = 64, F1 = 128, F2 = 256, F3 = 728, F4 = 728, AF = 728, AOUT = 256, NEXTRA = 11;
+constexpr double BN_EPS = 1e-3;
+
+enum Kind { SEP, CONV, DECONV, BNONLY };
+
+struct LayerDecl {
+    std::string key;
+    Kind kind;
+    int cin, cout, k = 1, stride = 1, rate = 1;
+    std::string scope;             // conv / separable-conv / transposed-conv scope
+    std::vector<std::string> bn;   // batch norms applied after it, in order
+    std::string extra_bn;          // the ASPP rate branches' second batch_then_activ
+};
+
+// tf.variable_scope default-name uniquifier inside scope 'nn' (denoiser.py:514)
+struct Scope {
+    std::map<std::string, int> n;
+    std::string operator()(const std::string& base) {
+        const int k = n[base]++;
+        return k == 0 ? "nn/" + base : "nn/" + base + "_" + std::to_string(k);
+    }
+};
+
+// every parameterised layer of architecture() in creation order (mirror of emdenoise.denoiser.declare_layers("D"))
+std::vector<LayerDecl> declare_layers() {
+    Scope sc;
+    std::vector<LayerDecl> L;
+    auto sep = [&](const std::string& key, int cin, int cout, int stride = 1, int rate = 1, bool extra = false) {
+        LayerDecl d{key, SEP, cin, cout, 3, stride, rate};
+        d.scope = sc("SeparableConv2d");
+        d.bn = {d.scope + "/BatchNorm", sc("BatchNorm")};   // normalizer_fn inside the layer's scope (:123), then batch_then_activ (:134)
+        if (extra) d.extra_bn = sc("BatchNorm");
+        L.push_back(d);
+    };
+    auto conv = [&](const std::string& key, int cin, int cout, int k = 1, int stride = 1) {
+        LayerDecl d{key, CONV, cin, cout, k, stride, 1};
+        d.scope = sc("Conv");
+        d.bn = {sc("BatchNorm")};
+        L.push_back(d);
+    };
+    auto deconv = [&](const std::string& key, int cin, int cout) {
+        LayerDecl d{key, DECONV, cin, cout, 3, 2, 1};
+        d.scope = sc("Conv2d_transpose");
+        d.bn = {sc("BatchNorm")};
+        L.push_back(d);
+    };
+    sep("cnn0", 1, F0); sep("cnn0_last", F0, F0); sep("cnn0_strided", F0, F1, 2);
+    conv("residual0", 1, F1, 1, 2);
+    sep("cnn1", F1, F1); sep("cnn1_last", F1, F1); sep("cnn1_strided", F1, F1, 2);
+    conv("residual1", F1, F1, 1, 2);
+    sep("cnn2", F1, F2); sep("cnn2_last", F2, F2); sep("cnn2_strided", F2, F2, 2);
+    conv("residual2", F1, F2, 1, 2);
+    sep("cnn3", F2, F3); sep("cnn3_last", F3, F3); sep("cnn3_strided", F3, F3, 2);
+    conv("residual3", F2, F3, 1, 2);
+    sep("cnn4_a", F3, F4); sep("cnn4_b", F4, F4); sep("cnn4_last", F4, F4);
+    for (int i = 0; i < NEXTRA; ++i)
+        for (int j = 0; j < 3; ++j) sep("middle" + std::to_string(i) + "_" + std::to_string(j), F4, F4);
+    conv("aspp_conv1x1", F4, AF);
+    sep("aspp_small", F4, AF, 1, 6, true); sep("aspp_medium", F4, AF, 1, 12, true); sep("aspp_large", F4, AF, 1, 18, true);
+    {
+        LayerDecl d{"aspp_pooling_bn", BNONLY, F4, F4};
+        d.bn = {sc("BatchNorm")};   // :199-200
+        L.push_back(d);
+    }
+    conv("aspp_reduce", 5 * AF, AOUT);
+    sep("deconv2_a", AOUT + F1, F2); sep("deconv2_b", F2, F2);
+    conv("residual2_d", AOUT + F1, F2);
+    deconv("deconv2to1", F2, F2);
+    sep("deconv1_a", F2 + F1, F1); sep("deconv1_b", F1, F1);
+    conv("residual1_d", F2 + F1, F1);
+    deconv("deconv1to0", F1, F1);
+    sep("deconv0_a", F1, F0); sep("deconv0_b", F0, F0);
+    conv("residual0_d", F1, F0);
+    conv("deconv_final", F0, 1, 3);   // :387 -- kernel_size defaults to 3
+    return L;
+}
+
+
+struct Packed {   // bf16 hi / lo planes on the device (one allocation, lo behind hi)
+    uint16_t* hi = nullptr;
+    uint16_t* lo = nullptr;
+};
+
+struct LayerParams {
+    LayerDecl d;
+    float* dw = nullptr;                          // [9][Cin]
+    Packed pw;                                    // pointwise / 1x1 / 3x3 conv weights
+    Packed phase[4];                              // transposed conv
+    float *scale = nullptr, *shift = nullptr;     // folded affine(s)
+    float *scale2 = nullptr, *shift2 = nullptr;   // the extra batch norm of the ASPP rate branches
+    float *w9 = nullptr, *a = nullptr;            // layers fed by the 1-channel image: depthwise taps, outer-product vector
+    float* wfin = nullptr;                        // final 3x3 -> 1 conv: [9][Cin]
+    float scale_f = 1.f, shift_f = 0.f;
+};
+
+}  // namespace
+
+struct emd_graph {   // the handle behind emd_graph_t
+    std::map<std::string, LayerParams> P;
+    std::vector<void*> allocs;
+    float *unit4 = nullptr, *zero4 = nullptr;
+    std::string error;
+};
+
+namespace {
+
+typedef std::map<std::string, std::pair<const float*, long>> WeightMap;
+
+bool fetch(const WeightMap& w, const std::string& name, long count, const float** out, std::string* err) {
+    auto it = w.find(name);
+    if (it == w.end()) {
+        *err = "emd_graph_create: missing variable " + name;
+        return false;
+    }
+    if (it->second.second != count) {
+        *err = "emd_graph_create: " + name + ": " + std::to_string(it->second.second) + " elements, expected " + std::to_string(count);
+        return false;
+    }
+    *out = it->second.first;
+    return true;
+}
+
+template <typename T>
+T* upload(emd_graph* g, const T* host, size_t n) {
+    void* d = nullptr;
+    if (hipMalloc(&d, n * sizeof(T) < 16 ? 16 : n * sizeof(T)) != hipSuccess) return nullptr;
+    g->allocs.push_back(d);
+    if (hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return static_cast<T*>(d);
+}
+
+float* upload_f(emd_graph* g, const std::vector<double>& v) {
+    std::vector<float> f(v.begin(), v.end());
+    return upload(g, f.data(), f.size());
+}
+
+// host weights [taps][a][b] -> packed planes on the device
+bool pack(emd_graph* g, const float* w, int taps, int cin, int cout, int cout_major, Packed* out) {
+    const size_t n = emd_packed_weight_elems(taps, cin, cout), npad = (n + 63) / 64 * 64;
+    std::vector<uint16_t> both(2 * npad, 0);
+    if (emd_pack_weights_bf16(w, taps, cin, cout, cout_major, both.data(), both.data() + npad) != EMD_OK) return false;
+    uint16_t* d = upload(g, both.data(), both.size());
+    if (!d) return false;
+    out->hi = d;
+    out->lo = d + npad;
+    return true;
+}
+
+// inference batch norm as y = x * gs + hs (float64)
+bool bn_affine(const WeightMap& w, const std::string& scope, int C, std::vector<double>* gs, std::vector<double>* hs, std::string* err) {
+    const float *gamma, *beta, *mean, *var;
+    if (!fetch(w, scope + "/gamma", C, &gamma, err) || !fetch(w, scope + "/beta", C, &beta, err) ||
+        !fetch(w, scope + "/moving_mean", C, &mean, err) || !fetch(w, scope + "/moving_variance", C, &var, err))
+        return false;
+    gs->resize(C);
+    hs->resize(C);
+    for (int c = 0; c < C; ++c) {
+        (*gs)[c] = (double)gamma[c] / std::sqrt((double)var[c] + BN_EPS);
+        (*hs)[c] = (double)beta[c] - (double)mean[c] * (*gs)[c];
+    }
+    return true;
+}
+
+// bias + the layer's consecutive batch norms -> one affine (scale, shift)
+bool fold(const WeightMap& w, const LayerDecl& d, const float* bias, std::vector<double>* s, std::vector<double>* t, std::string* err) {
+    const int C = d.cout;
+    s->assign(C, 1.0);
+    t->assign(C, 0.0);
+    if (bias)
+        for (int c = 0; c < C; ++c) (*t)[c] = bias[c];
+    for (const std::string& scope : d.bn) {
+        std::vector<double> gs, hs;
+        if (!bn_affine(w, scope, C, &gs, &hs, err)) return false;
+        for (int c = 0; c < C; ++c) {
+            (*s)[c] *= gs[c];
+            (*t)[c] = (*t)[c] * gs[c] + hs[c];
+        }
+    }
+    return true;
+}
+
+// ---- workspace: a first-fit free-list allocator over the caller's buffer; in measuring mode it only tracks the peak
+struct Arena {
+    unsigned char* base = nullptr;
+    size_t cap = 0, peak = 0;
+    bool measuring = false;
+    std::map<size_t, size_t> live;   // offset -> size
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        size_t off = 0;
+        for (auto& kv : live) {   // ordered by offset: first gap that fits
+            if (kv.first - off >= bytes) break;
+            off = kv.first + kv.second;
+        }
+        if (!measuring && off + bytes > cap) return nullptr;
+        live[off] = bytes;
+        if (off + bytes > peak) peak = off + bytes;
+        return measuring ? reinterpret_cast<void*>(off + 4096) : static_cast<void*>(base + off);   // measuring: a fake non-null address
+    }
+    void release(void* p) {
+        if (!p) return;
+        const size_t off = measuring ? reinterpret_cast<size_t>(p) - 4096 : static_cast<size_t>(static_cast<unsigned char*>(p) - base);
+        live.erase(off);
+    }
+};
+
+struct T4 {   // an activation: channels [c0, c0 + C) of a [B,H,W,ld] fp32 buffer
+    float* buf = nullptr;
+    int B = 0, H = 0, W = 0, C = 0, ld = 0, c0 = 0;
+    float* ptr() const { return buf + c0; }
+    T4 slice(int off, int n) const {
+        T4 t = *this;
+        t.c0 = c0 + off;
+        t.C = n;
+        return t;
+    }
+};
+
+struct Run {
+    emd_graph* g;
+    Arena* ar;
+    hipStream_t st;
+    bool dry;
+    int rc = EMD_OK;
+
+    T4 E(int B, int H, int W, int C) {
+        T4 t;
+        t.B = B; t.H = H; t.W = W; t.C = C; t.ld = C;
+        t.buf = static_cast<float*>(ar->alloc((size_t)B * H * W * C * 4));
+        if (!t.buf && rc == EMD_OK) rc = emd::fail(EMD_E_INVALID, "emd_graph_run: workspace too small");
+        return t;
+    }
+    void* raw(size_t bytes) {
+        void* p = ar->alloc(bytes);
+        if (!p && rc == EMD_OK) rc = emd::fail(EMD_E_INVALID, "emd_graph_run: workspace too small");
+        return p;
+    }
+    void free(T4& t) {
+        ar->release(t.buf);
+        t.buf = nullptr;
+    }
+    void call(int code) {
+        if (code != EMD_OK && rc == EMD_OK) rc = code;
+    }
+    bool live() const { return !dry && rc == EMD_OK; }
+
+    static bool split_gemm_ok(long npix, int cout, int ktot) {
+        return cout >= 128 && ktot >= 512 && ((npix + 255) / 256) * ((cout + 127) / 128) >= 192;
+    }
+    static bool deconv_fused_ok(long npix) { return npix >= 256L * 192; }
+
+    // strided_conv_block (denoiser.py:110-136); out: optional destination (a concat slice); split_out: write a split32 tensor
+    T4 sep(const std::string& key, const T4& x, const T4* out_opt, const T4* res, void** split_out = nullptr) {
+        const LayerParams& p = g->P[key];
+        const LayerDecl& d = p.d;
+        const int Ho = (x.H + d.stride - 1) / d.stride, Wo = (x.W + d.stride - 1) / d.stride;
+        const long M = (long)x.B * Ho * Wo;
+        T4 out;
+        const bool want_split = split_out != nullptr;
+        const int ld_split = emd_split32_ld(d.cout);
+        if (want_split) {
+            *split_out = raw((size_t)M * ld_split * 4);
+        } else {
+            out = out_opt ? *out_opt : E(x.B, Ho, Wo, d.cout);
+        }
+        if (emd_sep3x3_fused_supported(x.H, x.W, d.cin, d.cout, d.stride, d.rate)) {
+            if (live()) {
+                if (want_split)
+                    call(emd_sep3x3_fused_out_f32(x.ptr(), x.ld, p.dw, p.pw.hi, p.pw.lo, p.scale, p.shift, p.scale2, p.shift2,
+                                                  res ? res->ptr() : nullptr, res ? res->ld : 0, *split_out, ld_split, x.B, x.H, x.W, d.cin,
+                                                  d.cout, EMD_ACT_RELU6, st));
+                else
+                    call(emd_sep3x3_fused_f32(x.ptr(), x.ld, p.dw, p.pw.hi, p.pw.lo, p.scale, p.shift, p.scale2, p.shift2,
+                                              res ? res->ptr() : nullptr, res ? res->ld : 0, out.ptr(), out.ld, x.B, x.H, x.W, d.cin, d.cout,
+                                              EMD_ACT_RELU6, EMD_PREC_BF16X3, st));
+            }
+            return out;
+        }
+        if (emd_conv1x1_split32_supported(M, d.cin, d.cout)) {
+            const int ldd = emd_split32_ld(d.cin);
+            void* dsp = raw((size_t)M * ldd * 4);
+            if (live()) {
+                call(emd_dw3x3_split32_f32(x.ptr(), x.ld, p.dw, dsp, ldd, x.B, x.H, x.W, d.cin, d.stride, d.rate, st));
+                if (want_split)
+                    call(emd_conv1x1_split32_out_f32(dsp, ldd, p.pw.hi, p.pw.lo, p.scale, p.shift, p.scale2, p.shift2,
+                                                     res ? res->ptr() : nullptr, res ? res->ld : 0, *split_out, ld_split, M, d.cin, d.cout,
+                                                     EMD_ACT_RELU6, st));
+                else
+                    call(emd_conv1x1_split32_f32(dsp, ldd, p.pw.hi, p.pw.lo, p.scale, p.shift, p.scale2, p.shift2,
+                                                 res ? res->ptr() : nullptr, res ? res->ld : 0, out.ptr(), out.ld, M, d.cin, d.cout,
+                                                 EMD_ACT_RELU6, st));
+            }
+            ar->release(dsp);
+            return out;
+        }
+        if (want_split && rc == EMD_OK) rc = emd::fail(EMD_E_UNSUPPORTED, "emd_graph_run: no split32-writing kernel for this layer shape");
+        T4 tmp = E(x.B, Ho, Wo, d.cin);
+        if (live()) {
+            call(emd_dw3x3_f32(x.ptr(), x.ld, p.dw, tmp.ptr(), tmp.ld, x.B, x.H, x.W, d.cin, d.stride, d.rate, st));
+            call(emd_conv1x1_f32(tmp.ptr(), tmp.ld, p.pw.hi, p.pw.lo, p.scale, p.shift, p.scale2, p.shift2, res ? res->ptr() : nullptr,
+                                 res ? res->ld : 0, out.ptr(), out.ld, x.B, Ho, Wo, d.cin, d.cout, 1, EMD_ACT_RELU6, EMD_PREC_BF16X3, st));
+        }
+        free(tmp);
+        return out;
+    }
+
+    // slim.conv2d(k = 1[, stride 2]) + bias + BN + relu6; xs: the input already in split32 form (shared by the ASPP branches)
+    T4 conv1x1(const std::string& key, const T4& x, const T4* out_opt, const void* xs = nullptr, int ldxs = 0) {
+        const LayerParams& p = g->P[key];
+        const LayerDecl& d = p.d;
+        const int Ho = (x.H + d.stride - 1) / d.stride, Wo = (x.W + d.stride - 1) / d.stride;
+        T4 out = out_opt ? *out_opt : E(x.B, Ho, Wo, d.cout);
+        if (!live()) return out;
+        if (xs && d.stride == 1 && split_gemm_ok((long)x.B * Ho * Wo, d.cout, d.cin))
+            call(emd_conv1x1_split32_f32(xs, ldxs, p.pw.hi, p.pw.lo, p.scale, p.shift, nullptr, nullptr, nullptr, 0, out.ptr(), out.ld,
+                                         (long)x.B * Ho * Wo, d.cin, d.cout, EMD_ACT_RELU6, st));
+        else
+            call(emd_conv1x1_f32(x.ptr(), x.ld, p.pw.hi, p.pw.lo, p.scale, p.shift, nullptr, nullptr, nullptr, 0, out.ptr(), out.ld, x.B, x.H,
+                                 x.W, d.cin, d.cout, d.stride, EMD_ACT_RELU6, EMD_PREC_BF16X3, st));
+        return out;
+    }
+
+    // slim.conv2d_transpose(k = 3, stride 2) + bias + BN + relu6 into `out`; x fp32, or xs a split32 tensor
+    void deconv(const std::string& key, const T4* x, const void* xs, int B, int H, int W, const T4& out) {
+        const LayerParams& p = g->P[key];
+        const LayerDecl& d = p.d;
+        const uint16_t* hi[4] = {p.phase[0].hi, p.phase[1].hi, p.phase[2].hi, p.phase[3].hi};
+        const uint16_t* lo[4] = {p.phase[0].lo, p.phase[1].lo, p.phase[2].lo, p.phase[3].lo};
+        const long npix = (long)B * H * W;
+        const int ldx = emd_split32_ld(d.cin);
+        if (deconv_fused_ok(npix) || (d.cin >= 256 && split_gemm_ok(npix, d.cout, 4 * d.cin))) {
+            void* tmp = nullptr;
+            if (!xs) {
+                tmp = raw((size_t)npix * ldx * 4);
+                if (live()) call(emd_to_split32_f32(x->ptr(), x->ld, tmp, ldx, npix, d.cin, st));
+                xs = tmp;
+            }
+            if (live()) {
+                if (deconv_fused_ok(npix))
+                    call(emd_deconv3x3s2_fused_split32_f32(xs, ldx, hi, lo, p.scale, p.shift, out.ptr(), out.ld, B, H, W, d.cin, d.cout,
+                                                           EMD_ACT_RELU6, 0, st));
+                else
+                    call(emd_deconv3x3s2_split32_f32(xs, ldx, hi, lo, p.scale, p.shift, out.ptr(), out.ld, B, H, W, d.cin, d.cout,
+                                                     EMD_ACT_RELU6, 0, st));
+            }
+            ar->release(tmp);
+            return;
+        }
+        if (live())
+            call(emd_deconv3x3s2_f32(x->ptr(), x->ld, hi, lo, p.scale, p.shift, out.ptr(), out.ld, B, H, W, d.cin, d.cout, EMD_ACT_RELU6,
+                                     EMD_PREC_BF16X3, st));
+    }
+
+    // the decoder pair that reads the same tensor (denoiser.py:356-359, :368-371, :380-383)
+    void sep_and_projection(const std::string& sk, const std::string& ck, const T4& x, T4* sep_out, T4* proj_out) {
+        const LayerParams &ps = g->P[sk], &pc = g->P[ck];
+        if (!ps.scale2 && emd_sep3x3_dual_supported(x.H, x.W, x.C, ps.d.cout, pc.d.cout) && ps.d.cout <= 64 && pc.d.cout <= 64) {
+            *sep_out = E(x.B, x.H, x.W, ps.d.cout);
+            *proj_out = E(x.B, x.H, x.W, pc.d.cout);
+            if (live())
+                call(emd_sep3x3_dual_f32(x.ptr(), x.ld, ps.dw, ps.pw.hi, ps.pw.lo, ps.scale, ps.shift, sep_out->ptr(), sep_out->ld, pc.pw.hi,
+                                         pc.pw.lo, pc.scale, pc.shift, proj_out->ptr(), proj_out->ld, x.B, x.H, x.W, x.C, ps.d.cout, pc.d.cout,
+                                         EMD_ACT_RELU6, st));
+            return;
+        }
+        *proj_out = conv1x1(ck, x, nullptr);
+        *sep_out = sep(sk, x, nullptr, nullptr);
+    }
+
+    // architecture() (denoiser.py:248-398) on x [B,S,S,1] -> y [B,S,S,1]
+    void forward(const float* xin, float* yout, int B, int S) {
+        const int S2 = S / 2, S4 = S / 4, S16 = S / 16;
+        auto& P = g->P;
+        // encoder 0 (:252-264): cnn0 = relu6(d * a + t) is an outer product of the 1-channel depthwise result d -- cnn0_last's patch
+        // loader rebuilds it (emd_sep3x3_fused_gen_f32) where the fused kernel covers the shape
+        T4 cnn0_last;
+        if (emd_sep3x3_fused_supported(S, S, F0, F0, 1, 1)) {
+            T4 d4 = E(B, S, S, 4);
+            cnn0_last = E(B, S, S, F0);
+            if (live()) {
+                const LayerParams &pc = P["cnn0"], &pl = P["cnn0_last"];
+                call(emd_cin1_f32(xin, pc.w9, g->unit4, g->zero4, d4.ptr(), d4.ld, B, S, S, 4, 1, 0, st));
+                call(emd_sep3x3_fused_gen_f32(d4.ptr(), d4.ld, pc.a, pc.shift, EMD_ACT_RELU6, pl.dw, pl.pw.hi, pl.pw.lo, pl.scale, pl.shift, nullptr,
+                                              nullptr, nullptr, 0, cnn0_last.ptr(), cnn0_last.ld, B, S, S, F0, F0, EMD_ACT_RELU6, EMD_PREC_BF16X3, 0, st));
+            }
+            free(d4);
+        } else {
+            T4 cnn0 = E(B, S, S, F0);
+            if (live()) call(emd_cin1_f32(xin, P["cnn0"].w9, P["cnn0"].a, P["cnn0"].shift, cnn0.ptr(), cnn0.ld, B, S, S, F0, 1, 1, st));
+            cnn0_last = sep("cnn0_last", cnn0, nullptr, nullptr);
+            free(cnn0);
+        }
+        T4 residual0 = E(B, S2, S2, F1);
+        if (live()) call(emd_cin1_f32(xin, nullptr, P["residual0"].a, P["residual0"].shift, residual0.ptr(), residual0.ld, B, S, S, F1, 2, 1, st));
+        T4 concat1 = E(B, S2, S2, F2 + F1);
+        T4 c1s = concat1.slice(F2, F1);
+        T4 cnn0_strided = sep("cnn0_strided", cnn0_last, &c1s, &residual0);
+        free(cnn0_last);
+        free(residual0);
+        // encoder 1 (:267-279)
+        T4 residual1 = conv1x1("residual1", cnn0_strided, nullptr);
+        T4 cnn1 = sep("cnn1", cnn0_strided, nullptr, nullptr);
+        T4 cnn1_last = sep("cnn1_last", cnn1, nullptr, nullptr);
+        T4 concat2 = E(B, S4, S4, AOUT + F1);
+        T4 c2s = concat2.slice(AOUT, F1);
+        T4 cnn1_strided = sep("cnn1_strided", cnn1_last, &c2s, &residual1);
+        free(cnn1); free(cnn1_last); free(residual1);
+        // encoder 2 (:282-294)
+        T4 residual2 = conv1x1("residual2", cnn1_strided, nullptr);
+        T4 cnn2 = sep("cnn2", cnn1_strided, nullptr, nullptr);
+        T4 cnn2_last = sep("cnn2_last", cnn2, nullptr, nullptr);
+        T4 cnn2_strided = sep("cnn2_strided", cnn2_last, nullptr, &residual2);
+        free(cnn2); free(cnn2_last); free(residual2);
+        // encoder 3 (:297-309)
+        T4 residual3 = conv1x1("residual3", cnn2_strided, nullptr);
+        T4 cnn3 = sep("cnn3", cnn2_strided, nullptr, nullptr);
+        T4 cnn3_last = sep("cnn3_last", cnn3, nullptr, nullptr);
+        T4 cnn3_strided = sep("cnn3_strided", cnn3_last, nullptr, &residual3);
+        free(cnn2_strided); free(cnn3); free(cnn3_last); free(residual3);
+        // encoder 4 (:312-322) and the middle flow (:324-325)
+        T4 t = sep("cnn4_a", cnn3_strided, nullptr, nullptr);
+        T4 t2 = sep("cnn4_b", t, nullptr, nullptr);
+        free(t);
+        T4 cur = sep("cnn4_last", t2, nullptr, &cnn3_strided);
+        free(t2);
+        free(cnn3_strided);
+        for (int i = 0; i < NEXTRA; ++i) {
+            const std::string k = "middle" + std::to_string(i) + "_";
+            T4 a = sep(k + "0", cur, nullptr, nullptr);
+            T4 b = sep(k + "1", a, nullptr, nullptr);
+            free(a);
+            T4 nxt = sep(k + "2", b, nullptr, &cur);
+            free(b);
+            free(cur);
+            cur = nxt;
+        }
+        // ASPP (:152-216): the five branches write straight into their slices of the 3640-channel concat
+        T4 cat = E(B, S16, S16, 5 * AF);
+        void* curs = nullptr;
+        const int ldcs = emd_split32_ld(AF);
+        const long npix16 = (long)B * S16 * S16;
+        if (split_gemm_ok(npix16, AF, cur.C)) {
+            curs = raw((size_t)npix16 * ldcs * 4);
+            if (live()) call(emd_to_split32_f32(cur.ptr(), cur.ld, curs, ldcs, npix16, cur.C, st));
+        }
+        T4 s0 = cat.slice(0, AF), s1 = cat.slice(AF, AF), s2 = cat.slice(2 * AF, AF), s3 = cat.slice(3 * AF, AF), s4 = cat.slice(4 * AF, AF);
+        conv1x1("aspp_conv1x1", cur, &s0, curs, ldcs);
+        sep("aspp_small", cur, &s1, nullptr);
+        sep("aspp_medium", cur, &s2, nullptr);
+        sep("aspp_large", cur, &s3, nullptr);
+        // :185-189 the pooled tensor is discarded; :199 "pooling" = an identity resize of the INPUT, then BN + relu6 (:200)
+        if (live())
+            call(emd_affine_relu6_f32(cur.ptr(), cur.ld, P["aspp_pooling_bn"].scale, P["aspp_pooling_bn"].shift, s4.ptr(), s4.ld, npix16, AF, 1, st));
+        T4 aspp = conv1x1("aspp_reduce", cat, nullptr);
+        free(cur);
+        free(cat);
+        ar->release(curs);
+        // decoder (:350-384)
+        T4 c2a = concat2.slice(0, AOUT);
+        if (live()) call(emd_resize_bilinear_f32(aspp.ptr(), aspp.ld, c2a.ptr(), c2a.ld, B, S16, S16, S4, S4, AOUT, st));
+        free(aspp);
+        T4 residual2_d = conv1x1("residual2_d", concat2, nullptr);
+        T4 d2a = sep("deconv2_a", concat2, nullptr, nullptr);
+        const bool so2 = deconv_fused_ok((long)B * S4 * S4) && S4 % 8 == 0 && S4 % 16 == 0;
+        void* deconv2_s = nullptr;
+        T4 deconv2 = sep("deconv2_b", d2a, nullptr, &residual2_d, so2 ? &deconv2_s : nullptr);
+        free(d2a); free(residual2_d); free(concat2);
+        T4 c1a = concat1.slice(0, F2);
+        deconv("deconv2to1", so2 ? nullptr : &deconv2, deconv2_s, B, S4, S4, c1a);
+        free(deconv2);
+        ar->release(deconv2_s);
+        // deconv1_a + residual1_d read concat1 (128 | 128 columns: two launches)
+        T4 residual1_d = conv1x1("residual1_d", concat1, nullptr);
+        T4 d1a = sep("deconv1_a", concat1, nullptr, nullptr);
+        const bool so1 = deconv_fused_ok((long)B * S2 * S2) && S2 % 8 == 0 && S2 % 16 == 0;
+        void* deconv1_s = nullptr;
+        T4 deconv1 = sep("deconv1_b", d1a, nullptr, &residual1_d, so1 ? &deconv1_s : nullptr);
+        free(d1a); free(residual1_d); free(concat1);
+        T4 deconv1to0 = E(B, S, S, F1);
+        deconv("deconv1to0", so1 ? nullptr : &deconv1, deconv1_s, B, S2, S2, deconv1to0);
+        free(deconv1);
+        ar->release(deconv1_s);
+        T4 d0a, residual0_d;
+        sep_and_projection("deconv0_a", "residual0_d", deconv1to0, &d0a, &residual0_d);
+        T4 deconv0 = sep("deconv0_b", d0a, nullptr, &residual0_d);
+        free(deconv1to0); free(d0a); free(residual0_d);
+        if (live()) {
+            const LayerParams& pf = P["deconv_final"];   // no output clip in D (:396)
+            call(emd_conv3x3_cout1_f32(deconv0.ptr(), deconv0.ld, pf.wfin, pf.scale_f, pf.shift_f, yout, B, S, S, F0, 1, 0.f, 0, st));
+        }
+        free(deconv0);
+    }
+};
+
+}  // namespace
+
+extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const char* const* names, const float* const* data,
+                                const long* counts) {
+    EMD_REQUIRE(out && names && data && counts && n_vars > 0, EMD_E_INVALID, "emd_graph_create: null argument");
+    EMD_REQUIRE(variant == 0, EMD_E_UNSUPPORTED, "emd_graph_create: variant 0 (graph D, machine_learning/denoiser.py) only");
+    *out = nullptr;
+    WeightMap w;
+    for (int i = 0; i < n_vars; ++i) {
+        EMD_REQUIRE(names[i] && data[i] && counts[i] > 0, EMD_E_INVALID, "emd_graph_create: null variable entry");
+        w[names[i]] = {data[i], counts[i]};
+    }
+    emd_graph* g = new emd_graph();
+    std::string err;
+    bool ok = true;
+    const float u4[4] = {1.f, 0.f, 0.f, 0.f}, z4[4] = {0.f, 0.f, 0.f, 0.f};
+    g->unit4 = upload(g, u4, 4);
+    g->zero4 = upload(g, z4, 4);
+    ok = g->unit4 && g->zero4;
+    if (!ok) err = "emd_graph_create: device allocation failed";
+    for (const LayerDecl& d : declare_layers()) {
+        if (!ok) break;
+        LayerParams p;
+        p.d = d;
+        std::vector<double> s, t;
+        if (d.kind == SEP) {
+            const float *dw, *pw;
+            ok = fetch(w, d.scope + "/depthwise_weights", 9L * d.cin, &dw, &err) && fetch(w, d.scope + "/pointwise_weights", (long)d.cin * d.cout, &pw, &err) &&
+                 fold(w, d, nullptr, &s, &t, &err);
+            if (!ok) break;
+            if (d.cin == 1) {   // cnn0: depthwise on the 1-channel image, then an outer product
+                std::vector<double> a(d.cout);
+                for (int c = 0; c < d.cout; ++c) a[c] = (double)pw[c] * s[c];
+                p.w9 = upload(g, dw, 9);
+                p.a = upload_f(g, a);
+                p.shift = upload_f(g, t);
+                ok = p.w9 && p.a && p.shift;
+            } else {
+                p.dw = upload(g, dw, 9 * (size_t)d.cin);   // [3][3][Cin][1] == [9][Cin]
+                ok = p.dw && pack(g, pw, 1, d.cin, d.cout, 0, &p.pw);
+                p.scale = upload_f(g, s);
+                p.shift = upload_f(g, t);
+                ok = ok && p.scale && p.shift;
+            }
+            if (ok && !d.extra_bn.empty()) {
+                std::vector<double> gs, hs;
+                ok = bn_affine(w, d.extra_bn, d.cout, &gs, &hs, &err);
+                if (ok) {
+                    p.scale2 = upload_f(g, gs);
+                    p.shift2 = upload_f(g, hs);
+                    ok = p.scale2 && p.shift2;
+                }
+            }
+        } else if (d.kind == CONV) {
+            const float *wt, *bias;
+            ok = fetch(w, d.scope + "/weights", (long)d.k * d.k * d.cin * d.cout, &wt, &err) && fetch(w, d.scope + "/biases", d.cout, &bias, &err) &&
+                 fold(w, d, bias, &s, &t, &err);
+            if (!ok) break;
+            if (d.cin == 1) {   // residual0
+                std::vector<double> a(d.cout);
+                for (int c = 0; c < d.cout; ++c) a[c] = (double)wt[c] * s[c];
+                p.a = upload_f(g, a);
+                p.shift = upload_f(g, t);
+                ok = p.a && p.shift;
+            } else if (d.cout == 1) {   // deconv_final: [3][3][Cin][1] == [9][Cin]
+                p.wfin = upload(g, wt, 9 * (size_t)d.cin);
+                p.scale_f = (float)s[0];
+                p.shift_f = (float)t[0];
+                ok = p.wfin != nullptr;
+            } else {
+                ok = pack(g, wt, d.k * d.k, d.cin, d.cout, 0, &p.pw);
+                p.scale = upload_f(g, s);
+                p.shift = upload_f(g, t);
+                ok = ok && p.scale && p.shift;
+            }
+        } else if (d.kind == DECONV) {
+            const float *wt, *bias;   // [3][3][Cout][Cin]
+            ok = fetch(w, d.scope + "/weights", 9L * d.cin * d.cout, &wt, &err) && fetch(w, d.scope + "/biases", d.cout, &bias, &err) &&
+                 fold(w, d, bias, &s, &t, &err);
+            if (!ok) break;
+            for (int ph = 0; ph < 4 && ok; ++ph) {
+                int ky[4], kx[4];
+                const int nt = emd_deconv_phase_taps(ph, ky, kx);
+                std::vector<float> sub((size_t)nt * d.cout * d.cin);
+                for (int q = 0; q < nt; ++q)
+                    std::memcpy(sub.data() + (size_t)q * d.cout * d.cin, wt + (size_t)(ky[q] * 3 + kx[q]) * d.cout * d.cin, sizeof(float) * d.cout * d.cin);
+                ok = pack(g, sub.data(), nt, d.cin, d.cout, 1, &p.phase[ph]);
+            }
+            p.scale = upload_f(g, s);
+            p.shift = upload_f(g, t);
+            ok = ok && p.scale && p.shift;
+        } else {
+            std::vector<double> gs, hs;
+            ok = bn_affine(w, d.bn[0], d.cout, &gs, &hs, &err);
+            if (ok) {
+                p.scale = upload_f(g, gs);
+                p.shift = upload_f(g, hs);
+                ok = p.scale && p.shift;
+            }
+        }
+        if (!ok && err.empty()) err = "emd_graph_create: device allocation or weight packing failed at layer " + d.key;
+        g->P[d.key] = p;
+    }
+    if (!ok) {
+        emd::set_error("%s", err.c_str());
+        for (void* q : g->allocs) (void)hipFree(q);
+        delete g;
+        return EMD_E_INVALID;
+    }
+    *out = g;
+    return EMD_OK;
+}
+
+extern "C" size_t emd_graph_workspace_bytes(emd_graph* g, int B, int S) {
+    if (!g || B < 1 || S < 16 || S % 16) return 0;
+    Arena ar;
+    ar.measuring = true;
+    Run r{g, &ar, nullptr, true};
+    r.forward(nullptr, nullptr, B, S);
+    return ar.peak + 256;
+}
+
+extern "C" int emd_graph_run(emd_graph* g, const float* x, float* y, int B, int S, void* workspace, size_t workspace_bytes,
+                             emd_stream_t stream) {
+    EMD_REQUIRE(g && x && y && workspace, EMD_E_INVALID, "emd_graph_run: null pointer");
+    EMD_REQUIRE(B >= 1 && S >= 16 && S % 16 == 0, EMD_E_INVALID, "emd_graph_run: square crops with side a multiple of 16, B >= 1");
+    EMD_REQUIRE(x != y, EMD_E_INVALID, "emd_graph_run: the output aliases the input");
+    unsigned char* base = static_cast<unsigned char*>(workspace);
+    const size_t skew = (256 - (reinterpret_cast<uintptr_t>(base) & 255)) & 255;
+    EMD_REQUIRE(workspace_bytes > skew, EMD_E_INVALID, "emd_graph_run: workspace too small");
+    Arena ar;
+    ar.base = base + skew;
+    ar.cap = workspace_bytes - skew;
+    Run r{g, &ar, static_cast<hipStream_t>(stream), false};
+    r.forward(x, y, B, S);
+    return r.rc;
+}
+
+extern "C" void emd_graph_destroy(emd_graph* g) {
+    if (!g) return;
+    for (void* q : g->allocs) (void)hipFree(q);
+    delete g;
+}

@@ -634,6 +634,29 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
             out["pointwise"]["isolated_32768x728x728"] = iso
         except Exception as e:
             out["pointwise"]["isolated_32768x728x728"] = {"error": f"{type(e).__name__}: {e}"}
+    if primary and rank == 0 and B and a.precision == "bf16x3":
+        # the same graph through the library's native executor (emd_graph_create / _run: the launch sequence in C++, single stream)
+        try:
+            from emdenoise.graph_exec import NativeGraph
+
+            nat = NativeGraph(weights, dev)
+            yn = nat.forward(x)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(yn, box[0]))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                nat.forward(x)
+            e1.record()
+            torch.cuda.synchronize()
+            out["native_executor"] = {"ms_per_step": round(e0.elapsed_time(e1) / 5, 3), "bit_identical_to_python_engine": same,
+                                      "workspace_GiB": round(nat.workspace_bytes(B, H) / 2 ** 30, 2),
+                                      "note": "emd_graph_run (csrc/graph_exec.hip): layer table, BN folding, packing, kernel selection and launch order "
+                                              "in the library; single stream (the Python engine runs the 1/16-resolution flow as two halves on two streams)"}
+            nat.close()
+            del nat, yn
+        except Exception as e:
+            out["native_executor"] = {"error": f"{type(e).__name__}: {e}"}
     if primary and rank == 0 and B:
         # end to end from pinned host memory: H2D copy + forward + D2H copy of the same batch
         try:
@@ -1062,7 +1085,7 @@ def worker(a):
         "roofline": prim["roofline"],
     }
     for k in ("median_hipevent_ms", "cpu_baseline", "rel_l2_vs_oracle", "psnr_vs_oracle_db", "parity_note", "matrix_cores", "depthwise", "pointwise",
-              "kernel_family_ms", "from_pinned_host", "tflops_algorithmic", "loss_first_tower", "allreduce", "d_fake_first", "d_out_first"):
+              "kernel_family_ms", "from_pinned_host", "native_executor", "tflops_algorithmic", "loss_first_tower", "allreduce", "d_fake_first", "d_out_first"):
         if k in prim:
             out[k] = prim[k]
     if rank == 0 and primary == "D" and not multi:

@@ -578,6 +578,24 @@ int emd_gen_lq_f32(const float* img, const float* scale, float* lq, float* truth
                    unsigned long long seed, unsigned long long first_image, void* workspace, emd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Graph D as a native executor (csrc/graph_exec.hip): architecture() of machine_learning/denoiser.py:58-398 for
+ * a host that is not Python.  emd_graph_create takes the weights as HOST float32 arrays keyed by TensorFlow variable name
+ * (the names tf.train.Saver stores under scope 'nn', :514: nn/SeparableConv2d[_k]/{depthwise_weights,pointwise_weights},
+ * nn/SeparableConv2d[_k]/BatchNorm/{beta,gamma,moving_mean,moving_variance}, nn/BatchNorm[_k]/..., nn/Conv[_k]/{weights,biases},
+ * nn/Conv2d_transpose[_k]/{weights,biases}; 658 variables), folds the inference batch norms (float64), packs the matrix-core
+ * weights and uploads them into device memory owned by the handle.  emd_graph_run launches the whole forward pass on `stream`:
+ * x, y device float32 [B,S,S,1] (S a multiple of 16; no output clip, :396), activations in the caller's `workspace` (device
+ * memory, emd_graph_workspace_bytes(g, B, S) bytes).  Same kernels in the same order as emdenoise.denoiser.DenoiserEngine:
+ * bit-identical results.  variant: 0 = graph D (the only one built). */
+typedef struct emd_graph emd_graph_t;
+int emd_graph_create(emd_graph_t** graph, int variant, int n_vars, const char* const* names, const float* const* host_data,
+                     const long* counts);
+size_t emd_graph_workspace_bytes(emd_graph_t* graph, int B, int S);
+int emd_graph_run(emd_graph_t* graph, const float* x, float* y, int B, int S, void* workspace, size_t workspace_bytes,
+                  emd_stream_t stream);
+void emd_graph_destroy(emd_graph_t* graph);
+
+/* ------------------------------------------------------------------------------------------------
  * Host utility (no GPU): CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start).
  * Used by the TFRecord reader (emdenoise.input_pipeline) for the container that
  * misc_py/TFRecord_creator.py:57-85 writes with tf.python_io.TFRecordWriter. */

@@ -1,0 +1,76 @@
+"""The native graph executor (csrc/graph_exec.hip: emd_graph_create / _workspace_bytes / _run / _destroy) against the
+Python engine and the oracle.  The executor re-derives everything from the TensorFlow-named weights on its own (layer table, folded
+batch norms, packed weights, kernel selection, launch order, workspace planning), so bit-identity with DenoiserEngine checks all of it."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.synth_inputs import synthetic_lq
+
+
+def test_create_reports_a_missing_or_misshapen_variable():
+    """Argument validation runs before any device work for the first missing name (no GPU needed for this branch)."""
+    import emdenoise
+    from emdenoise import _lib
+
+    lib = _lib.load()
+    w = emdenoise.synthetic_weights()
+    names = [n for n in w if not n.endswith("/gamma")][:5]
+    arrays = [np.ascontiguousarray(w[n], np.float32) for n in names]
+    h = C.c_void_p()
+    rc = lib.emd_graph_create(C.byref(h), 1, len(names), (C.c_char_p * 5)(*[n.encode() for n in names]),
+                              (C.c_void_p * 5)(*[a.ctypes.data for a in arrays]), (C.c_long * 5)(*[a.size for a in arrays]))
+    assert rc == -2 and b"variant" in lib.emd_last_error()          # only graph D is built
+    assert lib.emd_graph_workspace_bytes(None, 1, 64) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S", [(2, 64), (1, 48), (4, 512)])
+def test_native_graph_equals_the_python_engine(B, S):
+    import emdenoise
+    from emdenoise.graph_exec import NativeGraph
+
+    dev = torch.device("cuda", 0)
+    w = emdenoise.synthetic_weights()
+    eng = emdenoise.DenoiserEngine(w, dev, "bf16x3")
+    nat = NativeGraph(w, dev)
+    x = torch.from_numpy(synthetic_lq(B, S, S, seed=70 + S)).to(dev)
+    want = eng.forward(x)
+    got = nat.forward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    again = nat.forward(x)                                           # the workspace is reused; nothing stale in it matters
+    torch.cuda.synchronize()
+    assert torch.equal(again, want)
+    assert nat.workspace_bytes(B, S) > 0
+    nat.close()
+
+
+@pytest.mark.gpu
+def test_native_graph_matches_the_oracle_and_reports_errors():
+    import emdenoise
+    from emdenoise import _lib
+    from emdenoise.graph_exec import NativeGraph
+    from oracle import denoiser_graph as G
+
+    dev = torch.device("cuda", 0)
+    w = emdenoise.synthetic_weights()
+    nat = NativeGraph(w, dev)
+    x = synthetic_lq(2, 64, 64, seed=5)
+    ref = G.architecture(x, w, 64, dtype=torch.float64).numpy()
+    got = nat.forward(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 3e-4
+    # a workspace that is too small is reported, not overrun
+    xs = torch.from_numpy(x).to(dev)
+    small = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    rc = nat.lib.emd_graph_run(nat._h, C.c_void_p(xs.data_ptr()), C.c_void_p(torch.empty_like(xs).data_ptr()), 2, 64, C.c_void_p(small.data_ptr()),
+                               C.c_size_t(small.numel()), _lib.stream_ptr())
+    assert rc != 0 and b"workspace" in nat.lib.emd_last_error()
+    torch.cuda.synchronize()
+    bad = dict(w)
+    del bad["nn/Conv_3/biases"]
+    with pytest.raises(_lib.EmdError, match="missing variable nn/Conv_3/biases"):
+        NativeGraph(bad, dev)
+    nat.close()
