@@ -544,7 +544,7 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
             if (!ok) break;
             if (d.cin == 1) {   // cnn0: depthwise on the 1-channel image, then an outer product
                 std::vector<double> a(d.cout);
-                for (int c = 0; c < d.cout; ++c) a[c] = (double)pw[c] * s[c];
+                for (int c = 0; c < d.cout; ++c) a[c] = (double)pw[c] * (double)(float)s[c];   // the folded scale is a float32 value (as in denoiser.py)
                 p.w9 = upload(g, dw, 9);
                 p.a = upload_f(g, a);
                 p.shift = upload_f(g, t);
@@ -572,7 +572,7 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
             if (!ok) break;
             if (d.cin == 1) {   // residual0
                 std::vector<double> a(d.cout);
-                for (int c = 0; c < d.cout; ++c) a[c] = (double)wt[c] * s[c];
+                for (int c = 0; c < d.cout; ++c) a[c] = (double)wt[c] * (double)(float)s[c];
                 p.a = upload_f(g, a);
                 p.shift = upload_f(g, t);
                 ok = p.a && p.shift;
