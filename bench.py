@@ -975,7 +975,7 @@ METRIC = {"T": "megapixels/sec trained (512x512x1 LQ/HQ pairs)", "G": "megapixel
 
 
 # ================================================================================================
-def dry_run(a, rank, world):
+def dry_run(a, rank, world, real_stdout=None):
     """The launch / rendezvous / sharding / timing / reporting path with a host stand-in for the step: no GPU, no kernels.
     Exercised by tests/test_bench_launch.py with two ranks over gloo."""
     import numpy as np
@@ -1009,18 +1009,30 @@ def dry_run(a, rank, world):
                           "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
                           "config": {"workload": f"dry run: host stand-in for the step on [{Bl},{S},{S},1] per rank", "global_batch": total,
                                      "shards": shards, "sharding": shard_note(a, world, Bl, total)},
-                          "roofline": None, "cpu_baseline": None}), flush=True)
+                          "roofline": None, "cpu_baseline": None}), file=real_stdout or sys.stdout, flush=True)
     return 0
 
 
 def worker(a):
+    # stdout carries ONE JSON line and nothing else: libraries that print to fd 1 (RCCL's version banner at communicator
+    # creation does) are sent to stderr for the life of the process, the line goes to a duplicate of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    try:
+        return _worker(a, real_stdout)
+    finally:
+        real_stdout.flush()
+
+
+def _worker(a, real_stdout):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.dry_run:
-        return dry_run(a, rank, world)
+        return dry_run(a, rank, world, real_stdout)
 
     import torch
 
@@ -1114,7 +1126,7 @@ def worker(a):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     return 1 if failed else 0
 
 
