@@ -60,6 +60,7 @@ class _Graph:
         self.calibrate = None  # optional dict: batch statistics of every BN input are written here AND used
         self.training = False  # phase=True (denoiser-multi-gpu.py:214): batch statistics, differentiable
         self.moving_updates = None  # training: dict scope/moving_* -> updated value (decay 0.999, unbiased variance)
+        self.saved = None  # optional dict scope -> {"d": depthwise output, "r": conv / pointwise / transposed-conv output (bias included)}
 
     # ---- denoiser.py:71-84
     def _batch_norm_fn(self, x, scope=None):
@@ -109,7 +110,10 @@ class _Graph:
             wn, bn = "/weights", "/biases"
         w = self.get(scope + wn, (kernel_size, kernel_size, x.shape[-1], filters))
         b = self.get(scope + bn, (filters,))
-        return T.conv2d_t(x, w, b, stride=stride, rate=rate)
+        y = T.conv2d_t(x, w, b, stride=stride, rate=rate)
+        if self.saved is not None:
+            self.saved[scope] = {"r": y.detach()}
+        return y
 
     def conv_block_not_sep(self, x, filters, kernel_size=3, stride=1):
         return self.batch_then_activ(self._conv(x, filters, kernel_size, stride))
@@ -121,8 +125,10 @@ class _Graph:
         cin = x.shape[-1]
         dw = self.get(scope + "/depthwise_weights", (3, 3, cin, 1))
         pw = self.get(scope + "/pointwise_weights", (1, 1, cin, filters))
-        y = T.depthwise_conv2d_t(x, dw, stride=stride, rate=rate)
-        y = T.conv2d_t(y, pw, None)
+        d = T.depthwise_conv2d_t(x, dw, stride=stride, rate=rate)
+        y = T.conv2d_t(d, pw, None)
+        if self.saved is not None:
+            self.saved[scope] = {"d": d.detach(), "r": y.detach()}
         y = self._batch_norm_fn(y, scope + "/BatchNorm")
         return self.batch_then_activ(y)
 
@@ -134,7 +140,10 @@ class _Graph:
         scope = self.names.unique("conv2d_transpose" if self.twin else "Conv2d_transpose")
         w = self.get(scope + ("/kernel" if self.twin else "/weights"), (3, 3, filters, x.shape[-1]))
         b = self.get(scope + ("/bias" if self.twin else "/biases"), (filters,))
-        return self.batch_then_activ(T.conv2d_transpose_s2_t(x, w, b))
+        y = T.conv2d_transpose_s2_t(x, w, b)
+        if self.saved is not None:
+            self.saved[scope] = {"r": y.detach()}
+        return self.batch_then_activ(y)
 
     # ---- denoiser.py:152-216
     def aspp_block_twin(self, x, aspp_size):
@@ -270,12 +279,13 @@ def architecture(inputs, weights, cropsize=512, dtype=torch.float32, trace=None,
         return g.build(x.to(dtype), cropsize)
 
 
-def tower_gradients(inputs, truth, weights, cropsize, dtype=torch.float64, variant="Dprime", trace=None):
+def tower_gradients(inputs, truth, weights, cropsize, dtype=torch.float64, variant="Dprime", trace=None, saved=None):
     """One tower of the training twin (misc_py/denoiser-multi-gpu.py:752-782): architecture(phase=True) on
     ``inputs``, mse = mean((out-truth)^2), loss = 1000*mse if mse < 1e-3 else sqrt(1000*mse) (+ weight_decay * sum of
     l2 losses with weight_decay = 0, :117), tf.gradients(loss, trainable variables) via PyTorch autograd.
     -> dict(out, mse, loss, grads {name: numpy}, moving {name: numpy updated moving statistics}).
-    Use float64: PyTorch's float32 CPU convolution backward was seen to crash (heap corruption) on the GPU box's host."""
+    float64 by default.  The float32 form works in CPU-only processes; inside a process that has also initialised the GPU runtime
+    PyTorch-CPU's float32 conv backward has twice aborted with glibc heap corruption -- do not call it there."""
     leaves = {}
 
     def get(name, shape):
@@ -292,6 +302,7 @@ def tower_gradients(inputs, truth, weights, cropsize, dtype=torch.float64, varia
     g.training = True
     g.moving_updates = {}
     g.trace = trace  # optional list: every relu6 output (detached by the caller if kept)
+    g.saved = saved  # optional dict: per conv scope, the tensors a hand-written backward pass saves (see _Graph.saved)
     x = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(inputs))
     t = truth if isinstance(truth, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(truth))
     out = g.build(x.to(dtype), cropsize)

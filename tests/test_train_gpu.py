@@ -116,6 +116,49 @@ def test_gradients_reference_regime():
         assert rel_l2(st[n], v) < 1e-6, n
 
 
+def test_gradients_with_the_oracles_forward_values():
+    """VERDICT r1 item 1e -- is the 2-3e-2 of the reference regime really mask flips?  The trainer's forward pass is teacher
+    forced at every conv output (DenoiserTrainer.teacher: the depthwise, pointwise / conv / transposed-conv results are replaced
+    by the oracle's float64 values right after the kernels have produced them), so batch statistics, activations and the relu6 /
+    clip masks of the backward pass are the oracle's to float32 rounding; the BACKWARD pass is untouched (same kernels, same
+    split-bf16 GEMMs).  If the gradient then agrees at the per-kernel level (bar 3e-4, i.e. two orders of magnitude under the
+    free-running figure) the discrepancy of the free-running run is its forward error acting through the masks."""
+    from emdenoise import trainer as TR
+    from oracle import denoiser_graph as G
+
+    S, B = 64, 1
+    w = weights()
+    lq, hq = synthetic_pair(B, S, S, seed=3)
+    saved = {}
+    ref = G.tower_gradients(lq, hq, w, S, dtype=torch.float64, saved=saved)
+    tr = TR.DenoiserTrainer(w, dev())
+    teacher = {}
+    for key, L in tr.layers.items():
+        if L.scope not in saved:
+            continue
+        t = {k: v.numpy() for k, v in saved[L.scope].items()}
+        if L.kind in ("conv", "deconv") and L.bn:      # the trainer's GEMM leaves the bias to the batch mean (it cancels there)
+            t["r"] = t["r"] - np.asarray(w[L.scope + "/" + L.bname], np.float64)
+        if L.kind == "conv" and L.cout == 1:            # the final 3x3 -> 1 conv likewise runs without its bias
+            pass
+        teacher[L.scope] = t
+    x, t_ = torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev())
+    names = [n for n in ref["grads"] if np.abs(ref["grads"][n]).max() > 1e-9]
+    b = flat(ref["grads"], names)
+    tr.zero_grad()
+    tr.tower(x, t_)
+    free = rel_l2(flat(tr.gradients(), names), b)
+    tr.teacher = teacher
+    tr.zero_grad()
+    out, res = tr.tower(x, t_)
+    torch.cuda.synchronize()
+    forced = rel_l2(flat(tr.gradients(), names), b)
+    print(f"gradient vs float64 oracle at {S} px: free running {free:.2e}; with the oracle's conv outputs forced into the forward pass "
+          f"{forced:.2e} (output {rel_l2(out.cpu().numpy(), ref['out'].numpy()):.1e}, loss {abs(res[1].item() - ref['loss']) / ref['loss']:.1e})")
+    assert rel_l2(out.cpu().numpy(), ref["out"].numpy()) < 2e-6
+    assert forced < 3e-4 and forced < free / 20
+
+
 def test_tower_at_512_against_the_committed_golden():
     """BASELINE configs[3]'s size: ONE tower of graph D' on a 512x512 LQ/HQ pair against tests/golden/dprime_tower_512.json
     (float64 oracle autograd, tests/golden/make_train_golden.py): loss, mse, 64 output probes, the gradient norm of every
