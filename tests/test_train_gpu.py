@@ -121,8 +121,8 @@ def test_gradients_with_the_oracles_forward_values():
     forced at every conv output (DenoiserTrainer.teacher: the depthwise, pointwise / conv / transposed-conv results are replaced
     by the oracle's float64 values right after the kernels have produced them), so batch statistics, activations and the relu6 /
     clip masks of the backward pass are the oracle's to float32 rounding; the BACKWARD pass is untouched (same kernels, same
-    split-bf16 GEMMs).  If the gradient then agrees at the per-kernel level (bar 3e-4, i.e. two orders of magnitude under the
-    free-running figure) the discrepancy of the free-running run is its forward error acting through the masks."""
+    split-bf16 GEMMs).  Measured: 1.74e-2 free running -> 1.74e-5 forced (bar 5e-5, the per-kernel level): the discrepancy of the
+    free-running run IS its forward error acting through the masks, not the backward kernels."""
     from emdenoise import trainer as TR
     from oracle import denoiser_graph as G
 
@@ -156,7 +156,7 @@ def test_gradients_with_the_oracles_forward_values():
     print(f"gradient vs float64 oracle at {S} px: free running {free:.2e}; with the oracle's conv outputs forced into the forward pass "
           f"{forced:.2e} (output {rel_l2(out.cpu().numpy(), ref['out'].numpy()):.1e}, loss {abs(res[1].item() - ref['loss']) / ref['loss']:.1e})")
     assert rel_l2(out.cpu().numpy(), ref["out"].numpy()) < 2e-6
-    assert forced < 3e-4 and forced < free / 20
+    assert forced < 5e-5 and forced < free / 100
 
 
 def test_tower_at_512_against_the_committed_golden():
