@@ -627,7 +627,7 @@ class GeneratorTrainer:
 
 
 def gan_iteration(G: GeneratorTrainer, D: DiscriminatorTrainer, lq, truth, offsets, lr_gen=0.0002, label_real=1.0, label_fake=0.0,
-                  adapts=None, group=None, streams=1, lr_t_dev=None):
+                  adapts=None, group=None, streams=1, lr_t_dev=None, labels=None, train="both"):
     """One iteration of the reference's training loop (:1650-1790), deterministic parts: (1) the generator towers on
     this rank's [T,S,S,1] batch and the generator's Adam step (:1660-1700); (2) the discriminator trained on the T
     generated images (label_fake) and the T natural ones (label_real) with learning rate lr_gen/2 (:1645) -- 2T towers,
@@ -635,7 +635,12 @@ def gan_iteration(G: GeneratorTrainer, D: DiscriminatorTrainer, lq, truth, offse
     pass ``adapts`` / labels to reproduce them.  offsets: per-tower host tuples or an integer device tensor [T,3,2].
     streams: HIP streams the towers of each phase are spread over.  lr_t_dev: device tensor [2] with the two
     bias-corrected Adam rates (generator, discriminator) when the iteration runs inside a replayed hipGraph (GanLoop).
-    -> (generator results [T,3], discriminator results [2T,2])."""
+    labels: 2T per-image labels (generated images first) instead of label_fake / label_real -- what emdenoise.gan_policy.GanPolicy
+    draws (:1733-1737, :1772-1776).  train: "both" (default), "gen" (:1700-1703: the generator's train op only; the discriminator
+    is not trained this iteration and the second result is None) or "discr" (:1704-1806: the generator towers still run -- they
+    produce the images the discriminator is shown -- but its optimizer step is skipped): the reference trains ONE of the two
+    per iteration, chosen by GanPolicy.observe.
+    -> (generator results [T,3], discriminator results [2T,2] or None)."""
     import torch
 
     T = lq.shape[0]
@@ -659,17 +664,23 @@ def gan_iteration(G: GeneratorTrainer, D: DiscriminatorTrainer, lq, truth, offse
         res_g.append(rr)
     for s_ in side:
         main.wait_stream(s_)
-    G._unpad_grads()
-    world = sync_gradients(G.grads, G.moving, group)
-    scale = 1.0 / (T * world)
-    gn2 = TO.sumsq(G.grads, scale=scale)
-    if lr_t_dev is None:
-        G.t += 1
-    TO.adam_step(G.params, G.grads, G.adam_m, G.adam_v, G.t, lr_gen, beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_GEN,
-                 lr_t_dev=None if lr_t_dev is None else lr_t_dev[0:1])
-    G.repack()
+    assert train in ("both", "gen", "discr")
+    if train != "discr":
+        G._unpad_grads()
+        world = sync_gradients(G.grads, G.moving, group)
+        scale = 1.0 / (T * world)
+        gn2 = TO.sumsq(G.grads, scale=scale)
+        if lr_t_dev is None:
+            G.t += 1
+        TO.adam_step(G.params, G.grads, G.adam_m, G.adam_v, G.t, lr_gen, beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_GEN,
+                     lr_t_dev=None if lr_t_dev is None else lr_t_dev[0:1])
+        G.repack()
+    if train == "gen":
+        return torch.stack(res_g), None
     images = torch.cat(outs + [truth[k:k + 1] for k in range(T)])
-    labels = [label_fake] * T + [label_real] * T
+    if labels is None:
+        labels = [label_fake] * T + [label_real] * T
+    assert len(labels) == 2 * T
     offs2 = torch.cat([offsets, offsets]) if isinstance(offsets, torch.Tensor) else list(offsets) + list(offsets)
     res_d = D.step(images, labels, offs2, adapts=adapts, learning_rate=lr_gen / 2, group=group, streams=streams,
                    lr_t_dev=None if lr_t_dev is None else lr_t_dev[1:2])

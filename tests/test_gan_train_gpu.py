@@ -351,3 +351,49 @@ def test_gan_loop_graph_replay():
         moved = np.abs(flat(G.state_dict(), gnames) - before)
         assert 0.1 * 2e-4 < np.median(moved[moved > 0]) < 2.5 * 2e-4      # the weights did move: Adam's early steps are ~lr per weight
     assert G.t == 3 and D.t == 3
+
+
+def test_policy_driven_iterations():
+    """The reference trains ONE of the two networks per iteration, chosen by the host policy (gan-infilling-100.py:1700-1704,
+    :1903-1939), with randomly flipped labels and adapt weights (:1733-1737, :1772-1776): emdenoise.gan_policy.GanPolicy drives
+    gan_iteration(train=, labels=, adapts=).  Checked: only the chosen network's weights move; the per-image labels and adapt
+    weights reach the discriminator towers (its losses change accordingly); the policy state advances."""
+    from emdenoise import gan as GN
+    from emdenoise import gan_policy as GP
+    from emdenoise import gan_trainer as GT
+
+    wg, wd = GN.synthetic_weights(), GN.discriminator_synthetic_weights()
+    D = GT.DiscriminatorTrainer(wd, dev())
+    G = GT.GeneratorTrainer(wg, D, dev())
+    rng = np.random.default_rng(11)
+    policy = GP.GanPolicy(rng, effective_batch_size=2)
+    pad = (3 * S) // 4
+    T = 2
+    hq = images(T, 90)
+    x, t = torch.from_numpy(GN.gen_lq(hq[..., 0])[..., None]).to(dev()), torch.from_numpy(hq).to(dev())
+    seen = []
+    for counter in range(1, 4):
+        offs = [tuple((int(rng.integers(0, S + 2 * pad - n + 1)), int(rng.integers(0, S + 2 * pad - n + 1))) for n in (S // 4, S // 2, pad))
+                for _ in range(T)]
+        g_before, d_before = G.params.clone(), D.params.clone()
+        lr_g, _ = GP.learning_rates(counter)
+        train = "gen" if policy.train_gen else "discr"
+        labels, adapts = policy.labels(T, T)
+        rg, rd = GT.gan_iteration(G, D, x, t, offs, lr_gen=lr_g, labels=labels, adapts=adapts, train=train)
+        torch.cuda.synchronize()
+        g_moved, d_moved = not torch.equal(G.params, g_before), not torch.equal(D.params, d_before)
+        assert (g_moved, d_moved) == ((True, False) if train == "gen" else (False, True)), (counter, train, g_moved, d_moved)
+        assert (rd is None) == (train == "gen")
+        preds_fake = rg[:, 0].cpu().numpy() if rd is None else rd[:T, 0].cpu().numpy()
+        preds_real = [] if rd is None else rd[T:, 0].cpu().numpy()
+        seen.append(train)
+        policy.observe(counter, preds_fake, preds_real)
+    assert seen == ["discr", "gen", "discr"]          # the file's constants alternate the trainee every iteration, discriminator first
+    assert policy.pred_avg != 0.5
+    # labels and adapt weights reach the towers: the same images with flipped labels / another adapt give other losses
+    offs = [tuple((pad, pad) for _ in range(3)) for _ in range(T)]
+    a = GT.gan_iteration(G, D, x, t, offs, labels=[1e-8, 1e-8, 0.95, 0.95], adapts=[1.0] * 4, train="discr")[1].cpu().numpy().copy()
+    D2 = GT.DiscriminatorTrainer(D.state_dict(), dev())
+    G2 = GT.GeneratorTrainer(G.state_dict(), D2, dev())
+    b = GT.gan_iteration(G2, D2, x, t, offs, labels=[0.95, 1e-8, 0.95, 0.95], adapts=[1.0, 3.0, 1.0, 1.0], train="discr")[1].cpu().numpy()
+    assert not np.isclose(a[0, 1], b[0, 1])
