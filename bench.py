@@ -16,9 +16,10 @@ A "step" is one pass of the hot path over one batch that is already resident in 
   A  BASELINE configs[4]: one adversarial training iteration of the in-filling GAN.
   S  SURVEY.md 8f rank 4: the small separable autoencoder (misc_py/apply_autoencoders.py) on 160-px crops.
 Default ("all"): the JSON line's metric/value/roofline/cpu_baseline are workload D's, measured with --steps/--warmup
-(default 20 / 5); K, X, T, G, S, A ride along under "workload_<letter>" with short fixed step counts.  A rider that throws
-is reported in the line AND makes the exit code non-zero (with more than one rank it re-raises at once, so that the
-launcher tears every rank down instead of leaving the others in a collective).
+(default 20 / 5); with one rank K, X, T, G, S, A ride along under "workload_<letter>" with short fixed step counts, and a rider that
+throws is reported in the line AND makes the exit code non-zero.  With more than one rank only the primary workload runs (the
+training step's scaling: `--workload T --gpus N`); any exception there re-raises at once, so that the launcher tears every rank
+down instead of leaving the others in a collective.
 
 Multi-GPU: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the ranks itself -- a parent
 that has touched neither torch nor the GPU runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
@@ -1053,7 +1054,10 @@ def _worker(a, real_stdout):
 
     if a.workload in ("all", "both"):
         primary = "D"
-        riders = [] if a.no_riders else (["K"] if a.workload == "both" else (["T"] if multi else ["K", "X", "T", "G", "S", "A"]))
+        # more than one rank: the primary workload only.  The training step is the one workload with a collective, and a failure in
+        # a rider would take the inference scaling figure down with it (a rider's exception tears every rank down): its scaling
+        # is measured on its own with `--workload T --gpus N`
+        riders = [] if (a.no_riders or multi) else (["K"] if a.workload == "both" else ["K", "X", "T", "G", "S", "A"])
     else:
         primary, riders = a.workload, []
 
