@@ -47,7 +47,13 @@ struct SplitGemmParams {
     unsigned wlo_delta;       // persistent kernel: byte distance Wlo - Whi (one allocation)
     long long* stamps;        // dev builds only: 5 s_memtime stamps per workgroup (NULL otherwise)
     int out_split;            // pointwise kernel: C is a split32 tensor (pitch ldc 4-byte units), for a following split32 GEMM
+    int nt;                   // non-temporal output stores: the output is not re-read by this launch, L2 is kept for the operands
 };
+
+// Non-temporal output stores are the default (graph D: 26.0 -> 25.5 ms, PMC fetch of the transposed convs 5.97 -> 3.83 GB per launch:
+// the outputs no longer push the re-read input rows out of L2).  EMD_NT (dev) masks them: bit 0 = the implicit-GEMM convolutions here,
+// bit 2 = the pointwise GEMM (bit 1: sep_fused.hip).
+inline int split_nt(int bit) { static const int v = [] { const char* e = getenv("EMD_NT"); return e ? atoi(e) : 7; }(); return (v >> bit) & 1; }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -55,7 +61,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int SBN = 128, SBK = 32;
 
 // BM = 256: 8 waves, one workgroup per CU; BM = 128: 4 waves, two workgroups per CU.  NS = LDS stages (DMA runs NS-1 K steps ahead).
-template <int BM, int NS, bool PIPE = false>
+// WREG (with PIPE): the W tile travels global -> registers -> ds_write_b128 instead of by LDS-DMA, one K step earlier than the A tile's
+// DMA.  Why: a K step moves 32 KB of A + 16 KB of W into LDS in 1850 cycles = 26 B/clk/CU, and LDS-DMA from L2 tops out at about 30
+// B/clk/CU (MI355X_MICROARCH.md, gather into LDS: 66-73 GB/s per CU) -- the K loop runs at the DMA rate, not at the MFMA rate
+// (1536 cycles).  With the W third of the bytes on the vector-load path the DMA carries 32 KB per step.  Same LDS image, same bits.
+// DIRECT: the MFMA operands trade places (D^T = W x A^T: the same products in the same K order), so a lane ends up with four
+// CONSECUTIVE channels of one pixel in each accumulator quad (pixel = lane & 31, channels 8g + 4(lane >> 5) .. +3) and the epilogue
+// leaves straight from the registers in 16-byte stores: no staging tile, no barrier, and a wave that has issued its 16 stores is done --
+// the workgroup's LDS and registers go to the next one while the stores drain.
+template <int BM, int NS, bool PIPE = false, bool WREG = false, bool DIRECT = false>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmParams p) {
     constexpr int NW = BM / 32;                                                       // waves
     constexpr int NT = NW * 64;
@@ -109,10 +123,23 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (long)kt * 128), (lptr_t)(sb + (wv * 32 + q * 8) * 128), 16, 0, 0);
+        if constexpr (!WREG) {
 #pragma unroll
-        for (int q = 0; q < WQ; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[q] + (long)kt * 64),
-                                             (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
+            for (int q = 0; q < WQ; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[q] + (long)kt * 64),
+                                                 (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
+        }
+    };
+    // WREG: this lane's WQ pieces of a W tile, global -> registers / registers -> the LDS image the DMA would have written
+    u32x4 wreg[WQ];
+    auto w_load = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) wreg[q] = *reinterpret_cast<const u32x4*>(wsrc[q] + (long)kt * 64);
+    };
+    auto w_store = [&](int stage) {
+        unsigned char* sb = smem + stage * STAGE + A_STAGE;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) *reinterpret_cast<u32x4*>(sb + (wv * (WQ * 8) + q * 8) * 128 + lane * 16) = wreg[q];
     };
 
     f32x16 acc[2][2];
@@ -152,9 +179,15 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {           // small terms first (as gemm_conv.hip)
+                if constexpr (DIRECT) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+                } else {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                }
             }
     };
     if constexpr (PIPE) {
@@ -164,6 +197,14 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
         static_assert(NS == 3, "the pipelined loop needs three stages");
         issue(0, 0);
         issue(1, 1 < nk ? 1 : nk - 1);
+        if constexpr (WREG) {   // W tiles 0 and 1 into their stages, tile 2 into the registers
+            w_load(0);
+            w_store(0);
+            w_load(1 < nk ? 1 : nk - 1);
+            w_store(1);
+            w_load(2 < nk ? 2 : nk - 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
@@ -172,12 +213,20 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
         int s0 = 0, s1 = 1, s2 = 2;   // stage of tile kt / kt+1 / the one being refilled (held tile kt-1)
         for (int kt = 0; kt < nk; ++kt) {
             if (kt > 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (WREG) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // + the previous step's W stores
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
+            // WREG: the registers hold W tile kt+2 (loaded a step ago, waited for above): into the stage the A DMA below fills.
+            // The stores go BEFORE the DMA pieces: hipcc puts vmcnt(0) in front of a ds_write that follows LDS-DMA.
+            if constexpr (WREG) w_store(s2);
             {
                 const int nx = kt + 2;
                 issue(s2, nx < nk ? nx : nk - 1);   // beyond the end: re-read the last tile into a stage nobody computes on
+            }
+            if constexpr (WREG) {
+                const int nx = kt + 3;
+                w_load(nx < nk ? nx : nk - 1);
             }
             load_frags(f1, smem + s0 * STAGE, 1);
             mfma12(f0);
@@ -187,10 +236,19 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
             // there).  The DMA pieces write LDS, so the compiler keeps every ds_read of the step behind them: first half step
             // = 12 MFMAs on f0 with the 6 DMA pieces, then the 8 reads of f1, between them; second half step = 12 MFMAs
             // on f1 with the 8 reads of the next tile's f0 between them
+            if constexpr (WREG) {   // the 2 W stores, 4 DMA pieces, the 2 W loads, then the reads of f1
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);       // DS write (W tile kt+2)
 #pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // VMEM (LDS-DMA piece)
+                for (int g = 0; g < 6; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // VMEM (4 LDS-DMA pieces, then W tile kt+3 into registers)
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // VMEM (LDS-DMA piece)
+                }
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -238,6 +296,64 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
     }
     long long t2 = 0, t3 = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMA groups of the last steps
+    if constexpr (DIRECT) {
+        if (p.stamps) t2 = t3 = __builtin_amdgcn_s_memtime();
+        const float hi = p.act == 1 ? 6.f : __builtin_inff();
+        const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;
+        const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+        const bool two = p.scale2 != nullptr;
+        const int Np = p.out_split ? (p.N + 31) / 32 * 32 : p.N;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + j * 32 + g * 8 + fh * 4;
+                if (n >= Np) continue;
+                const bool real = n < p.N;
+                f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, t1v = s1, s2 = {1.f, 1.f, 1.f, 1.f}, t2v = s1;
+                if (real) {
+                    s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
+                    t1v = *reinterpret_cast<const f32x4*>(p.shift1 + n);
+                    if (two) {
+                        s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
+                        t2v = *reinterpret_cast<const f32x4*>(p.shift2 + n);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const long pix = m0 + wm * 64 + i * 32 + fr;
+                    if (pix >= p.M) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float u = fmaf(acc[i][j][4 * g + c], s1[c], t1v[c]);
+                        u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                        if (two) u = fminf(fmaxf(fmaf(u, s2[c], t2v[c]), 0.f), hi2);
+                        v[c] = u;
+                    }
+                    if (p.res && real) v += *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n);
+                    if (!p.out_split) {
+                        if (p.nt) store_nt16(p.C + pix * p.ldc + n, v);
+                        else *reinterpret_cast<f32x4*>(p.C + pix * p.ldc + n) = v;
+                    } else {   // four channels = 8 bytes in the hi half of the 128-byte line, 8 in the lo half
+                        if (!real) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        unsigned h0, l0, h1, l1;
+                        split2(v[0], v[1], h0, l0);
+                        split2(v[2], v[3], h1, l1);
+                        unsigned char* gl = reinterpret_cast<unsigned char*>(p.C) + pix * (long)p.ldc * 4 + (n >> 5) * 128 + (n & 31) * 2;
+                        *reinterpret_cast<u32x2*>(gl) = u32x2{h0, h1};
+                        *reinterpret_cast<u32x2*>(gl + 64) = u32x2{l0, l1};
+                    }
+                }
+            }
+        if (p.stamps && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            long long* o = p.stamps + (long)blockIdx.x * 8;
+            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = __builtin_amdgcn_s_memtime();
+            o[5] = 0; o[6] = r0; o[7] = __builtin_amdgcn_s_memrealtime();
+        }
+        return;
+    }
     __syncthreads();  // all fragment reads (and DMA writes) done before the staging tile overlays the stages
     if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
 
@@ -291,7 +407,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const SplitGemmPa
         // the output stage: fp32 NHWC, or the split32 layout (16-byte stores through the pair exchange of emd::dw_store)
         auto put = [&](long pix, f32x4 v) {
             if (!p.out_split) {
-                *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = v;
+                if (p.nt) store_nt16(outp + pix * p.ldc + n, v);
+                else *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = v;
                 return;
             }
             if (!real) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -899,8 +1016,12 @@ __global__ __launch_bounds__(512, 2) void gemm_split_conv_kernel(const SplitConv
                 const bool odd = q & 1;
                 const unsigned r0 = emd::swap_pair(odd ? h0 : l0), r1 = emd::swap_pair(odd ? h1 : l1);
                 unsigned char* g = reinterpret_cast<unsigned char*>(p.C) + pix * (long)p.ldc * 4 + (n >> 5) * 128;
-                if (!odd) *reinterpret_cast<u32x4*>(g + (q & 7) * 8) = u32x4{h0, h1, r0, r1};
-                else *reinterpret_cast<u32x4*>(g + 64 + ((q - 1) & 7) * 8) = u32x4{r0, r1, l0, l1};
+                u32x4* dst = reinterpret_cast<u32x4*>(!odd ? g + (q & 7) * 8 : g + 64 + ((q - 1) & 7) * 8);
+                const u32x4 val = !odd ? u32x4{h0, h1, r0, r1} : u32x4{r0, r1, l0, l1};
+                if (p.nt) store_nt16(dst, val);
+                else *dst = val;
+            } else if (p.nt) {
+                store_nt16(p.C + pix * p.ldc + n, f32x4{v.x, v.y, v.z, v.w});
             } else {
                 *reinterpret_cast<float4*>(p.C + pix * p.ldc + n) = v;
             }
@@ -1213,13 +1334,17 @@ static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, co
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.M = M; p.lda_bytes = (long)ldx * 4; p.N = Cout; p.Cin = Cin; p.Ktot = (Cin + kBK - 1) / kBK * kBK;
     p.ldc = ldy; p.ldres = ldres; p.act = act; p.stats_part = stats_part; p.out_split = out_split ? 1 : 0;
+    p.nt = split_nt(2);
     // kernel variant: 3 = 256-row tiles, 3 stages, pipelined K loop, 32x32x16 MFMAs; 5 = the same on 16x16x32 MFMAs;
     // dev knobs for A/B runs: EMD_SPLIT_VARIANT / emd_debug_split_variant = 0 (256 rows, 2 stages), 1 (256, 3, plain loop),
-    // 2 (128 rows, 2 stages, two workgroups per CU), 4 (persistent, epilogue stores inside the next tile's K loop)
+    // 2 (128 rows, 2 stages, two workgroups per CU), 4 (persistent, epilogue stores inside the next tile's K loop),
+    // 6 (variant 3 with the W tile through registers instead of LDS-DMA: WREG), 7 (variant 3 with the epilogue straight from
+    // the registers: DIRECT)
     static const int variant = [] { const char* e = getenv("EMD_SPLIT_VARIANT"); return e ? atoi(e) : -1; }();
     int v = variant;
     if (g_variant_override >= 0) v = g_variant_override;
-    if (stats_part || out_split) v = 3;   // the statistics epilogue and the split32 output live in the default kernel
+    if (stats_part && v != 6) v = 3;
+    if (out_split && v != 6 && v != 7) v = 3;   // the statistics epilogue and the split32 output live in the default kernel (and its WREG form)
     if (v < 0) v = 3;   // default: the pipelined 32x32x16 kernel -- bit-identical to emd_conv1x1_f32, so a result does not depend on
                         // which of the two a batch size selects.  Variant 5 (16x16x32 MFMAs: same cycles, the chip holds 1.86
                         // instead of 1.73 GHz, 97.9 vs 103.7 us on 32768 x 728 x 728) sums a K step in another order (2e-7).
@@ -1243,6 +1368,8 @@ static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, co
     }
     else if (v == 2) hipLaunchKernelGGL((gemm_split_kernel<128, 2>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     else if (v == 5) hipLaunchKernelGGL(gemm_split16_kernel, dim3((unsigned)nblk), dim3(512), 0, st, p);
+    else if (v == 6) hipLaunchKernelGGL((gemm_split_kernel<256, 3, true, true>), dim3((unsigned)nblk), dim3(512), 0, st, p);
+    else if (v == 7) hipLaunchKernelGGL((gemm_split_kernel<256, 3, true, false, true>), dim3((unsigned)nblk), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((gemm_split_kernel<256, 3, true>), dim3((unsigned)nblk), dim3(512), 0, st, p);
     return emd::check_launch("gemm_split_kernel");
 }
@@ -1288,6 +1415,7 @@ int launch_conv(SplitConvParams& c, hipStream_t st, bool four = false) {
     p.n_mtiles = (int)((p.M + 255) / 256);
     p.n_ntiles = (p.N + bn - 1) / bn;
     p.stamps = nullptr;
+    p.nt = split_nt(0);
     const long nblk = (long)p.n_mtiles * p.n_ntiles;
     if (nblk <= 0 || nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "split32 conv: grid too large");
     if (p.M > 0x7fffffffL || (!c.flat && (long)(p.M / ((long)c.Hg * c.Wg)) * c.Ha * c.Wa > 0x7fffffffL))

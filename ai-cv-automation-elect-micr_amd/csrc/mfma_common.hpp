@@ -11,6 +11,16 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;      // native vectors for the staging registers:
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // HIP's float4/uint4 structs end up in scratch
+
+// 16-byte global store with the non-temporal hint.  Inline asm on purpose: behind a run-time flag, "if (nt) __builtin_nontemporal_store
+// else plain store" is merged into ONE plain store by the optimizer (the merged store keeps only the metadata both sides share).
+// The s_nop covers the store-data hazard the compiler cannot see inside the asm.
+__device__ __forceinline__ void store_nt16(void* dst, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_nt16(void* dst, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" ::"v"(dst), "v"(v) : "memory");
+}
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr int kBK = 64;       // channel padding unit of the packed weights (and the GEMM's K step)

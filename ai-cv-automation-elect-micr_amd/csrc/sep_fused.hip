@@ -61,7 +61,14 @@ struct SepParams {
     int N2, ldy2;
     int out_split;        // y is a split32 tensor (pitch ldy 4-byte units; N % 32 == 0): the consumer is a split32 GEMM
     long long* stamps;    // dev hook: per-workgroup phase cycle sums (NULL otherwise)
+    int nt;               // outputs leave with non-temporal stores (they are not re-read by this launch: keep L2 for the patch halos)
+    int xcd;              // workgroup -> tile map that gives each XCD (workgroup id mod 8) one contiguous run of tiles
 };
+
+// Knobs of the 512^2 / 256^2 layers' cache behaviour (dev): EMD_NT bit 1 = non-temporal output stores here (default on), EMD_SEP_XCD = 0
+// turns the XCD-contiguous tile order off.
+inline int sep_nt() { static const int v = [] { const char* e = getenv("EMD_NT"); return e ? atoi(e) : 7; }(); return (v >> 1) & 1; }
+inline int sep_xcd() { static const int v = [] { const char* e = getenv("EMD_SEP_XCD"); return e ? atoi(e) : 1; }(); return v; }
 
 // BN = columns of the workgroup's GEMM tile: 64 / 128 (one output), or with DUAL the two outputs side by side: 128 = 64 | 64 on an
 // 8 x 16 pixel tile, 256 = 128 | 128 on a 4 x 16 pixel tile (TH = 4: the accumulators of both outputs fit the same registers).
@@ -96,9 +103,20 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
-    const int xbase = blockIdx.x * p.tpw * TW, y0 = blockIdx.y * TH;
+    // Workgroups are handed to the 8 XCDs round-robin (id mod 8), so in launch order the tile under this one -- which shares two of
+    // its ten patch rows -- runs on another XCD and the halo is fetched once per L2.  p.xcd: XCD k takes the k-th eighth of the tiles.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;   // a multiple of 8 (host check)
+        const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned t = (id & 7) * (total >> 3) + (id >> 3);
+        bx = t % gridDim.x;
+        by = (t / gridDim.x) % gridDim.y;
+        bz = t / (gridDim.x * gridDim.y);
+    }
+    const int xbase = bx * p.tpw * TW, y0 = by * TH;
     int x0 = xbase;       // tile whose chunks are being computed (the epilogue's tile)
-    const long img = (long)blockIdx.z * p.H * p.W;  // pixel index of this image's (0,0)
+    const long img = (long)bz * p.H * p.W;  // pixel index of this image's (0,0)
 
     // ---- patch loader role: float4 #idx of the patch = (patch pixel idx/8, channel group idx%8)
     const float* psrc[P_PASSES];  // source pixel + channel group of chunk 0, or the zero buffer (padding / unused slots)
@@ -368,7 +386,8 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             // output stage: fp32 NHWC, or (single-output instances) the split32 layout through the pair exchange of emd::dw_store
             auto put = [&](int r, f32x4 v) {
                 if (DUAL || !p.out_split) {
-                    *reinterpret_cast<f32x4*>(ytile + tpix(r) * ldo) = v;
+                    if (p.nt) store_nt16(ytile + tpix(r) * ldo, v);
+                    else *reinterpret_cast<f32x4*>(ytile + tpix(r) * ldo) = v;
                     return;
                 }
                 unsigned h0, l0, h1, l1;
@@ -441,6 +460,8 @@ int launch(const SepParams& p, int B, int passes, hipStream_t st) {
     q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / 8) * B);
     q.stamps = g_sep_stamps;
     const dim3 grid(tiles_w / q.tpw, p.H / 8, B);
+    q.nt = sep_nt();
+    q.xcd = sep_xcd() && ((long)grid.x * grid.y * grid.z) % 8 == 0;
     if (p.gen_a) {
         if (passes == 3)
             hipLaunchKernelGGL((sep_fused_kernel<BN, 3, true>), grid, dim3(256), 0, st, q);
@@ -462,6 +483,8 @@ int launch_dual(const SepParams& p, int B, hipStream_t st) {
     q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / th) * B);
     q.stamps = g_sep_stamps;
     const dim3 grid(tiles_w / q.tpw, p.H / th, B);
+    q.nt = sep_nt();
+    q.xcd = sep_xcd() && ((long)grid.x * grid.y * grid.z) % 8 == 0;
     if (wide)
         hipLaunchKernelGGL((sep_fused_kernel<256, 3, false, 4, true>), grid, dim3(256), 0, st, q);
     else

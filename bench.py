@@ -614,9 +614,9 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
             wpk = ops.PackedWeights((np.random.default_rng(0).standard_normal((1, 728, 728)) * 0.05).astype(np.float32), False, dev)
             one, zero = torch.ones(728, device=dev), torch.zeros(728, device=dev)
             o = ops.Act.empty(B, 32, 32, 728, dev)
-            tms = {-1: [], 5: []}
+            tms = {-1: [], 5: [], 6: []}
             for _ in range(3):
-                for v in (-1, 5):
+                for v in (-1, 5, 6):
                     lib.emd_debug_split_variant(v)
                     ops.conv1x1_split32(xs, wpk, one, zero, o)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -629,7 +629,7 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
             lib.emd_debug_split_variant(-1)
             fl = 6.0 * B * 1024 * 728 * 728
             iso = {}
-            for v, nm in ((-1, "default_32x32x16"), (5, "variant_16x16x32")):
+            for v, nm in ((-1, "default_32x32x16"), (5, "variant_16x16x32"), (6, "variant_w_through_registers")):
                 us = float(np.median(tms[v]))
                 iso[nm] = {"us": round(us, 1), "issued_tflops": round(fl / us / 1e6, 1), "frac_of_2500": round(fl / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4)}
             out["pointwise"]["isolated_32768x728x728"] = iso

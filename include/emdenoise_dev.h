@@ -6,10 +6,13 @@
  * not call them.  Every symbol the shared library exports with an emd_ prefix is declared either in emdenoise.h or
  * here (tests/test_abi.py checks both directions).
  *
- * Environment knobs read once per process by the same translation units (same rule: speed only, default off):
+ * Environment knobs read once per process by the same translation units (same rule: speed only, default = the measured-best path):
  *   EMD_SPLIT_VARIANT  csrc/gemm_split.hip  pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
  *   EMD_SEP_TPW        csrc/sep_fused.hip   tiles per workgroup of the fused separable conv (0 = rule)
  *   EMD_DW_TH          csrc/dw_misc.hip     strip height of the rolling depthwise kernel (0 = rule)
+ *   EMD_NT             gemm_split / sep_fused   mask of the non-temporal output stores (default 7: bit 0 split32 convolutions,
+ *                                           bit 1 fused separable conv, bit 2 pointwise split32 GEMM)
+ *   EMD_SEP_XCD        csrc/sep_fused.hip   0 = launch-order tiles instead of one contiguous run of tiles per XCD
  */
 #ifndef EMDENOISE_DEV_H
 #define EMDENOISE_DEV_H

@@ -93,7 +93,7 @@ def test_dw3x3_reflect_split32_equals_reflect_then_split(B, H, W, C, stride):
     assert torch.equal(got.buf.view(torch.int32), want.buf.view(torch.int32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv1x1_split32_kernel_variants_agree(variant):
     """Every tile / stage / loop variant of the GEMM (dev knob) gives the 32x32x16 kernel's bits (4 = the persistent form);
     variant 5 runs on 16x16x32 MFMAs, whose K-step sum is ordered differently: same error class (2e-7), not the same bits."""
@@ -287,6 +287,43 @@ def test_conv1x1_split32_with_split32_output(B, H, W, ci, co, res):
     ops.conv1x1_split32(xs, pw, s1, t1, got, res=r)
     torch.cuda.synchronize()
     assert torch.equal(got.buf.view(torch.int32), ops.to_split32(want).buf.view(torch.int32))
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,res,extra,split", [
+    (2, 32, 32, 728, 728, True, False, False), (1, 24, 20, 728, 728, False, True, False), (1, 8, 8, 160, 132, True, False, False),
+    (1, 8, 8, 48, 128, False, False, False), (2, 16, 16, 256, 256, True, False, True), (1, 24, 20, 728, 132, False, False, True),
+    (1, 8, 8, 64, 36, True, True, True)])
+def test_conv1x1_split32_direct_epilogue(B, H, W, ci, co, res, extra, split):
+    """Dev variant 7 (operands swapped, epilogue straight from the accumulator registers) writes the default kernel's bits: fp32 into a
+    channel slice of a wider buffer, or split32 (padding channels zero); ragged M, N tails, residual, second affine stage."""
+    from emdenoise import _lib, ops
+
+    lib = _lib.load()
+    x = rnd((B, H, W, ci), 61, positive=True)
+    pw = ops.PackedWeights(rnd((1, ci, co), 62, scale=(2.0 / (ci + co)) ** 0.5), False, dev())
+    s1, t1 = up(rnd((co,), 63, 0.3) + 1.0), up(rnd((co,), 64, 0.5))
+    kw = dict(scale2=up(rnd((co,), 65, 0.2) + 1.0) if extra else None, shift2=up(rnd((co,), 66, 0.3)) if extra else None,
+              res=ops.Act(up(rnd((B, H, W, co), 67))) if res else None)
+    xs = ops.to_split32(ops.Act(up(x)))
+
+    def run():
+        if split:
+            out = ops.SplitAct(B, H, W, co, dev())
+            out.buf.fill_(float("nan"))
+            ops.conv1x1_split32(xs, pw, s1, t1, out, **kw)
+            return out.buf.view(torch.int32).clone()
+        wide = torch.full((B, H, W, co + 8), float("nan"), dtype=torch.float32, device=dev())
+        ops.conv1x1_split32(xs, pw, s1, t1, ops.Act(wide, co, 4), **kw)
+        return wide.view(torch.int32).clone()
+
+    want = run()
+    try:
+        lib.emd_debug_split_variant(7)
+        got = run()
+        torch.cuda.synchronize()
+    finally:
+        lib.emd_debug_split_variant(-1)
+    assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("B,H,W,ci,co,res", [(2, 16, 32, 128, 128, True), (1, 8, 16, 64, 64, False), (1, 24, 48, 384, 96, True)])
