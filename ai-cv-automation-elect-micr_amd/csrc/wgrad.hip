@@ -300,11 +300,26 @@ extern "C" int emd_conv_wgrad_f32(const float* a, int lda, const float* dy, int 
     EMD_REQUIRE(p.M < (1L << 31), EMD_E_UNSUPPORTED, "emd_conv_wgrad_f32: more than 2^31 pixels");
     const int tk = mfma ? (K > 64 ? 128 : 64) : 64, tn = mfma ? (N > 64 ? 128 : 64) : 64;
     const int kt = (K + tk - 1) / tk, nt = (N + tn - 1) / tn;
-    long want = (mfma ? 1024 : 2048) / ((long)kt * nt * ntaps);  // enough workgroups to fill the chip a few times
-    if (want < 1) want = 1;
+    const long tiles = (long)kt * nt * ntaps;
     const long maxsplit = (p.M + (mfma ? 511 : 2047)) / (mfma ? 512 : 2048);
+    long want;
+    if (mfma) {
+        // MI355X: 256 CUs x 2 resident workgroups.  A grid a little over one round (576 workgroups on 512 slots) takes two rounds
+        // of time: aim at r whole rounds, r = 4 / 2 while a workgroup still gets 16 chunks of 64 pixels, else one round.
+        const long slots = 512;
+        want = slots / tiles;
+        for (int r = 4; r >= 2; r >>= 1)
+            if ((p.M / 64) / (slots * r / tiles > 0 ? slots * r / tiles : 1) >= 16) { want = slots * r / tiles; break; }
+    } else {
+        want = 2048 / tiles;  // enough workgroups to fill the chip a few times
+    }
+    if (want < 1) want = 1;
     p.msplit = (int)(want < maxsplit ? want : maxsplit);
     if (p.msplit < 1) p.msplit = 1;
+    if (mfma) {   // slices are whole 64-pixel chunks: drop the ones that rounding left empty
+        const long mper = ((p.M + p.msplit - 1) / p.msplit + 63) / 64 * 64;
+        p.msplit = (int)((p.M + mper - 1) / mper);
+    }
     EMD_REQUIRE((long)ntaps * p.msplit <= 65535, EMD_E_UNSUPPORTED, "emd_conv_wgrad_f32: grid too large");
     if (mfma) {
         const dim3 grid(kt, nt, ntaps * p.msplit);
