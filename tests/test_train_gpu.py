@@ -285,6 +285,13 @@ def test_batched_per_image_towers_equal_towers_of_one():
     spread = rel_l2(gb, ga)
     print(f"batched per-image towers vs {B} towers of one at {S} px: outputs, losses, moving statistics identical; gradient rel L2 {spread:.2e}")
     assert spread < 2e-6
+    # the same pass with its weight-gradient launches on a side stream (opt-in, EMD_T_WGRAD_STREAM=1)
+    c = TR.DenoiserTrainer(w, dev())
+    c.zero_grad()
+    oc, rc = c.tower(x, t, update_moving=True, per_image=True, wgrad_stream=True)
+    torch.cuda.synchronize()
+    assert torch.equal(oc, ob) and torch.equal(rc, rb) and torch.equal(c.moving, b.moving)
+    assert rel_l2(c.grads.detach().cpu().numpy().astype(np.float64), gb) < 2e-6
     # and through train_step: the same update from either form
     pa, pb = TR.DenoiserTrainer(w, dev()), TR.DenoiserTrainer(w, dev())
     pa.train_step(x, t, tower_batch=1, streams=2)
