@@ -14,6 +14,15 @@
 
 namespace {
 
+// Workgroup ids are dealt to the 8 XCDs round-robin (id mod 8).  xcd_run gives XCD k the k-th contiguous eighth of the tile
+// list instead, so the tiles that share halo rows / columns (neighbours in the list) run on ONE XCD at about the same time and the
+// shared input lines are fetched into that L2 once (tools/dw_traffic.sh: fetched bytes per shape).  EMD_DW_XCD=0 turns it off.
+__device__ __forceinline__ int xcd_run(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+inline int dw_xcd() { static const int v = [] { const char* e = getenv("EMD_DW_XCD"); return e ? atoi(e) : 1; }(); return v; }
+
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
@@ -40,7 +49,7 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
                                                      const float* __restrict__ w, float* __restrict__ y,
                                                      int ldy, int H, int W, int C4, long nthreads, int nstrip, int C4t,
                                                      const float* __restrict__ pre_s = nullptr,
-                                                     const float* __restrict__ pre_t = nullptr) {
+                                                     const float* __restrict__ pre_t = nullptr, int xcd = 0) {
     // PRE: the input is relu(x * pre_s + pre_t) per channel -- the batch-statistics norm + relu of the previous separable
     // block (misc_py/modified_Xception.py:302-323) applied on the fly instead of in a pass of its own
     // C4t = channel quads per pixel that have a thread: C4, or ceil32(C)/4 when the split32 padding is written too.
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
     // 32 x 32 x 728 maps; a copy of the same bytes takes 30).
     (void)nthreads;
     const int ncb = (C4t + 15) >> 4, npb = (W + 15) >> 4;
-    int bidx = blockIdx.x;
+    int bidx = xcd ? xcd_run(blockIdx.x, gridDim.x) : blockIdx.x;
     const int cblk = bidx % ncb;
     bidx /= ncb;
     const int pblk = bidx % npb;
@@ -138,12 +147,12 @@ __global__ __launch_bounds__(256) void dw3x3_generic(const float* __restrict__ x
                                                      int ldy, int H, int W, int C4, int Ho, int Wo,
                                                      int stride, int rate, int pt, int pl, long nthreads, int C4t,
                                                      const float* __restrict__ pre_s = nullptr,
-                                                     const float* __restrict__ pre_t = nullptr) {
+                                                     const float* __restrict__ pre_t = nullptr, int xcd = 0) {
     // a workgroup = 4 x 4 output pixels x 16 channel quads: the overlapping windows of neighbouring outputs are served by
     // the workgroup's L1 instead of by neighbouring workgroups on other XCDs (see dw3x3_s1_roll)
     (void)nthreads;
     const int ncb = (C4t + 15) >> 4, npx = (Wo + 3) >> 2, npy = (Ho + 3) >> 2;
-    int bidx = blockIdx.x;
+    int bidx = xcd ? xcd_run(blockIdx.x, gridDim.x) : blockIdx.x;
     const int cblk = bidx % ncb;
     bidx /= ncb;
     const int bx = bidx % npx;
@@ -678,18 +687,18 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
         if (TH == 32)
-            hipLaunchKernelGGL((dw3x3_s1_roll<32, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t);
+            hipLaunchKernelGGL((dw3x3_s1_roll<32, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd());
         else if (TH == 16)
-            hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t);
+            hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd());
         else
-            hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t);
+            hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd());
         return emd::check_launch("dw3x3_s1_roll");
     }
     const long nthreads = (long)B * ((Ho + 3) / 4) * ((Wo + 3) / 4) * ((C4t + 15) / 16) * 256;
     int rc = grid_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL((dw3x3_generic<SPLIT, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, Ho, Wo, stride, rate, pt,
-                       pl, nthreads, C4t, pre_s, pre_t);
+                       pl, nthreads, C4t, pre_s, pre_t, dw_xcd());
     return emd::check_launch("dw3x3_generic");
 }
 
