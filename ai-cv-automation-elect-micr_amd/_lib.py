@@ -246,6 +246,7 @@ SIGNATURES = {
     "emd_graph_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "emd_graph_run": (C.c_int, [C.c_void_p, _c_float_p, _c_float_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "emd_graph_destroy": (None, [C.c_void_p]),
+    "emd_graph_set_two_streams": (C.c_int, [C.c_void_p, C.c_int]),
     # ---- device-side training input functions (csrc/input_ops.hip)
     "emd_philox4x32_u32": (C.c_int, [C.c_void_p, C.c_long, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),
     "emd_get_scale_f32": (C.c_int, [_c_float_p, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),

@@ -9,6 +9,7 @@
 // one explicit handle of the ABI); activations live in the caller's workspace (emd_graph_workspace_bytes), nothing else is
 // allocated, no global state.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -120,6 +121,19 @@ struct emd_graph {   // the handle behind emd_graph_t
     std::vector<void*> allocs;
     float *unit4 = nullptr, *zero4 = nullptr;
     std::string error;
+    // the two side streams of the 1/16-resolution flow (Run::middle_two_streams) and their fork / join events; made on first use
+    bool two_streams = false;   // emd_graph_set_two_streams
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+    bool streams_ok() {
+        if (side[0]) return true;
+        bool ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+        for (int h = 0; h < 2 && ok; ++h)
+            ok = hipStreamCreateWithFlags(&side[h], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&join[h], hipEventDisableTiming) == hipSuccess;
+        if (!ok) side[0] = nullptr;   // single-stream launch sequence instead
+        return ok;
+    }
 };
 
 namespace {
@@ -387,6 +401,81 @@ struct Run {
         *sep_out = sep(sk, x, nullptr, nullptr);
     }
 
+    // One residual block of the 1/16-resolution flow on *cur (a whole batch or a part of one): blk = -1 encoder 4 (:312-322, *cur is the
+    // caller's tensor and stays), blk >= 0 middle block blk (:324-325, *cur came from this arena and is released).  last_out: where
+    // the final block writes (a part of the caller's output tensor), or NULL.
+    void middle_block(int blk, T4* cur, const T4* last_out) {
+        const bool last = blk == NEXTRA - 1;
+        const std::string k = blk < 0 ? "cnn4_" : "middle" + std::to_string(blk) + "_";
+        T4 a = sep(blk < 0 ? k + "a" : k + "0", *cur, nullptr, nullptr);
+        T4 b = sep(blk < 0 ? k + "b" : k + "1", a, nullptr, nullptr);
+        free(a);
+        T4 nxt = sep(blk < 0 ? k + "last" : k + "2", b, last ? last_out : nullptr, cur);
+        free(b);
+        if (blk >= 0) free(*cur);
+        *cur = nxt;
+    }
+
+    // The same flow with the two halves of the batch on two streams, block by block (as emdenoise/streams.py TwoHalves: one half's
+    // depthwise kernels share the chip with the other half's GEMMs; the images are independent, same bits).  Each half allocates from
+    // its own sub-arena -- a buffer released on one stream is never handed to the other -- carved out of the caller's workspace.
+    T4 middle_two_streams(const T4& x) {
+        const int half = x.B / 2;
+        T4 out = E(x.B, x.H, x.W, F4);
+        auto part = [&](const T4& t, int h) {
+            T4 v = t;
+            v.B = half;
+            if (v.buf) v.buf += (size_t)h * half * t.H * t.W * t.ld;
+            return v;
+        };
+        // what one half needs: the same launch sequence against a measuring arena
+        size_t need;
+        {
+            Arena m;
+            m.measuring = true;
+            Run sub{g, &m, nullptr, true};
+            T4 c = part(x, 0);
+            c.buf = reinterpret_cast<float*>(4096);
+            T4 o = c;
+            o.C = o.ld = F4;
+            sub.middle_block(-1, &c, NEXTRA == 0 ? &o : nullptr);
+            for (int i = 0; i < NEXTRA; ++i) sub.middle_block(i, &c, &o);
+            need = m.peak + 256;
+        }
+        Arena sub[2];
+        void* mem[2];
+        for (int h = 0; h < 2; ++h) {
+            mem[h] = raw(need);
+            sub[h].measuring = dry;
+            sub[h].base = static_cast<unsigned char*>(mem[h]);
+            sub[h].cap = need;
+        }
+        if (rc != EMD_OK) return out;
+        Arena* ar0 = ar;
+        hipStream_t st0 = st;
+        if (live()) {
+            call(hipEventRecord(g->fork, st0) == hipSuccess ? EMD_OK : emd::fail(EMD_E_LAUNCH, "emd_graph_run: hipEventRecord failed"));
+            for (int h = 0; h < 2; ++h)
+                call(hipStreamWaitEvent(g->side[h], g->fork, 0) == hipSuccess ? EMD_OK : emd::fail(EMD_E_LAUNCH, "emd_graph_run: hipStreamWaitEvent failed"));
+        }
+        T4 cur[2] = {part(x, 0), part(x, 1)}, oh[2] = {part(out, 0), part(out, 1)};
+        for (int blk = -1; blk < NEXTRA; ++blk)
+            for (int h = 0; h < 2; ++h) {
+                ar = &sub[h];
+                st = dry ? st0 : g->side[h];
+                middle_block(blk, &cur[h], &oh[h]);
+            }
+        ar = ar0;
+        st = st0;
+        if (!dry) {   // join even after an error: the main stream must not run ahead of launches already issued
+            for (int h = 0; h < 2; ++h)
+                if (hipEventRecord(g->join[h], g->side[h]) != hipSuccess || hipStreamWaitEvent(st0, g->join[h], 0) != hipSuccess)
+                    call(emd::fail(EMD_E_LAUNCH, "emd_graph_run: stream join failed"));
+        }
+        for (int h = 0; h < 2; ++h) ar->release(mem[h]);
+        return out;
+    }
+
     // architecture() (denoiser.py:248-398) on x [B,S,S,1] -> y [B,S,S,1]
     void forward(const float* xin, float* yout, int B, int S) {
         const int S2 = S / 2, S4 = S / 4, S16 = S / 16;
@@ -438,22 +527,16 @@ struct Run {
         T4 cnn3_strided = sep("cnn3_strided", cnn3_last, nullptr, &residual3);
         free(cnn2_strided); free(cnn3); free(cnn3_last); free(residual3);
         // encoder 4 (:312-322) and the middle flow (:324-325)
-        T4 t = sep("cnn4_a", cnn3_strided, nullptr, nullptr);
-        T4 t2 = sep("cnn4_b", t, nullptr, nullptr);
-        free(t);
-        T4 cur = sep("cnn4_last", t2, nullptr, &cnn3_strided);
-        free(t2);
-        free(cnn3_strided);
-        for (int i = 0; i < NEXTRA; ++i) {
-            const std::string k = "middle" + std::to_string(i) + "_";
-            T4 a = sep(k + "0", cur, nullptr, nullptr);
-            T4 b = sep(k + "1", a, nullptr, nullptr);
-            free(a);
-            T4 nxt = sep(k + "2", b, nullptr, &cur);
-            free(b);
-            free(cur);
-            cur = nxt;
+        T4 cur;
+        if (g->two_streams && B % 2 == 0 && emd_conv1x1_split32_supported((long)(B / 2) * S16 * S16, F4, F4) && (dry || g->streams_ok())) {
+            cur = middle_two_streams(cnn3_strided);
+        } else {
+            T4 x4 = cnn3_strided;
+            middle_block(-1, &x4, nullptr);
+            cur = x4;
+            for (int i = 0; i < NEXTRA; ++i) middle_block(i, &cur, nullptr);
         }
+        free(cnn3_strided);
         // ASPP (:152-216): the five branches write straight into their slices of the 3640-channel concat
         T4 cat = E(B, S16, S16, 5 * AF);
         void* curs = nullptr;
@@ -650,8 +733,19 @@ extern "C" int emd_graph_run(emd_graph* g, const float* x, float* y, int B, int 
     return r.rc;
 }
 
+extern "C" int emd_graph_set_two_streams(emd_graph* g, int on) {
+    EMD_REQUIRE(g, EMD_E_INVALID, "emd_graph_set_two_streams: null handle");
+    g->two_streams = on != 0;
+    return EMD_OK;
+}
+
 extern "C" void emd_graph_destroy(emd_graph* g) {
     if (!g) return;
     for (void* q : g->allocs) (void)hipFree(q);
+    for (int h = 0; h < 2; ++h) {
+        if (g->join[h]) (void)hipEventDestroy(g->join[h]);
+        if (g->side[0] && g->side[h]) (void)hipStreamDestroy(g->side[h]);
+    }
+    if (g->fork) (void)hipEventDestroy(g->fork);
     delete g;
 }

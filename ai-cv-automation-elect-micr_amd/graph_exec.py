@@ -33,6 +33,10 @@ class NativeGraph:
         self._h = handle
         self._ws = None
 
+    def set_two_streams(self, on):
+        """The 1/16-resolution flow of an even batch as two halves on two internal streams (same bits; default off)."""
+        _lib.check(self.lib.emd_graph_set_two_streams(self._h, 1 if on else 0), "emd_graph_set_two_streams")
+
     def workspace_bytes(self, B, S):
         return int(self.lib.emd_graph_workspace_bytes(self._h, B, S))
 

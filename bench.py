@@ -653,7 +653,7 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
             out["native_executor"] = {"ms_per_step": round(e0.elapsed_time(e1) / 5, 3), "bit_identical_to_python_engine": same,
                                       "workspace_GiB": round(nat.workspace_bytes(B, H) / 2 ** 30, 2),
                                       "note": "emd_graph_run (csrc/graph_exec.hip): layer table, BN folding, packing, kernel selection and launch order "
-                                              "in the library; single stream (the Python engine runs the 1/16-resolution flow as two halves on two streams)"}
+                                              "in the library; single stream (emd_graph_set_two_streams: the Python engine's two-halves form, measured slower from C)"}
             nat.close()
             del nat, yn
         except Exception as e:

@@ -594,6 +594,11 @@ size_t emd_graph_workspace_bytes(emd_graph_t* graph, int B, int S);
 int emd_graph_run(emd_graph_t* graph, const float* x, float* y, int B, int S, void* workspace, size_t workspace_bytes,
                   emd_stream_t stream);
 void emd_graph_destroy(emd_graph_t* graph);
+/* Launch-order option (speed only, same bits): on != 0 runs the 1/16-resolution flow (denoiser.py:312-325) of an even batch as two
+ * halves on two internal streams, forked from and joined to `stream` (capturable), as the Python engine does; the workspace size
+ * changes with it (ask emd_graph_workspace_bytes afterwards).  Default off: measured slower from a host that enqueues as fast as C
+ * does. */
+int emd_graph_set_two_streams(emd_graph_t* graph, int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Host utility (no GPU): CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start).

@@ -27,7 +27,7 @@ def test_create_reports_a_missing_or_misshapen_variable():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,S", [(2, 64), (1, 48), (4, 512)])
+@pytest.mark.parametrize("B,S", [(2, 64), (1, 48), (4, 512), (16, 512)])   # 16 x 512^2: set_two_streams runs the 1/16-resolution flow as two halves
 def test_native_graph_equals_the_python_engine(B, S):
     import emdenoise
     from emdenoise.graph_exec import NativeGraph
@@ -44,6 +44,10 @@ def test_native_graph_equals_the_python_engine(B, S):
     again = nat.forward(x)                                           # the workspace is reused; nothing stale in it matters
     torch.cuda.synchronize()
     assert torch.equal(again, want)
+    nat.set_two_streams(True)                                        # launch-order option: same bits (taken at 16 x 512^2, a no-op below)
+    two = nat.forward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(two, want)
     assert nat.workspace_bytes(B, S) > 0
     nat.close()
 
