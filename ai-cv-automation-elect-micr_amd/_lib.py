@@ -16,6 +16,13 @@ EMD_K_SYMMETRIC = 1
 _c_float_p = C.c_void_p  # device pointers travel as integers
 
 # name -> (restype, argtypes): must list every symbol include/emdenoise.h declares
+class PackJob(C.Structure):
+    """include/emdenoise.h emd_pack_job_t"""
+    _fields_ = [("w", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("tap_sel", C.c_ulonglong), ("total", C.c_long),
+                ("first_block", C.c_long), ("n_blocks", C.c_long), ("ntaps", C.c_int), ("cin", C.c_int), ("cout", C.c_int),
+                ("cout_major", C.c_int), ("cpad", C.c_int), ("pad_", C.c_int)]
+
+
 SIGNATURES = {
     "emd_version": (C.c_int, []),
     "emd_last_error": (C.c_char_p, []),
@@ -128,6 +135,10 @@ SIGNATURES = {
     # w src_taps ntaps tap_sel Cin Cout cout_major hi lo stream
     "emd_pack_weights_dev": (C.c_int, [_c_float_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    # job w src_taps ntaps tap_sel Cin Cout cout_major hi lo  /  jobs_dev n_jobs n_blocks stream
+    "emd_pack_job_fill": (C.c_int, [C.c_void_p, _c_float_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p]),
+    "emd_pack_weights_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_void_p]),
     # dy ldd whi wlo scale1 shift1 res ldres dx ldx B H W Cout Cin precision stream
     "emd_conv1x1_s2_bwd_data_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
                                               _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,

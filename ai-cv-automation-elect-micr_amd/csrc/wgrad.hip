@@ -273,6 +273,33 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     lo[idx] = __builtin_bit_cast(uint16_t, l);
 }
 
+// every pack of a model in one launch: block -> job by binary search over the jobs' first blocks, then pack_weights_kernel's body
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const emd_pack_job_t* __restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    const long blk = blockIdx.x;
+    while (lo < hi) {   // the last job whose first_block <= blk (block-uniform)
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= blk) lo = mid;
+        else hi = mid - 1;
+    }
+    const emd_pack_job_t j = jobs[lo];
+    const long idx = (blk - j.first_block) * 256 + threadIdx.x;
+    if (idx >= j.total) return;
+    const int c = (int)(idx % j.cpad);
+    const long r = idx / j.cpad;
+    const int t = (int)(r % j.ntaps);
+    const int n = (int)(r / j.ntaps);
+    float v = 0.f;
+    if (c < j.cin && n < j.cout) {
+        const long st = (long)((j.tap_sel >> (4 * t)) & 15);
+        v = j.cout_major ? j.w[(st * j.cout + n) * j.cin + c] : j.w[(st * j.cin + c) * j.cout + n];
+    }
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    j.hi[idx] = __builtin_bit_cast(uint16_t, h);
+    j.lo[idx] = __builtin_bit_cast(uint16_t, l);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -352,4 +379,33 @@ extern "C" int emd_pack_weights_dev(const float* w, int src_taps, int ntaps, con
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), w, ntaps, sel, Cin, Cout, cout_major, cpad, total, hi, lo);
     return emd::check_launch("pack_weights_kernel");
+}
+
+extern "C" int emd_pack_job_fill(emd_pack_job_t* job, const float* w, int src_taps, int ntaps, const int* tap_sel, int Cin, int Cout,
+                                 int cout_major, uint16_t* hi, uint16_t* lo) {
+    EMD_REQUIRE(job && w && hi && lo, EMD_E_INVALID, "emd_pack_job_fill: null pointer");
+    EMD_REQUIRE(src_taps >= 1 && src_taps <= 9 && ntaps >= 1 && ntaps <= 9 && Cin >= 1 && Cout >= 1, EMD_E_INVALID,
+                "emd_pack_job_fill: bad shape");
+    EMD_REQUIRE(tap_sel || ntaps == src_taps, EMD_E_INVALID, "emd_pack_job_fill: a tap subset needs tap_sel");
+    unsigned long long sel = 0;
+    for (int t = 0; t < ntaps; ++t) {
+        const int s = tap_sel ? tap_sel[t] : t;
+        EMD_REQUIRE(s >= 0 && s < src_taps, EMD_E_INVALID, "emd_pack_job_fill: tap_sel out of range");
+        sel |= (unsigned long long)s << (4 * t);
+    }
+    const int cpad = (Cin + kBK - 1) / kBK * kBK;
+    const long npad = (Cout + kNPadTo - 1) / kNPadTo * kNPadTo;
+    job->w = w; job->hi = hi; job->lo = lo; job->tap_sel = sel;
+    job->total = npad * ntaps * cpad;
+    job->first_block = 0;
+    job->n_blocks = (job->total + 255) / 256;
+    job->ntaps = ntaps; job->cin = Cin; job->cout = Cout; job->cout_major = cout_major ? 1 : 0; job->cpad = cpad; job->pad_ = 0;
+    return EMD_OK;
+}
+
+extern "C" int emd_pack_weights_batch_dev(const emd_pack_job_t* jobs_dev, int n_jobs, long n_blocks, emd_stream_t stream) {
+    EMD_REQUIRE(jobs_dev && n_jobs >= 1, EMD_E_INVALID, "emd_pack_weights_batch_dev: null table / no jobs");
+    EMD_REQUIRE(n_blocks >= 1 && n_blocks <= 0x7fffffffL, EMD_E_UNSUPPORTED, "emd_pack_weights_batch_dev: bad block count");
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)n_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), jobs_dev, n_jobs);
+    return emd::check_launch("pack_weights_batch_kernel");
 }

@@ -47,6 +47,38 @@ class DevPackedWeights:
         return self
 
 
+class PackBatch:
+    """Every DevPackedWeights.pack call of a model as ONE launch (emd_pack_weights_batch_dev): add() the calls once -- the
+    pointers must stay where they are -- then run() after every optimizer step."""
+
+    def __init__(self, device):
+        self.device, self.jobs, self.table, self.n_blocks, self._keep = device, [], None, 0, []
+
+    def add(self, dst: DevPackedWeights, w_dev, src_taps, cout_major, tap_sel=None):
+        assert self.table is None and w_dev.is_contiguous() and w_dev.numel() == src_taps * dst.cin * dst.cout
+        job = _lib.PackJob()
+        rc = _lib.load().emd_pack_job_fill(C.byref(job), _p(w_dev), src_taps, dst.taps, _ints(tap_sel) if tap_sel is not None else None,
+                                           dst.cin, dst.cout, 1 if cout_major else 0, _p(dst.hi), _p(dst.lo))
+        _lib.check(rc, "emd_pack_job_fill")
+        job.first_block = self.n_blocks
+        self.n_blocks += job.n_blocks
+        self.jobs.append(job)
+        self._keep.append((dst, w_dev))
+
+    def run(self, stream=None):
+        import numpy as np
+        import torch
+
+        if not self.jobs:
+            return
+        if self.table is None:
+            arr = (_lib.PackJob * len(self.jobs))(*self.jobs)
+            host = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            self.table = torch.from_numpy(host).to(self.device)
+        _lib.check(_lib.load().emd_pack_weights_batch_dev(_p(self.table), len(self.jobs), self.n_blocks, _lib.stream_ptr(stream)),
+                   "emd_pack_weights_batch_dev")
+
+
 def conv_wgrad(a: Act, dy: Act, dw_dev, taps_dy=None, taps_dx=None, sa=1, stream=None):
     """dw_dev [ntaps][a.C][dy.C] += sum over dy's grid of a[src_t] (x) dy."""
     ntaps = 1 if taps_dy is None else len(taps_dy)

@@ -114,6 +114,8 @@ class DenoiserTrainer:
         self.dw_flip = {}
         self._streams, self._graphs = [], {}
         self._wg_side, self._wg_keep = None, []   # side stream of the weight-gradient launches of a batched pass (see _wg)
+        self._pack_batch = None
+        self._flip_idx = self._flip_flat = None
         self._per_image = False
         self.teacher = None   # test hook: scope -> {"d": ..., "r": ...} reference tensors that REPLACE the forward's conv outputs (see _force)
         self.repack()
@@ -140,25 +142,47 @@ class DenoiserTrainer:
         self.pad_w["cnn0_dw"][:, 0].copy_(self.v[L0.scope + "/depthwise_weights"].view(9))
         self.pad_w["cnn0_pw"][0, 0].copy_(self.v[L0.scope + "/pointwise_weights"].view(L0.cout))
         self.pad_w["residual0"][0, 0].copy_(self.v[R0.scope + "/" + R0.wname].view(R0.cout))
-        for key, L in self.layers.items():
-            if L.kind == "sep" or (L.kind == "conv" and L.cout > 1):
-                w = self._w(key)
-                taps = w.shape[0]
-                self.pk_f[key].pack(w, taps, cout_major=False)
-                if key in self.pk_b:  # K = Cout, N = Cin: the same array read "cout_major"; taps reversed
-                    self.pk_b[key].pack(w.contiguous(), taps, cout_major=True, tap_sel=list(range(taps))[::-1])
-            elif L.kind == "deconv":
-                w = self._w(key)
-                for ph in range(4):
-                    sel = [ky * 3 + kx for (ky, kx) in ops.deconv_phase_taps(ph)]
-                    self.pk_f[key][ph].pack(w, 9, cout_major=True, tap_sel=sel)
-                self.pk_b[key].pack(w, 9, cout_major=False)
-            if L.kind == "sep" and L.stride == 1 and L.cin > 1:
-                # taps reversed for the stride-1 data gradient; updated IN PLACE (a captured hipGraph keeps the pointer)
-                if key not in self.dw_flip:
-                    self.dw_flip[key] = self._dw(key).flip(0).contiguous()
-                else:
-                    self.dw_flip[key].copy_(self._dw(key).flip(0))
+        if self._pack_batch is None:
+            # every pack of the model as one launch (emd_pack_weights_batch_dev): the job table is built once, the parameter
+            # views and the packed planes it points at never move
+            pb = TO.PackBatch(self.device)
+            for key, L in self.layers.items():
+                if L.kind == "sep" or (L.kind == "conv" and L.cout > 1):
+                    w = self._w(key)
+                    taps = w.shape[0]
+                    pb.add(self.pk_f[key], w, taps, cout_major=False)
+                    if key in self.pk_b:  # K = Cout, N = Cin: the same array read "cout_major"; taps reversed
+                        pb.add(self.pk_b[key], w, taps, cout_major=True, tap_sel=list(range(taps))[::-1])
+                elif L.kind == "deconv":
+                    w = self._w(key)
+                    for ph in range(4):
+                        sel = [ky * 3 + kx for (ky, kx) in ops.deconv_phase_taps(ph)]
+                        pb.add(self.pk_f[key][ph], w, 9, cout_major=True, tap_sel=sel)
+                    pb.add(self.pk_b[key], w, 9, cout_major=False)
+            self._pack_batch = pb
+        self._pack_batch.run()
+        # taps reversed for the stride-1 data gradients: one gather from the flat parameter vector into one buffer that the per-layer
+        # [9][C] views point into; updated IN PLACE (a captured hipGraph keeps the pointers)
+        import torch
+
+        if self._flip_idx is None:
+            keys = [k for k, L in self.layers.items() if L.kind == "sep" and L.stride == 1 and L.cin > 1]
+            idx, off = [], 0
+            for k in keys:
+                w = self._dw(k)
+                base = (w.data_ptr() - self.params.data_ptr()) // 4
+                assert w.is_contiguous() and 0 <= base and base + w.numel() <= self.params.numel()
+                c = w.shape[1]
+                idx.append(torch.arange(base, base + 9 * c, dtype=torch.int64).view(9, c).flip(0).reshape(-1))
+                off += 9 * c
+            self._flip_idx = torch.cat(idx).to(self.device)
+            self._flip_flat = torch.empty(off, dtype=torch.float32, device=self.device)
+            off = 0
+            for k in keys:
+                c = self._dw(k).shape[1]
+                self.dw_flip[k] = self._flip_flat[off:off + 9 * c].view(9, c)
+                off += 9 * c
+        torch.index_select(self.params, 0, self._flip_idx, out=self._flip_flat)
 
     def state_dict(self):
         """TF variable name -> numpy array (parameters and moving statistics)."""

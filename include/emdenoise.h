@@ -313,6 +313,24 @@ int emd_conv_wgrad_f32(const float* a, int lda, const float* dy, int ldd, float*
 int emd_pack_weights_dev(const float* w, int src_taps, int ntaps, const int* tap_sel, int Cin, int Cout, int cout_major,
                          uint16_t* hi, uint16_t* lo, emd_stream_t stream);
 
+/* All of a model's packs in ONE launch (the re-pack after an optimizer step is ~860 packs of a few KB..MB each: launch-bound one
+ * by one).  A job = one emd_pack_weights_dev call; emd_pack_job_fill validates the arguments on the host and fills the derived
+ * fields; the caller numbers the jobs' blocks consecutively (first_block = sum of the earlier jobs' n_blocks), copies the table
+ * to the device once (the pointers in it do not change between steps) and passes the total block count. */
+typedef struct emd_pack_job {
+    const float* w;
+    uint16_t* hi;
+    uint16_t* lo;
+    unsigned long long tap_sel;   /* 4 bits per packed tap: its source tap */
+    long total;                   /* packed elements of one plane */
+    long first_block;             /* caller-assigned */
+    long n_blocks;                /* ceil(total / 256) */
+    int ntaps, cin, cout, cout_major, cpad, pad_;
+} emd_pack_job_t;
+int emd_pack_job_fill(emd_pack_job_t* job, const float* w, int src_taps, int ntaps, const int* tap_sel, int Cin, int Cout,
+                      int cout_major, uint16_t* hi, uint16_t* lo);
+int emd_pack_weights_batch_dev(const emd_pack_job_t* jobs_dev, int n_jobs, long n_blocks, emd_stream_t stream);
+
 /* Data gradient of the stride-2 1x1 conv (residual branches, :225-238 with strides=2):
  * dx[b,2i,2j,:] = dy[b,i,j,:] * W^T (+ res at the same pixels); other pixels of dx are left as they are.
  * dy [B,ceil(H/2),ceil(W/2),Cout]; dx [B,H,W,Cin]; whi/wlo packed with (Cin:=Cout, Cout:=Cin, cout_major 1). */

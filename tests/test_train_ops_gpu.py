@@ -119,6 +119,38 @@ def test_pack_weights_dev_matches_host_pack():
         assert torch.equal(hp.hi, dp.hi) and torch.equal(hp.lo, dp.lo)
 
 
+def test_pack_weights_batch_equals_the_single_packs():
+    """emd_pack_weights_batch_dev (one launch for a whole job table) writes what the same packs write one by one: both
+    orientations, reversed taps, the tap subsets of a transposed conv, a 4-channel pad, sizes that end inside a block."""
+    from emdenoise import ops, train_ops as TO
+
+    specs = [(1, 100, 72, False, None), (1, 72, 100, True, [0]), (9, 64, 36, False, None), (9, 36, 64, True, list(range(9))[::-1]),
+             (1, 4, 64, False, None), (1, 728, 728, False, None)]
+    ws, single, batched = [], [], []
+    pb = TO.PackBatch(dev())
+    for i, (taps, ci, co, cm, sel) in enumerate(specs):
+        shape = (taps, co, ci) if cm else (taps, ci, co)
+        w = d32(rnd(shape, 30 + i))
+        ws.append(w)
+        single.append(TO.DevPackedWeights(taps, ci, co, dev()).pack(w, taps, cout_major=cm, tap_sel=sel))
+        b = TO.DevPackedWeights(taps, ci, co, dev())
+        b.hi.fill_(-1); b.lo.fill_(-1)
+        pb.add(b, w, taps, cout_major=cm, tap_sel=sel)
+        batched.append(b)
+    wd = d32(rnd((9, 40, 24), 40))
+    for ph in range(4):
+        sel = [ky * 3 + kx for (ky, kx) in ops.deconv_phase_taps(ph)]
+        single.append(TO.DevPackedWeights(len(sel), 24, 40, dev()).pack(wd, 9, cout_major=True, tap_sel=sel))
+        b = TO.DevPackedWeights(len(sel), 24, 40, dev())
+        pb.add(b, wd, 9, cout_major=True, tap_sel=sel)
+        batched.append(b)
+    pb.run()
+    pb.run()   # the table is built once and reused
+    torch.cuda.synchronize()
+    for a, b in zip(single, batched):
+        assert torch.equal(a.hi, b.hi) and torch.equal(a.lo, b.lo)
+
+
 @pytest.mark.parametrize("B,H,W,ci,co,k,stride,rate", [
     (2, 16, 16, 64, 128, 1, 1, 1), (1, 8, 8, 728, 728, 1, 1, 1), (1, 16, 16, 128, 64, 3, 1, 6), (1, 9, 11, 64, 64, 3, 1, 1),
     (2, 16, 16, 128, 256, 1, 2, 1), (1, 7, 9, 256, 728, 1, 2, 1),
