@@ -546,21 +546,21 @@ class DenoiserTrainer:
         self._put(G, deconv0, lambda dst: TO.conv3x3_cout1_bwd_data(drf.buf, wf, dst))
         # decoder 0: deconv0 = sep_b(sep_a(deconv1to0)) + residual0_d(deconv1to0)
         g = grad(deconv0)
-        self._conv_bwd("residual0_d", g, C["residual0_d"], G)
         self._sep_bwd("deconv0_b", g, C["deconv0_b"], G)
         self._sep_bwd("deconv0_a", grad(C["deconv0_b"]["x"]), C["deconv0_a"], G)
+        self._conv_bwd("residual0_d", g, C["residual0_d"], G)   # after the separable branch: a GEMM can ADD its data gradient, a depthwise kernel cannot
         self._deconv_bwd("deconv1to0", grad(deconv1to0), C["deconv1to0"], G)
         # decoder 1
         g = grad(deconv1)
-        self._conv_bwd("residual1_d", g, C["residual1_d"], G)
         self._sep_bwd("deconv1_b", g, C["deconv1_b"], G)
         self._sep_bwd("deconv1_a", grad(C["deconv1_b"]["x"]), C["deconv1_a"], G)
+        self._conv_bwd("residual1_d", g, C["residual1_d"], G)   # after the separable branch: a GEMM can ADD its data gradient, a depthwise kernel cannot
         self._deconv_bwd("deconv2to1", gconcat1.slice(0, f2), C["deconv2to1"], G)
         # decoder 2
         g = grad(deconv2)
-        self._conv_bwd("residual2_d", g, C["residual2_d"], G)
         self._sep_bwd("deconv2_b", g, C["deconv2_b"], G)
         self._sep_bwd("deconv2_a", grad(C["deconv2_b"]["x"]), C["deconv2_a"], G)
+        self._conv_bwd("residual2_d", g, C["residual2_d"], G)   # after the separable branch: a GEMM can ADD its data gradient, a depthwise kernel cannot
         self._put(G, aspp, lambda dst: TO.resize_bilinear_bwd(gconcat2.slice(0, aspp_output), dst))
         # ASPP
         self._conv_bwd("aspp_reduce", grad(aspp), C["aspp_reduce"], G)          # writes gcat (all five slices)
@@ -592,10 +592,10 @@ class DenoiserTrainer:
         # encoders 3..0: y = sep_strided(sep_last(sep(x))) + residual_conv(x)
         def encoder(keys, res_key, y, need_dx=True):
             gy = grad(y)
-            self._conv_bwd(res_key, gy, C[res_key], G, need_dx=need_dx)
             self._sep_bwd(keys[2], gy, C[keys[2]], G)
             self._sep_bwd(keys[1], grad(C[keys[2]]["x"]), C[keys[1]], G)
             self._sep_bwd(keys[0], grad(C[keys[1]]["x"]), C[keys[0]], G, need_dx=need_dx)
+            self._conv_bwd(res_key, gy, C[res_key], G, need_dx=need_dx)   # last: its data gradient is added by the GEMM (no axpy pass)
 
         # cnn1_strided / cnn0_strided live in concat2 / concat1: their gradients started in the decoder (the slices of
         # gconcat2 / gconcat1 written above); the encoder-side consumers below add into them
