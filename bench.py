@@ -925,7 +925,7 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
            "steps": steps, "warmup": warmup, "dtype": "bf16x3 GEMMs (split-bf16 MFMA inputs, fp32 accumulate), fp32 elsewhere",
            "config": {"workload": f"T: graph D' training step (misc_py/denoiser-multi-gpu.py), [{B},{S},{S},1] fp32 LQ/HQ pairs per GPU, "
                                   f"towers of {tb}, Nesterov momentum 0.9, lr 1e-3",
-                      "global_batch": B * world, "tower_batch": tb, "tower_mode": a.tower_mode, "streams": a.train_streams, "hip_graph": not a.no_graph,
+                      "global_batch": B * world, "tower_batch": tb, "tower_mode": a.tower_mode, "batched_groups": (TR.DenoiserTrainer.batched_groups(B) if a.tower_mode == "batched" and tb == 1 else None), "streams": a.train_streams, "hip_graph": not a.no_graph,
                       "precision": a.precision, "parallelism": f"dp{world}",
                       "algorithmic_tflop_per_step_per_gpu": round(tflop, 3)},
            "tflops_algorithmic": round(tflop / (ms / 1e3), 1),
