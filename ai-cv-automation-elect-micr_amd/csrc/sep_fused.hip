@@ -494,9 +494,15 @@ int launch_dual(const SepParams& p, int B, hipStream_t st) {
 
 }  // namespace
 
+// 128 < Cout <= 256: one N tile of 256 columns on 4 x 16 pixel tiles (sep_fused_kernel<256, PASSES, false, 4>).  Against depthwise ->
+// HBM -> pointwise at [32,128,128,.]: 128 -> 256 256 vs 335 us, 256 -> 256 (+ residual) 537 vs 609 us, 384 -> 256 773 vs 734 us: the
+// rule takes it up to Cin = 256.  EMD_SEP_WIDE (dev): 0 = never, 2 = whenever it fits.
+inline int sep_wide() { static const int v = [] { const char* e = getenv("EMD_SEP_WIDE"); return e ? atoi(e) : 1; }(); return v; }
+
 extern "C" int emd_sep3x3_fused_supported(int H, int W, int Cin, int Cout, int stride, int rate) {
+    const bool wide = Cout > 128 && Cout <= 256 && (sep_wide() == 2 || (sep_wide() == 1 && Cin <= 256));
     return stride == 1 && rate == 1 && H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && Cin >= 32 && Cin <= 4096 && Cout % 4 == 0 &&
-           Cout >= 4 && Cout <= 128;
+           Cout >= 4 && (Cout <= 128 || wide);
 }
 
 static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
@@ -510,7 +516,7 @@ static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint1
     EMD_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), EMD_E_INVALID, "emd_sep3x3_fused_f32: scale2/shift2 pair");
     EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_sep3x3_fused_f32: bad shape");
     EMD_REQUIRE(emd_sep3x3_fused_supported(H, W, Cin, Cout, 1, 1), EMD_E_UNSUPPORTED,
-                "emd_sep3x3_fused_f32: needs H%8==0, W%16==0, Cin%32==0, Cout%4==0, Cout<=128 (use emd_dw3x3_f32 + emd_conv1x1_f32)");
+                "emd_sep3x3_fused_f32: needs H%8==0, W%16==0, Cin%32==0, Cout%4==0, Cout<=128 or Cout<=256 with Cin<=256 (use emd_dw3x3_f32 + emd_conv1x1_f32)");
     EMD_REQUIRE(B <= 65535, EMD_E_UNSUPPORTED, "emd_sep3x3_fused_f32: B > 65535");
     EMD_REQUIRE(9L * W * (ldy > ldres ? ldy : ldres) < (1L << 31), EMD_E_UNSUPPORTED,
                 "emd_sep3x3_fused_f32: 9 image rows of the output must span fewer than 2^31 floats");
@@ -533,6 +539,19 @@ static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint1
     p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act; p.reflect = reflect;
     p.gen_a = gen_a; p.gen_t = gen_t; p.gen_act = gen_act; p.out_split = out_split ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (Cout > 128) {   // the wide single-output form (dev): 4 x 16 pixel tiles, split-bf16 only, no generated input
+        EMD_REQUIRE(!gen_a, EMD_E_UNSUPPORTED, "emd_sep3x3_fused_gen_f32: Cout > 128 has no generated-input form");
+        SepParams q = p;
+        const int tiles_w = p.W / 16;
+        q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / 4) * B);
+        q.stamps = g_sep_stamps;
+        const dim3 grid(tiles_w / q.tpw, p.H / 4, B);
+        q.nt = sep_nt();
+        q.xcd = sep_xcd() && ((long)grid.x * grid.y * grid.z) % 8 == 0;
+        if (precision == 3) hipLaunchKernelGGL((sep_fused_kernel<256, 3, false, 4, false>), grid, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((sep_fused_kernel<256, 1, false, 4, false>), grid, dim3(256), 0, st, q);
+        return emd::check_launch("sep_fused_kernel<wide>");
+    }
     return Cout <= 64 ? launch<64>(p, B, precision, st) : launch<128>(p, B, precision, st);
 }
 

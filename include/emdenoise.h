@@ -145,7 +145,8 @@ int emd_deconv3x3s2_f32(const float* x, int ldx, const uint16_t* const whi[4], c
  * pointwise 1x1 on the matrix cores -> fused epilogue (above).  The depthwise result never reaches HBM.
  * replaces: slim.separable_convolution2d + normalizer BN + batch_then_activ (+ the residual "+=").
  * Supported when emd_sep3x3_fused_supported() returns 1: stride 1, rate 1, H%8==0, W%16==0, Cin%32==0,
- * Cout%4==0, Cout<=128 (one N tile); otherwise call emd_dw3x3_f32 + emd_conv1x1_f32.
+ * Cout%4==0, Cout<=128 (one N tile), or Cout<=256 with Cin<=256 (one 256-column tile on 4 x 16 pixels; no generated-input form);
+ * otherwise call emd_dw3x3_f32 + emd_conv1x1_f32.
  * x [B,H,W,Cin] ldx; dw [3][3][Cin]; whi/wlo packed pointwise weights (taps=1); y [B,H,W,Cout] ldy. */
 int emd_sep3x3_fused_supported(int H, int W, int Cin, int Cout, int stride, int rate);
 int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,

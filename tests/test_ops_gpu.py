@@ -266,6 +266,49 @@ def test_sep_fused(B, H, W, ci, co, res, extra, prec):
     assert np.isnan(full[..., :4]).all() and np.isnan(full[..., 4 + co:]).all()   # nothing written outside the slice
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,res,extra,split", [
+    (2, 16, 32, 128, 256, False, False, False),   # cnn2
+    (1, 24, 16, 256, 256, True, False, True),     # deconv2_b: residual, split32 output for the transposed conv
+    (2, 8, 48, 64, 160, True, True, False),       # N tail inside the 256-column tile, second affine
+])
+def test_sep_fused_wide(B, H, W, ci, co, res, extra, split):
+    """128 < Cout <= 256 (Cin <= 256): the one-tile-of-256-columns form on 4 x 16 pixel tiles against the oracle and, for the split32
+    output, against emd_to_split32_f32 of its own fp32 output."""
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 240, positive=True)
+    dw = rnd((3, 3, ci, 1), 241, 0.35)
+    pw = rnd((1, 1, ci, co), 242, scale=(2.0 / (ci + co)) ** 0.5)
+    s1, t1 = rnd((co,), 243, 0.2) + 1, rnd((co,), 244, 0.5)
+    s2, t2 = rnd((co,), 245, 0.2) + 1, rnd((co,), 246, 0.5)
+    r = rnd((B, H, W, co), 247, positive=True)
+    y = T.relu6_t(T.conv2d_t(T.depthwise_conv2d_t(t64(x), t64(dw)), t64(pw)) * t64(s1) + t64(t1))
+    if extra:
+        y = T.relu6_t(y * t64(s2) + t64(t2))
+    if res:
+        y = y + t64(r)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    xa = to_act(x, ld=ci + 64, c0=32)
+    assert ops.sep_fused_supported(xa, co, 1, 1)
+    kw = dict(scale2=d(s2) if extra else None, shift2=d(t2) if extra else None, res=to_act(r, ld=co + 12, c0=8) if res else None)
+    pk = ops.PackedWeights(pw[0], False, dev())
+    out = out_act(B, H, W, co, ld=co + 8, c0=4)
+    ops.sep_fused(xa, d(dw[..., 0]), pk, d(s1), d(t1), out, **kw)
+    torch.cuda.synchronize()
+    got = out.torch().cpu().numpy()
+    assert rel_l2(got, y.numpy()) < TOL_X3
+    full = out.buf.cpu().numpy()
+    assert np.isnan(full[..., :4]).all() and np.isnan(full[..., 4 + co:]).all()
+    if split:
+        sp = ops.SplitAct(B, H, W, co, dev())
+        sp.buf.fill_(float("nan"))
+        ops.sep_fused(xa, d(dw[..., 0]), pk, d(s1), d(t1), sp, **kw)
+        want = ops.to_split32(ops.Act(out.torch().contiguous()))
+        torch.cuda.synchronize()
+        assert torch.equal(sp.buf.view(torch.int32), want.buf.view(torch.int32))
+
+
 @pytest.mark.parametrize("B,H,W,ci,co,gen_act,reflect,extra", [
     (2, 32, 48, 64, 64, 1, False, False),     # graph D's cnn0 -> cnn0_last
     (1, 64, 64, 64, 64, 1, False, True),      # several tiles per workgroup
@@ -391,7 +434,8 @@ def test_sep_fused_falls_back_cleanly():
 
     x = to_act(rnd((1, 12, 16, 64), 48))       # H % 8 != 0
     assert not ops.sep_fused_supported(x, 64, 1, 1)
-    assert not ops.sep_fused_supported(to_act(rnd((1, 8, 16, 64), 49)), 256, 1, 1)   # more than one N tile
+    assert not ops.sep_fused_supported(to_act(rnd((1, 8, 16, 64), 49)), 260, 1, 1)   # more than one 256-column N tile
+    assert not ops.sep_fused_supported(to_act(rnd((1, 8, 16, 384), 49)), 256, 1, 1)  # the 256-column form stops at Cin = 256
     with pytest.raises(_lib.EmdError, match="emd_dw3x3_f32"):
         ops.sep_fused(x, torch.zeros(9 * 64, device=dev()), ops.PackedWeights(rnd((1, 64, 64), 50), False, dev()),
                       torch.ones(64, device=dev()), torch.zeros(64, device=dev()), out_act(1, 12, 16, 64))
