@@ -72,7 +72,9 @@ inline int sep_xcd() { static const int v = [] { const char* e = getenv("EMD_SEP
 
 // BN = columns of the workgroup's GEMM tile: 64 / 128 (one output), or with DUAL the two outputs side by side: 128 = 64 | 64 on an
 // 8 x 16 pixel tile, 256 = 128 | 128 on a 4 x 16 pixel tile (TH = 4: the accumulators of both outputs fit the same registers).
-template <int BN, int PASSES, bool GEN, int TH = 8, bool DUAL = false>
+// WRES (BN = 64, Cin <= 64): the whole pointwise weight matrix (at most two 32-channel chunks, 10 KB each with the lo plane) is put into
+// LDS once per workgroup instead of once per (tile, chunk): with a generated input it was 90 % of the bytes the loader moved.
+template <int BN, int PASSES, bool GEN, int TH = 8, bool DUAL = false, bool WRES = false>
 __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     constexpr int TW = 16, BM = TH * TW, BK = 32;
     constexpr int PH = TH + 2, PW = TW + 2, NPX = PH * PW;  // 10 x 18 = 180 patch pixels (6 x 18 = 108 for TH = 4)
@@ -86,7 +88,9 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
     constexpr int NPT = BM / 32;                             // pixels per thread along W in the depthwise role (4 or 2)
     static_assert(TM >= 1 && TN == 2 && (!DUAL || (!GEN && PASSES == 3 && WN >= 2)), "tile shape");
     constexpr int LDS_STAGE = BN + 4;
-    constexpr int PATCH_BYTES = NPX * PLD * 4, A_BYTES = NPL * BM * LDK * 2, B_BYTES = NPL * BN * LDK * 2;
+    constexpr int B_CHUNK = NPL * BN * LDK * 2;               // one chunk's W tile (hi [+ lo] plane)
+    constexpr int PATCH_BYTES = NPX * PLD * 4, A_BYTES = NPL * BM * LDK * 2, B_BYTES = B_CHUNK * (WRES ? 2 : 1);
+    static_assert(!WRES || (BN == 64 && !DUAL), "the resident-W form is the 64-column single-output instance");
     constexpr int STAGE_BYTES = BM * LDS_STAGE * 4;
     constexpr int DW_BYTES = 9 * BK * 4;                     // the chunk's depthwise weights [9][32]
     constexpr int DW_OFF = PATCH_BYTES + A_BYTES + B_BYTES > STAGE_BYTES ? PATCH_BYTES + A_BYTES + B_BYTES : STAGE_BYTES;   // clear of the staging tile
@@ -172,6 +176,13 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nchunks = p.Cin / BK;
+    if constexpr (WRES) {   // both chunks' W tiles, once (visible after the loop's first barrier)
+        for (int c = 0; c < nchunks; ++c) {
+            auto Bc = reinterpret_cast<uint16_t(*)[BN][LDK]>(smem + PATCH_BYTES + A_BYTES + c * B_CHUNK);
+            *reinterpret_cast<u32x4*>(&Bc[0][w_row][w_col]) = *reinterpret_cast<const u32x4*>(whi + c * BK);
+            if (NPL == 2) *reinterpret_cast<u32x4*>(&Bc[NPL - 1][w_row][w_col]) = *reinterpret_cast<const u32x4*>(wlo + c * BK);
+        }
+    }
     const int total = p.tpw * nchunks;   // (tile, chunk) steps of this workgroup: the staging pipeline runs on across tiles, so
                                          // a tile's epilogue overlaps the loads of the next tile's first chunk
     const int fr = lane & 31, fh = lane >> 5;
@@ -201,10 +212,12 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                 if (idx < NPX * 8) *reinterpret_cast<f32x4*>(patch + (idx >> 3) * PLD + (idx & 7) * 4) = preg[q];
             }
             if (tid < 72) *reinterpret_cast<f32x4*>(wks + tid * 4) = wkreg;
+            if constexpr (!WRES) {
 #pragma unroll
-            for (int q = 0; q < W_PASSES; ++q) {
-                *reinterpret_cast<u32x4*>(&Bs[0][w_row + 64 * q][w_col]) = wh[q];
-                if (NPL == 2) *reinterpret_cast<u32x4*>(&Bs[NPL - 1][w_row + 64 * q][w_col]) = wl[q];
+                for (int q = 0; q < W_PASSES; ++q) {
+                    *reinterpret_cast<u32x4*>(&Bs[0][w_row + 64 * q][w_col]) = wh[q];
+                    if (NPL == 2) *reinterpret_cast<u32x4*>(&Bs[NPL - 1][w_row + 64 * q][w_col]) = wl[q];
+                }
             }
             __syncthreads();  // (1) patch + W tile of chunk `it` visible
         }
@@ -238,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
         }
         // the chunk's 9 x 32 depthwise weights travel through LDS too: one 16-byte load for 72 threads instead of nine for every thread
         if (tid < 72) wkreg = *reinterpret_cast<const f32x4*>(p.dw + ((long)(tid >> 3) * p.Cin + c0n) + (tid & 7) * 4);
+        if constexpr (!WRES)
 #pragma unroll
         for (int q = 0; q < W_PASSES; ++q) {
             constexpr int HALF = W_PASSES / 2;
@@ -310,11 +324,12 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                     if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(&As[NPL - 1][r][ks * 16 + fh * 8]);
                 }
             }
+            auto Bc = WRES ? reinterpret_cast<uint16_t(*)[BN][LDK]>(smem + PATCH_BYTES + A_BYTES + (it % nchunks) * B_CHUNK) : Bs;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int r = wn * (BN / WN) + j * 32 + fr;
-                bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[0][r][ks * 16 + fh * 8]);
-                if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[NPL - 1][r][ks * 16 + fh * 8]);
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Bc[0][r][ks * 16 + fh * 8]);
+                if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(&Bc[NPL - 1][r][ks * 16 + fh * 8]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -453,8 +468,26 @@ int tiles_per_workgroup(int tiles_w, long wgs1) {
     return tpw;
 }
 
+// BN = 64, Cin <= 64, split-bf16: the pointwise weights stay in LDS for the workgroup's whole life
+int launch_wres(const SepParams& p, int B, hipStream_t st) {
+    SepParams q = p;
+    const int tiles_w = p.W / 16;
+    q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / 8) * B);
+    q.stamps = g_sep_stamps;
+    const dim3 grid(tiles_w / q.tpw, p.H / 8, B);
+    q.nt = sep_nt();
+    q.xcd = sep_xcd() && ((long)grid.x * grid.y * grid.z) % 8 == 0;
+    if (p.gen_a) hipLaunchKernelGGL((sep_fused_kernel<64, 3, true, 8, false, true>), grid, dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((sep_fused_kernel<64, 3, false, 8, false, true>), grid, dim3(256), 0, st, q);
+    return emd::check_launch("sep_fused_kernel<resident W>");
+}
+
 template <int BN>
 int launch(const SepParams& p, int B, int passes, hipStream_t st) {
+    if constexpr (BN == 64) {
+        static const int wres = [] { const char* e = getenv("EMD_SEP_WRES"); return e ? atoi(e) : 1; }();   // dev knob: 0 = per-chunk W loads
+        if (wres && p.Cin <= 64 && passes == 3) return launch_wres(p, B, st);
+    }
     SepParams q = p;
     const int tiles_w = p.W / 16;
     q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / 8) * B);

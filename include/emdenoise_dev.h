@@ -13,6 +13,9 @@
  *   EMD_NT             gemm_split / sep_fused   mask of the non-temporal output stores (default 7: bit 0 split32 convolutions,
  *                                           bit 1 fused separable conv, bit 2 pointwise split32 GEMM)
  *   EMD_SEP_XCD        csrc/sep_fused.hip   0 = launch-order tiles instead of one contiguous run of tiles per XCD
+ *   EMD_SEP_WIDE       csrc/sep_fused.hip   256-column single-output form: 0 never, 1 (default) Cin <= 256, 2 whenever it fits
+ *   EMD_SEP_WRES       csrc/sep_fused.hip   0 = per-chunk pointwise weight loads in the 64-column instances (default: resident in LDS)
+ *   EMD_DW_XCD         csrc/dw_misc.hip     0 = launch-order tiles in the depthwise kernels
  */
 #ifndef EMDENOISE_DEV_H
 #define EMDENOISE_DEV_H
