@@ -187,6 +187,12 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                                          // a tile's epilogue overlaps the loads of the next tile's first chunk
     const int fr = lane & 31, fh = lane >> 5;
 
+    constexpr bool EARLY_RES = BN == 64 && !DUAL;
+    constexpr int E_C4 = BN / 4, E_RPP = 256 / E_C4, E_NROWS = BM / E_RPP;
+    f32x4 rve[EARLY_RES ? E_NROWS : 1];
+#pragma unroll
+    for (int k = 0; k < (EARLY_RES ? E_NROWS : 1); ++k) rve[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     if (p.stamps) tprev = __builtin_amdgcn_s_memtime();
 #define SEP_STAMP(i) if (p.stamps) { const long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tprev; tprev = t_; }
@@ -261,6 +267,20 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
             } else {
                 wh[q] = *reinterpret_cast<const u32x4*>(whi + (long)q * 64 * p.Cpad + c0n);
                 if (NPL == 2) wl[q] = *reinterpret_cast<const u32x4*>(wlo + (long)q * 64 * p.Cpad + c0n);
+            }
+        }
+        // 64-column instances: a thread's 8 residual vectors (32 registers) of the CURRENT tile are requested here, at the start of the
+        // tile's last chunk: they land under its depthwise and MFMA phases (the 128-column instances have no room: they ask four
+        // rows at a time in the epilogue, two exposed round trips per tile)
+        if (EARLY_RES && p.res && it >= 0 && (it + 1) % nchunks == 0) {
+            const int ecol = (tid % E_C4) * 4, eer = tid / E_C4;
+            if (ecol < p.N) {
+                const float* __restrict__ rt = p.res + (img + (long)y0 * p.W) * p.ldres + ecol;
+#pragma unroll
+                for (int k = 0; k < E_NROWS; ++k) {
+                    const int r = eer + k * E_RPP;
+                    rve[k] = *reinterpret_cast<const f32x4*>(rt + ((r >> 4) * p.W + (r & 15) + x0) * p.ldres);
+                }
             }
         }
         SEP_STAMP(1)
@@ -415,7 +435,13 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
                 if (!odd) *reinterpret_cast<u32x4*>(g + (q & 7) * 8) = u32x4{h0, h1, r0, r1};
                 else *reinterpret_cast<u32x4*>(g + 64 + ((q - 1) & 7) * 8) = u32x4{r0, r1, l0, l1};
             };
-            if (p.res && !DUAL) {
+            if (EARLY_RES && p.res) {
+#pragma unroll
+                for (int k = 0; k < NROWS; ++k) {
+                    const int r = er + k * ROWS_PER_PASS;
+                    put(r, finish(*reinterpret_cast<const f32x4*>(&stage[r][ncol])) + rve[k]);
+                }
+            } else if (p.res && !DUAL) {
                 // residual values are requested four rows at a time, before the first of them is used (the registers of the
                 // next chunk's prefetch are live here: no room for all NROWS at once)
 #pragma unroll
