@@ -28,6 +28,7 @@ struct LayerDecl {
     std::string key;
     Kind kind;
     int cin, cout, k = 1, stride = 1, rate = 1;
+    std::string wname = "weights", bname = "biases";   // slim names; tf.layers (variant D'): kernel / bias
     std::string scope;             // conv / separable-conv / transposed-conv scope
     std::vector<std::string> bn;   // batch norms applied after it, in order
     std::string extra_bn;          // the ASPP rate branches' second batch_then_activ
@@ -42,8 +43,11 @@ struct Scope {
     }
 };
 
-// every parameterised layer of architecture() in creation order (mirror of emdenoise.denoiser.declare_layers("D"))
-std::vector<LayerDecl> declare_layers() {
+// every parameterised layer of architecture() in creation order (mirror of emdenoise.denoiser.declare_layers): twin = false graph D
+// (machine_learning/denoiser.py:248-398, slim layers), twin = true graph D' (misc_py/denoiser-multi-gpu.py:200-540 with phase=False:
+// tf.layers convs named conv2d_k / conv2d_transpose_k with kernel / bias, named ASPP convs, dense dilated 3x3 ASPP branches, a real
+// image-level branch)
+std::vector<LayerDecl> declare_layers(bool twin) {
     Scope sc;
     std::vector<LayerDecl> L;
     auto sep = [&](const std::string& key, int cin, int cout, int stride = 1, int rate = 1, bool extra = false) {
@@ -53,15 +57,18 @@ std::vector<LayerDecl> declare_layers() {
         if (extra) d.extra_bn = sc("BatchNorm");
         L.push_back(d);
     };
-    auto conv = [&](const std::string& key, int cin, int cout, int k = 1, int stride = 1) {
-        LayerDecl d{key, CONV, cin, cout, k, stride, 1};
-        d.scope = sc("Conv");
-        d.bn = {sc("BatchNorm")};
+    auto conv = [&](const std::string& key, int cin, int cout, int k = 1, int stride = 1, int rate = 1, const char* name = nullptr,
+                    bool bn = true) {
+        LayerDecl d{key, CONV, cin, cout, k, stride, rate};
+        d.scope = twin ? (name ? std::string("nn/") + name : sc("conv2d")) : sc("Conv");
+        if (twin) { d.wname = "kernel"; d.bname = "bias"; }
+        if (bn) d.bn = {sc("BatchNorm")};
         L.push_back(d);
     };
     auto deconv = [&](const std::string& key, int cin, int cout) {
         LayerDecl d{key, DECONV, cin, cout, 3, 2, 1};
-        d.scope = sc("Conv2d_transpose");
+        d.scope = twin ? sc("conv2d_transpose") : sc("Conv2d_transpose");
+        if (twin) { d.wname = "kernel"; d.bname = "bias"; }
         d.bn = {sc("BatchNorm")};
         L.push_back(d);
     };
@@ -76,14 +83,24 @@ std::vector<LayerDecl> declare_layers() {
     sep("cnn4_a", F3, F4); sep("cnn4_b", F4, F4); sep("cnn4_last", F4, F4);
     for (int i = 0; i < NEXTRA; ++i)
         for (int j = 0; j < 3; ++j) sep("middle" + std::to_string(i) + "_" + std::to_string(j), F4, F4);
-    conv("aspp_conv1x1", F4, AF);
-    sep("aspp_small", F4, AF, 1, 6, true); sep("aspp_medium", F4, AF, 1, 12, true); sep("aspp_large", F4, AF, 1, 18, true);
-    {
+    if (!twin) {
+        conv("aspp_conv1x1", F4, AF);
+        sep("aspp_small", F4, AF, 1, 6, true); sep("aspp_medium", F4, AF, 1, 12, true); sep("aspp_large", F4, AF, 1, 18, true);
         LayerDecl d{"aspp_pooling_bn", BNONLY, F4, F4};
         d.bn = {sc("BatchNorm")};   // :199-200
         L.push_back(d);
+        conv("aspp_reduce", 5 * AF, AOUT);
+    } else {   // denoiser-multi-gpu.py:291-361
+        conv("aspp_conv1x1", F4, AF, 1, 1, 1, "1x1");
+        conv("aspp_small", F4, AF, 3, 1, 6, "lowRate");
+        conv("aspp_medium", F4, AF, 3, 1, 12, "mediumRate");
+        conv("aspp_large", F4, AF, 3, 1, 18, "highRate");
+        conv("aspp_image_conv", F4, AF, 1, 1, 1, "imageLevel", false);   // conv -> resize -> BN -> relu6
+        LayerDecl d{"aspp_pooling_bn", BNONLY, AF, AF};
+        d.bn = {sc("BatchNorm")};
+        L.push_back(d);
+        conv("aspp_reduce", 5 * AF, AOUT, 1, 1, 1, "pellet");
     }
-    conv("aspp_reduce", 5 * AF, AOUT);
     sep("deconv2_a", AOUT + F1, F2); sep("deconv2_b", F2, F2);
     conv("residual2_d", AOUT + F1, F2);
     deconv("deconv2to1", F2, F2);
@@ -122,6 +139,7 @@ struct emd_graph {   // the handle behind emd_graph_t
     float *unit4 = nullptr, *zero4 = nullptr;
     std::string error;
     // the two side streams of the 1/16-resolution flow (Run::middle_two_streams) and their fork / join events; made on first use
+    bool twin = false;          // variant 1: graph D' (the training twin's inference graph)
     bool two_streams = false;   // emd_graph_set_two_streams
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
@@ -345,13 +363,39 @@ struct Run {
         const int Ho = (x.H + d.stride - 1) / d.stride, Wo = (x.W + d.stride - 1) / d.stride;
         T4 out = out_opt ? *out_opt : E(x.B, Ho, Wo, d.cout);
         if (!live()) return out;
+        const int act = d.bn.empty() ? EMD_ACT_NONE : EMD_ACT_RELU6;   // conv + bias alone (D' image-level branch), or + BN + relu6
         if (xs && d.stride == 1 && split_gemm_ok((long)x.B * Ho * Wo, d.cout, d.cin))
             call(emd_conv1x1_split32_f32(xs, ldxs, p.pw.hi, p.pw.lo, p.scale, p.shift, nullptr, nullptr, nullptr, 0, out.ptr(), out.ld,
-                                         (long)x.B * Ho * Wo, d.cin, d.cout, EMD_ACT_RELU6, st));
+                                         (long)x.B * Ho * Wo, d.cin, d.cout, act, st));
         else
             call(emd_conv1x1_f32(x.ptr(), x.ld, p.pw.hi, p.pw.lo, p.scale, p.shift, nullptr, nullptr, nullptr, 0, out.ptr(), out.ld, x.B, x.H,
-                                 x.W, d.cin, d.cout, d.stride, EMD_ACT_RELU6, EMD_PREC_BF16X3, st));
+                                 x.W, d.cin, d.cout, d.stride, act, EMD_PREC_BF16X3, st));
         return out;
+    }
+
+    // tf.layers.conv2d(kernel_size = 3, dilation_rate, 'same') + bias + BN + relu6: D' dense ASPP rate branches
+    // (misc_py/denoiser-multi-gpu.py:306-328); xs: the input already in split32 form, or NULL (converted here when the split32 GEMM pays)
+    void conv3x3(const std::string& key, const T4& x, const T4& out, const void* xs, int ldxs) {
+        const LayerParams& p = g->P[key];
+        const LayerDecl& d = p.d;
+        const long npix = (long)x.B * x.H * x.W;
+        if (d.stride == 1 && split_gemm_ok(npix, d.cout, 9 * d.cin)) {
+            void* tmp = nullptr;
+            if (!xs) {
+                ldxs = emd_split32_ld(d.cin);
+                tmp = raw((size_t)npix * ldxs * 4);
+                if (live()) call(emd_to_split32_f32(x.ptr(), x.ld, tmp, ldxs, npix, d.cin, st));
+                xs = tmp;
+            }
+            if (live())
+                call(emd_conv3x3_split32_f32(xs, ldxs, p.pw.hi, p.pw.lo, p.scale, p.shift, nullptr, nullptr, nullptr, 0, out.ptr(), out.ld, x.B,
+                                             x.H, x.W, d.cin, d.cout, 1, d.rate, EMD_ACT_RELU6, 0, st));
+            ar->release(tmp);
+            return;
+        }
+        if (live())
+            call(emd_conv3x3_f32(x.ptr(), x.ld, p.pw.hi, p.pw.lo, p.scale, p.shift, nullptr, nullptr, nullptr, 0, out.ptr(), out.ld, x.B, x.H, x.W,
+                                 d.cin, d.cout, d.stride, d.rate, EMD_ACT_RELU6, EMD_PREC_BF16X3, st));
     }
 
     // slim.conv2d_transpose(k = 3, stride 2) + bias + BN + relu6 into `out`; x fp32, or xs a split32 tensor
@@ -548,12 +592,30 @@ struct Run {
         }
         T4 s0 = cat.slice(0, AF), s1 = cat.slice(AF, AF), s2 = cat.slice(2 * AF, AF), s3 = cat.slice(3 * AF, AF), s4 = cat.slice(4 * AF, AF);
         conv1x1("aspp_conv1x1", cur, &s0, curs, ldcs);
-        sep("aspp_small", cur, &s1, nullptr);
-        sep("aspp_medium", cur, &s2, nullptr);
-        sep("aspp_large", cur, &s3, nullptr);
-        // :185-189 the pooled tensor is discarded; :199 "pooling" = an identity resize of the INPUT, then BN + relu6 (:200)
-        if (live())
-            call(emd_affine_relu6_f32(cur.ptr(), cur.ld, P["aspp_pooling_bn"].scale, P["aspp_pooling_bn"].shift, s4.ptr(), s4.ld, npix16, AF, 1, st));
+        if (!g->twin) {
+            sep("aspp_small", cur, &s1, nullptr);
+            sep("aspp_medium", cur, &s2, nullptr);
+            sep("aspp_large", cur, &s3, nullptr);
+            // :185-189 the pooled tensor is discarded; :199 "pooling" = an identity resize of the INPUT, then BN + relu6 (:200)
+            if (live())
+                call(emd_affine_relu6_f32(cur.ptr(), cur.ld, P["aspp_pooling_bn"].scale, P["aspp_pooling_bn"].shift, s4.ptr(), s4.ld, npix16, AF, 1, st));
+        } else {
+            // D' (denoiser-multi-gpu.py:306-345): dense dilated 3x3 branches, and a real image-level branch:
+            // avg-pool 2x2 -> 1x1 conv + bias -> bilinear back to [aspp, aspp] -> BN -> relu6
+            conv3x3("aspp_small", cur, s1, curs, ldcs);
+            conv3x3("aspp_medium", cur, s2, curs, ldcs);
+            conv3x3("aspp_large", cur, s3, curs, ldcs);
+            const int Hp = (S16 + 1) / 2;
+            T4 pooled = E(B, Hp, Hp, AF);
+            if (live()) call(emd_avgpool2x2_f32(cur.ptr(), cur.ld, pooled.ptr(), pooled.ld, B, S16, S16, AF, st));
+            T4 img = conv1x1("aspp_image_conv", pooled, nullptr);
+            T4 up = E(B, S16, S16, AF);
+            if (live()) {
+                call(emd_resize_bilinear_f32(img.ptr(), img.ld, up.ptr(), up.ld, B, Hp, Hp, S16, S16, AF, st));
+                call(emd_affine_relu6_f32(up.ptr(), up.ld, P["aspp_pooling_bn"].scale, P["aspp_pooling_bn"].shift, s4.ptr(), s4.ld, npix16, AF, 1, st));
+            }
+            free(pooled); free(img); free(up);
+        }
         T4 aspp = conv1x1("aspp_reduce", cat, nullptr);
         free(cur);
         free(cat);
@@ -588,8 +650,8 @@ struct Run {
         T4 deconv0 = sep("deconv0_b", d0a, nullptr, &residual0_d);
         free(deconv1to0); free(d0a); free(residual0_d);
         if (live()) {
-            const LayerParams& pf = P["deconv_final"];   // no output clip in D (:396)
-            call(emd_conv3x3_cout1_f32(deconv0.ptr(), deconv0.ld, pf.wfin, pf.scale_f, pf.shift_f, yout, B, S, S, F0, 1, 0.f, 0, st));
+            const LayerParams& pf = P["deconv_final"];   // no output clip in D (:396); D' clips to [0, 1] in-graph (denoiser-multi-gpu.py:534-538)
+            call(emd_conv3x3_cout1_f32(deconv0.ptr(), deconv0.ld, pf.wfin, pf.scale_f, pf.shift_f, yout, B, S, S, F0, g->twin ? 2 : 1, 0.f, 0, st));
         }
         free(deconv0);
     }
@@ -600,7 +662,8 @@ struct Run {
 extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const char* const* names, const float* const* data,
                                 const long* counts) {
     EMD_REQUIRE(out && names && data && counts && n_vars > 0, EMD_E_INVALID, "emd_graph_create: null argument");
-    EMD_REQUIRE(variant == 0, EMD_E_UNSUPPORTED, "emd_graph_create: variant 0 (graph D, machine_learning/denoiser.py) only");
+    EMD_REQUIRE(variant == 0 || variant == 1, EMD_E_UNSUPPORTED,
+                "emd_graph_create: variant 0 (graph D, machine_learning/denoiser.py) or 1 (graph D', misc_py/denoiser-multi-gpu.py, phase=False)");
     *out = nullptr;
     WeightMap w;
     for (int i = 0; i < n_vars; ++i) {
@@ -608,6 +671,7 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
         w[names[i]] = {data[i], counts[i]};
     }
     emd_graph* g = new emd_graph();
+    g->twin = variant == 1;
     std::string err;
     bool ok = true;
     const float u4[4] = {1.f, 0.f, 0.f, 0.f}, z4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -615,7 +679,7 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
     g->zero4 = upload(g, z4, 4);
     ok = g->unit4 && g->zero4;
     if (!ok) err = "emd_graph_create: device allocation failed";
-    for (const LayerDecl& d : declare_layers()) {
+    for (const LayerDecl& d : declare_layers(g->twin)) {
         if (!ok) break;
         LayerParams p;
         p.d = d;
@@ -650,7 +714,7 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
             }
         } else if (d.kind == CONV) {
             const float *wt, *bias;
-            ok = fetch(w, d.scope + "/weights", (long)d.k * d.k * d.cin * d.cout, &wt, &err) && fetch(w, d.scope + "/biases", d.cout, &bias, &err) &&
+            ok = fetch(w, d.scope + "/" + d.wname, (long)d.k * d.k * d.cin * d.cout, &wt, &err) && fetch(w, d.scope + "/" + d.bname, d.cout, &bias, &err) &&
                  fold(w, d, bias, &s, &t, &err);
             if (!ok) break;
             if (d.cin == 1) {   // residual0
@@ -672,7 +736,7 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
             }
         } else if (d.kind == DECONV) {
             const float *wt, *bias;   // [3][3][Cout][Cin]
-            ok = fetch(w, d.scope + "/weights", 9L * d.cin * d.cout, &wt, &err) && fetch(w, d.scope + "/biases", d.cout, &bias, &err) &&
+            ok = fetch(w, d.scope + "/" + d.wname, 9L * d.cin * d.cout, &wt, &err) && fetch(w, d.scope + "/" + d.bname, d.cout, &bias, &err) &&
                  fold(w, d, bias, &s, &t, &err);
             if (!ok) break;
             for (int ph = 0; ph < 4 && ok; ++ph) {

@@ -14,10 +14,13 @@ from . import _lib
 
 
 class NativeGraph:
-    """architecture() of machine_learning/denoiser.py:58-398 behind the C ABI."""
+    """architecture() behind the C ABI: variant "D" = machine_learning/denoiser.py:58-398, "Dprime" = the training twin
+    misc_py/denoiser-multi-gpu.py:200-540 run with phase=False (the graph a trained checkpoint of that script serves)."""
 
-    def __init__(self, weights, device):
+    def __init__(self, weights, device, variant="D"):
         import torch
+
+        code = {"D": 0, "Dprime": 1}[variant]
 
         self.lib = _lib.load()
         self.device = device
@@ -29,7 +32,7 @@ class NativeGraph:
         c_counts = (C.c_long * n)(*[a.size for a in arrays])
         handle = C.c_void_p()
         with torch.cuda.device(device):
-            _lib.check(self.lib.emd_graph_create(C.byref(handle), 0, n, c_names, c_data, c_counts), "emd_graph_create")
+            _lib.check(self.lib.emd_graph_create(C.byref(handle), code, n, c_names, c_data, c_counts), "emd_graph_create")
         self._h = handle
         self._ws = None
 
@@ -41,7 +44,7 @@ class NativeGraph:
         return int(self.lib.emd_graph_workspace_bytes(self._h, B, S))
 
     def forward(self, x):
-        """x: torch CUDA float32 [B,S,S,1] contiguous -> [B,S,S,1] (no output clip, denoiser.py:396)."""
+        """x: torch CUDA float32 [B,S,S,1] contiguous -> [B,S,S,1] (D: no output clip, denoiser.py:396; D': clipped to [0,1])."""
         import torch
 
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[3] == 1 and x.shape[1] == x.shape[2]

@@ -605,7 +605,10 @@ int emd_gen_lq_f32(const float* img, const float* scale, float* lq, float* truth
  * weights and uploads them into device memory owned by the handle.  emd_graph_run launches the whole forward pass on `stream`:
  * x, y device float32 [B,S,S,1] (S a multiple of 16; no output clip, :396), activations in the caller's `workspace` (device
  * memory, emd_graph_workspace_bytes(g, B, S) bytes).  Same kernels in the same order as emdenoise.denoiser.DenoiserEngine:
- * bit-identical results.  variant: 0 = graph D (the only one built). */
+ * bit-identical results.  variant: 0 = graph D; 1 = graph D', the inference graph of the training twin
+ * misc_py/denoiser-multi-gpu.py:200-540 (phase=False): tf.layers variable names (nn/conv2d[_k]/{kernel,bias}, nn/conv2d_transpose[_k]/...,
+ * the ASPP convs nn/{1x1,lowRate,mediumRate,highRate,imageLevel,pellet}), dense dilated 3x3 ASPP branches, a real image-level
+ * branch, output clipped to [0,1] (:534-538). */
 typedef struct emd_graph emd_graph_t;
 int emd_graph_create(emd_graph_t** graph, int variant, int n_vars, const char* const* names, const float* const* host_data,
                      const long* counts);

@@ -20,9 +20,9 @@ def test_create_reports_a_missing_or_misshapen_variable():
     names = [n for n in w if not n.endswith("/gamma")][:5]
     arrays = [np.ascontiguousarray(w[n], np.float32) for n in names]
     h = C.c_void_p()
-    rc = lib.emd_graph_create(C.byref(h), 1, len(names), (C.c_char_p * 5)(*[n.encode() for n in names]),
+    rc = lib.emd_graph_create(C.byref(h), 2, len(names), (C.c_char_p * 5)(*[n.encode() for n in names]),
                               (C.c_void_p * 5)(*[a.ctypes.data for a in arrays]), (C.c_long * 5)(*[a.size for a in arrays]))
-    assert rc == -2 and b"variant" in lib.emd_last_error()          # only graph D is built
+    assert rc == -2 and b"variant" in lib.emd_last_error()          # 0 = graph D, 1 = graph D' 
     assert lib.emd_graph_workspace_bytes(None, 1, 64) == 0
 
 
@@ -77,4 +77,25 @@ def test_native_graph_matches_the_oracle_and_reports_errors():
     del bad["nn/Conv_3/biases"]
     with pytest.raises(_lib.EmdError, match="missing variable nn/Conv_3/biases"):
         NativeGraph(bad, dev)
+    nat.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S", [(2, 64), (8, 512)])   # 8 x 512^2: the dense ASPP branches take the split32 implicit GEMM
+def test_native_graph_dprime_equals_the_python_engine(B, S):
+    """variant 1: graph D' (misc_py/denoiser-multi-gpu.py:200-540, phase=False) -- tf.layers variable names, dense dilated 3x3 ASPP
+    branches, the image-level branch, the in-graph clip -- bit for bit against DenoiserEngine(variant="Dprime")."""
+    import emdenoise
+    from emdenoise.graph_exec import NativeGraph
+
+    dev = torch.device("cuda", 0)
+    w = emdenoise.synthetic_weights(variant="Dprime")
+    eng = emdenoise.DenoiserEngine(w, dev, "bf16x3", variant="Dprime")
+    nat = NativeGraph(w, dev, variant="Dprime")
+    x = torch.from_numpy(synthetic_lq(B, S, S, seed=90 + S)).to(dev)
+    want = eng.forward(x)
+    got = nat.forward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0
     nat.close()
