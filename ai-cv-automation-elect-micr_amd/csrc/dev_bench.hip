@@ -7,10 +7,13 @@ using namespace emd;
 
 namespace {
 
-// Plain stream copy, one float4 per lane per iteration, grid-stride: the practical HBM roof of a read + write kernel.
+// Plain stream copy, ONE float4 per lane and no loop: the workgroups in flight cover one contiguous window that moves through the
+// buffer, which is what the DRAM pages like -- the practical HBM roof of a read + write kernel (6.1-6.2 TB/s at 1 GiB each way).
+// A grid-stride loop over the same bytes (every lane touching addresses a whole grid apart, the form this benchmark had first)
+// reaches 3.5-5.0 TB/s: tools/membench.hip, tools/membench2.hip.
 __global__ void __launch_bounds__(256) stream_copy_kernel(const f32x4* __restrict__ a, f32x4* __restrict__ b, long n4) {
-    const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) b[i] = a[i];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) b[i] = a[i];
 }
 
 // Back-to-back v_mfma_f32_32x32x16_bf16 on register operands, 4 independent accumulators per wave, one wave per SIMD when
@@ -43,8 +46,8 @@ extern "C" int emd_debug_stream_copy_f32(const float* src, float* dst, long n, e
     EMD_REQUIRE(src && dst && n > 0 && n % 4 == 0, EMD_E_INVALID, "emd_debug_stream_copy_f32: n must be a positive multiple of 4");
     EMD_REQUIRE(emd::aligned16(src) && emd::aligned16(dst), EMD_E_ALIGN, "emd_debug_stream_copy_f32: 16-byte alignment");
     const long n4 = n / 4;
-    long blocks = (n4 + 256 * 8 - 1) / (256 * 8);   // 8 float4 per lane
-    if (blocks > 65536) blocks = 65536;
+    const long blocks = (n4 + 255) / 256;
+    EMD_REQUIRE(blocks <= 0x7fffffffL, EMD_E_UNSUPPORTED, "emd_debug_stream_copy_f32: more than 2^31 workgroups");
     hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), n4);
     return emd::check_launch("stream_copy_kernel");

@@ -21,7 +21,13 @@ __device__ __forceinline__ int xcd_run(int bid, int nb) {
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
-inline int dw_xcd() { static const int v = [] { const char* e = getenv("EMD_DW_XCD"); return e ? atoi(e) : 1; }(); return v; }
+// Rule: maps up to 128 x 128 (there the shared halo lines are a large part of a tile's bytes: 32 x 32 x 728 runs 40.5 -> 31.5 us); on the
+// 256^2 / 512^2 maps eight separate sweeps cost DRAM locality more than the halo hits save (565 -> 581 us at 512^2 x 64, stride 2).
+// EMD_DW_XCD: 0 = never, 2 = always.
+inline int dw_xcd(int H, int W) {
+    static const int v = [] { const char* e = getenv("EMD_DW_XCD"); return e ? atoi(e) : 1; }();
+    return v == 2 || (v == 1 && (long)H * W <= 128L * 128);
+}
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
@@ -687,18 +693,18 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
         if (TH == 32)
-            hipLaunchKernelGGL((dw3x3_s1_roll<32, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd());
+            hipLaunchKernelGGL((dw3x3_s1_roll<32, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
         else if (TH == 16)
-            hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd());
+            hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
         else
-            hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd());
+            hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
         return emd::check_launch("dw3x3_s1_roll");
     }
     const long nthreads = (long)B * ((Ho + 3) / 4) * ((Wo + 3) / 4) * ((C4t + 15) / 16) * 256;
     int rc = grid_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL((dw3x3_generic<SPLIT, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, Ho, Wo, stride, rate, pt,
-                       pl, nthreads, C4t, pre_s, pre_t, dw_xcd());
+                       pl, nthreads, C4t, pre_s, pre_t, dw_xcd(H, W));
     return emd::check_launch("dw3x3_generic");
 }
 
