@@ -92,3 +92,31 @@ def test_host_param_packing():
     assert blk[36] == 1.0 and blk[37] == 0.5
     w = np.arange(9, dtype=np.float32).reshape(1, 3, 3)
     assert not emdenoise.KernelParams(w, np.zeros_like(w), np.ones(1, np.float32)).symmetric
+
+
+def test_pack_job_struct_layout_matches_the_header():
+    """emd_pack_job_fill is host-only: the ctypes mirror of emd_pack_job_t (emdenoise._lib.PackJob) must land every field where the
+    C struct has it (a mismatch would put garbage pointers into the job table of emd_pack_weights_batch_dev)."""
+    import ctypes as C
+
+    from emdenoise import _lib
+
+    lib = _lib.load()
+    job = _lib.PackJob()
+    sel = (C.c_int * 2)(1, 0)
+    rc = lib.emd_pack_job_fill(C.byref(job), C.c_void_p(0x1000), 3, 2, sel, 100, 72, 1, C.c_void_p(0x2000), C.c_void_p(0x3000))
+    assert rc == 0
+    assert (job.w, job.hi, job.lo) == (0x1000, 0x2000, 0x3000)
+    assert job.tap_sel == (1 | (0 << 4)) and (job.ntaps, job.cin, job.cout, job.cout_major) == (2, 100, 72, 1)
+    assert job.cpad == 128 and job.total == 128 * 2 * 128 and job.n_blocks == (job.total + 255) // 256 and job.first_block == 0
+    assert C.sizeof(_lib.PackJob) == 80
+    # a tap subset needs tap_sel; out-of-range selections are refused
+    assert lib.emd_pack_job_fill(C.byref(job), C.c_void_p(0x1000), 3, 2, None, 100, 72, 1, C.c_void_p(0x2000), C.c_void_p(0x3000)) != 0
+    bad = (C.c_int * 2)(3, 0)
+    assert lib.emd_pack_job_fill(C.byref(job), C.c_void_p(0x1000), 3, 2, bad, 100, 72, 1, C.c_void_p(0x2000), C.c_void_p(0x3000)) != 0
+
+
+def test_batched_groups_rule():
+    from emdenoise.trainer import DenoiserTrainer as T
+
+    assert [T.batched_groups(b) for b in (1, 2, 4, 6, 8, 12, 16)] == [1, 1, 2, 2, 4, 4, 4]
