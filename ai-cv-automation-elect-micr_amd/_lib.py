@@ -249,6 +249,7 @@ SIGNATURES = {
                                       _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]),
     "emd_sep3x3_dual_supported": (C.c_int, [C.c_int] * 5),
+    "emd_sep3x3_dual_preferred": (C.c_int, [C.c_int] * 5),
     # x ldx dw whi wlo scale1 shift1 y ldy w2hi w2lo scale_b shift_b y2 ldy2 B H W Cin Cout Cout2 act stream
     "emd_sep3x3_dual_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int,
                                       C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 7 + [C.c_void_p]),
@@ -274,6 +275,7 @@ SIGNATURES = {
 
 # development hooks (include/emdenoise_dev.h): not part of the drop-in boundary, bound for tools/ and bench.py's A/B legs
 DEV_SIGNATURES = {
+    "emd_debug_knob": (C.c_int, [C.c_char_p, C.c_long]),
     "emd_debug_split_variant": (None, [C.c_int]),
     "emd_debug_split_stamps": (None, [C.c_void_p]),
     "emd_debug_sep_stamps": (None, [C.c_void_p]),
@@ -310,7 +312,19 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # dev convenience for the A/B tools under tools/: EMD_KNOBS="sep_pipe=0,sep_tpw=4" is applied through the dev hook
+    # emd_debug_knob (include/emdenoise_dev.h) -- read HERE, by the Python host; the library itself never reads the environment
+    for kv in filter(None, os.environ.get("EMD_KNOBS", "").split(",")):
+        k, _, v = kv.partition("=")
+        if lib.emd_debug_knob(k.strip().encode(), int(v)) != 0:
+            raise EmdError(f"EMD_KNOBS: unknown knob {k!r}")
     return lib
+
+
+def knob(name: str, value: int):
+    """Development knob of the library (include/emdenoise_dev.h); raises on an unknown name."""
+    if load().emd_debug_knob(name.encode(), int(value)) != 0:
+        raise EmdError(f"unknown knob {name!r}")
 
 
 def check(rc: int, what: str = ""):

@@ -16,16 +16,16 @@ namespace {
 
 // Workgroup ids are dealt to the 8 XCDs round-robin (id mod 8).  xcd_run gives XCD k the k-th contiguous eighth of the tile
 // list instead, so the tiles that share halo rows / columns (neighbours in the list) run on ONE XCD at about the same time and the
-// shared input lines are fetched into that L2 once (tools/dw_traffic.sh: fetched bytes per shape).  EMD_DW_XCD=0 turns it off.
+// shared input lines are fetched into that L2 once (tools/dw_traffic.sh: fetched bytes per shape).  the dev knob dw_xcd = 0 turns it off.
 __device__ __forceinline__ int xcd_run(int bid, int nb) {
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 // Rule: maps up to 128 x 128 (there the shared halo lines are a large part of a tile's bytes: 32 x 32 x 728 runs 40.5 -> 31.5 us); on the
 // 256^2 / 512^2 maps eight separate sweeps cost DRAM locality more than the halo hits save (565 -> 581 us at 512^2 x 64, stride 2).
-// EMD_DW_XCD: 0 = never, 2 = always.
+// Dev knob dw_xcd (emd_debug_knob): 0 = never, 2 = always.
 inline int dw_xcd(int H, int W) {
-    static const int v = [] { const char* e = getenv("EMD_DW_XCD"); return e ? atoi(e) : 1; }();
+    const int v = emd::g_knobs.dw_xcd;
     return v == 2 || (v == 1 && (long)H * W <= 128L * 128);
 }
 
@@ -685,7 +685,7 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
     if (stride == 1 && rate == 1) {
         // strip height: 16 rows (input re-read factor 18/16) measured 1-4 % faster than 8 on the 256^2/512^2 layers;
         // short images keep 8 so that small maps still spread over the chip
-        static const int th_force = [] { const char* e = getenv("EMD_DW_TH"); return e ? atoi(e) : 0; }();
+        const int th_force = emd::g_knobs.dw_th;
         const int TH = th_force == 8 || th_force == 16 || th_force == 32 ? th_force : (H >= 64 ? 16 : 8);
         const int nstrip = (H + TH - 1) / TH;
         const long nblocks = (long)B * nstrip * ((W + 15) / 16) * ((C4t + 15) / 16);

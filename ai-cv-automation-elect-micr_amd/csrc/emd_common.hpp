@@ -45,6 +45,25 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 constexpr int kWave = 64;  // CDNA4 wavefront
 
+// Development knobs: the ONLY process-global mutable state of the library, set through emd_debug_knob (include/emdenoise_dev.h),
+// never read from the environment.  Defaults = the measured-best path; they change speed, not results (DESIGN.md lists the exceptions).
+struct Knobs {
+    int sep_pipe = 1;        // 1: the LDS-DMA pipelined fused separable conv (sep_pipe.hip) where it covers the shape; 0: sep_fused.hip
+    int sep_mode = -1;       // sep_pipe schedule of the one-output instances: -1 = rule, 0 / 1 = the patch two / one steps ahead
+    int sep_nw = 0;          // sep_pipe waves per workgroup: 0 = rule, 8 (8 x 32 tiles, one workgroup per CU) or 4 (8 x 16 tiles, two per CU; <= 64 output channels)
+    int sep_ablate = 0;      // sep_pipe phase ablation bits for timing experiments (results are wrong when non-zero)
+    int sep_tpw = 0;         // tiles per workgroup of the fused separable convs (0 = rule)
+    int sep_xcd = 1;         // one contiguous run of tiles per XCD
+    int sep_wide = 1;        // sep_fused 256-column single-output form: 0 never, 1 Cin <= 256, 2 whenever it fits
+    int sep_wres = 1;        // sep_fused 64-column instances keep the pointwise weights resident in LDS
+    int nt_mask = 7;         // non-temporal output stores: bit 0 split32 convolutions, bit 1 fused separable conv, bit 2 pointwise GEMM
+    int dw_xcd = 1;          // XCD-contiguous tile order in the depthwise kernels
+    int dw_th = 0;           // strip height of the rolling depthwise kernel (0 = rule)
+    int split_variant = -1;  // pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
+    long long* sep_stamps = nullptr;   // device buffer for the in-kernel phase stamps of the fused separable convs
+};
+extern Knobs g_knobs;
+
 // Per-channel reductions over [npix, C] (batch statistics, batch-norm backward sums) run as "slabs" of rows, one
 // workgroup per (64 channels, slab), combined by a second small kernel.  At most 512 slabs, at least 64 rows each:
 // small maps (a 32x32 tower) still spread over tens of workgroups, large ones give every thread a few hundred rows.

@@ -51,9 +51,9 @@ struct SplitGemmParams {
 };
 
 // Non-temporal output stores are the default (graph D: 26.0 -> 25.5 ms, PMC fetch of the transposed convs 5.97 -> 3.83 GB per launch:
-// the outputs no longer push the re-read input rows out of L2).  EMD_NT (dev) masks them: bit 0 = the implicit-GEMM convolutions here,
+// the outputs no longer push the re-read input rows out of L2).  The dev knob nt_mask masks them: bit 0 = the implicit-GEMM convolutions here,
 // bit 2 = the pointwise GEMM (bit 1: sep_fused.hip).
-inline int split_nt(int bit) { static const int v = [] { const char* e = getenv("EMD_NT"); return e ? atoi(e) : 7; }(); return (v >> bit) & 1; }
+inline int split_nt(int bit) { return (emd::g_knobs.nt_mask >> bit) & 1; }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -1336,12 +1336,11 @@ static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, co
     p.ldc = ldy; p.ldres = ldres; p.act = act; p.stats_part = stats_part; p.out_split = out_split ? 1 : 0;
     p.nt = split_nt(2);
     // kernel variant: 3 = 256-row tiles, 3 stages, pipelined K loop, 32x32x16 MFMAs; 5 = the same on 16x16x32 MFMAs;
-    // dev knobs for A/B runs: EMD_SPLIT_VARIANT / emd_debug_split_variant = 0 (256 rows, 2 stages), 1 (256, 3, plain loop),
+    // dev knobs for A/B runs: emd_debug_knob("split_variant") / emd_debug_split_variant = 0 (256 rows, 2 stages), 1 (256, 3, plain loop),
     // 2 (128 rows, 2 stages, two workgroups per CU), 4 (persistent, epilogue stores inside the next tile's K loop),
     // 6 (variant 3 with the W tile through registers instead of LDS-DMA: WREG), 7 (variant 3 with the epilogue straight from
     // the registers: DIRECT)
-    static const int variant = [] { const char* e = getenv("EMD_SPLIT_VARIANT"); return e ? atoi(e) : -1; }();
-    int v = variant;
+    int v = emd::g_knobs.split_variant;
     if (g_variant_override >= 0) v = g_variant_override;
     if (stats_part && v != 6) v = 3;
     if (out_split && v != 6 && v != 7) v = 3;   // the statistics epilogue and the split32 output live in the default kernel (and its WREG form)

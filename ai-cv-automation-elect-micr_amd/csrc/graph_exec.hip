@@ -432,7 +432,7 @@ struct Run {
     // the decoder pair that reads the same tensor (denoiser.py:356-359, :368-371, :380-383)
     void sep_and_projection(const std::string& sk, const std::string& ck, const T4& x, T4* sep_out, T4* proj_out) {
         const LayerParams &ps = g->P[sk], &pc = g->P[ck];
-        if (!ps.scale2 && emd_sep3x3_dual_supported(x.H, x.W, x.C, ps.d.cout, pc.d.cout) && ps.d.cout <= 64 && pc.d.cout <= 64) {
+        if (!ps.scale2 && emd_sep3x3_dual_preferred(x.H, x.W, x.C, ps.d.cout, pc.d.cout)) {
             *sep_out = E(x.B, x.H, x.W, ps.d.cout);
             *proj_out = E(x.B, x.H, x.W, pc.d.cout);
             if (live())

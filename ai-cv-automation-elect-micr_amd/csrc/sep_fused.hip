@@ -21,7 +21,7 @@
 // tiles side by side with the staging pipeline running on across them; DESIGN.md 3.3 has the measurements.
 #include <cstdlib>
 
-#include "mfma_common.hpp"
+#include "sep_params.hpp"
 
 using namespace emd;
 
@@ -31,44 +31,10 @@ namespace {
 // the load where it is issued instead of a whole depthwise + MFMA phase later)
 __device__ __attribute__((aligned(16))) float g_zero_px[4096];
 
-struct SepParams {
-    const float* x;       // [B,H,W,Cin] pixel stride ldx
-    const float* dw;      // [9][Cin]
-    const uint16_t* Whi;  // [Npad][Cpad]
-    const uint16_t* Wlo;
-    float* y;             // [B,H,W,N] pixel stride ldy
-    const float* res;
-    const float* scale1;
-    const float* shift1;
-    const float* scale2;
-    const float* shift2;
-    int H, W, Cin, Cpad, N;
-    int ldx, ldy, ldres, act;
-    int reflect;          // 1: the patch border is tf.pad(REFLECT) of the image (graph G), 0: zero (TF SAME)
-    int tpw;              // output tiles per workgroup, side by side along W
-    // generated input (layers fed by a 1-channel image): x is a one-value-per-pixel tensor d (pitch ldx) and the Cin-channel
-    // input the depthwise stage sees is act(d * gen_a[c] + gen_t[c]) -- never written to memory
-    const float* gen_a;
-    const float* gen_t;
-    int gen_act;
-    // second output of the DUAL instances (emd_sep3x3_dual_f32): y2 = relu6(x * W2 * scale_b + shift_b), a 1x1 conv of the block's
-    // INPUT -- the decoder's residual projection (denoiser.py:359/:371/:383), which reads the same tensor as the separable conv
-    const uint16_t* W2hi;
-    const uint16_t* W2lo;
-    float* y2;
-    const float* scale_b;
-    const float* shift_b;
-    int N2, ldy2;
-    int out_split;        // y is a split32 tensor (pitch ldy 4-byte units; N % 32 == 0): the consumer is a split32 GEMM
-    long long* stamps;    // dev hook: per-workgroup phase cycle sums (NULL otherwise)
-    int nt;               // outputs leave with non-temporal stores (they are not re-read by this launch: keep L2 for the patch halos)
-    int xcd;              // workgroup -> tile map that gives each XCD (workgroup id mod 8) one contiguous run of tiles
-};
-
-// Knobs of the 512^2 / 256^2 layers' cache behaviour (dev): EMD_NT bit 1 = non-temporal output stores here (default on), EMD_SEP_XCD = 0
+// Knobs of the 512^2 / 256^2 layers' cache behaviour (dev, emd_debug_knob): nt_mask bit 1 = non-temporal output stores here (default on), sep_xcd = 0
 // turns the XCD-contiguous tile order off.
-inline int sep_nt() { static const int v = [] { const char* e = getenv("EMD_NT"); return e ? atoi(e) : 7; }(); return (v >> 1) & 1; }
-inline int sep_xcd() { static const int v = [] { const char* e = getenv("EMD_SEP_XCD"); return e ? atoi(e) : 1; }(); return v; }
+inline int sep_nt() { return (g_knobs.nt_mask >> 1) & 1; }
+inline int sep_xcd() { return g_knobs.sep_xcd; }
 
 // BN = columns of the workgroup's GEMM tile: 64 / 128 (one output), or with DUAL the two outputs side by side: 128 = 64 | 64 on an
 // 8 x 16 pixel tile, 256 = 128 | 128 on a 4 x 16 pixel tile (TH = 4: the accumulators of both outputs fit the same registers).
@@ -482,11 +448,10 @@ __global__ __launch_bounds__(256, 2) void sep_fused_kernel(const SepParams p) {
 #undef SEP_STAMP
 }
 
-long long* g_sep_stamps = nullptr;   // dev hook, see emd_debug_sep_stamps
 
 // several tiles per workgroup where that still leaves >= 8 workgroups per CU
 int tiles_per_workgroup(int tiles_w, long wgs1) {
-    static const int force = [] { const char* e = getenv("EMD_SEP_TPW"); return e ? atoi(e) : 0; }();
+    const int force = g_knobs.sep_tpw;
     int tpw = 1;
     for (int t = 8; t >= 2; t >>= 1)
         if (tiles_w % t == 0 && wgs1 / t >= 2048) { tpw = t; break; }
@@ -499,7 +464,7 @@ int launch_wres(const SepParams& p, int B, hipStream_t st) {
     SepParams q = p;
     const int tiles_w = p.W / 16;
     q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / 8) * B);
-    q.stamps = g_sep_stamps;
+    q.stamps = g_knobs.sep_stamps;
     const dim3 grid(tiles_w / q.tpw, p.H / 8, B);
     q.nt = sep_nt();
     q.xcd = sep_xcd() && ((long)grid.x * grid.y * grid.z) % 8 == 0;
@@ -511,13 +476,13 @@ int launch_wres(const SepParams& p, int B, hipStream_t st) {
 template <int BN>
 int launch(const SepParams& p, int B, int passes, hipStream_t st) {
     if constexpr (BN == 64) {
-        static const int wres = [] { const char* e = getenv("EMD_SEP_WRES"); return e ? atoi(e) : 1; }();   // dev knob: 0 = per-chunk W loads
+        const int wres = g_knobs.sep_wres;   // dev knob: 0 = per-chunk W loads
         if (wres && p.Cin <= 64 && passes == 3) return launch_wres(p, B, st);
     }
     SepParams q = p;
     const int tiles_w = p.W / 16;
     q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / 8) * B);
-    q.stamps = g_sep_stamps;
+    q.stamps = g_knobs.sep_stamps;
     const dim3 grid(tiles_w / q.tpw, p.H / 8, B);
     q.nt = sep_nt();
     q.xcd = sep_xcd() && ((long)grid.x * grid.y * grid.z) % 8 == 0;
@@ -540,7 +505,7 @@ int launch_dual(const SepParams& p, int B, hipStream_t st) {
     const bool wide = p.N > 64 || p.N2 > 64;
     const int th = wide ? 4 : 8;
     q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / th) * B);
-    q.stamps = g_sep_stamps;
+    q.stamps = g_knobs.sep_stamps;
     const dim3 grid(tiles_w / q.tpw, p.H / th, B);
     q.nt = sep_nt();
     q.xcd = sep_xcd() && ((long)grid.x * grid.y * grid.z) % 8 == 0;
@@ -555,8 +520,8 @@ int launch_dual(const SepParams& p, int B, hipStream_t st) {
 
 // 128 < Cout <= 256: one N tile of 256 columns on 4 x 16 pixel tiles (sep_fused_kernel<256, PASSES, false, 4>).  Against depthwise ->
 // HBM -> pointwise at [32,128,128,.]: 128 -> 256 256 vs 335 us, 256 -> 256 (+ residual) 537 vs 609 us, 384 -> 256 773 vs 734 us: the
-// rule takes it up to Cin = 256.  EMD_SEP_WIDE (dev): 0 = never, 2 = whenever it fits.
-inline int sep_wide() { static const int v = [] { const char* e = getenv("EMD_SEP_WIDE"); return e ? atoi(e) : 1; }(); return v; }
+// rule takes it up to Cin = 256.  dev knob sep_wide: 0 = never, 2 = whenever it fits.
+inline int sep_wide() { return g_knobs.sep_wide; }
 
 extern "C" int emd_sep3x3_fused_supported(int H, int W, int Cin, int Cout, int stride, int rate) {
     const bool wide = Cout > 128 && Cout <= 256 && (sep_wide() == 2 || (sep_wide() == 1 && Cin <= 256));
@@ -598,12 +563,13 @@ static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint1
     p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act; p.reflect = reflect;
     p.gen_a = gen_a; p.gen_t = gen_t; p.gen_act = gen_act; p.out_split = out_split ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (emd::sep_pipe_covers(p, precision)) return emd::sep_pipe_launch(p, B, st);   // W % 32 == 0: the LDS-DMA pipelined kernel
     if (Cout > 128) {   // the wide single-output form (dev): 4 x 16 pixel tiles, split-bf16 only, no generated input
         EMD_REQUIRE(!gen_a, EMD_E_UNSUPPORTED, "emd_sep3x3_fused_gen_f32: Cout > 128 has no generated-input form");
         SepParams q = p;
         const int tiles_w = p.W / 16;
         q.tpw = tiles_per_workgroup(tiles_w, (long)tiles_w * (p.H / 4) * B);
-        q.stamps = g_sep_stamps;
+        q.stamps = g_knobs.sep_stamps;
         const dim3 grid(tiles_w / q.tpw, p.H / 4, B);
         q.nt = sep_nt();
         q.xcd = sep_xcd() && ((long)grid.x * grid.y * grid.z) % 8 == 0;
@@ -660,7 +626,7 @@ extern "C" int emd_sep3x3_fused_gen_f32(const float* d, int ldd, const float* ge
 }
 
 // dev hook (not in the header): per-workgroup phase cycle sums for tools/sep_bench.py
-extern "C" void emd_debug_sep_stamps(void* buf) { g_sep_stamps = static_cast<long long*>(buf); }
+extern "C" void emd_debug_sep_stamps(void* buf) { g_knobs.sep_stamps = static_cast<long long*>(buf); }
 
 // The decoder pair "separable conv + 1x1 residual projection of the same input" in ONE launch (machine_learning/denoiser.py:356-359,
 // :368-371, :380-383: deconv*_a = strided_conv_block(concat) and residual*_d = conv_block_not_sep(concat, kernel_size=1)):
@@ -672,6 +638,15 @@ extern "C" int emd_sep3x3_dual_supported(int H, int W, int Cin, int Cout, int Co
     const bool wide = Cout > 64 || Cout2 > 64;
     return H % (wide ? 4 : 8) == 0 && W % 16 == 0 && Cin % 32 == 0 && Cin >= 32 && Cin <= 4096 && Cout % 4 == 0 && Cout2 % 4 == 0 &&
            Cout >= 4 && Cout2 >= 4 && Cout <= 128 && Cout2 <= 128;
+}
+
+// 1 when the one-launch form is the faster route for the shape (a pure function of the shape; graph D's decoder pairs): always for two
+// outputs of up to 64 channels; for wider ones only where the LDS-DMA pipelined kernel takes the launch (W % 32 == 0, H % 8 == 0:
+// 384 -> 128 | 128 at 256^2 2.07 ms against 1.32 + 0.99 for the pair; the 4 x 16-tile form of sep_fused.hip is slower than the pair).
+extern "C" int emd_sep3x3_dual_preferred(int H, int W, int Cin, int Cout, int Cout2) {
+    if (!emd_sep3x3_dual_supported(H, W, Cin, Cout, Cout2)) return 0;
+    if (Cout <= 64 && Cout2 <= 64) return 1;
+    return H % 8 == 0 && W % 32 == 0;
 }
 
 extern "C" int emd_sep3x3_dual_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
@@ -700,5 +675,6 @@ extern "C" int emd_sep3x3_dual_f32(const float* x, int ldx, const float* dw, con
     p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
     p.ldx = ldx; p.ldy = ldy; p.ldres = 0; p.act = act; p.reflect = 0;
     p.W2hi = w2hi; p.W2lo = w2lo; p.y2 = y2; p.scale_b = scale_b; p.shift_b = shift_b; p.N2 = Cout2; p.ldy2 = ldy2;
+    if (emd::sep_pipe_covers(p, 3)) return emd::sep_pipe_launch(p, B, static_cast<hipStream_t>(stream));
     return launch_dual(p, B, static_cast<hipStream_t>(stream));
 }

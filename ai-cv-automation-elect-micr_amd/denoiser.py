@@ -360,10 +360,9 @@ class DenoiserEngine:
         shape (the input is then read from HBM once), two otherwise."""
         Ls, ps, Lc, pc = self.layers[sep_key], self.P[sep_key], self.layers[conv_key], self.P[conv_key]
         if (self.fuse_sep and self.precision == ops.PREC_BF16X3 and os.environ.get("EMD_D_DUAL", "1") != "0" and "scale2" not in ps
-                and Ls.stride == 1 and Ls.rate == 1 and Lc.stride == 1 and ops.sep_dual_supported(x, Ls.cout, Lc.cout)
-                # measured (profiles/r02_d_sequence.txt): the 64 | 64 form (deconv0_a + residual0_d at 512^2) takes 2.25 ms against
-                # 1.19 + 1.63 for the pair; the 128 | 128 form on 4-row tiles (deconv1_a + residual1_d) 2.67 against 0.98 + 1.29
-                and (max(Ls.cout, Lc.cout) <= 64 or os.environ.get("EMD_D_DUAL_WIDE", "0") == "1")):
+                # the one-launch form where it is the faster route: 64 | 64 columns (deconv0_a + residual0_d at 512^2: 2.14 ms against
+                # 1.43 + 1.63 for the pair) and, on the LDS-DMA pipelined kernel, 128 | 128 (deconv1_a + residual1_d: 2.07 against 1.21 + 0.99)
+                and Ls.stride == 1 and Ls.rate == 1 and Lc.stride == 1 and ops.sep_dual_preferred(x, Ls.cout, Lc.cout)):
             out = ops.Act.empty(x.B, x.H, x.W, Ls.cout, self.device)
             out2 = ops.Act.empty(x.B, x.H, x.W, Lc.cout, self.device)
             return ops.sep_dual(x, ps["dw"], ps["pw"], pc["pw"], ps["scale"], ps["shift"], out, pc["scale"], pc["shift"], out2)

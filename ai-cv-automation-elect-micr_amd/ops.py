@@ -176,6 +176,11 @@ def sep_dual_supported(x: Act, cout: int, cout2: int) -> bool:
     return bool(_lib.load().emd_sep3x3_dual_supported(x.H, x.W, x.C, cout, cout2))
 
 
+def sep_dual_preferred(x: Act, cout: int, cout2: int) -> bool:
+    """True where the one-launch form is also the faster route (emd_sep3x3_dual_preferred)."""
+    return bool(_lib.load().emd_sep3x3_dual_preferred(x.H, x.W, x.C, cout, cout2))
+
+
 def sep_dual(x: Act, dw_dev, w: PackedWeights, w2: PackedWeights, scale1, shift1, out: Act, scale_b, shift_b, out2: Act, act=True,
              stream=None):
     """One launch for a decoder pair (emd_sep3x3_dual_f32): out = act(pw(dw3x3(x)) * scale1 + shift1) and

@@ -451,8 +451,10 @@ int emd_instnorm_tanh_f32(const float* x, const float* mean, const float* var, f
  *   y2 = relu6((x . W2) * scale_b + shift_b)                    W2 packed as for emd_conv1x1_f32; bias and BN folded into scale_b / shift_b
  * The 384- / 128-channel input -- the largest tensors of the decoder -- is read from HBM once instead of twice.
  * Split-bf16 precision.  Supported (emd_sep3x3_dual_supported): W%16==0, Cin%32==0, both Cout%4==0 and <= 128,
- * H%8==0 (H%4==0 when either output has more than 64 channels). */
+ * H%8==0 (H%4==0 when either output has more than 64 channels).  emd_sep3x3_dual_preferred: 1 where the one-launch form is also the
+ * faster route (always up to 64 | 64 channels; wider only for H%8==0, W%32==0) -- what a graph executor should ask. */
 int emd_sep3x3_dual_supported(int H, int W, int Cin, int Cout, int Cout2);
+int emd_sep3x3_dual_preferred(int H, int W, int Cin, int Cout, int Cout2);
 int emd_sep3x3_dual_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
                         const float* scale1, const float* shift1, float* y, int ldy, const uint16_t* w2hi,
                         const uint16_t* w2lo, const float* scale_b, const float* shift_b, float* y2, int ldy2, int B, int H,

@@ -6,16 +6,21 @@
  * not call them.  Every symbol the shared library exports with an emd_ prefix is declared either in emdenoise.h or
  * here (tests/test_abi.py checks both directions).
  *
- * Environment knobs read once per process by the same translation units (same rule: speed only, default = the measured-best path):
- *   EMD_SPLIT_VARIANT  csrc/gemm_split.hip  pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
- *   EMD_SEP_TPW        csrc/sep_fused.hip   tiles per workgroup of the fused separable conv (0 = rule)
- *   EMD_DW_TH          csrc/dw_misc.hip     strip height of the rolling depthwise kernel (0 = rule)
- *   EMD_NT             gemm_split / sep_fused   mask of the non-temporal output stores (default 7: bit 0 split32 convolutions,
- *                                           bit 1 fused separable conv, bit 2 pointwise split32 GEMM)
- *   EMD_SEP_XCD        csrc/sep_fused.hip   0 = launch-order tiles instead of one contiguous run of tiles per XCD
- *   EMD_SEP_WIDE       csrc/sep_fused.hip   256-column single-output form: 0 never, 1 (default) Cin <= 256, 2 whenever it fits
- *   EMD_SEP_WRES       csrc/sep_fused.hip   0 = per-chunk pointwise weight loads in the 64-column instances (default: resident in LDS)
- *   EMD_DW_XCD         csrc/dw_misc.hip     0 = launch-order tiles in the depthwise kernels
+ * Nothing in the library reads the environment.  The kernel-selection knobs are fields of one struct (csrc/emd_common.hpp, emd::Knobs),
+ * set by name through emd_debug_knob; defaults = the measured-best path:
+ *   sep_pipe (1)        1: the LDS-DMA pipelined fused separable conv (csrc/sep_pipe.hip) where it covers the shape, 0: csrc/sep_fused.hip
+ *   sep_mode (-1)       sep_pipe schedule of the one-output instances: -1 = rule, 0 / 1 = the patch requested two / one steps ahead
+ *   sep_nw (0)          sep_pipe waves per workgroup: 0 = rule, 8 (8 x 32 pixel tiles, one workgroup per CU) or 4 (8 x 16 tiles, two per CU)
+ *   sep_ablate (0)      sep_pipe timing experiments: bit 0 no depthwise stage, 1 no MFMA stage, 2 no epilogue, 3 no patch DMA after the
+ *                       prologue, 4 no weight DMA after it, 5 no residual loads -- RESULTS ARE WRONG when non-zero
+ *   sep_tpw (0)         tiles per workgroup of the fused separable convs (0 = rule)
+ *   sep_xcd (1)         0 = launch-order tiles instead of one contiguous run of tiles per XCD
+ *   sep_wide (1)        sep_fused 256-column single-output form: 0 never, 1 Cin <= 256, 2 whenever it fits
+ *   sep_wres (1)        0 = per-chunk pointwise weight loads in sep_fused's 64-column instances (default: resident in LDS)
+ *   nt_mask (7)         non-temporal output stores: bit 0 split32 convolutions, bit 1 sep_fused, bit 2 pointwise split32 GEMM
+ *   dw_xcd (1)          depthwise kernels: 0 = launch-order tiles, 1 = XCD-contiguous up to 128 x 128 maps, 2 = always
+ *   dw_th (0)           strip height of the rolling depthwise kernel (0 = rule)
+ *   split_variant (-1)  pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
  */
 #ifndef EMDENOISE_DEV_H
 #define EMDENOISE_DEV_H
@@ -23,6 +28,8 @@
 extern "C" {
 #endif
 
+/* Set one of the knobs above by name.  Returns 0, or -1 for an unknown name. */
+int emd_debug_knob(const char* name, long value);
 /* Force the pipeline variant of emd_conv1x1_split32_f32 (csrc/gemm_split.hip); -1 restores the dispatch rule. */
 void emd_debug_split_variant(int v);
 /* Device buffer that the split32 GEMM writes s_memtime phase stamps into (NULL = off). */
