@@ -364,7 +364,9 @@ struct Run {
         T4 out = out_opt ? *out_opt : E(x.B, Ho, Wo, d.cout);
         if (!live()) return out;
         const int act = d.bn.empty() ? EMD_ACT_NONE : EMD_ACT_RELU6;   // conv + bias alone (D' image-level branch), or + BN + relu6
-        if (xs && d.stride == 1 && split_gemm_ok((long)x.B * Ho * Wo, d.cout, d.cin))
+        // the pointwise split32 GEMM (16x16x32 MFMAs) serves a layer at every batch size or at none (another K-step summation order than
+        // the register-staged kernel: image b of a batch must equal the image alone)
+        if (xs && d.stride == 1 && emd_conv1x1_split32_supported(1L << 20, d.cin, d.cout))
             call(emd_conv1x1_split32_f32(xs, ldxs, p.pw.hi, p.pw.lo, p.scale, p.shift, nullptr, nullptr, nullptr, 0, out.ptr(), out.ld,
                                          (long)x.B * Ho * Wo, d.cin, d.cout, act, st));
         else
@@ -586,7 +588,7 @@ struct Run {
         void* curs = nullptr;
         const int ldcs = emd_split32_ld(AF);
         const long npix16 = (long)B * S16 * S16;
-        if (split_gemm_ok(npix16, AF, cur.C)) {
+        if (emd_conv1x1_split32_supported(1L << 20, cur.C, AF) || (g->twin && split_gemm_ok(npix16, AF, 9 * cur.C))) {
             curs = raw((size_t)npix16 * ldcs * 4);
             if (live()) call(emd_to_split32_f32(cur.ptr(), cur.ld, curs, ldcs, npix16, cur.C, st));
         }
@@ -634,9 +636,9 @@ struct Run {
         deconv("deconv2to1", so2 ? nullptr : &deconv2, deconv2_s, B, S4, S4, c1a);
         free(deconv2);
         ar->release(deconv2_s);
-        // deconv1_a + residual1_d read concat1 (128 | 128 columns: two launches)
-        T4 residual1_d = conv1x1("residual1_d", concat1, nullptr);
-        T4 d1a = sep("deconv1_a", concat1, nullptr, nullptr);
+        // deconv1_a + residual1_d read concat1: one launch (128 | 128 columns) where emd_sep3x3_dual_preferred says so
+        T4 residual1_d, d1a;
+        sep_and_projection("deconv1_a", "residual1_d", concat1, &d1a, &residual1_d);
         const bool so1 = deconv_fused_ok((long)B * S2 * S2) && S2 % 8 == 0 && S2 % 16 == 0;
         void* deconv1_s = nullptr;
         T4 deconv1 = sep("deconv1_b", d1a, nullptr, &residual1_d, so1 ? &deconv1_s : nullptr);

@@ -399,13 +399,18 @@ class DenoiserEngine:
         return (self.precision == ops.PREC_BF16X3 and cout >= 128 and ktot >= 512
                 and (-(-npix // 256)) * (-(-cout // 128)) >= 192)
 
+    def _pw_split_ok(self, cin, cout):
+        """The pointwise split32 GEMM (16x16x32 MFMAs since round 3) serves a layer at EVERY batch size or at none: its K-step sum is
+        ordered differently from the register-staged kernel's, and image b of a batch must equal the image alone."""
+        return self.precision == ops.PREC_BF16X3 and ops.conv1x1_split32_supported(1 << 20, cin, cout)
+
     def _conv1x1(self, key, x, out=None, res=None, xs=None):
         """xs: x already converted to split32 (shared by several consumers, e.g. the ASPP branches)."""
         L, p = self.layers[key], self.P[key]
         Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
         if out is None:
             out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
-        if xs is not None and L.stride == 1 and self._split_gemm_ok(x.B * Ho * Wo, L.cout, L.cin):
+        if xs is not None and L.stride == 1 and self._pw_split_ok(L.cin, L.cout):
             return ops.conv1x1_split32(xs, p["pw"], p["scale"], p["shift"], out, act=bool(L.bn), res=res)
         ops.conv1x1(x, p["pw"], p["scale"], p["shift"], out, stride=L.stride, act=bool(L.bn), res=res,
                     precision=self.precision)
@@ -544,7 +549,8 @@ class DenoiserEngine:
         # ASPP (:152-216): the five branches write straight into their slices of the 3640-channel concat
         af = aspp_filters
         cat = E(S16, 5 * af)
-        curs = ops.to_split32(cur) if self._split_gemm_ok(B * S16 * S16, af, cur.C) else None   # shared by the GEMM branches
+        curs = (ops.to_split32(cur) if self._pw_split_ok(cur.C, af) or (self.variant != "D" and self._split_gemm_ok(B * S16 * S16, af, 9 * cur.C))
+                else None)   # shared by the GEMM branches
         self._conv1x1("aspp_conv1x1", cur, out=cat.slice(0, af), xs=curs)
         if self.variant == "D":
             self._sep("aspp_small", cur, out=cat.slice(af, af))

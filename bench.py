@@ -75,6 +75,10 @@ def parse_args(argv=None):
                     help="workload T, towers of 1: the towers on --train-streams HIP streams, or as ONE batched pass with per-image batch-norm statistics")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying captured hipGraphs (T / A / S)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-child", default=None, metavar="DIR",
+                    help="internal: run the CPU-baseline legs of --cpu-legs in THIS process (no GPU: HIP_VISIBLE_DEVICES is empty) and "
+                         "write <leg>.json / <leg>_ref.npy into DIR")
+    ap.add_argument("--cpu-legs", default="", help="internal: comma-separated workloads for --cpu-child")
     ap.add_argument("--no-riders", action="store_true", help="with --workload all: the primary workload only")
     ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3",
                     help="matrix-core mode: bf16x3 = split-bf16 parity mode (default), bf16 = fast mode (never reported as parity)")
@@ -359,8 +363,205 @@ def measured_peaks(torch, dev):
 
 
 # ------------------------------------------------------------------------------------------------
-# CPU baselines: the ORACLE timed on the host cores (reported next to the GPU number; never shipped)
+# host-side inputs of every workload (numpy only): ONE definition, used by the GPU leg and by the CPU-baseline child
 # ------------------------------------------------------------------------------------------------
+def inputs_K(a, B, first):
+    import numpy as np
+
+    import emdenoise
+
+    x_host = synthetic_lq(max(B, 1), a.size, a.size, seed=1234 + first)[:max(B, 1)]
+    x_host = (x_host / np.maximum(x_host.mean(axis=(1, 2, 3), keepdims=True), 1e-9)).astype(np.float32)  # noise-removal-kernels.py:525-527
+    rng = np.random.default_rng(7)
+    pairs = emdenoise.kernel_denoiser.sym_pairs(3)
+    wsc = [(rng.standard_normal(len(pairs)) * 0.15 + 1.0 / 9).astype(np.float32) for _ in range(2)]
+    bsc = [np.zeros(len(pairs), np.float32), (rng.standard_normal(len(pairs)) * 0.5).astype(np.float32)]
+    return x_host, emdenoise.KernelParams.from_symmetric(wsc, bsc, [1.0, 1.3], 3)
+
+
+def inputs_G(a, B, first):
+    from emdenoise import gan as GN
+
+    return GN.gen_lq(2.0 * synthetic_lq(max(B, 1), a.size, a.size, seed=77 + first)[..., 0] - 1.0)[..., None]
+
+
+def inputs_S(a, B, first):
+    import numpy as np
+
+    x_host = synthetic_lq(max(B, 1), 160, 160, seed=160 + first)
+    return (x_host / x_host.mean(axis=(1, 2, 3), keepdims=True)).astype(np.float32)
+
+
+def inputs_A(a, rank):
+    import numpy as np
+
+    from emdenoise import gan as GN
+
+    T, S = a.gan_batch, a.size
+    hq = (2.0 * synthetic_lq(T, S, S, seed=177 + rank) - 1.0).astype(np.float32)
+    lq = GN.gen_lq(hq[..., 0])[..., None]
+    rng = np.random.default_rng(5 + rank)
+    pad = (3 * S) // 4
+    offsets = [tuple((int(rng.integers(0, S + 2 * pad - n + 1)), int(rng.integers(0, S + 2 * pad - n + 1))) for n in (S // 4, S // 2, pad))
+               for _ in range(T)]
+    return hq, lq, offsets
+
+
+def inputs_T(a, rank):
+    import numpy as np
+
+    B, S = a.train_batch, a.size
+    rng = np.random.default_rng(4321 + rank)
+    hq = synthetic_lq(B, S, S, seed=99 + rank)          # smooth synthetic micrographs as the clean images
+    lq = np.clip(hq + rng.normal(0.0, 0.1, hq.shape).astype(np.float32), 0.0, 1.0)
+    return hq, lq
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines: the ORACLE timed on the host cores (reported next to the GPU number; never shipped).
+# They run in a CHILD process that is started before this process has touched the GPU and that never sees one
+# (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES empty): oneDNN's threads do not share a process with the HIP
+# runtime (two aborts on record came from exactly that combination) and do not compete with the launch thread.
+# ------------------------------------------------------------------------------------------------
+def cpu_leg(a, w):
+    """One CPU-baseline leg in the current (GPU-free) process -> (cpu_baseline dict, reference array or None, extra dict)."""
+    import numpy as np
+    import torch
+
+    import emdenoise
+
+    torch.set_num_threads(CPU_THREADS)
+    B, first, _ = local_batch(a, 0, 1)
+    S = a.size
+    if w == "K":
+        x_host, params = inputs_K(a, B, first)
+        cb, y = cpu_baseline_K(x_host[:B], params.wmaps, params.bmaps, params.s)
+        return cb, y, {}
+    if w == "D":
+        cb, y = cpu_baseline_D(synthetic_lq(max(B, 1), S, S, seed=1234 + first)[:B], emdenoise.synthetic_weights())
+        return cb, y, {}
+    if w == "X":
+        from emdenoise import xception as X
+        from oracle import xception_graph as XG
+
+        x_host = synthetic_lq(max(B, 1), S, S, seed=1234 + first)
+        n = min(B, 2)   # X normalises with the statistics of the batch it is given: parity is defined on the SAME sub-batch
+        t0 = time.perf_counter()
+        ref = XG.architecture(x_host[:n], X.synthetic_weights(), S, dtype=torch.float32).numpy()
+        el = time.perf_counter() - t0
+        return ({"value": round(n * S * S / 1e6 / el, 4), "unit": "MPx/s", "cores": CPU_THREADS, "kind": "port",
+                 "sample": f"1 pass over the first {n} images ([{n},{S},{S},1]), oracle/xception_graph.py "
+                           f"(PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}, ref, {"n": n})
+    if w == "G":
+        from emdenoise import gan as GN
+        from oracle import gan_graph as GG
+
+        x_host = inputs_G(a, B, first)
+        t0 = time.perf_counter()
+        ref = GG.generator(x_host[:1], GN.synthetic_weights(), S, dtype=torch.float32).numpy()
+        el = time.perf_counter() - t0
+        return ({"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s in-filled", "cores": CPU_THREADS, "kind": "port",
+                 "sample": f"1 image ([1,{S},{S},1]), oracle/gan_graph.py (PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}, ref, {})
+    if w == "S":
+        from emdenoise import autoencoder as AE
+        from oracle import autoencoder_graph as AG
+
+        x_host = inputs_S(a, B, first)
+        t0 = time.perf_counter()
+        ref = AG.architecture(x_host[:B], AE.synthetic_weights(16), 16, dtype=torch.float32).numpy()
+        el = time.perf_counter() - t0
+        return ({"value": round(B * 160 * 160 / 1e6 / el, 4), "unit": "MPx/s", "cores": CPU_THREADS, "kind": "port",
+                 "sample": f"the same [{B},160,160,1] batch, oracle/autoencoder_graph.py (PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"},
+                ref, {})
+    if w == "A":
+        from emdenoise import gan as GN
+        from oracle import gan_graph as GG
+
+        hq, lq, offsets = inputs_A(a, 0)
+        t0 = time.perf_counter()
+        GG.generator_tower(lq[:1], hq[:1], GN.synthetic_weights(), GN.discriminator_synthetic_weights(), offsets[0])
+        el = time.perf_counter() - t0
+        return ({"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s trained (GAN)", "cores": CPU_THREADS, "kind": "port",
+                 "sample": f"ONE generator tower ([1,{S},{S},1]: generator + 2 discriminator passes, forward + backward), "
+                           f"oracle/gan_graph.py generator_tower (PyTorch-CPU autograd, float64, {CPU_THREADS} threads), "
+                           f"{el:.1f} s; discriminator towers and optimizer steps not included"}, None, {})
+    if w == "T":
+        from emdenoise import denoiser as D
+        from oracle import denoiser_graph as G
+
+        hq, lq = inputs_T(a, 0)
+        t0 = time.perf_counter()
+        G.tower_gradients(lq[:1], hq[:1], D.synthetic_weights(variant="Dprime"), S, dtype=torch.float32)
+        el = time.perf_counter() - t0
+        return ({"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s trained", "cores": CPU_THREADS, "kind": "port",
+                 "sample": f"forward + backward of ONE tower of 1 image ([1,{S},{S},1]), oracle/denoiser_graph.py "
+                           f"tower_gradients (PyTorch-CPU autograd, float32, {CPU_THREADS} threads), {el:.1f} s; "
+                           "optimizer step not included"}, None, {})
+    raise ValueError(w)
+
+
+def cpu_child(a):
+    """--cpu-child DIR: every requested leg, each isolated from the others' failures; results on disk for the parent."""
+    import numpy as np
+
+    assert not any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")), "the CPU child must not see a GPU"
+    rc = 0
+    for w in filter(None, a.cpu_legs.split(",")):
+        print(f"[bench cpu-child] leg {w} ...", file=sys.stderr, flush=True)
+        try:
+            cb, ref, extra = cpu_leg(a, w)
+            if ref is not None:
+                np.save(os.path.join(a.cpu_child, f"{w}_ref.npy"), ref)
+            rec = {"cpu_baseline": cb, "extra": extra}
+        except Exception as e:   # reported in the line; the other legs still run
+            import traceback
+
+            traceback.print_exc()
+            rec = {"error": f"{type(e).__name__}: {e}"}
+            rc = 1
+        with open(os.path.join(a.cpu_child, f"{w}.json"), "w") as f:
+            json.dump(rec, f)
+    return rc
+
+
+def run_cpu_child(a, argv, legs):
+    """Start the CPU-baseline child (this process has not imported torch and has not touched the GPU), wait for it, collect
+    {leg: {"cpu_baseline": ..., "ref": array | None, "extra": {...}} | {"error": ...}}."""
+    import tempfile
+
+    import numpy as np
+
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="emd_cpu_") as d:
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        cmd = [sys.executable, os.path.abspath(__file__), *[x for x in argv if x not in ("--no-riders",)], "--cpu-child", d, "--cpu-legs", ",".join(legs)]
+        t0 = time.perf_counter()
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL)
+        print(f"[bench] CPU-baseline child ({','.join(legs)}): exit code {proc.returncode}, {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
+        for w in legs:
+            try:
+                rec = json.load(open(os.path.join(d, f"{w}.json")))
+            except OSError:
+                rec = {"error": f"the CPU-baseline child wrote no result for {w} (exit code {proc.returncode})"}
+            rp = os.path.join(d, f"{w}_ref.npy")
+            rec["ref"] = np.load(rp) if os.path.exists(rp) else None
+            out[w] = rec
+    return out
+
+
+def attach_cpu(out, cpu, w, got_fn=None):
+    """Put leg w's CPU baseline (and, with got_fn, the parity figures against its reference output) into a workload's result."""
+    rec = (cpu or {}).get(w)
+    if not rec:
+        return
+    if "error" in rec:
+        out["cpu_baseline"] = {"error": rec["error"]}
+        return
+    out["cpu_baseline"] = rec["cpu_baseline"]
+    if got_fn is not None and rec.get("ref") is not None:
+        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(got_fn(rec), rec["ref"])
+
+
 def cpu_baseline_K(x_host, W, Bm, s, budget_s=10.0):
     """oracle/k_oracle.c (plain-C port of graph K, OpenMP over rows)."""
     import numpy as np
@@ -434,19 +635,13 @@ def shard_note(a, world, Bl, total):
 # ================================================================================================
 # workloads
 # ================================================================================================
-def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
+def bench_K(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
     import numpy as np
 
     (B, first, total), H, W = local_batch(a, rank, world), a.size, a.size
     steps = a.steps if (primary and a.steps is not None) else 200
     warmup = a.warmup if (primary and a.warmup is not None) else 20
-    x_host = synthetic_lq(max(B, 1), H, W, seed=1234 + first)[:max(B, 1)]
-    x_host = (x_host / np.maximum(x_host.mean(axis=(1, 2, 3), keepdims=True), 1e-9)).astype(np.float32)  # noise-removal-kernels.py:525-527
-    rng = np.random.default_rng(7)
-    pairs = emdenoise.kernel_denoiser.sym_pairs(3)
-    wsc = [(rng.standard_normal(len(pairs)) * 0.15 + 1.0 / 9).astype(np.float32) for _ in range(2)]
-    bsc = [np.zeros(len(pairs), np.float32), (rng.standard_normal(len(pairs)) * 0.5).astype(np.float32)]
-    params = emdenoise.KernelParams.from_symmetric(wsc, bsc, [1.0, 1.3], 3)
+    x_host, params = inputs_K(a, B, first)
     pd = torch.from_numpy(params.packed()).to(dev)
     x = torch.from_numpy(x_host[:B]).to(dev)
     y = torch.empty_like(x)
@@ -511,14 +706,12 @@ def bench_K(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
             del xb, yb
         except Exception as e:  # out of memory on a shared card: the primary figure stands on its own
             out["roofline"]["batch256"] = {"error": f"{type(e).__name__}: {e}"}
-    if want_cpu and B:
-        cb, y_cpu = cpu_baseline_K(x_host[:B], params.wmaps, params.bmaps, params.s)
-        out["cpu_baseline"] = cb
-        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(y.cpu().numpy()[..., 0], y_cpu)
+    if B:
+        attach_cpu(out, cpu, "K", lambda rec: y.cpu().numpy()[..., 0])
     return out
 
 
-def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
+def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
     import numpy as np
 
     from emdenoise import ops
@@ -675,14 +868,12 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
                                        "note": "pinned host -> HBM, forward, HBM -> pinned host, one batch, best of 3 (never the headline value)"}
         except Exception as e:
             out["from_pinned_host"] = {"error": f"{type(e).__name__}: {e}"}
-    if want_cpu and B:
-        cb, y_cpu = cpu_baseline_D(x_host[:B], weights)
-        out["cpu_baseline"] = cb
-        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(box[0][:1].cpu().numpy(), y_cpu)
+    if B:
+        attach_cpu(out, cpu, "D", lambda rec: box[0][:1].cpu().numpy())
     return out
 
 
-def bench_X(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
+def bench_X(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
     """BASELINE configs[2], second graph of that name: misc_py/modified_Xception.py at 512x512."""
     import numpy as np
 
@@ -720,26 +911,18 @@ def bench_X(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
                         "algorithmic_flops_per_step": dec_fl, "kernel_ms_per_step": round(dec_ms, 3),
                         "how": "HIP events around every launch of the family in one extra step; flops from the launch arguments"},
            "kernel_family_ms": fam.table()}
-    if want_cpu and B:
-        from oracle import xception_graph as XG
-
-        torch.set_num_threads(CPU_THREADS)
+    if B and cpu and "X" in cpu and "error" not in cpu["X"]:
         # X normalises with the statistics of the batch it is given, so parity is defined per batch: the GPU runs the SAME
-        # sub-batch the CPU leg runs (2 images: ~25 s of CPU work), and that pair is what rel_l2_vs_oracle compares
-        n = min(B, 2)
-        t0 = time.perf_counter()
-        ref = XG.architecture(x_host[:n], weights, H, dtype=torch.float32).numpy()
-        el = time.perf_counter() - t0
-        got = eng.forward(x[:n].contiguous()).cpu().numpy()
-        out["cpu_baseline"] = {"value": round(n * H * W / 1e6 / el, 4), "unit": "MPx/s", "cores": CPU_THREADS, "kind": "port",
-                               "sample": f"1 pass over the first {n} images ([{n},{H},{W},1]), oracle/xception_graph.py "
-                                         f"(PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}
-        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(got, ref)
+        # sub-batch the CPU leg ran (2 images: ~25 s of CPU work), and that pair is what rel_l2_vs_oracle compares
+        n = cpu["X"]["extra"]["n"]
+        attach_cpu(out, cpu, "X", lambda rec: eng.forward(x[:n].contiguous()).cpu().numpy())
         out["parity_note"] = f"GPU and oracle both on the sub-batch [{n},{H},{W},1] (batch-statistics norms: the output depends on the batch)"
+    else:
+        attach_cpu(out, cpu, "X")
     return out
 
 
-def bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
+def bench_G(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
     """BASELINE configs[4], forward part: the in-filling GAN's GENERATOR (misc_py/gan-infilling-100.py:133-374) on
     1/64-sampled 512x512 images."""
     from emdenoise import gan as GN, ops
@@ -747,7 +930,7 @@ def bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     (B, first, total), S = local_batch(a, rank, world), a.size
     steps = a.steps if (primary and a.steps is not None) else 5
     warmup = a.warmup if (primary and a.warmup is not None) else 1
-    x_host = GN.gen_lq(2.0 * synthetic_lq(max(B, 1), S, S, seed=77 + first)[..., 0] - 1.0)[..., None]
+    x_host = inputs_G(a, B, first)
     weights = GN.synthetic_weights()
     eng = GN.GeneratorEngine(weights, dev, a.precision)
     x = torch.from_numpy(x_host[:B]).to(dev)
@@ -782,21 +965,12 @@ def bench_G(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
                         "algorithmic_flops_per_step": mf, "kernel_ms_per_step": round(mm, 3),
                         "note": "<= 128 channels at 256-512 px: the graph is HBM-bound, the matrix-core fraction is low by construction"},
            "kernel_family_ms": fam.table()}
-    if want_cpu and B:
-        from oracle import gan_graph as GG
-
-        torch.set_num_threads(CPU_THREADS)
-        t0 = time.perf_counter()
-        ref = GG.generator(x_host[:1], weights, S, dtype=torch.float32).numpy()
-        el = time.perf_counter() - t0
-        got = box[0][:1].cpu().numpy()
-        out["cpu_baseline"] = {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s in-filled", "cores": CPU_THREADS, "kind": "port",
-                               "sample": f"1 image ([1,{S},{S},1]), oracle/gan_graph.py (PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}
-        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(got, ref)
+    if B:
+        attach_cpu(out, cpu, "G", lambda rec: box[0][:1].cpu().numpy())
     return out
 
 
-def bench_S(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
+def bench_S(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
     """the small separable autoencoder of misc_py/apply_autoencoders.py (:91-187), the reference's
     own size: 160x160 crops, encoding_features 16, a batch of `--batch` crops per GPU with per-image batch statistics."""
     import numpy as np
@@ -806,8 +980,7 @@ def bench_S(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     (B, first, total), S = local_batch(a, rank, world), 160
     steps = a.steps if (primary and a.steps is not None) else 10
     warmup = a.warmup if (primary and a.warmup is not None) else 2
-    x_host = synthetic_lq(max(B, 1), S, S, seed=160 + first)
-    x_host = (x_host / x_host.mean(axis=(1, 2, 3), keepdims=True)).astype(np.float32)
+    x_host = inputs_S(a, B, first)
     weights = AE.synthetic_weights(16)
     eng = AE.AutoencoderEngine(weights, dev, 16)
     x = torch.from_numpy(x_host[:B]).to(dev)
@@ -827,21 +1000,12 @@ def bench_S(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
                                   "encoding_features 16, per-image batch-statistics norms", "precision": "bf16x3", "hip_graph": not a.no_graph},
            "roofline": {"bound": "hbm", "kernel": "whole forward (45 short launches at 160 px: launch / latency bound)",
                         "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}}
-    if want_cpu and B:
-        from oracle import autoencoder_graph as AG
-
-        torch.set_num_threads(CPU_THREADS)
-        t0 = time.perf_counter()
-        ref = AG.architecture(x_host[:B], weights, 16, dtype=torch.float32).numpy()
-        el = time.perf_counter() - t0
-        got = box[0].cpu().numpy()
-        out["cpu_baseline"] = {"value": round(B * S * S / 1e6 / el, 4), "unit": "MPx/s", "cores": CPU_THREADS, "kind": "port",
-                               "sample": f"the same [{B},{S},{S},1] batch, oracle/autoencoder_graph.py (PyTorch-CPU float32, {CPU_THREADS} threads), {el:.1f} s"}
-        out["psnr_vs_oracle_db"], out["rel_l2_vs_oracle"] = psnr_rel(got, ref)
+    if B:
+        attach_cpu(out, cpu, "S", lambda rec: box[0].cpu().numpy())
     return out
 
 
-def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
+def bench_A(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
     """BASELINE configs[4]: one iteration of the in-filling GAN's training loop (misc_py/gan-infilling-100.py:1650-1790)
     on `--gan-batch` 512x512 images per GPU: generator towers through the discriminator (feature matching), generator
     Adam step, then the discriminator trained on the generated and the natural images (2T towers) and its Adam step."""
@@ -852,14 +1016,9 @@ def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     T, S = a.gan_batch, a.size
     steps = a.steps if (primary and a.steps is not None) else 3
     warmup = a.warmup if (primary and a.warmup is not None) else 1
-    hq = (2.0 * synthetic_lq(T, S, S, seed=177 + rank) - 1.0).astype(np.float32)
-    lq = GN.gen_lq(hq[..., 0])[..., None]
+    hq, lq, offsets = inputs_A(a, rank)
     D = GT.DiscriminatorTrainer(GN.discriminator_synthetic_weights(), dev, a.precision)
     G = GT.GeneratorTrainer(GN.synthetic_weights(), D, dev, a.precision)
-    rng = np.random.default_rng(5 + rank)
-    pad = (3 * S) // 4
-    offsets = [tuple((int(rng.integers(0, S + 2 * pad - n + 1)), int(rng.integers(0, S + 2 * pad - n + 1))) for n in (S // 4, S // 2, pad))
-               for _ in range(T)]
     x, t = torch.from_numpy(lq).to(dev), torch.from_numpy(hq).to(dev)
     box = [None]
     loop = GT.GanLoop(G, D, streams=a.train_streams) if (world == 1 and not a.no_graph) else None
@@ -881,21 +1040,11 @@ def bench_A(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
            "d_fake_first": float(rg[0, 0].item()), "d_out_first": float(rd[0, 0].item())}
     out["roofline"] = {"bound": "hbm", "kernel": "whole iteration (<= 128-channel separable convs at 256-512 px dominate)",
                        "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
-    if want_cpu:
-        from oracle import gan_graph as GG
-
-        torch.set_num_threads(CPU_THREADS)
-        t0 = time.perf_counter()
-        GG.generator_tower(lq[:1], hq[:1], GN.synthetic_weights(), GN.discriminator_synthetic_weights(), offsets[0])
-        el = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s trained (GAN)", "cores": CPU_THREADS, "kind": "port",
-                               "sample": f"ONE generator tower ([1,{S},{S},1]: generator + 2 discriminator passes, forward + backward), "
-                                         f"oracle/gan_graph.py generator_tower (PyTorch-CPU autograd, float64, {CPU_THREADS} threads), "
-                                         f"{el:.1f} s; discriminator towers and optimizer steps not included"}
+    attach_cpu(out, cpu, "A")
     return out
 
 
-def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
+def bench_T(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
     """BASELINE configs[3]: graph D' TRAINING (misc_py/denoiser-multi-gpu.py): data-parallel steps of `--train-batch`
     512x512 LQ/HQ pairs per GPU (bs=64 over 8 GPUs => 8 per GPU), towers of `--tower-batch` images (1 = the
     reference, :763), gradients averaged over all towers and ranks (one RCCL all-reduce of the flat gradient vector),
@@ -907,9 +1056,7 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     B, S, tb = a.train_batch, a.size, a.tower_batch
     steps = a.steps if (primary and a.steps is not None) else 3
     warmup = a.warmup if (primary and a.warmup is not None) else 1
-    rng = np.random.default_rng(4321 + rank)
-    hq = synthetic_lq(B, S, S, seed=99 + rank)          # smooth synthetic micrographs as the clean images
-    lq = np.clip(hq + rng.normal(0.0, 0.1, hq.shape).astype(np.float32), 0.0, 1.0)
+    hq, lq = inputs_T(a, rank)
     weights = D.synthetic_weights(variant="Dprime")
     tr = TR.DenoiserTrainer(weights, dev, a.precision)
     x, t = torch.from_numpy(lq).to(dev), torch.from_numpy(hq).to(dev)
@@ -954,19 +1101,7 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, want_cpu, primary):
     out["roofline"] = {"bound": "mfma", "kernel": "whole step (forward + data-gradient + weight-gradient GEMMs dominate)", "achieved": out["tflops_algorithmic"],
                        "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(out["tflops_algorithmic"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
-    if want_cpu:
-        from oracle import denoiser_graph as G
-
-        torch.set_num_threads(CPU_THREADS)
-        t0 = time.perf_counter()
-        # float64: PyTorch-CPU's float32 conv backward has twice died of glibc heap corruption in a process that had also
-        # initialised the GPU runtime (never in a CPU-only process on the same host)
-        G.tower_gradients(lq[:1], hq[:1], weights, S, dtype=torch.float64)
-        el = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(S * S / 1e6 / el, 4), "unit": "MPx/s trained", "cores": CPU_THREADS, "kind": "port",
-                               "sample": f"forward + backward of ONE tower of 1 image ([1,{S},{S},1]), oracle/denoiser_graph.py "
-                                         f"tower_gradients (PyTorch-CPU autograd, float64, {CPU_THREADS} threads), {el:.1f} s; "
-                                         "optimizer step not included"}
+    attach_cpu(out, cpu, "T")
     return out
 
 
@@ -1035,6 +1170,21 @@ def _worker(a, real_stdout):
     if a.dry_run:
         return dry_run(a, rank, world, real_stdout)
 
+    multi = world > 1
+    if a.workload in ("all", "both"):
+        primary = "D"
+        # more than one rank: the primary workload only.  The training step is the one workload with a collective, and a failure in
+        # a rider would take the inference scaling figure down with it (a rider's exception tears every rank down): its scaling
+        # is measured on its own with `--workload T --gpus N`
+        riders = [] if (a.no_riders or multi) else (["K"] if a.workload == "both" else ["K", "X", "T", "G", "S", "A"])
+    else:
+        primary, riders = a.workload, []
+    # the CPU baselines FIRST, in a child that never sees a GPU, while this process has not yet loaded torch or the HIP runtime
+    cpu = None
+    if rank == 0 and not multi and not a.no_cpu_baseline:
+        assert "torch" not in sys.modules, "the CPU-baseline child must be started before this process loads torch / HIP"
+        cpu = run_cpu_child(a, a.argv, [primary] + [w for w in riders if w != "A"])
+
     import torch
 
     import emdenoise
@@ -1049,30 +1199,19 @@ def _worker(a, real_stdout):
         dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         dist = dist_mod
     timer = Timer(torch, dist, dev)
-    multi = world > 1
-    want_cpu = rank == 0 and not multi and not a.no_cpu_baseline
-
-    if a.workload in ("all", "both"):
-        primary = "D"
-        # more than one rank: the primary workload only.  The training step is the one workload with a collective, and a failure in
-        # a rider would take the inference scaling figure down with it (a rider's exception tears every rank down): its scaling
-        # is measured on its own with `--workload T --gpus N`
-        riders = [] if (a.no_riders or multi) else (["K"] if a.workload == "both" else ["K", "X", "T", "G", "S", "A"])
-    else:
-        primary, riders = a.workload, []
 
     def note(msg):   # progress on stderr: a run that dies mid-way says where (stdout carries the one JSON line only)
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     note(f"workload {primary} (primary) ...")
-    res = {primary: BENCHES[primary](a, torch, emdenoise, dev, timer, rank, world, want_cpu, True)}
+    res = {primary: BENCHES[primary](a, torch, emdenoise, dev, timer, rank, world, cpu, True)}
     note(f"workload {primary}: {res[primary]['ms_per_step']:.3f} ms per step")
     failed = []
     for w in riders:
         try:
             note(f"rider {w} ...")
-            res[w] = BENCHES[w](a, torch, emdenoise, dev, timer, rank, world, want_cpu and w != "A", False)
+            res[w] = BENCHES[w](a, torch, emdenoise, dev, timer, rank, world, cpu, False)
             note(f"rider {w}: {res[w]['ms_per_step']:.3f} ms per step")
         except Exception as e:
             if multi:   # the other ranks sit in this workload's collectives: fail the job, the launcher tears every rank down
@@ -1137,6 +1276,9 @@ def _worker(a, real_stdout):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse_args(argv)
+    a.argv = list(argv)
+    if a.cpu_child:
+        return cpu_child(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(a, argv)
     return worker(a)

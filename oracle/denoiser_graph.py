@@ -14,6 +14,7 @@ Variables are fetched by their TensorFlow names, generated in graph-construction
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -279,13 +280,13 @@ def architecture(inputs, weights, cropsize=512, dtype=torch.float32, trace=None,
         return g.build(x.to(dtype), cropsize)
 
 
-def tower_gradients(inputs, truth, weights, cropsize, dtype=torch.float64, variant="Dprime", trace=None, saved=None):
+def tower_gradients(inputs, truth, weights, cropsize, dtype=torch.float64, variant="Dprime", trace=None, saved=None, _native=False):
     """One tower of the training twin (misc_py/denoiser-multi-gpu.py:752-782): architecture(phase=True) on
     ``inputs``, mse = mean((out-truth)^2), loss = 1000*mse if mse < 1e-3 else sqrt(1000*mse) (+ weight_decay * sum of
     l2 losses with weight_decay = 0, :117), tf.gradients(loss, trainable variables) via PyTorch autograd.
     -> dict(out, mse, loss, grads {name: numpy}, moving {name: numpy updated moving statistics}).
-    float64 by default.  The float32 form works in CPU-only processes; inside a process that has also initialised the GPU runtime
-    PyTorch-CPU's float32 conv backward has twice aborted with glibc heap corruption -- do not call it there."""
+    float64 by default; the float32 form runs on ATen's native convolution kernels, not oneDNN (see below; ORACLE_MKLDNN=1 puts
+    oneDNN back for diagnosis)."""
     leaves = {}
 
     def get(name, shape):
@@ -298,6 +299,13 @@ def tower_gradients(inputs, truth, weights, cropsize, dtype=torch.float64, varia
             leaves[name] = t
         return leaves[name]
 
+    if dtype == torch.float32 and not _native and os.environ.get("ORACLE_MKLDNN", "0") != "1":
+        # PyTorch-CPU's float32 convolutions go to oneDNN, float64 to ATen's own kernels.  On the GPU boxes' host (EPYC 9575F) the oneDNN
+        # float32 backward of this tower aborts with glibc heap corruption -- deterministically, in a process that has loaded neither
+        # libemdenoise.so nor the HIP device runtime (gpurun_out/r3i) -- and runs clean on ATen's kernels.  The oracle is a
+        # checker: it takes the path that works on every host.
+        with torch.backends.mkldnn.flags(enabled=False):
+            return tower_gradients(inputs, truth, weights, cropsize, dtype=torch.float32, variant=variant, trace=trace, saved=saved, _native=True)
     g = _Graph(get, dtype, variant)
     g.training = True
     g.moving_updates = {}

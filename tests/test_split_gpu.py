@@ -95,8 +95,9 @@ def test_dw3x3_reflect_split32_equals_reflect_then_split(B, H, W, C, stride):
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv1x1_split32_kernel_variants_agree(variant):
-    """Every tile / stage / loop variant of the GEMM (dev knob) gives the 32x32x16 kernel's bits (4 = the persistent form);
-    variant 5 runs on 16x16x32 MFMAs, whose K-step sum is ordered differently: same error class (2e-7), not the same bits."""
+    """Every tile / stage / loop variant of the GEMM on 32x32x16 MFMAs (dev knob) gives variant 3's bits (4 = the persistent form);
+    variant 5 -- the default since round 3 -- runs on 16x16x32 MFMAs, whose K-step sum is ordered differently: same error class
+    (2e-7), not the same bits."""
     from emdenoise import _lib, ops
 
     lib = _lib.load()
@@ -106,6 +107,7 @@ def test_conv1x1_split32_kernel_variants_agree(variant):
     pw = ops.PackedWeights(w, False, dev())
     s1, t1 = up(rnd((384,), 44, 0.3) + 1.0), up(rnd((384,), 45, 0.5))
     xs = ops.to_split32(ops.Act(up(x)))
+    lib.emd_debug_split_variant(3)
     ref = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(4, 32, 32, 384, dev()), res=ops.Act(up(r)))
     try:
         lib.emd_debug_split_variant(variant)
@@ -146,17 +148,27 @@ def test_conv1x1_split32(B, H, W, ci, co, res, extra):
     kw = dict(scale2=up(s2) if extra else None, shift2=up(t2) if extra else None, res=ops.Act(up(r)) if res else None)
     # the split32 output sits in a channel slice of a wider NaN-filled buffer (tf.concat targets, denoiser.py:203)
     wide = torch.full((B, H, W, co + 8), float("nan"), dtype=torch.float32, device=dev())
-    got = ops.conv1x1_split32(ops.to_split32(xa), pw, up(s1), up(t1), ops.Act(wide, co, 4), **kw)
+    from emdenoise import _lib
+
+    xs = ops.to_split32(xa)
+    got = ops.conv1x1_split32(xs, pw, up(s1), up(t1), ops.Act(wide, co, 4), **kw)
     old = ops.conv1x1(xa, pw, up(s1), up(t1), ops.Act.empty(B, H, W, co, dev()), precision=ops.PREC_BF16X3, **kw)
-    torch.cuda.synchronize()
+    try:   # the 32x32x16 form of the split32 GEMM sums exactly as the register-staged kernel does
+        _lib.load().emd_debug_split_variant(3)
+        v3 = ops.conv1x1_split32(xs, pw, up(s1), up(t1), ops.Act.empty(B, H, W, co, dev()), **kw)
+        torch.cuda.synchronize()
+    finally:
+        _lib.load().emd_debug_split_variant(-1)
     assert rel_l2(got.torch().cpu().numpy(), ref.numpy()) < TOL_X3
-    assert torch.equal(got.torch(), old.torch()), "split32 GEMM must reproduce emd_conv1x1_f32 bit for bit"
+    assert torch.equal(v3.torch(), old.torch()), "the 32x32x16 split32 GEMM must reproduce emd_conv1x1_f32 bit for bit"
+    assert float((got.torch() - old.torch()).norm() / old.torch().norm()) < 1e-6   # the default (16x16x32 MFMAs): another summation order
     assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
 
 
 def test_conv1x1_split32_full_size_identity():
-    """BASELINE size (B=32, 32x32x728 -> 728): the default kernel is bit-identical to the register-staged kernel over all
-    32768 rows; the 16x16x32-MFMA variant agrees to 1e-6 relative."""
+    """BASELINE size (B=32, 32x32x728 -> 728): the 32x32x16 form is bit-identical to the register-staged kernel over all 32768 rows; the
+    default (16x16x32 MFMAs) agrees to 1e-6 relative, and its 128-row form (what a batch of 4 images runs on) gives the bits of the
+    256-row form -- image b of a batch == the image alone, whatever kernel shape the batch size selects."""
     from emdenoise import ops
 
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -169,15 +181,17 @@ def test_conv1x1_split32_full_size_identity():
     xa = ops.Act(x)
     xs = ops.to_split32(xa)
     b = ops.conv1x1(xa, pw, s, t, ops.Act.empty(32, 32, 32, 728, dev()))
-    a = ops.conv1x1_split32(xs, pw, s, t, ops.Act.empty(32, 32, 32, 728, dev()))     # the default kernel
+    d = ops.conv1x1_split32(xs, pw, s, t, ops.Act.empty(32, 32, 32, 728, dev()))     # the default kernel: 16x16x32 MFMAs, 256-row tiles
+    d4 = ops.conv1x1_split32(ops.to_split32(ops.Act(x[8:12].contiguous())), pw, s, t, ops.Act.empty(4, 32, 32, 728, dev()))   # 128-row tiles
     try:
-        _lib.load().emd_debug_split_variant(5)                                        # the 16x16x32-MFMA variant
-        d = ops.conv1x1_split32(xs, pw, s, t, ops.Act.empty(32, 32, 32, 728, dev()))
+        _lib.load().emd_debug_split_variant(3)                                        # the 32x32x16 form
+        a = ops.conv1x1_split32(xs, pw, s, t, ops.Act.empty(32, 32, 32, 728, dev()))
         torch.cuda.synchronize()
     finally:
         _lib.load().emd_debug_split_variant(-1)
     assert torch.equal(a.buf, b.buf)
     assert float((d.buf - b.buf).norm() / b.buf.norm()) < 1e-6
+    assert torch.equal(d4.buf, d.buf[8:12])
 
 
 def test_split32_argument_checks():
@@ -194,7 +208,7 @@ def test_split32_argument_checks():
     assert lib.emd_conv1x1_split32_supported(524288, 256, 256) == 1
     assert lib.emd_conv1x1_split32_supported(2097152, 384, 128) == 0
     assert lib.emd_conv1x1_split32_supported(32768, 64, 728) == 0
-    assert lib.emd_conv1x1_split32_supported(1024, 728, 728) == 0
+    assert lib.emd_conv1x1_split32_supported(1024, 728, 728) == 1   # round 3: at every M (the 128-row form below 192 tiles of 256 rows)
 
 
 @pytest.mark.parametrize("B,H,W,ci,co,stride,rate,two_stage", [
@@ -316,8 +330,9 @@ def test_conv1x1_split32_direct_epilogue(B, H, W, ci, co, res, extra, split):
         ops.conv1x1_split32(xs, pw, s1, t1, ops.Act(wide, co, 4), **kw)
         return wide.view(torch.int32).clone()
 
-    want = run()
     try:
+        lib.emd_debug_split_variant(3)
+        want = run()
         lib.emd_debug_split_variant(7)
         got = run()
         torch.cuda.synchronize()
@@ -395,7 +410,7 @@ def test_deconv3x3s2_split32_against_the_oracle(B, H, W, ci, co):
 def test_split32_convs_random_shapes_match_register_staged_kernels():
     """Seeded sweep over ragged shapes (M, N and K tails, 1..3 M tiles, strides, dilations): every split32 GEMM form gives
     the bits of its register-staged twin -- the DMA source addressing (per-tap rows, zero line, swizzle) has no shape it gets wrong."""
-    from emdenoise import ops
+    from emdenoise import _lib, ops
 
     rng = np.random.default_rng(2024)
     for case in range(24):
@@ -422,7 +437,13 @@ def test_split32_convs_random_shapes_match_register_staged_kernels():
         else:              # pointwise
             pw = ops.PackedWeights(rnd((1, ci, co), 400 + case, 0.05), False, dev())
             want = ops.conv1x1(xa, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()))
-            got = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()))
+            got = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()))       # default: 16x16x32 MFMAs, 128-row tiles here
+            _lib.load().emd_debug_split_variant(3)
+            got3 = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()))      # the 32x32x16 form: the twin's bits
+            _lib.load().emd_debug_split_variant(-1)
+            torch.cuda.synchronize()
+            assert float((got.buf - want.buf).norm() / want.buf.norm()) < 1e-6, (case, kind, B, H, W, ci, co)
+            got = got3
         torch.cuda.synchronize()
         assert torch.equal(got.buf, want.buf), (case, kind, B, H, W, ci, co)
 
