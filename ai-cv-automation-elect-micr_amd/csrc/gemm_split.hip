@@ -1447,6 +1447,301 @@ static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, co
     return emd::check_launch("gemm_split_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------- the transposed conv, one launch
+namespace {
+
+// 4 x 4 transpose inside a lane quad (two DPP exchange rounds): in, lane i holds column i of a block (r[k] = a[k][i]); out, row i.
+// Turns four rows x one channel of the 32x32 MFMA C/D layout into one row x four consecutive channels: 16-byte stores without
+// a staging tile (sep_pipe.hip has the same helper).
+__device__ __forceinline__ void quad_transpose4(float (&r)[4], int li) {
+    const bool b0 = li & 1, b1 = li & 2;
+    float s0 = b0 ? r[0] : r[1], s1 = b0 ? r[2] : r[3];
+    s0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+    s1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+    r[0] = b0 ? s0 : r[0]; r[1] = b0 ? r[1] : s0;
+    r[2] = b0 ? s1 : r[2]; r[3] = b0 ? r[3] : s1;
+    float t0 = b1 ? r[0] : r[2], t1 = b1 ? r[1] : r[3];
+    t0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t0), 0x4E, 0xF, 0xF, true));
+    t1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x4E, 0xF, 0xF, true));
+    r[0] = b1 ? t0 : r[0]; r[2] = b1 ? r[2] : t0;
+    r[1] = b1 ? t1 : r[1]; r[3] = b1 ? r[3] : t1;
+}
+
+// slim.conv2d_transpose(k = 3, s = 2) (machine_learning/denoiser.py:138-150) as ONE launch, round 3 form: the four output phases of a
+// workgroup's 256 input pixels back to back as in gemm_split_conv_kernel<BN, true> (same K loops, same products in the same order:
+// bit-identical), but the epilogue leaves straight from the accumulators (quad transpose, 16-byte non-temporal stores) and touches no
+// LDS -- so the DMA of the NEXT phase's first K steps is issued before the stores of this one, and the stores (the layer writes four
+// times what it reads: 4.3 GB for deconv1to0) drain under the next K loop instead of between two of them.  fp32 output, no residual.
+template <int BN>
+__global__ __launch_bounds__(512, 2) void deconv4_split_kernel(const SplitConvParams cp) {
+    const SplitGemmParams& p = cp.g;
+    constexpr int BM = 256, NS = BN == 128 ? 3 : 4, WQ = BN / 64, TN = BN / 64;
+    constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128, STAGE = A_STAGE + W_STAGE;
+    constexpr int E = 8 * TN;   // stores per wave and phase
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int nblk = p.n_mtiles * p.n_ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.n_ntiles, nt = bid % p.n_ntiles;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int drow = lane >> 3, dchunk = lane & 7;
+    int pi[4], pj[4], pb[4], pc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wv * 32 + q * 8 + drow;
+        pc[q] = (dchunk ^ ((row >> 1) & 7)) * 16;
+        const long m = m0 + row;
+        if (m < p.M) {
+            const int j = (int)(m % cp.Wg);
+            const long t = m / cp.Wg;
+            pi[q] = (int)(t % cp.Hg); pj[q] = j; pb[q] = (int)(t / cp.Hg) * cp.Ha * cp.Wa;
+        } else {
+            pi[q] = -(1 << 20); pj[q] = 0; pb[q] = 0;    // beyond M: every tap reads zeros
+        }
+    }
+    const int fr = lane & 31, fh = lane >> 5;
+    const int sw = (fr >> 1) & 7;
+    const int a_off = (wm * 64 + fr) * 128;
+    const int w_off = A_STAGE + (wn * (BN / 2) + fr) * 128;
+
+    // ---- epilogue roles.  Before the transpose a lane holds channel n0 + wn BN/2 + 32 j + fr of rows (e & 3) + 8 (e >> 2) + 4 fh;
+    // after it, row 8 q + 4 fh + li and channels 4 cq .. 4 cq + 3 of the 32-column group
+    const int li = fr & 3, cq = fr >> 2;
+    long dst0[2][4];     // output pixel of phase (0, 0) for this lane's rows, -1 beyond M
+    bool full = true;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long m = m0 + wm * 64 + i * 32 + 8 * q + 4 * fh + li;
+            long d = -1;
+            if (m < p.M) {
+                const int j = (int)(m % cp.Wg);
+                const long t = m / cp.Wg;
+                d = ((t / cp.Hg) * cp.Hc + (t % cp.Hg) * 2) * (long)cp.Wc + 2 * j;
+            }
+            dst0[i][q] = d;
+            full = full && d >= 0;
+        }
+    float es1[TN], et1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + fr;
+        es1[j] = n < p.N ? p.scale1[n] : 0.f;
+        et1[j] = n < p.N ? p.shift1[n] : 0.f;
+        asm volatile("" ::"v"(es1[j]), "v"(et1[j]));   // waited for here, not behind the DMA groups in the loop
+        full = full && (n0 + wn * (BN / 2) + j * 32 + 31 < p.N);
+    }
+    full = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(!full) == 0);   // per wave: no masked store, the store count is exact
+    const float hi = p.act == 1 ? 6.f : __builtin_inff();
+    const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+
+    // ---- per-phase state
+    const uint16_t* __restrict__ Whi = cp.Whi4[0];
+    const uint16_t* __restrict__ Wlo = cp.Wlo4[0];
+    int ntaps = cp.ntaps4[0];
+    unsigned long long dyp = cp.dyp4[0], dxp = cp.dxp4[0];
+    const unsigned char* asrc[4];
+    const unsigned char* wsrc[WQ];
+    auto set_tap = [&](int tap) {
+        const int dy = (int)((dyp >> (7 * tap)) & 127) - 64, dx = (int)((dxp >> (7 * tap)) & 127) - 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int iy = pi[q] * cp.sa + dy, ix = pj[q] * cp.sa + dx;
+            const bool ok = iy >= 0 && iy < cp.Ha && ix >= 0 && ix < cp.Wa;
+            const long pix = (long)pb[q] + (long)iy * cp.Wa + ix;
+            asrc[q] = (ok ? p.A + pix * p.lda_bytes : g_zero_buf) + pc[q];
+        }
+    };
+    auto set_phase = [&](int ph) {
+        Whi = cp.Whi4[ph]; Wlo = cp.Wlo4[ph]; ntaps = cp.ntaps4[ph]; dyp = cp.dyp4[ph]; dxp = cp.dxp4[ph];
+        const int Ktot = ntaps * cp.Cpad;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int row = wv * (WQ * 8) + q * 8 + drow;
+            const int c = dchunk ^ ((row >> 1) & 7);
+            const uint16_t* plane = (c & 4) ? Wlo : Whi;
+            wsrc[q] = reinterpret_cast<const unsigned char*>(plane + (long)(n0 + row) * Ktot + (c & 3) * 8);
+        }
+    };
+    auto issue = [&](int stage, int tap, int kc) {
+        unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (long)kc * 128), (lptr_t)(sb + (wv * 32 + q * 8) * 128), 16, 0, 0);
+        const long wk = ((long)tap * cp.Cpad + (long)kc * 32) * 2;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[q] + wk), (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    struct Frags { bf16x8 ah[2], al[2], bh[TN], bl[TN]; };
+    auto load_frags = [&](Frags& f, const unsigned char* sb, int ks) {
+        const int ch = ((ks * 2 + fh) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + ch);
+            f.al[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + (ch ^ 64));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + ch);
+            f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + (ch ^ 64));
+        }
+    };
+    auto mfma12 = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    int total = 0, dtap = 0, dkc = 0, dstep = 0;
+    auto advance = [&]() {
+        if (dstep + 1 < total) {
+            ++dstep;
+            if (++dkc == cp.nkc) {
+                dkc = 0;
+                ++dtap;
+                set_tap(dtap);
+            }
+        }
+    };
+    auto prologue = [&](int ph) {   // the first NS - 1 K steps of phase ph into stages 0 .. NS - 2
+        set_phase(ph);
+        total = ntaps * cp.nkc;
+        dtap = dkc = dstep = 0;
+        set_tap(0);
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) {
+            issue(s, dtap, dkc);
+            advance();
+        }
+    };
+    prologue(0);
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ++ph) {
+        // K steps 0 and 1 landed; NS-3 younger DMA groups (4 + WQ pieces each) may stay in flight across every barrier -- and, from the
+        // second phase on, the previous phase's E stores, which were issued after this phase's first groups
+        if (ph > 0 && full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * (4 + WQ) + E) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * (4 + WQ)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        Frags f0, f1;
+        load_frags(f0, smem, 0);
+        int s0 = 0, s1 = 1, s2 = NS - 1;
+        for (int st = 0; st < total; ++st) {
+            if (st > 0) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * (4 + WQ)) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            issue(s2, dtap, dkc);
+            load_frags(f1, smem + s0 * STAGE, 1);
+            mfma12(f0);
+            load_frags(f0, smem + s1 * STAGE, 0);
+            mfma12(f1);
+            if constexpr (TN == 2) {
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            }
+            s2 = s0;
+            s0 = s1;
+            s1 = s1 + 1 == NS ? 0 : s1 + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+        }
+        // every wave's fragment reads are done and this wave's surplus DMA groups have landed: the stages are free for the next phase
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int py = ph >> 1, px = ph & 1;
+        if (ph < 3) prologue(ph + 1);
+        // ---- epilogue of phase ph, straight from the accumulators
+        const long poff = (long)py * cp.Wc + px;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n4 = n0 + wn * (BN / 2) + j * 32 + 4 * cq;
+            const bool ncol = n4 < p.N;
+            const float s1 = es1[j], t1 = et1[j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float r[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float u = fmaf(acc[i][j][4 * q + k], s1, t1);
+                        r[k] = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                    }
+                    quad_transpose4(r, li);
+                    if (ncol && dst0[i][q] >= 0) store_nt16(p.C + (dst0[i][q] + poff) * p.ldc + n4, f32x4{r[0], r[1], r[2], r[3]});
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------- convolutions on split32 input
 namespace {
 
@@ -1493,6 +1788,11 @@ int launch_conv(SplitConvParams& c, hipStream_t st, bool four = false) {
     if (nblk <= 0 || nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "split32 conv: grid too large");
     if (p.M > 0x7fffffffL || (!c.flat && (long)(p.M / ((long)c.Hg * c.Wg)) * c.Ha * c.Wa > 0x7fffffffL))
         return emd::fail(EMD_E_UNSUPPORTED, "split32 conv: more than 2^31 pixels");   // the kernel keeps pixel indices in 32 bits
+    if (four && !c.out_split && !p.res && !p.scale2 && emd::g_knobs.deconv_direct) {   // round 3: epilogue from the registers, next phase's DMA first
+        if (bn == 64) hipLaunchKernelGGL((deconv4_split_kernel<64>), dim3((unsigned)nblk), dim3(512), 0, st, c);
+        else hipLaunchKernelGGL((deconv4_split_kernel<128>), dim3((unsigned)nblk), dim3(512), 0, st, c);
+        return emd::check_launch("deconv4_split_kernel");
+    }
     if (four) {
         if (bn == 64) hipLaunchKernelGGL((gemm_split_conv_kernel<64, true>), dim3((unsigned)nblk), dim3(512), 0, st, c);
         else hipLaunchKernelGGL((gemm_split_conv_kernel<128, true>), dim3((unsigned)nblk), dim3(512), 0, st, c);
