@@ -49,7 +49,7 @@ CPU_THREADS = min(16, os.cpu_count() or 1)  # a 1-GPU box owns a 16-CPU share; m
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 D_GMAC_MATRIX_B32_512 = 2218.3  # pointwise 1304.5 + dense 1x1 295.3 - final 4.8 + conv-T 618.5 ... per B=32 batch
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
 
 
 # ================================================================================================
@@ -80,6 +80,10 @@ def parse_args(argv=None):
                          "write <leg>.json / <leg>_ref.npy into DIR")
     ap.add_argument("--cpu-legs", default="", help="internal: comma-separated workloads for --cpu-child")
     ap.add_argument("--no-riders", action="store_true", help="with --workload all: the primary workload only")
+    ap.add_argument("--profile-clean", action="store_true",
+                    help="for rocprofv3: the primary workload's timed steps and NOTHING else in the process (no per-family attribution pass, no "
+                         "isolated-GEMM / peak micro-benchmarks, no native executor, no pinned-host pass, no CPU legs): per-kernel averages of "
+                         "the trace then mean one thing")
     ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3",
                     help="matrix-core mode: bf16x3 = split-bf16 parity mode (default), bf16 = fast mode (never reported as parity)")
     return ap.parse_args(argv)
@@ -113,17 +117,51 @@ def launch_ranks(a, argv):
 # ================================================================================================
 # helpers shared by the workloads
 # ================================================================================================
+def csrc_sha16():
+    """Hash of the kernel sources (csrc/*.hip, *.hpp, *.cpp): what a committed PMC traffic file was measured on.  (The GPU box has no
+    .git, and committing the file itself moves HEAD: the kernels' text is the thing that must not have changed.)"""
+    import hashlib
+
+    d = os.path.join(ROOT, "ai-cv-automation-elect-micr_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC run (tools/collect_traffic.sh: FETCH_SIZE and WRITE_SIZE in
     separate passes, gfx950 correction applied).  bench.py cannot profile itself, so `traffic` is the figure of that run for
-    the same kernels and shapes; (None, None) if no file is there."""
+    the same kernels and shapes -- and ONLY while the kernel sources are the ones it was measured on (csrc_sha16 in the file):
+    (None, why) otherwise."""
     for name in PMC_FILES:
         path = os.path.join(ROOT, "profiles", name)
         try:
-            return json.load(open(path))["kernels"], "profiles/" + name
+            d = json.load(open(path))
         except Exception:
             continue
+        if d.get("csrc_sha16") != csrc_sha16():
+            return None, f"profiles/{name} was measured on other kernel sources (csrc_sha16 {d.get('csrc_sha16')} != {csrc_sha16()}): stale, not reported"
+        return d["kernels"], "profiles/" + name
     return None, None
+
+
+def whole_step_traffic_roofline(w, ms, kernel):
+    """Graphs S and A have no closed-form algorithmic byte count here (S: 45 launches with per-image statistics; A: ~3000 launches of a
+    whole GAN iteration): their roofline is the MEASURED HBM traffic of one step (committed PMC run, "<w>:*step total*") over the step
+    time -- how busy the memory system is, an upper bound of the algorithmic fraction."""
+    tr, src = pmc_traffic()
+    rec = (tr or {}).get(f"{w}:*step total*")
+    if not rec:
+        return {"bound": "hbm", "kernel": kernel, "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None, "traffic_source": src}
+    by = rec["hbm_bytes_per_step_corrected"]
+    ach = by / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+            "traffic": round(by), "traffic_source": src,
+            "how": "achieved = PMC HBM bytes of one step (FETCH_SIZE, WRITE_SIZE in separate rocprofv3 passes, gfx950 correction) / step time: "
+                   "traffic-based, not algorithmic"}
 
 
 def synthetic_lq(B, H, W, seed=1234):
@@ -259,15 +297,18 @@ class FamilyTimer:
             elif name in ("deconv3x3s2", "deconv3x3s2_split32", "deconv3x3s2_fused"):
                 x, wp = args[0], args[1]
                 self.flops[name] = self.flops.get(name, 0.0) + 2.0 * x.B * x.H * x.W * 9 * wp[0].cin * wp[0].cout
-            elif name == "sep_fused":
+            elif name == "sep_fused":   # algorithmic bytes of a fused separable launch: in + out (+ residual), fp32
                 x, w = args[0], args[2]
                 self.flops[name] = self.flops.get(name, 0.0) + 2.0 * x.B * x.H * x.W * w.cin * w.cout
-            elif name == "sep_fused_gen":
+                self.bytes_[name] = self.bytes_.get(name, 0.0) + 4.0 * x.B * x.H * x.W * (w.cin + w.cout * (2 if kw.get("res") is not None else 1))
+            elif name == "sep_fused_gen":   # the generated input is one value per pixel
                 d, w = args[0], args[4]
                 self.flops[name] = self.flops.get(name, 0.0) + 2.0 * d.B * d.H * d.W * w.cin * w.cout
+                self.bytes_[name] = self.bytes_.get(name, 0.0) + 4.0 * d.B * d.H * d.W * (1 + w.cout * (2 if kw.get("res") is not None else 1))
             elif name == "sep_dual":
                 x, w, w2 = args[0], args[2], args[3]
                 self.flops[name] = self.flops.get(name, 0.0) + 2.0 * x.B * x.H * x.W * w.cin * (w.cout + w2.cout)
+                self.bytes_[name] = self.bytes_.get(name, 0.0) + 4.0 * x.B * x.H * x.W * (w.cin + w.cout + w2.cout)
             elif name in ("dw3x3", "dw3x3_split32"):   # algorithmic bytes: fp32 in + out (a split32 output has the bytes of its fp32 twin)
                 xin, out = args[0], args[2]
                 self.bytes_[name] = self.bytes_.get(name, 0.0) + 4.0 * xin.C * (xin.B * xin.H * xin.W + out.B * out.H * out.W)
@@ -731,6 +772,12 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
 
     ms = timer.run(step, steps, warmup)
     med = timer.median_event_ms
+    if a.profile_clean:
+        return {"value": total * H * W / 1e6 / (ms / 1e3), "unit": "MPx/s", "ms_per_step": ms, "median_hipevent_ms": med, "steps": steps, "warmup": warmup,
+                "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)",
+                "config": {"workload": f"D: modified-Xception encoder-decoder (machine_learning/denoiser.py), [{B},{H},{W},1] fp32 per GPU", "profile_clean": True},
+                "roofline": {"bound": "hbm", "achieved": round(d_graph_algorithmic_bytes(B, H) / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": round(d_graph_algorithmic_bytes(B, H) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None}}
     # per-kernel-family device time of ONE more step on the single-stream launch sequence (with the two half batches staggered on
     # two streams -- DenoiserEngine.forward -- a launch's event pair would also span the other half's kernels)
     two, pipe = eng.two_streams, eng.pipeline
@@ -749,6 +796,11 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
     pw728_ms = sum(e0.elapsed_time(e1) for (e0, e1), sh in zip(fam.ev.get("conv1x1_split32", []), fam.pw_shapes) if 728 in sh[:2])
     pw728_flops = 3.0 * sum(sh[3] for sh in fam.pw_shapes if 728 in sh[:2])
     pw728_n = sum(1 for sh in fam.pw_shapes if 728 in sh[:2])
+    # north_star's "depthwise path": EVERY launch that contains a depthwise stage -- the standalone depthwise kernels and the fused
+    # separable convs (depthwise -> pointwise in one kernel, one or two outputs) -- algorithmic bytes over their summed device time
+    DWP = ("dw3x3", "dw3x3_split32", "sep_fused", "sep_fused_gen", "sep_dual")
+    dwp_ms = sum(fam.ms.get(k, 0.0) for k in DWP)
+    dwp_bytes = sum(fam.bytes_.get(k, 0.0) for k in DWP)
     scale = (B / 32.0) * (H * W) / (512.0 * 512.0)
     alg_flops = 2.0 * D_GMAC_MATRIX_B32_512 * 1e9 * scale
     passes = 3 if a.precision == "bf16x3" else 1
@@ -771,6 +823,13 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
                      "algorithmic_bytes_per_step": alg_bytes,
                      "algorithmic_note": "fp32 activation bytes of a fully fused graph: in + out (+ residual) per layer, no depthwise intermediates "
                                          "(bench.d_graph_algorithmic_bytes; 80.0 GB at B=32, 512^2: SURVEY 8d's 118 GB unfused - 45 GB depthwise intermediates + 6.5 GB residual reads)",
+                     "depthwise_frac": round(dw_bytes / (max(dw_ms, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "depthwise_path_frac": round(dwp_bytes / (max(dwp_ms, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "pointwise_frac": round(pw728_flops / (max(pw728_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "targets_note": "north_star's two targets, where the driver keeps them: depthwise_frac = standalone depthwise launches, "
+                                     "depthwise_path_frac = every launch with a depthwise stage (standalone + fused separable convs), both algorithmic "
+                                     "bytes / device time / 8 TB/s (target 0.70); pointwise_frac = issued bf16 flops of the 728-channel pointwise "
+                                     "GEMMs / device time / 2.5 PFLOP/s (target 0.40); details under depthwise / depthwise_path / pointwise",
                      "traffic": traffic, "traffic_source": src,
                      "hbm_busy_frac": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
                      "hbm_busy_note": "PMC bytes per step / step time / 8 TB/s (traffic above the algorithmic bytes = re-reads and unfused intermediates)",
@@ -786,7 +845,12 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
                       "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(dw_ms, 3),
                       "achieved_GBps": round(dw_bytes / (max(dw_ms, 1e-9) * 1e-3) / 1e9, 1),
                       "frac_of_8TBps": round(dw_bytes / (max(dw_ms, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-        "pointwise": {"bound": "mfma", "kernel": "gemm_split_kernel (the 1x1 halves of the 728-channel separable convs, LDS-DMA from split32)",
+        "depthwise_path": {"bound": "hbm", "kernel": "every launch with a depthwise stage: dw3x3* (standalone) + sep_fused / sep_fused_gen / sep_dual (fused)",
+                           "launches": sum(fam.launches.get(k, 0) for k in DWP), "algorithmic_bytes_per_step": dwp_bytes, "ms_per_step": round(dwp_ms, 3),
+                           "achieved_GBps": round(dwp_bytes / (max(dwp_ms, 1e-9) * 1e-3) / 1e9, 1),
+                           "frac_of_8TBps": round(dwp_bytes / (max(dwp_ms, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                           "by_family": {k: {"ms": round(fam.ms.get(k, 0.0), 3), "GB": round(fam.bytes_.get(k, 0.0) / 1e9, 2)} for k in DWP if k in fam.ms}},
+        "pointwise": {"bound": "mfma", "kernel": "gemm_split16_kernel (the 1x1 halves of the 728-channel separable convs, LDS-DMA from split32)",
                       "launches": fam.launches.get("conv1x1_split32", 0), "issued_flops_per_step": pw_flops, "ms_per_step": round(pw_ms, 3),
                       "issued_tflops": round(pw_flops / (max(pw_ms, 1e-9) * 1e-3) / 1e12, 1),
                       "frac_of_2500": round(pw_flops / (max(pw_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -807,9 +871,9 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
             wpk = ops.PackedWeights((np.random.default_rng(0).standard_normal((1, 728, 728)) * 0.05).astype(np.float32), False, dev)
             one, zero = torch.ones(728, device=dev), torch.zeros(728, device=dev)
             o = ops.Act.empty(B, 32, 32, 728, dev)
-            tms = {-1: [], 5: [], 6: []}
+            tms = {-1: [], 3: [], 6: []}
             for _ in range(3):
-                for v in (-1, 5, 6):
+                for v in (-1, 3, 6):
                     lib.emd_debug_split_variant(v)
                     ops.conv1x1_split32(xs, wpk, one, zero, o)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -822,7 +886,7 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
             lib.emd_debug_split_variant(-1)
             fl = 6.0 * B * 1024 * 728 * 728
             iso = {}
-            for v, nm in ((-1, "default_32x32x16"), (5, "variant_16x16x32"), (6, "variant_w_through_registers")):
+            for v, nm in ((-1, "default_16x16x32"), (3, "variant_32x32x16"), (6, "variant_w_through_registers_32x32x16")):
                 us = float(np.median(tms[v]))
                 iso[nm] = {"us": round(us, 1), "issued_tflops": round(fl / us / 1e6, 1), "frac_of_2500": round(fl / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4)}
             out["pointwise"]["isolated_32768x728x728"] = iso
@@ -851,6 +915,36 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
             del nat, yn
         except Exception as e:
             out["native_executor"] = {"error": f"{type(e).__name__}: {e}"}
+    if primary and rank == 0 and B >= 8 and B % 8 == 0:
+        # strong scaling of a global batch of B over 8 GPUs is B / 8 images per GPU: what ONE GPU makes of that sub-batch bounds the
+        # 8-GPU figure from above (inference has no collective): projected_strong_scaling_8 = T(B) / T(B / 8).  Eager and as one
+        # replayed hipGraph (a small batch's launch queue can drain).
+        try:
+            from emdenoise.graphed import GraphedForward
+
+            xs8 = x[:B // 8].contiguous()
+
+            def timed(fn, n=20):
+                for _ in range(3):
+                    fn(xs8)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn(xs8)
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / n
+
+            t_eager = timed(eng.forward)
+            t_graph = timed(GraphedForward(eng))
+            t_small = min(t_eager, t_graph)
+            out["small_batch"] = {"batch": B // 8, "ms_eager": round(t_eager, 3), "ms_hipgraph": round(t_graph, 3),
+                                  "projected_strong_scaling_8": round(ms / t_small, 2),
+                                  "note": f"T({B}) / T({B // 8}) on this GPU: the ceiling of the 8-GPU strong-scaling figure for a global batch of {B} "
+                                          "(north_star target >= 6.5; inference shards whole images, no collective)"}
+        except Exception as e:
+            out["small_batch"] = {"error": f"{type(e).__name__}: {e}"}
     if primary and rank == 0 and B:
         # end to end from pinned host memory: H2D copy + forward + D2H copy of the same batch
         try:
@@ -998,8 +1092,7 @@ def bench_S(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
            "steps": steps, "warmup": warmup, "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)",
            "config": {"workload": f"S: separable autoencoder (misc_py/apply_autoencoders.py), [{B},{S},{S},1] fp32 per GPU, "
                                   "encoding_features 16, per-image batch-statistics norms", "precision": "bf16x3", "hip_graph": not a.no_graph},
-           "roofline": {"bound": "hbm", "kernel": "whole forward (45 short launches at 160 px: launch / latency bound)",
-                        "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}}
+           "roofline": whole_step_traffic_roofline("S", ms, "whole forward (45 short launches at 160 px: launch / latency bound)")}
     if B:
         attach_cpu(out, cpu, "S", lambda rec: box[0].cpu().numpy())
     return out
@@ -1038,8 +1131,7 @@ def bench_A(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
                       "global_batch": T * world, "precision": a.precision, "parallelism": f"dp{world}",
                       "streams": a.train_streams, "hip_graph": loop is not None},
            "d_fake_first": float(rg[0, 0].item()), "d_out_first": float(rd[0, 0].item())}
-    out["roofline"] = {"bound": "hbm", "kernel": "whole iteration (<= 128-channel separable convs at 256-512 px dominate)",
-                       "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
+    out["roofline"] = whole_step_traffic_roofline("A", ms, "whole iteration (<= 128-channel separable convs at 256-512 px dominate)")
     attach_cpu(out, cpu, "A")
     return out
 
@@ -1181,7 +1273,9 @@ def _worker(a, real_stdout):
         primary, riders = a.workload, []
     # the CPU baselines FIRST, in a child that never sees a GPU, while this process has not yet loaded torch or the HIP runtime
     cpu = None
-    if rank == 0 and not multi and not a.no_cpu_baseline:
+    if a.profile_clean:
+        riders = []
+    if rank == 0 and not multi and not a.no_cpu_baseline and not a.profile_clean:
         assert "torch" not in sys.modules, "the CPU-baseline child must be started before this process loads torch / HIP"
         cpu = run_cpu_child(a, a.argv, [primary] + [w for w in riders if w != "A"])
 
@@ -1240,10 +1334,10 @@ def _worker(a, real_stdout):
         "roofline": prim["roofline"],
     }
     for k in ("median_hipevent_ms", "cpu_baseline", "rel_l2_vs_oracle", "psnr_vs_oracle_db", "parity_note", "matrix_cores", "depthwise", "pointwise",
-              "kernel_family_ms", "from_pinned_host", "native_executor", "tflops_algorithmic", "loss_first_tower", "allreduce", "d_fake_first", "d_out_first"):
+              "depthwise_path", "small_batch", "kernel_family_ms", "from_pinned_host", "native_executor", "tflops_algorithmic", "loss_first_tower", "allreduce", "d_fake_first", "d_out_first"):
         if k in prim:
             out[k] = prim[k]
-    if rank == 0 and primary == "D" and not multi:
+    if rank == 0 and primary == "D" and not multi and not a.profile_clean:
         note("on-box peaks ...")
         pk = out["measured_peaks"] = measured_peaks(torch, dev)
         # the same fractions against what THIS device delivers (nominal and measured peaks, both stated)
