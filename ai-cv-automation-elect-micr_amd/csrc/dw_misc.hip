@@ -686,7 +686,11 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
         // strip height: 16 rows (input re-read factor 18/16) measured 1-4 % faster than 8 on the 256^2/512^2 layers;
         // short images keep 8 so that small maps still spread over the chip
         const int th_force = emd::g_knobs.dw_th;
-        const int TH = th_force == 8 || th_force == 16 || th_force == 32 ? th_force : (H >= 64 ? 16 : 8);
+        int TH = th_force == 4 || th_force == 8 || th_force == 16 || th_force == 32 ? th_force : (H >= 64 ? 16 : 8);
+        // small batches of small maps (4 images of 32 x 32 x 728: 384 workgroups of 8 rows): a thread's 10 dependent row loads are the
+        // kernel's whole life and most CUs hold one workgroup -- 4-row strips double the workgroups and halve the chain (same bits:
+        // the three row contributions of an output are added in the same order at every strip height)
+        if (!th_force && TH == 8 && (long)B * ((H + 7) / 8) * ((W + 15) / 16) * ((C4t + 15) / 16) < 1024) TH = 4;
         const int nstrip = (H + TH - 1) / TH;
         const long nblocks = (long)B * nstrip * ((W + 15) / 16) * ((C4t + 15) / 16);
         const long nthreads = nblocks * 256;
@@ -696,6 +700,8 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
             hipLaunchKernelGGL((dw3x3_s1_roll<32, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
         else if (TH == 16)
             hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
+        else if (TH == 4)
+            hipLaunchKernelGGL((dw3x3_s1_roll<4, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
         else
             hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
         return emd::check_launch("dw3x3_s1_roll");

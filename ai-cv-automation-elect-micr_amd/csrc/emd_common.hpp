@@ -60,6 +60,7 @@ struct Knobs {
     int nt_mask = 7;         // non-temporal output stores: bit 0 split32 convolutions, bit 1 fused separable conv, bit 2 pointwise GEMM
     int dw_xcd = 1;          // XCD-contiguous tile order in the depthwise kernels
     int dw_th = 0;           // strip height of the rolling depthwise kernel (0 = rule)
+    int split_narrow = 1;    // pointwise split32 GEMM: 128 x 64 tiles where 128 x 128 tiles leave CUs idle (0 = never)
     int split_variant = -1;  // pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
     long long* sep_stamps = nullptr;   // device buffer for the in-kernel phase stamps of the fused separable convs
 };

@@ -509,11 +509,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 // BM = 256: 8 waves (4 x 2 of 64 x 64), the chip-filling form; BM = 128: 4 waves (2 x 2), one workgroup per CU, for the small batches
 // whose 256-row tiles would leave most CUs idle (M = 4096: 96 workgroups of 256 rows, 192 of 128).  Same products in the same order:
 // the two forms are bit-identical, so a result does not depend on the batch size that selected one of them.
-template <int BM>
+// BN = 64 (with BM = 128): 128 x 64 tiles, two workgroups per CU -- the batch-of-4 shapes (M = 4096) then run as 384 workgroups instead of 192.
+template <int BM, int BN = SBN>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemmParams p) {
-    constexpr int NS = 3, NT = BM * 2, WQ = SBN / (BM / 32) / 8;
-    constexpr int A_STAGE = BM * 128, W_STAGE = SBN * 128, STAGE = A_STAGE + W_STAGE;
-    constexpr int EPI_LD = SBN + 4;
+    constexpr int NS = 3, NT = BM * 2, WQ = BN / (BM / 32) / 8, TJ = BN / 32;   // TJ 16-column MFMA tiles per wave
+    constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128, STAGE = A_STAGE + W_STAGE;
+    constexpr int EPI_LD = BN + 4;
     constexpr int EPI_BYTES = BM * EPI_LD * 4;
     constexpr int SMEM_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemm
     }
     const int mt = bid / p.n_ntiles, nt = bid % p.n_ntiles;
     const long m0 = (long)mt * BM;
-    const int n0 = nt * SBN;
+    const int n0 = nt * BN;
 
     const int drow = lane >> 3, dchunk = lane & 7;
     const unsigned char* asrc[4];
@@ -561,19 +562,19 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemm
                                              (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
     };
 
-    f32x4v acc[4][4];
+    f32x4v acc[4][TJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     // fragment addressing: lane reads row r16 = lane & 15 of a 16-row block, logical chunk plane*4 + (lane >> 4)
     const int r16 = lane & 15, q4 = lane >> 4;
     const int sw = (r16 >> 1) & 7;
     const int ch_hi = ((q4 ^ sw) & 7) << 4, ch_lo = (((4 + q4) ^ sw) & 7) << 4;
     const int a_off = (wm * 64 + r16) * 128;              // + i*16*128
-    const int w_off = A_STAGE + (wn * 64 + r16) * 128;    // + j*16*128
-    struct Frags { bf16x8 ah[4], al[4], bh[4], bl[4]; };
+    const int w_off = A_STAGE + (wn * (BN / 2) + r16) * 128;    // + j*16*128
+    struct Frags { bf16x8 ah[4], al[4], bh[TJ], bl[TJ]; };
     auto load_frags = [&](Frags& f, const unsigned char* sb) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemm
             f.al[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 2048 + ch_lo);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TJ; ++j) {
             f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 2048 + ch_hi);
             f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 2048 + ch_lo);
         }
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemm
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < TJ; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
@@ -616,17 +617,31 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemm
         issue(s2, kt + 2 < nk ? kt + 2 : nk - 1);
         load_frags(nxt, smem + s1 * STAGE);      // tile kt+1: certified by this step's barrier
         mfma48(cur);
+        if constexpr (TJ == 4) {
 #pragma unroll
-        for (int g = 0; g < 4 + WQ; ++g) {   // the step's DMA pieces, two MFMAs apart
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        }
+            for (int g = 0; g < 4 + WQ; ++g) {   // the step's DMA pieces, two MFMAs apart
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if constexpr (48 - 2 * (4 + WQ) - 32 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 48 - 2 * (4 + WQ) - 32, 0);
+        } else {   // 24 MFMAs, 4 + WQ DMA pieces, 12 fragment reads
+#pragma unroll
+            for (int g = 0; g < 4 + WQ; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 24 - (4 + WQ) - 12, 0);
         }
-        if constexpr (48 - 2 * (4 + WQ) - 32 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 48 - 2 * (4 + WQ) - 32, 0);
         const int t = s0; s0 = s1; s1 = s2; s2 = t;
     };
     for (int kt = 0; kt < nk; kt += 2) {
@@ -640,7 +655,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemm
     // ---- epilogue: C/D layout of mfma_16x16: col = lane & 15, rows 4*(lane >> 4) + e; from the staging tile on it is the 32x32x16
     // kernel's (residual, statistics, split32 output)
     float(*stage)[EPI_LD] = reinterpret_cast<float(*)[EPI_LD]>(smem);
-    constexpr int C4 = SBN / 4;             // 32 float4 chunks per staged row
+    constexpr int C4 = BN / 4;              // float4 chunks per staged row
     constexpr int ROWS_PER_PASS = NT / C4;
     constexpr int NROWS = BM / ROWS_PER_PASS;   // 16 rows per thread
     const int ec = (tid % C4) * 4, er = tid / C4;
@@ -660,9 +675,9 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemm
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) stage[wm * 64 + i * 16 + 4 * q4 + e][wn * 64 + j * 16 + r16] = acc[i][j][e];
+            for (int e = 0; e < 4; ++e) stage[wm * 64 + i * 16 + 4 * q4 + e][wn * (BN / 2) + j * 16 + r16] = acc[i][j][e];
     __syncthreads();
     if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
     double ssum[4] = {0.0, 0.0, 0.0, 0.0}, ssq[4] = {0.0, 0.0, 0.0, 0.0};
@@ -747,15 +762,15 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemm
     }
     if (p.stats_part) {   // block-uniform
         __syncthreads();  // the staging tile has been read out
-        double(*red)[SBN][2] = reinterpret_cast<double(*)[SBN][2]>(smem);   // [row groups][128 channels][sum, sum of squares]
+        double(*red)[BN][2] = reinterpret_cast<double(*)[BN][2]>(smem);   // [row groups][128 channels][sum, sum of squares]
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             red[er][ec + c][0] = ssum[c];
             red[er][ec + c][1] = ssq[c];
         }
         __syncthreads();
-        if (tid < 2 * SBN) {
-            const int which = tid / SBN, col = tid % SBN;
+        if (tid < 2 * BN) {
+            const int which = tid / BN, col = tid % BN;
             if (n0 + col < p.N) {
                 double t = 0.0;
 #pragma unroll
@@ -1421,9 +1436,12 @@ static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, co
     if (v < 0) v = 5;
     p.stamps = g_stamps;
     const bool small = v == 5 && !stats_part && ((M + 255) / 256) * ((Cout + SBN - 1) / SBN) < 192;   // (statistics partials: one per 256 rows)
-    const int bm = (v == 2 || small) ? 128 : 256;
+    // ... and 64-column tiles (two workgroups per CU) where even the 128-row tiles leave CUs idle: a batch of 4 at 512^2 is M = 4096,
+    // 192 tiles of 128 x 128 on 256 CUs, 384 of 128 x 64.  All forms give the same bits (same products, same K order).
+    const bool narrow = small && !out_split && ((M + 127) / 128) * ((Cout + SBN - 1) / SBN) < 256 && emd::g_knobs.split_narrow;
+    const int bm = (v == 2 || small) ? 128 : 256, bn = narrow ? 64 : SBN;
     p.n_mtiles = (int)((M + bm - 1) / bm);
-    p.n_ntiles = (Cout + SBN - 1) / SBN;
+    p.n_ntiles = (Cout + bn - 1) / bn;
     const long nblk = (long)p.n_mtiles * p.n_ntiles;
     if (nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "emd_conv1x1_split32_f32: grid too large");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1439,6 +1457,7 @@ static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, co
         hipLaunchKernelGGL(gemm_split_persist_kernel, dim3(grid), dim3(512), 0, st, p);
     }
     else if (v == 2) hipLaunchKernelGGL((gemm_split_kernel<128, 2>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else if (v == 5 && narrow) hipLaunchKernelGGL((gemm_split16_kernel<128, 64>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     else if (v == 5 && small) hipLaunchKernelGGL(gemm_split16_kernel<128>, dim3((unsigned)nblk), dim3(256), 0, st, p);
     else if (v == 5) hipLaunchKernelGGL(gemm_split16_kernel<256>, dim3((unsigned)nblk), dim3(512), 0, st, p);
     else if (v == 6) hipLaunchKernelGGL((gemm_split_kernel<256, 3, true, true>), dim3((unsigned)nblk), dim3(512), 0, st, p);

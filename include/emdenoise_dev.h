@@ -21,6 +21,7 @@
  *   nt_mask (7)         non-temporal output stores: bit 0 split32 convolutions, bit 1 sep_fused, bit 2 pointwise split32 GEMM
  *   dw_xcd (1)          depthwise kernels: 0 = launch-order tiles, 1 = XCD-contiguous up to 128 x 128 maps, 2 = always
  *   dw_th (0)           strip height of the rolling depthwise kernel (0 = rule)
+ *   split_narrow (1)    pointwise split32 GEMM: 128 x 64 tiles for the small batches whose 128 x 128 tiles leave CUs idle (0 = never)
  *   split_variant (-1)  pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
  */
 #ifndef EMDENOISE_DEV_H

@@ -182,7 +182,9 @@ def test_conv1x1_split32_full_size_identity():
     xs = ops.to_split32(xa)
     b = ops.conv1x1(xa, pw, s, t, ops.Act.empty(32, 32, 32, 728, dev()))
     d = ops.conv1x1_split32(xs, pw, s, t, ops.Act.empty(32, 32, 32, 728, dev()))     # the default kernel: 16x16x32 MFMAs, 256-row tiles
-    d4 = ops.conv1x1_split32(ops.to_split32(ops.Act(x[8:12].contiguous())), pw, s, t, ops.Act.empty(4, 32, 32, 728, dev()))   # 128-row tiles
+    d4 = ops.conv1x1_split32(ops.to_split32(ops.Act(x[8:12].contiguous())), pw, s, t, ops.Act.empty(4, 32, 32, 728, dev()))   # 128 x 64 tiles
+    d8 = ops.conv1x1_split32(ops.to_split32(ops.Act(x[16:24].contiguous())), pw, s, t, ops.Act.empty(8, 32, 32, 728, dev()))  # 128 x 128 tiles
+    d1 = ops.conv1x1_split32(ops.to_split32(ops.Act(x[31:32].contiguous())), pw, s, t, ops.Act.empty(1, 32, 32, 728, dev()))
     try:
         _lib.load().emd_debug_split_variant(3)                                        # the 32x32x16 form
         a = ops.conv1x1_split32(xs, pw, s, t, ops.Act.empty(32, 32, 32, 728, dev()))
@@ -191,7 +193,7 @@ def test_conv1x1_split32_full_size_identity():
         _lib.load().emd_debug_split_variant(-1)
     assert torch.equal(a.buf, b.buf)
     assert float((d.buf - b.buf).norm() / b.buf.norm()) < 1e-6
-    assert torch.equal(d4.buf, d.buf[8:12])
+    assert torch.equal(d4.buf, d.buf[8:12]) and torch.equal(d8.buf, d.buf[16:24]) and torch.equal(d1.buf, d.buf[31:32])
 
 
 def test_split32_argument_checks():

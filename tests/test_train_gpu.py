@@ -159,12 +159,20 @@ def test_gradients_with_the_oracles_forward_values():
     assert forced < 5e-5 and forced < free / 100
 
 
+# Bars of the 512^2 tower test = about 2x what the run on record measures (see the docstring); before round 3 they were scaled by the
+# oracle's own float32-vs-float64 noise and let rel L2 0.44 / cosine 0.935 pass.
+BAR_512 = {"norm_ratio": 5e-3, "rel": 3.5e-2, "cos": 0.9995, "worst_norm": 0.15}
+
+
 def test_tower_at_512_against_the_committed_golden():
     """BASELINE configs[3]'s size: ONE tower of graph D' on a 512x512 LQ/HQ pair against tests/golden/dprime_tower_512.json
     (float64 oracle autograd, tests/golden/make_train_golden.py): loss, mse, 64 output probes, the gradient norm of every
     trainable variable, and the relative L2 error / cosine of the whole 38.5 M-element gradient estimated from 48 seeded
-    Rademacher projections.  Bars as in test_gradients_reference_regime (the gradient of a relu6 / clip network is a
-    discontinuous function of the forward values; the fixture records what the oracle's own float32 run shows)."""
+    Rademacher projections.  The gradient of a relu6 / clip network is a discontinuous function of the forward values (the
+    fixture records that the oracle's own float32 run is 0.11 from its float64 run at this size), so the bars are empirical:
+    MEASURED on MI355X (round 3, gpurun_out/r3o/train512.log): |g| 73.7935 vs 73.8028 (1.3e-4), estimated relative L2 1.52e-2,
+    cosine 0.99988, worst per-variable norm ratio off by 7.0e-2; BAR_512 is about twice that.  The backward KERNELS are held to
+    2e-5 / 1e-5 on their own at these layer shapes in tests/test_train_ops_gpu.py (free of mask flips)."""
     import hashlib
     import json
     import os
@@ -199,9 +207,9 @@ def test_tower_at_512_against_the_committed_golden():
     # thirds of a million relu6 / clip units sit within rounding distance of a kink.  The bar for the split-bf16 forward (about
     # 10x float32's forward error => about 3x its mask flips) is therefore set relative to that figure, not to a constant.
     o = meta["oracle_f32_vs_f64"]
-    assert abs(na / meta["flat_l2"] - 1.0) < max(2e-2, 0.5 * o["rel_l2"])
-    assert rel < max(6e-2, 4.0 * o["rel_l2"]) and cos > min(0.998, 1.0 - 10.0 * (1.0 - o["cosine"]))
-    assert worst_norm < max(0.15, 4.0 * o["rel_l2"])
+    assert abs(na / meta["flat_l2"] - 1.0) < BAR_512["norm_ratio"]
+    assert rel < BAR_512["rel"] and cos > BAR_512["cos"]
+    assert worst_norm < BAR_512["worst_norm"]
 
 
 def test_tower_batch_and_accumulation():

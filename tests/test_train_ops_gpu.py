@@ -38,6 +38,15 @@ def leaf(a):
     (1, 16, 16, 128, 64, 3, 1, 6),      # dilated ASPP branch
     (2, 10, 6, 64, 64, 3, 2, 1),
     (2, 64, 64, 64, 128, 1, 1, 1),      # several M splits
+    # the layer shapes of ONE 512 x 512 tower (BASELINE configs[3]): where the M split sized to whole rounds of resident workgroups,
+    # the transposed staging and the atomics run at the sizes training uses (the gradient of the whole tower cannot be held to a
+    # tight bar there -- relu6 mask flips, test_train_gpu.py -- so each backward kernel is, on its own)
+    (1, 512, 512, 64, 64, 1, 1, 1),     # deconv0_b pointwise: M = 262144
+    (1, 512, 512, 128, 64, 1, 1, 1),    # deconv0_a pointwise / residual0_d
+    (1, 256, 256, 384, 128, 1, 1, 1),   # deconv1_a pointwise / residual1_d
+    (1, 128, 128, 384, 256, 1, 1, 1),   # deconv2_a
+    (1, 512, 512, 4, 128, 1, 2, 1),     # residual0: the zero-padded 1-channel image, stride 2
+    (1, 32, 32, 728, 728, 3, 1, 18),    # ASPP rate-18 branch at the tower's 32 x 32: most taps fall into the padding
 ])
 def test_conv_wgrad(B, H, W, ci, co, k, stride, rate):
     from emdenoise import train_ops as TO
@@ -186,7 +195,9 @@ def test_conv_data_gradient(B, H, W, ci, co, k, stride, rate):
 
 # ------------------------------------------------------------------------------------------------ depthwise
 @pytest.mark.parametrize("B,H,W,Cc,stride", [(2, 16, 16, 64, 1), (1, 13, 9, 128, 1), (1, 8, 8, 728, 1), (2, 16, 16, 64, 2),
-                                             (1, 9, 7, 256, 2), (2, 12, 12, 4, 1), (2, 64, 64, 64, 1), (1, 70, 80, 128, 1), (3, 64, 72, 4, 1)])
+                                             (1, 9, 7, 256, 2), (2, 12, 12, 4, 1), (2, 64, 64, 64, 1), (1, 70, 80, 128, 1), (3, 64, 72, 4, 1),
+                                             # one 512 x 512 tower's layers (rolling weight-gradient kernel at full height, stride-2 blocks)
+                                             (1, 512, 512, 64, 1), (1, 256, 256, 128, 1), (1, 512, 512, 64, 2), (1, 128, 128, 384, 1)])
 def test_dw3x3_backward(B, H, W, Cc, stride):
     from emdenoise import ops, train_ops as TO
     from oracle import tf_ops as T
@@ -271,7 +282,8 @@ def _bn_train_t(r, gamma, beta, eps=1e-3):
 
 
 @pytest.mark.parametrize("double", [True, False])
-@pytest.mark.parametrize("B,H,W,Cc,mask", [(2, 8, 8, 64, 1), (1, 16, 16, 728, 1), (2, 32, 32, 1, 2), (3, 5, 7, 128, 0)])
+@pytest.mark.parametrize("B,H,W,Cc,mask", [(2, 8, 8, 64, 1), (1, 16, 16, 728, 1), (2, 32, 32, 1, 2), (3, 5, 7, 128, 0),
+                                           (1, 512, 512, 64, 1), (1, 256, 256, 128, 1)])   # one 512 x 512 tower's largest layers
 def test_bn_train_forward_and_backward(double, B, H, W, Cc, mask):
     """r -> [BN1] -> BN2 -> relu6 [-> clip]: forward affine, moving-average updates and the backward, against
     autograd through two explicit batch-statistic normalisations (the outer one computes ITS statistics from the
@@ -332,6 +344,50 @@ def test_bn_train_forward_and_backward(double, B, H, W, Cc, mask):
     assert rel_l2(dr.torch().cpu().numpy(), gr.numpy()) < 1e-5
     assert rel_l2(dg2.cpu().numpy(), gg2.numpy()) < 1e-5
     assert rel_l2(db2.cpu().numpy(), gb2.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 256, 256, 128), (3, 512, 512, 64)])
+def test_bn_backward_per_image_at_tower_sizes(B, H, W, Cc):
+    """The batched-towers path (emd_bn_stats_images / _train_fold_images / _bn_bwd_{reduce,prep,apply}_images_f32) at the pixel
+    counts of a 512 x 512 tower: image b of the batch gives the bits of the one-image kernels run on it alone (the promise behind
+    DenoiserTrainer.tower(per_image=True)), and image 0 matches float64 autograd through the double batch norm + relu6."""
+    from emdenoise import ops, train_ops as TO
+
+    r = rnd((B, H, W, Cc), 127, 1.5) + 0.7
+    dy = rnd((B, H, W, Cc), 132)
+    g1, b1 = rnd((Cc,), 128, 0.3) + 1.0, rnd((Cc,), 129, 0.3)
+    g2, b2 = rnd((Cc,), 130, 0.3) + 1.2, rnd((Cc,), 131, 0.5) + 1.0
+    ra, dya = to_act(r), to_act(dy)
+    npix = H * W
+    mean, var = ops.bn_batch_stats_images(ra)
+    fold = TO.bn_train_fold(mean, var, d32(g2), d32(b2), npix, gamma1=d32(g1), beta1=d32(b1), images=B)
+    dg1, dg2, db2 = (torch.zeros(Cc, device=dev()) for _ in range(3))
+    dr = TO.bn_backward(dya, ra, fold, d32(g2), dg2, db2, out_act(B, H, W, Cc), mask=1, gamma1=d32(g1), dgamma1=dg1)
+    torch.cuda.synchronize()
+    acc1, acc2, accb = (torch.zeros(Cc, device=dev()) for _ in range(3))
+    for b in range(B):
+        rb, dyb = to_act(r[b:b + 1]), to_act(dy[b:b + 1])
+        m1, v1 = ops.bn_batch_stats(rb)
+        f1 = TO.bn_train_fold(m1, v1, d32(g2), d32(b2), npix, gamma1=d32(g1), beta1=d32(b1))
+        e1, e2, eb = (torch.zeros(Cc, device=dev()) for _ in range(3))
+        drb = TO.bn_backward(dyb, rb, f1, d32(g2), e2, eb, out_act(1, H, W, Cc), mask=1, gamma1=d32(g1), dgamma1=e1)
+        torch.cuda.synchronize()
+        assert torch.equal(drb.torch()[0], dr.torch()[b]), f"image {b}: the batched per-image kernels must give the one-image kernels' bits"
+        acc1 += e1; acc2 += e2; accb += eb
+    # parameter gradients: the batched form adds every image's contribution with float atomics / in another order: 1e-6
+    for got, want in ((dg1, acc1), (dg2, acc2), (db2, accb)):
+        assert float((got - want).norm() / want.norm().clamp_min(1e-20)) < 2e-6
+    # image 0 against float64 autograd
+    rl, l1, lb1, l2, lb2 = leaf(r[0:1]), leaf(g1), leaf(b1), leaf(g2), leaf(b2)
+    z = _bn_train_t(_bn_train_t(rl, l1, lb1), l2, lb2)
+    y = torch.clamp(z, 0.0, 6.0)
+    (gr,) = torch.autograd.grad(y, rl, t64(dy[0:1]))
+    # of 10^7 units one or two sit within float32 rounding of a relu6 kink, where the float32 forward and the float64 oracle pick
+    # different masks (a unit-sized error each): compared away from the kinks
+    away = ((z.detach().abs() > 1e-4) & ((z.detach() - 6.0).abs() > 1e-4)).numpy()
+    got0 = dr.torch()[0:1].cpu().numpy()
+    assert away.mean() > 0.999
+    assert rel_l2(got0[away], gr.numpy()[away]) < 1e-5
 
 
 def test_bias_gradient_reduction():
