@@ -302,6 +302,7 @@ def _side_streams(obj, n):
 # Generator side: _generator_tower_fn (:982-1046) and _train_op (:1330-1388).
 # ================================================================================================
 BN_EPS_GEN = 0.01
+BN_DECAY_GEN = 0.9997        # batch_decay_gen (:112)
 CLIP_GEN = 50.0                # :1379
 WEIGHT_NATURAL_STATS = 12.0    # :1035
 
@@ -310,7 +311,8 @@ class GeneratorTrainer:
     """Generator parameters, gradients and Adam moments on one GPU + the generator tower's forward / reverse pass.
 
     As the reference's loop evaluates it (:1660-1680): the generator's batch norms stay on their MOVING statistics
-    (``batch_norm_on_ph: False``), so each separable conv is depthwise -> pointwise -> fixed affine -> leaky_relu and
+    (``batch_norm_on_ph: False`` is fed whenever the tower gradients are evaluated, :1668 -- in BOTH phases of a run), so each
+    separable conv is depthwise -> pointwise -> fixed affine -> leaky_relu and
     there is no l2 term (decay = 0, :1039); concat(output, truth) is cropped once; the discriminator (phase=True, its
     parameters frozen here) scores the generated crops and supplies 15 feature maps of the generated and of the natural
     crops; loss = -log(clip(D(fake), 1e-8, 1)) + 12 * sum_l mean|f_l(fake) - f_l(natural)|.  The reverse pass goes
@@ -445,6 +447,15 @@ class GeneratorTrainer:
             else:
                 ops.dw3x3(x, self._dw(key), d, stride=L.stride)
         r = ops.conv1x1(d, self.pk_f[key], self.ones, self.zeros, self._E(d.B, Ho, Wo, L.cout), act=False, precision=self.precision)
+        if self._batch_stats:
+            # the train op's update ops (update_moving_statistics): both norms of the block on the BATCH statistics of this tower's
+            # image (the second norm's follow analytically from the first's, as in graph D'), moving averages assigned in the same launch
+            b1, b2 = L.scope + "/BatchNorm", L.outer_bn
+            mean, var = ops.bn_batch_stats(r)
+            f = TO.bn_train_fold(mean, var, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], d.B * Ho * Wo, gamma1=self.v[b1 + "/gamma"],
+                                 beta1=self.v[b1 + "/beta"], eps=BN_EPS_GEN, decay=BN_DECAY_GEN,
+                                 moving=(self.m[b1 + "/moving_mean"], self.m[b1 + "/moving_variance"], self.m[b2 + "/moving_mean"],
+                                         self.m[b2 + "/moving_variance"]))
         y = ops.affine_act(r, f["scale"], f["shift"], self._E(d.B, Ho, Wo, L.cout), act=ops.ACT_LEAKY, res=res)
         return y, {"x": x, "d": d, "r": r, "x_img": x_img}
 
@@ -486,18 +497,16 @@ class GeneratorTrainer:
             TO.dw3x3_bwd_data(dd, self._dw(key), dx, stride=L.stride)
         return dx
 
-    # ---- one tower
-    def tower(self, lq, truth, offsets):
-        """lq, truth: torch CUDA float32 [1,S,S,1] (missing pixels of lq = -1).  Adds the generator gradients into
-        self.grads.  -> (output [1,S,S,1], device tensor [D(fake), adversarial loss], device tensor [stat loss * 12])."""
+    _batch_stats = False   # True only inside update_moving_statistics
+
+    def _generator_forward(self, lq):
+        """generator_architecture (:133-374) on one image [1,S,S,1] with the trainer's parameters -> saved contexts + output."""
         import torch
 
         from . import gan as GN
 
-        assert lq.shape[0] == 1 and lq.shape[3] == 1 and truth.shape == lq.shape
         S = lq.shape[1]
         dev = self.device
-        self._pad_dirty = True
         C = {}
         # ---------------- generator forward (:341-372)
         enc0, C["enc0"] = self._sep_fwd("enc0", None, x_img=lq)
@@ -538,6 +547,37 @@ class GeneratorTrainer:
         out = torch.empty_like(raw)
         _lib.check(_lib.load().emd_instnorm_tanh_f32(ops._p(raw), ops._p(mean), ops._p(var), ops._p(out), 1, ops.C.c_long(S * S),
                                                      ops.C.c_float(GN.IN_EPS), _lib.stream_ptr()), "emd_instnorm_tanh_f32")
+        return C, out, raw, rawa, mean, var, fold_in, last
+
+    def update_moving_statistics(self, lq):
+        """What the reference's generator train op does besides applying the gradients while ``train_batch_norm_on`` (counter <
+        250 000, :1644, :1708-1712): the update ops of tower 0's batch norms (:866-871, :1384) run with batch_norm_on_ph = True -- one
+        forward pass of the generator on tower 0's image with every norm on BATCH statistics (each layer fed by the batch-normalised
+        output of the one before), assigning moving <- moving - (moving - batch) * (1 - 0.9997), the variance Bessel-corrected as the
+        fused batch norm does.  No gradient passes through it: the tower gradients themselves are evaluated with batch_norm_on_ph
+        False in both phases (:1668).  Afterwards the inference folds are rebuilt (repack)."""
+        self._batch_stats = True
+        try:
+            out = self._generator_forward(lq[0:1].contiguous())[1]
+        finally:
+            self._batch_stats = False
+        self.repack()
+        return out
+
+    # ---- one tower
+    def tower(self, lq, truth, offsets):
+        """lq, truth: torch CUDA float32 [1,S,S,1] (missing pixels of lq = -1).  Adds the generator gradients into
+        self.grads.  -> (output [1,S,S,1], device tensor [D(fake), adversarial loss], device tensor [stat loss * 12])."""
+        import torch
+
+        from . import gan as GN
+
+        assert lq.shape[0] == 1 and lq.shape[3] == 1 and truth.shape == lq.shape
+        S = lq.shape[1]
+        dev = self.device
+        self._pad_dirty = True
+        C, out, raw, rawa, mean, var, fold_in, last = self._generator_forward(lq)
+        w_last = self.v[self.conv_scope + "/weights"].view(9, GN.gen_features3)
         # ---------------- discriminator on the generated and on the natural crops (same offsets, :1008-1015)
         D = self.D
         crops_f = multiscale_crops(out, offsets)
@@ -627,7 +667,7 @@ class GeneratorTrainer:
 
 
 def gan_iteration(G: GeneratorTrainer, D: DiscriminatorTrainer, lq, truth, offsets, lr_gen=0.0002, label_real=1.0, label_fake=0.0,
-                  adapts=None, group=None, streams=1, lr_t_dev=None, labels=None, train="both"):
+                  adapts=None, group=None, streams=1, lr_t_dev=None, labels=None, train="both", batch_norm_on=False):
     """One iteration of the reference's training loop (:1650-1790), deterministic parts: (1) the generator towers on
     this rank's [T,S,S,1] batch and the generator's Adam step (:1660-1700); (2) the discriminator trained on the T
     generated images (label_fake) and the T natural ones (label_real) with learning rate lr_gen/2 (:1645) -- 2T towers,
@@ -639,7 +679,9 @@ def gan_iteration(G: GeneratorTrainer, D: DiscriminatorTrainer, lq, truth, offse
     draws (:1733-1737, :1772-1776).  train: "both" (default), "gen" (:1700-1703: the generator's train op only; the discriminator
     is not trained this iteration and the second result is None) or "discr" (:1704-1806: the generator towers still run -- they
     produce the images the discriminator is shown -- but its optimizer step is skipped): the reference trains ONE of the two
-    per iteration, chosen by GanPolicy.observe.
+    per iteration, chosen by GanPolicy.observe.  batch_norm_on (GanPolicy.batch_norm_on(counter): True for the first 250 000
+    iterations, :1644): the generator's train op also refreshes its moving statistics from tower 0's batch statistics
+    (GeneratorTrainer.update_moving_statistics) -- the gradients are on moving statistics either way, as in the reference.
     -> (generator results [T,3], discriminator results [2T,2] or None)."""
     import torch
 
@@ -672,6 +714,8 @@ def gan_iteration(G: GeneratorTrainer, D: DiscriminatorTrainer, lq, truth, offse
         gn2 = TO.sumsq(G.grads, scale=scale)
         if lr_t_dev is None:
             G.t += 1
+        if batch_norm_on:   # the update ops read the variables the towers were evaluated with (tf.group leaves the order open; this one is defined)
+            G.update_moving_statistics(lq)
         TO.adam_step(G.params, G.grads, G.adam_m, G.adam_v, G.t, lr_gen, beta1=ADAM_BETA1, grad_scale=scale, gnorm_sq=gn2, clip_norm=CLIP_GEN,
                      lr_t_dev=None if lr_t_dev is None else lr_t_dev[0:1])
         G.repack()

@@ -73,6 +73,7 @@ class _Gen:
         self.get, self.dtype, self.sc = get, dtype, _Scope("GAN/Gen")
         self.trace = None
         self.calibrate = None  # optional dict: batch statistics of every BN input are written here AND used
+        self.moving_updates = None   # dict: train_batch_norm = True (:170) -- batch statistics are used and the moving averages updated
 
     def _bn(self, x, scope):
         C = x.shape[-1]
@@ -83,6 +84,12 @@ class _Gen:
             self.calibrate[scope + "/moving_mean"] = mean.to(torch.float32).numpy().copy()
             self.calibrate[scope + "/moving_variance"] = var.to(torch.float32).numpy().copy()
             mean, var = mean.to(torch.float32).to(self.dtype), var.to(torch.float32).to(self.dtype)
+        if self.moving_updates is not None:   # is_training=True: tf.contrib.layers.batch_norm, fused, decay batch_decay_gen = 0.9997 (:112)
+            bm, bv = x.mean(dim=(0, 1, 2)), x.var(dim=(0, 1, 2), unbiased=False)
+            n = x.shape[0] * x.shape[1] * x.shape[2]
+            self.moving_updates[scope + "/moving_mean"] = mean - (mean - bm) * (1.0 - 0.9997)
+            self.moving_updates[scope + "/moving_variance"] = var - (var - bv * (n / max(n - 1, 1))) * (1.0 - 0.9997)   # Bessel-corrected
+            mean, var = bm, bv
         return (x - mean) * (gamma / torch.sqrt(var + BN_EPS_GEN)) + beta
 
     def batch_then_activ(self, x):
@@ -152,6 +159,25 @@ class _Gen:
         wt = w.permute(3, 2, 0, 1).contiguous()
         enc = F.conv2d(reflect_pad_t(enc, 1).permute(0, 3, 1, 2), wt, b).permute(0, 2, 3, 1)
         return torch.tanh(self.instance_norm(enc))
+
+
+def generator_moving_update(inputs, weights, cropsize=512, dtype=torch.float64):
+    """The generator train op's update ops while train_batch_norm_on (gan-infilling-100.py:1644, :1708-1712, :866-871, :1384): one
+    forward pass with is_training = True on every batch norm (:164-174) -> (output, {moving statistic name: updated value})."""
+    cache = {}
+
+    def get(name, shape):
+        if name not in cache:
+            w = weights[name]
+            assert tuple(w.shape) == tuple(shape), (name, w.shape, shape)
+            cache[name] = torch.from_numpy(np.ascontiguousarray(w)).to(dtype)
+        return cache[name]
+
+    g = _Gen(get, dtype)
+    g.moving_updates = {}
+    x = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(inputs))
+    out = g.build(x.to(dtype), cropsize)
+    return out, {k: v.numpy() for k, v in g.moving_updates.items()}
 
 
 def variable_specs(cropsize=64) -> "OrderedDict[str, tuple]":

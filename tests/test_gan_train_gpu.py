@@ -129,6 +129,65 @@ def test_generator_tower_gradients():
     assert rel_l2(a, b) < 8e-2 and cosine(a, b) > 0.997
 
 
+def test_generator_moving_statistics_phase():
+    """The first 250 000 iterations of a reference run (train_batch_norm_on, gan-infilling-100.py:1644): the generator's train op
+    also runs tower 0's batch-norm update ops with batch_norm_on_ph = True (:866-871, :1384, :1708-1712) -- one forward pass on BATCH
+    statistics that assigns the moving averages (decay 0.9997, Bessel-corrected variance) -- while the tower GRADIENTS are evaluated
+    with batch_norm_on_ph False in both phases (:1668).  At S = 512: every updated moving statistic against the oracle's float64
+    restatement (oracle/gan_graph.py generator_moving_update); then the tower of the NEXT iteration (moving statistics, now the
+    refreshed ones) against the oracle's tower on the oracle's refreshed statistics -- the gradient parity of phase one."""
+    from emdenoise import gan as GN
+    from emdenoise import gan_trainer as GT
+    from oracle import gan_graph as GG
+
+    wg, wd = dict(GN.synthetic_weights()), GN.discriminator_synthetic_weights()
+    # the shipped moving statistics were calibrated ON batch statistics (moving ~ batch: an update of 3e-4 x nothing); move them
+    # away first so that the update is a vector float32 can resolve
+    for n in list(wg):
+        if n.endswith("/moving_mean"):
+            wg[n] = (wg[n] + 0.25).astype(np.float32)
+        elif n.endswith("/moving_variance"):
+            wg[n] = (wg[n] * 1.5).astype(np.float32)
+    hq = images(1, 41)
+    lq = GN.gen_lq(hq[..., 0])[..., None]
+    out_ref, upd = GG.generator_moving_update(lq, wg, S)
+    D = GT.DiscriminatorTrainer(wd, dev())
+    tr = GT.GeneratorTrainer(wg, D, dev())
+    before = {n: v.copy() for n, v in tr.state_dict().items() if "moving_" in n}
+    tr.update_moving_statistics(torch.from_numpy(lq).to(dev()))
+    torch.cuda.synchronize()
+    st = tr.state_dict()
+    assert set(upd) == set(before), "every moving statistic of the generator is refreshed, nothing else"
+    worst = 0.0
+    for n, want in upd.items():
+        step_ref, step_got = want - np.asarray(wg[n], np.float64), st[n].astype(np.float64) - before[n]
+        worst = max(worst, rel_l2(step_got, step_ref))      # the UPDATE (3e-4 of the distance to the batch statistic), not the value
+        assert rel_l2(st[n], want) < 1e-6, n
+    print(f"generator moving-statistics update at {S} px: worst relative error of an update vector {worst:.2e}")
+    assert worst < 5e-3
+    # phase one's gradients: moving statistics (the refreshed ones) -- the oracle's tower on ITS refreshed statistics
+    wg2 = dict(wg)
+    wg2.update({n: v.astype(np.float32) for n, v in upd.items()})
+    ref = GG.generator_tower(lq, hq, wg2, wd, OFFSETS)
+    tr.zero_grad()
+    out, res, stat = tr.tower(torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev()), OFFSETS)
+    g = tr.gradients()
+    names = [n for n in g if np.abs(ref["grads"][n]).max() > 1e-9]
+    a, b = flat(g, names), flat(ref["grads"], names)
+    print(f"G tower after the update: out {rel_l2(out.cpu().numpy(), ref['output']):.2e}, grads rel-l2 {rel_l2(a, b):.2e} cos {cosine(a, b):.5f}")
+    assert rel_l2(out.cpu().numpy(), ref["output"]) < 1e-3
+    assert rel_l2(a, b) < 8e-2 and cosine(a, b) > 0.997
+    # and through gan_iteration: the flag refreshes the statistics, its absence leaves them alone
+    G2 = GT.GeneratorTrainer(wg, GT.DiscriminatorTrainer(wd, dev()), dev())
+    x, t = torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev())
+    m0 = G2.moving.clone()
+    GT.gan_iteration(G2, G2.D, x, t, [OFFSETS], train="gen", batch_norm_on=False)
+    assert torch.equal(G2.moving, m0)
+    GT.gan_iteration(G2, G2.D, x, t, [OFFSETS], train="gen", batch_norm_on=True)
+    torch.cuda.synchronize()
+    assert not torch.equal(G2.moving, m0)
+
+
 def test_generator_step_optimizer_arithmetic():
     """One generator step: the tower's gradient, clipped to global norm 50, through Adam(beta1 0.5), checked on the
     trainer's own gradient; the discriminator's parameters must not move."""
@@ -379,7 +438,8 @@ def test_policy_driven_iterations():
         lr_g, _ = GP.learning_rates(counter)
         train = "gen" if policy.train_gen else "discr"
         labels, adapts = policy.labels(T, T)
-        rg, rd = GT.gan_iteration(G, D, x, t, offs, lr_gen=lr_g, labels=labels, adapts=adapts, train=train)
+        rg, rd = GT.gan_iteration(G, D, x, t, offs, lr_gen=lr_g, labels=labels, adapts=adapts, train=train,
+                                  batch_norm_on=GP.batch_norm_on(counter))
         torch.cuda.synchronize()
         g_moved, d_moved = not torch.equal(G.params, g_before), not torch.equal(D.params, d_before)
         assert (g_moved, d_moved) == ((True, False) if train == "gen" else (False, True)), (counter, train, g_moved, d_moved)
