@@ -765,10 +765,12 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
         g->P[d.key] = p;
     }
     if (!ok) {
+        // a missing / mis-sized variable names itself in err; everything else on this path is a device allocation or upload
+        const bool dev_failure = err.find("device allocation") != std::string::npos || err.find("upload") != std::string::npos;
         emd::set_error("%s", err.c_str());
         for (void* q : g->allocs) (void)hipFree(q);
         delete g;
-        return EMD_E_INVALID;
+        return dev_failure ? EMD_E_ALLOC : EMD_E_INVALID;
     }
     *out = g;
     return EMD_OK;
@@ -776,11 +778,19 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
 
 extern "C" size_t emd_graph_workspace_bytes(emd_graph* g, int B, int S) {
     if (!g || B < 1 || S < 16 || S % 16) return 0;
-    Arena ar;
-    ar.measuring = true;
-    Run r{g, &ar, nullptr, true};
-    r.forward(nullptr, nullptr, B, S);
-    return ar.peak + 256;
+    // the larger of the two launch forms: a size asked for before emd_graph_set_two_streams stays valid after it
+    size_t need = 0;
+    const bool keep = g->two_streams;
+    for (int mode = 0; mode < 2; ++mode) {
+        g->two_streams = mode != 0;
+        Arena ar;
+        ar.measuring = true;
+        Run r{g, &ar, nullptr, true};
+        r.forward(nullptr, nullptr, B, S);
+        need = ar.peak > need ? ar.peak : need;
+    }
+    g->two_streams = keep;
+    return need + 256;
 }
 
 extern "C" int emd_graph_run(emd_graph* g, const float* x, float* y, int B, int S, void* workspace, size_t workspace_bytes,

@@ -191,9 +191,10 @@ __device__ inline long poisson_ptrs(double lam, unsigned long long pix, unsigned
     const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
     const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
     for (unsigned attempt = 0; attempt < 64; ++attempt) {   // acceptance > 0.7 per attempt: 64 fail with probability < 1e-33
-        // counter word 2 = 1 + attempt (0 is the small-lambda draw); the image index is folded into the key
-        const U4 r = philox4x32_10(U4{(unsigned)pix, (unsigned)(pix >> 32), 1u + attempt, kTagPoisson}, k0 ^ (unsigned)img,
-                                   k1 ^ (unsigned)(img >> 32));
+        // counter = (pixel, image low word, draw | image high bits << 8, tag), draw = 1 + attempt (0 is the small-lambda draw); the key
+        // is the seed alone.  (Until round 3 the image index was XORed into the key: seed 0 / image 1 and seed 1 / image 0 then drew
+        // the same noise field -- a per-rank seed scheme would have given ranks identical Poisson noise.)
+        const U4 r = philox4x32_10(U4{(unsigned)pix, (unsigned)img, (1u + attempt) | ((unsigned)(img >> 32) << 8), kTagPoisson}, k0, k1);
         const double U = u01(r.x, r.y) - 0.5, V = u01(r.z, r.w);
         const double us = 0.5 - fabs(U);
         const long k = (long)floor((2.0 * a / us + b) * U + lam + 0.43);
@@ -222,12 +223,12 @@ __global__ void __launch_bounds__(256) poisson_counts_kernel(const float* __rest
     double sumi = 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)nslab * 256) {
         const float v = img[(long)b * npix + i];
-        const double lam = (double)v * sc;   // numpy: float32 image * python float -> float64 product
+        const double lam = (double)v * sc;   // the rate in double (the reference's NumPy 1.x keeps float32 image * np.float64 scalar in float32:
+                                             // the last bits of a rate of ~100 counts, statistically irrelevant -- the sampler is not bit-matched anyway)
         long k = 0;
         if (lam > 0.0 && lam < 1e9) {
             if (lam < 10.0) {
-                const U4 r = philox4x32_10(U4{(unsigned)i, (unsigned)((unsigned long long)i >> 32), 0u, kTagPoisson},
-                                           k0 ^ (unsigned)gimg, k1 ^ (unsigned)(gimg >> 32));
+                const U4 r = philox4x32_10(U4{(unsigned)i, (unsigned)gimg, (unsigned)(gimg >> 32) << 8, kTagPoisson}, k0, k1);
                 k = poisson_small(lam, u01(r.x, r.y));
             } else {
                 k = poisson_ptrs(lam, (unsigned long long)i, gimg, k0, k1);
@@ -278,9 +279,10 @@ __global__ void gen_lq_final_kernel(const int2* __restrict__ part_mm, const doub
         si += __shfl_xor(si, o);
     }
     if (threadIdx.x == 0) {
-        // mean(lq) with lq = (c - mn) / (mx - mn):  (sum c / n - mn) / (mx - mn); constant counts -> lq = 0.5 everywhere
+        // mean(lq) with lq = (c - mn) / (mx - mn):  (sum c / n - mn) / (mx - mn).  Constant counts: the reference's scale0to1 receives
+        // the INT64 Poisson array there and ndarray.fill(0.5) on int64 stores 0 (denoiser-multi-gpu.py:797, :824): lq = 0, truth = 0 * img
         const double n = (double)npix;
-        const double mean_lq = (mx == mn) ? 0.5 : (sc / n - (double)mn) / ((double)mx - (double)mn);
+        const double mean_lq = (mx == mn) ? 0.0 : (sc / n - (double)mn) / ((double)mx - (double)mn);
         const double mean_img = si / n;
         stats[3 * b + 0] = (double)mn;
         stats[3 * b + 1] = (double)mx;
@@ -298,7 +300,7 @@ __global__ void gen_lq_apply_kernel(const int* __restrict__ counts, const float*
     const double d = mx - mn;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
         const long k = (long)b * npix + i;
-        lq[k] = (mx == mn) ? 0.5f : (float)(((double)counts[k] - mn) / d);
+        lq[k] = (mx == mn) ? 0.f : (float)(((double)counts[k] - mn) / d);   // constant counts: 0, not 0.5 (int64 fill, see above)
         if (truth) truth[k] = ratio * img[k];
     }
 }

@@ -58,7 +58,8 @@ def scale0to1(img):
     img = np.asarray(img)
     lo, hi = np.min(img), np.max(img)
     if lo == hi:
-        return np.full(img.shape, 0.5, np.float32)
+        # the reference's img.fill(0.5): 0.5 for a float image -- and 0 for the int64 Poisson counts gen_lq hands over (:797; fill casts)
+        return np.full(img.shape, 0.0 if np.issubdtype(np.asarray(img).dtype, np.integer) else 0.5, np.float32)
     return ((img - lo) / (hi - lo)).astype(np.float32)
 
 

@@ -37,6 +37,7 @@ extern "C" {
 #define EMD_E_UNSUPPORTED (-2) /* valid request this build has no kernel for */
 #define EMD_E_ALIGN (-3)       /* pointer / stride alignment requirement not met */
 #define EMD_E_LAUNCH (-4)      /* HIP reported an error at launch */
+#define EMD_E_ALLOC (-5)       /* a device allocation or upload inside the library failed (emd_graph_create only) */
 
 typedef void* emd_stream_t; /* hipStream_t */
 
@@ -610,7 +611,12 @@ int emd_gen_lq_f32(const float* img, const float* scale, float* lq, float* truth
  * bit-identical results.  variant: 0 = graph D; 1 = graph D', the inference graph of the training twin
  * misc_py/denoiser-multi-gpu.py:200-540 (phase=False): tf.layers variable names (nn/conv2d[_k]/{kernel,bias}, nn/conv2d_transpose[_k]/...,
  * the ASPP convs nn/{1x1,lowRate,mediumRate,highRate,imageLevel,pellet}), dense dilated 3x3 ASPP branches, a real image-level
- * branch, output clipped to [0,1] (:534-538). */
+ * branch, output clipped to [0,1] (:534-538).
+ * A handle is NOT re-entrant: emd_graph_run calls on one handle must be serialised by the caller (one stream, one thread at a
+ * time) -- the fork / join events and the side streams of the two-streams form belong to the handle; use one handle per
+ * concurrent stream (the weights are ~100 MB).  emd_graph_workspace_bytes returns the larger of the two launch forms' needs, so a
+ * size asked for before emd_graph_set_two_streams stays valid after it.  emd_graph_create returns EMD_E_ALLOC when a device
+ * allocation or upload fails (EMD_E_INVALID: a missing / mis-sized variable). */
 typedef struct emd_graph emd_graph_t;
 int emd_graph_create(emd_graph_t** graph, int variant, int n_vars, const char* const* names, const float* const* host_data,
                      const long* counts);
@@ -619,8 +625,8 @@ int emd_graph_run(emd_graph_t* graph, const float* x, float* y, int B, int S, vo
                   emd_stream_t stream);
 void emd_graph_destroy(emd_graph_t* graph);
 /* Launch-order option (speed only, same bits): on != 0 runs the 1/16-resolution flow (denoiser.py:312-325) of an even batch as two
- * halves on two internal streams, forked from and joined to `stream` (capturable), as the Python engine does; the workspace size
- * changes with it (ask emd_graph_workspace_bytes afterwards).  Default off: measured slower from a host that enqueues as fast as C
+ * halves on two internal streams, forked from and joined to `stream` (capturable), as the Python engine does.  If the side
+ * streams cannot be created the run falls back to the single-stream sequence (same results).  Default off: measured slower from a host that enqueues as fast as C
  * does. */
 int emd_graph_set_two_streams(emd_graph_t* graph, int on);
 

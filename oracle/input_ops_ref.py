@@ -68,7 +68,8 @@ def scale0to1(img):
     """:817-828."""
     lo, hi = np.min(img), np.max(img)
     if lo == hi:
-        return np.full(img.shape, 0.5, np.float32)
+        # img.fill(0.5): 0.5 for a float image, but ZERO for the int64 Poisson counts gen_lq passes in (:797 -- fill casts to the dtype)
+        return np.full(img.shape, 0.0 if np.issubdtype(np.asarray(img).dtype, np.integer) else 0.5, np.float32)
     return ((img - lo) / (hi - lo)).astype(np.float32)
 
 

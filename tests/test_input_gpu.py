@@ -73,7 +73,7 @@ def test_scale0to1_bit_exact_and_constant_image(rp):
 def test_gen_lq_tail_is_exact_given_the_counts(rp):
     rng = np.random.default_rng(9)
     img = np.stack([R.scale0to1(rng.random((128, 128)).astype(np.float32) ** 2) for _ in range(4)])[..., None]
-    img[3] = 0.0                                                   # an all-zero image: every count 0 -> lq 0.5 everywhere
+    img[3] = 0.0                                                   # an all-zero image: every count 0 -> lq 0 (int64 fill(0.5) stores 0)
     scale = np.array([30.0, 110.0, 700.0, 50.0], np.float32)
     lq, truth, counts = rp.gen_lq(torch.from_numpy(img).to(rp.device), torch.from_numpy(scale).to(rp.device), want_counts=True)
     lq, truth, counts = lq.cpu().numpy(), truth.cpu().numpy(), counts.cpu().numpy()
@@ -83,7 +83,8 @@ def test_gen_lq_tail_is_exact_given_the_counts(rp):
         np.testing.assert_array_equal(lq[b], ref_lq)               # float64 division rounded to float32, as numpy does it
         np.testing.assert_allclose(truth[b], ref_truth, rtol=2e-6)
         assert np.isclose(truth[b].mean(), lq[b].mean(), rtol=1e-5)   # truth carries the LQ mean (:868)
-    assert (counts[3] == 0).all() and (lq[3] == 0.5).all()
+    assert (counts[3] == 0).all() and (lq[3] == 0.0).all()
+    assert np.isnan(truth[3]).all()                                # (0 / 0) * img, as the reference computes it for an all-zero image
 
 
 def test_poisson_moments_per_intensity_bin(rp):
@@ -138,6 +139,13 @@ def test_draws_depend_on_image_and_pixel_not_on_batching(rp):
     rp.next_image = 0
     assert torch.equal(c_all[3:], c_tail)
     assert not torch.equal(c_all[0], c_all[1])
+    # the seed is the Philox KEY and the image index sits in the COUNTER: (seed, image) pairs with equal XOR -- seed 0 / image 1 and
+    # seed 1 / image 0, what a "seed = base + rank" scheme produces -- draw different noise fields
+    from emdenoise import input_pipeline as ip
+
+    a = ip.DeviceRecordParser(rp.device, seed=0, first_image=1).gen_lq(x[:1].contiguous(), scale[:1].contiguous(), want_counts=True)[2]
+    b = ip.DeviceRecordParser(rp.device, seed=1, first_image=0).gen_lq(x[:1].contiguous(), scale[:1].contiguous(), want_counts=True)[2]
+    assert not torch.equal(a, b)
 
 
 def test_record_parser_end_to_end(rp):

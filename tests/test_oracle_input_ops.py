@@ -68,4 +68,8 @@ def test_lq_and_truth_from_counts_match_the_host_gen_lq():
     np.testing.assert_array_equal(lq, lq2)
     np.testing.assert_array_equal(truth2, ((np.mean(lq) / np.mean(img)) * img).astype(np.float32))
     flat = np.full((8, 8), 3, np.int64)
-    assert (R.lq_and_truth_from_counts(flat, np.ones((8, 8), np.float32))[0] == 0.5).all()           # constant counts -> 0.5
+    # constant counts: the reference's scale0to1 fills an INT64 array with 0.5, which stores 0 (denoiser-multi-gpu.py:797, :824)
+    lq0, truth0 = R.lq_and_truth_from_counts(flat, np.ones((8, 8), np.float32))
+    assert (lq0 == 0.0).all() and (truth0 == 0.0).all()
+    assert (ip.gen_lq(np.ones((8, 8), np.float32), 3.0, Fixed(flat)) == 0.0).all()
+    assert (ip.scale0to1(np.full((4, 4), 2.5, np.float32)) == 0.5).all()                               # a constant FLOAT image: 0.5 (:823-824)
