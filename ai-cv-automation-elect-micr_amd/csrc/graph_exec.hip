@@ -315,9 +315,13 @@ struct Run {
         } else {
             out = out_opt ? *out_opt : E(x.B, Ho, Wo, d.cout);
         }
-        if (emd_sep3x3_fused_supported(x.H, x.W, d.cin, d.cout, d.stride, d.rate)) {
+        if (emd_sep3x3_fused_supported(x.H, x.W, d.cin, d.cout, d.stride, d.rate) && !(d.stride == 2 && want_split)) {
             if (live()) {
-                if (want_split)
+                if (d.stride == 2)
+                    call(emd_sep3x3_fused_s2_f32(x.ptr(), x.ld, p.dw, p.pw.hi, p.pw.lo, p.scale, p.shift, p.scale2, p.shift2,
+                                                 res ? res->ptr() : nullptr, res ? res->ld : 0, out.ptr(), out.ld, x.B, x.H, x.W, d.cin,
+                                                 d.cout, EMD_ACT_RELU6, st));
+                else if (want_split)
                     call(emd_sep3x3_fused_out_f32(x.ptr(), x.ld, p.dw, p.pw.hi, p.pw.lo, p.scale, p.shift, p.scale2, p.shift2,
                                                   res ? res->ptr() : nullptr, res ? res->ld : 0, *split_out, ld_split, x.B, x.H, x.W, d.cin,
                                                   d.cout, EMD_ACT_RELU6, st));

@@ -523,7 +523,14 @@ int launch_dual(const SepParams& p, int B, hipStream_t st) {
 // rule takes it up to Cin = 256.  dev knob sep_wide: 0 = never, 2 = whenever it fits.
 inline int sep_wide() { return g_knobs.sep_wide; }
 
+// stride 2 (round 3): only the LDS-DMA pipelined kernel has the form (csrc/sep_pipe.hip, STRIDE = 2) -- even sizes with H % 8 == 0,
+// W % 32 == 0 (output tiles of 4 x 16 pixels), Cout <= 256; emd_sep3x3_fused_s2_f32
+static bool sep_s2_supported(int H, int W, int Cin, int Cout) {
+    return H % 8 == 0 && W % 32 == 0 && Cin % 32 == 0 && Cin >= 32 && Cin <= 4064 && Cout % 4 == 0 && Cout >= 4 && Cout <= 256;
+}
+
 extern "C" int emd_sep3x3_fused_supported(int H, int W, int Cin, int Cout, int stride, int rate) {
+    if (stride == 2 && rate == 1) return sep_s2_supported(H, W, Cin, Cout);
     const bool wide = Cout > 128 && Cout <= 256 && (sep_wide() == 2 || (sep_wide() == 1 && Cin <= 256));
     return stride == 1 && rate == 1 && H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && Cin >= 32 && Cin <= 4096 && Cout % 4 == 0 &&
            Cout >= 4 && (Cout <= 128 || wide);
@@ -560,7 +567,7 @@ static int sep_fused_entry(const float* x, int ldx, const float* dw, const uint1
     p.x = x; p.dw = dw; p.Whi = whi; p.Wlo = wlo; p.y = y; p.res = res;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
-    p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act; p.reflect = reflect;
+    p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act; p.reflect = reflect; p.stride = 1;
     p.gen_a = gen_a; p.gen_t = gen_t; p.gen_act = gen_act; p.out_split = out_split ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (emd::sep_pipe_covers(p, precision)) return emd::sep_pipe_launch(p, B, st);   // W % 32 == 0: the LDS-DMA pipelined kernel
@@ -587,6 +594,37 @@ extern "C" int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, co
                                     int precision, emd_stream_t stream) {
     return sep_fused_entry(x, ldx, dw, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, B, H, W, Cin, Cout, act,
                            precision, 0, stream);
+}
+
+// The stride-2 separable block (strided_conv_block(stride=2), machine_learning/denoiser.py:258, :273, :288) in one launch: x [B,H,W,Cin]
+// (H, W even; TF SAME = no padding before, one pixel after) -> y [B,H/2,W/2,Cout].  Split-bf16.  Same arithmetic as emd_dw3x3_f32(stride 2)
+// followed by emd_conv1x1_f32; the depthwise result never exists in memory.
+extern "C" int emd_sep3x3_fused_s2_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                                       const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                                       const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                                       emd_stream_t stream) {
+    EMD_REQUIRE(x && dw && whi && wlo && scale1 && shift1 && y, EMD_E_INVALID, "emd_sep3x3_fused_s2_f32: null pointer");
+    EMD_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), EMD_E_INVALID, "emd_sep3x3_fused_s2_f32: scale2/shift2 pair");
+    EMD_REQUIRE(B >= 0 && H >= 2 && W >= 2, EMD_E_INVALID, "emd_sep3x3_fused_s2_f32: bad shape");
+    EMD_REQUIRE(sep_s2_supported(H, W, Cin, Cout), EMD_E_UNSUPPORTED,
+                "emd_sep3x3_fused_s2_f32: needs H%8==0, W%32==0, Cin%32==0, Cout%4==0, Cout<=256 (use emd_dw3x3_f32 + emd_conv1x1_f32)");
+    EMD_REQUIRE(B <= 65535, EMD_E_UNSUPPORTED, "emd_sep3x3_fused_s2_f32: B > 65535");
+    EMD_REQUIRE(ldx % 4 == 0 && ldx >= Cin && ldy % 4 == 0 && ldy >= Cout && (!res || (ldres % 4 == 0 && ldres >= Cout)), EMD_E_ALIGN,
+                "emd_sep3x3_fused_s2_f32: pixel strides must be multiples of 4 and >= the channel count");
+    EMD_REQUIRE(9L * W * (ldy > ldres ? ldy : ldres) < (1L << 31), EMD_E_UNSUPPORTED,
+                "emd_sep3x3_fused_s2_f32: 9 image rows of the output must span fewer than 2^31 floats");
+    EMD_REQUIRE(emd::aligned16(x) && emd::aligned16(dw) && emd::aligned16(whi) && emd::aligned16(wlo) && emd::aligned16(y) &&
+                    (!res || emd::aligned16(res)) && emd::aligned16(scale1) && emd::aligned16(shift1) &&
+                    (!scale2 || (emd::aligned16(scale2) && emd::aligned16(shift2))),
+                EMD_E_ALIGN, "emd_sep3x3_fused_s2_f32: pointers must be 16-byte aligned");
+    if (B == 0) return EMD_OK;
+    SepParams p{};
+    p.x = x; p.dw = dw; p.Whi = whi; p.Wlo = wlo; p.y = y; p.res = res;
+    p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
+    p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
+    p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act; p.stride = 2;
+    EMD_REQUIRE(emd::sep_pipe_covers(p, 3), EMD_E_UNSUPPORTED, "emd_sep3x3_fused_s2_f32: the pipelined kernel is switched off (dev knob sep_pipe)");
+    return emd::sep_pipe_launch(p, B, static_cast<hipStream_t>(stream));
 }
 
 // emd_sep3x3_fused_f32 writing y as a split32 tensor (Cout % 32 == 0; pitch ldy 4-byte units, % 32): the producer of a split32
@@ -673,7 +711,7 @@ extern "C" int emd_sep3x3_dual_f32(const float* x, int ldx, const float* dw, con
     p.x = x; p.dw = dw; p.Whi = whi; p.Wlo = wlo; p.y = y; p.res = nullptr;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = nullptr; p.shift2 = nullptr;
     p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
-    p.ldx = ldx; p.ldy = ldy; p.ldres = 0; p.act = act; p.reflect = 0;
+    p.ldx = ldx; p.ldy = ldy; p.ldres = 0; p.act = act; p.reflect = 0; p.stride = 1;
     p.W2hi = w2hi; p.W2lo = w2lo; p.y2 = y2; p.scale_b = scale_b; p.shift_b = shift_b; p.N2 = Cout2; p.ldy2 = ldy2;
     if (emd::sep_pipe_covers(p, 3)) return emd::sep_pipe_launch(p, B, static_cast<hipStream_t>(stream));
     return launch_dual(p, B, static_cast<hipStream_t>(stream));

@@ -19,6 +19,7 @@ struct SepParams {
     const float* shift2;
     int H, W, Cin, Cpad, N;
     int ldx, ldy, ldres, act;
+    int stride;           // 1, or 2 (sep_pipe.hip only: TF SAME on even sizes; H, W are the INPUT sizes, the output is H/2 x W/2)
     int reflect;          // 1: the patch border is tf.pad(REFLECT) of the image (graph G), 0: zero (TF SAME)
     int tpw;              // output tiles per workgroup, side by side along W
     // generated input (layers fed by a 1-channel image): x is a one-value-per-pixel tensor d (pitch ldx) and the Cin-channel

@@ -94,10 +94,14 @@ __device__ __forceinline__ unsigned xchg4(unsigned v, bool oddq) {
 
 // NW = 8: 512 threads, 8 x 32 pixel tiles, one workgroup per CU; NW = 4: 256 threads, 8 x 16 pixel tiles, two independent workgroups per
 // CU (80 KB of LDS each: one weight tile, up to 64 output channels) whose phases overlap each other without any schedule.
-template <int BN, bool DUAL, int MODE, bool OSPLIT, int NW = 8>
+// STRIDE = 2 (round 3; strided_conv_block with stride 2, machine_learning/denoiser.py:258, :273, :288: TF SAME on even sizes = no padding
+// before, one pixel after): output tile 4 x 16 pixels (64 GEMM rows) from a 9 x 33 pixel patch, a thread one output pixel x 4 channels
+// in stage 1 (9 patch + 9 weight reads), every wave one 32 x (BN / 4) accumulator block -- the depthwise result of the strided
+// blocks no longer goes through HBM (cnn0_strided: 0.54 GB written and read back per batch).
+template <int BN, bool DUAL, int MODE, bool OSPLIT, int NW = 8, int STRIDE = 1>
 __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p) {
-    constexpr int TW = 4 * NW, TH = 8, BM = TH * TW;
-    constexpr int PW = TW + 2, PH = TH + 2, PWS = PW + 1;     // 34 patch pixels per row at a slot pitch of 35 (odd: see above)
+    constexpr int TW = STRIDE == 2 ? 16 : 4 * NW, TH = STRIDE == 2 ? 4 : 8, BM = TH * TW;
+    constexpr int PW = STRIDE * TW + 3 - STRIDE, PH = STRIDE * TH + 3 - STRIDE, PWS = PW | 1;   // patch pixels per row; slot pitch odd (see above): 34 -> 35, 18 -> 19, 33
     constexpr int NPATCH = PH * PWS, NSLOT = NPATCH + 9;      // + 9 slots of depthwise weights (one tap's 32 channels = 128 B)
     constexpr int NPIECE = (NSLOT + 7) / 8;                   // 45 DMA pieces of 8 slots
     constexpr int PP = (NPIECE + NW - 1) / NW;                // 6 per wave (the surplus ones repeat the wave's previous piece)
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
     constexpr bool BDBL = BN <= 128 && NW == 8;               // two weight tiles in LDS
     constexpr int PB = BN / 8 / NW;                           // weight pieces per wave and step
     constexpr bool LEAD2 = MODE == 0;
-    constexpr int WN = BN / 64, WM = NW / WN, TM = BM / WM / 32, TN = 2;
+    constexpr int WN = STRIDE == 2 ? 4 : BN / 64, WM = NW / WN, TM = BM / WM / 32, TN = BN / WN / 32;   // a wave owns 32 TM rows x 32 TN columns
     constexpr int A_OFF = 2 * STAGE, B_OFF = A_OFF + A_BYTES;
     constexpr int SMEM = B_OFF + B_ONE * (BDBL ? 2 : 1);
     constexpr bool SWZ = DUAL;                                // patch chunks XORed with (pixel >> 1) & 3: the projection's centre reads
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
     static_assert(!(DUAL && OSPLIT), "split32 output: one-output instances only");
     static_assert(PP >= 2 && PB >= 1 && SMEM <= (NW == 8 ? 160 : 80) * 1024, "shape");
     static_assert(NW == 8 || NW == 4, "4 or 8 waves");
+    static_assert(STRIDE == 1 || (STRIDE == 2 && NW == 8 && !DUAL && BN >= 128 && TM == 1), "stride 2: 8 waves, one output, 128 or 256 columns");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -129,8 +134,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
         by = (t / gridDim.x) % gridDim.y;
         bz = t / (gridDim.x * gridDim.y);
     }
-    const int xbase = bx * p.tpw * TW, y0 = by * TH;
-    const long img = (long)bz * p.H * p.W;
+    const int xbase = bx * p.tpw * TW, y0 = by * TH;        // OUTPUT coordinates of the workgroup's first tile
+    const int Wo = p.W / STRIDE;                             // output row pitch in pixels (p.H, p.W: the input's)
+    const long img = (long)bz * p.H * p.W;                   // pixel index of this image's (0, 0) in the input ...
+    const long img_o = (long)bz * (p.H / STRIDE) * Wo;       // ... and in the output / residual
 
     // ---- DMA sources.  Lane l of a piece fills 16-byte chunk (l & 7) of slot 8 * piece + (l >> 3).
     const int drow = lane >> 3, dk = lane & 7;
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
             if (q >= NPIECE) q -= NW;
             const int slot = q * 8 + drow;
             const int py = slot / PWS, px = slot - py * PWS;
-            int gy = y0 - 1 + py, gx = xt - 1 + px;
+            int gy = STRIDE * y0 - (STRIDE == 1) + py, gx = STRIDE * xt - (STRIDE == 1) + px;
             if (p.reflect) {   // tf.pad(REFLECT, 1): -1 -> 1, H -> H - 2
                 gy = gy < 0 ? -gy : (gy >= p.H ? 2 * p.H - 2 - gy : gy);
                 gx = gx < 0 ? -gx : (gx >= p.W ? 2 * p.W - 2 - gx : gx);
@@ -197,8 +204,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
     const int blk = 2 * wv + (pgw >> 2), pgl = pgw & 3;
     const int rb = pgl >> 1, xb = (pgl & 1) ^ rb;
     constexpr int XO = TW / 8;                                 // 8-pixel blocks per tile row
-    const int dy = 2 * (blk / XO) + rb, dx = 8 * (blk % XO) + 4 * xb;
-    const int rd_base = (dy * PWS + dx) * 128;
+    // stride 2: a thread = ONE output pixel (tid >> 3 of the tile's 64) x 4 channels, patch pixel (2 oy + i, 2 ox + d)
+    const int dy = STRIDE == 2 ? (tid >> 3) / TW : 2 * (blk / XO) + rb, dx = STRIDE == 2 ? (tid >> 3) % TW : 8 * (blk % XO) + 4 * xb;
+    const int rd_base = (STRIDE * dy * PWS + STRIDE * dx) * 128;
     int rd_k[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) rd_k[m] = (SWZ ? (c4 ^ (((dx >> 1) + m) & 3)) : c4) * 16;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
     const int fr = lane & 31, fh = lane >> 5, sw = (fr >> 1) & 7;
     const int row0 = wm * TM * 32;                       // first of this wave's GEMM rows; row r = pixel (r / TW, r % TW) of the tile
     const int a_off = A_OFF + (row0 + fr) * 128;
-    const int b_off = B_OFF + (wn * 64 + fr) * 128;
+    const int b_off = B_OFF + (wn * (TN * 32) + fr) * 128;
     const bool out2 = DUAL && wn >= WN / 2;
 
     // ---- epilogue constants: lane = output channel
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
     const bool full = DUAL ? (p.N == BN / 2 && p.N2 == BN / 2) : p.N == BN;   // no lane is masked in the epilogue: store counts are exact
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = wn * 64 + j * 32 + fr;
+        const int n = wn * (TN * 32) + j * 32 + fr;
         const int nn = out2 ? n - BN / 2 : n;
         const bool valid = nn < nlim;
         es1[j] = valid ? (out2 ? p.scale_b : p.scale1)[nn] : 0.f;
@@ -257,8 +265,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
         if (++ic == nchunks) {
             ic = 0;
             const int xn = ixt + TW;
-            if (ixt >= 1 && xn + TW + 1 <= p.W) {   // both tiles clear of the left / right image edges: every real pixel moves 32 on
-                const long step = (long)TW * p.ldx;
+            if ((STRIDE == 2 || ixt >= 1) && STRIDE * (xn + TW) + 1 <= p.W) {   // both tiles clear of the left / right image edges: every real
+                const long step = (long)STRIDE * TW * p.ldx;                     // pixel moves one tile on
 #pragma unroll
                 for (int j = 0; j < PP; ++j) psrc[j] += ((pmove >> j) & 1) ? step : 0;
             } else {
@@ -274,6 +282,22 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
 
     auto stage1 = [&](const unsigned char* stg) {   // depthwise 3x3 from the patch -> bf16 hi / lo A rows
         if (abl & 1) return;
+        if constexpr (STRIDE == 2) {
+            const unsigned char* wkp = stg + NPATCH * 128 + c4 * 16;
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    o += *reinterpret_cast<const f32x4*>(wkp + (i * 3 + d) * 128) *
+                         *reinterpret_cast<const f32x4*>(stg + rd_base + (i * PWS + d) * 128 + c4 * 16);
+            unsigned h0, l0, h1, l1;
+            split2(o[0], o[1], h0, l0);
+            split2(o[2], o[3], h1, l1);
+            *reinterpret_cast<u32x2*>(smem + a_wr[0]) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(smem + (a_wr[0] ^ 64)) = u32x2{l0, l1};
+            return;
+        }
             const unsigned char* wkp = stg + NPATCH * 128 + c4 * 16;
             f32x4 o[4];
 #pragma unroll
@@ -312,15 +336,15 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
         const int li = fr & 3, cq = fr >> 2;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n4 = wn * 64 + j * 32 + 4 * cq;
+            const int n4 = wn * (TN * 32) + j * 32 + 4 * cq;
             const unsigned roff = (unsigned)((4 * fh + li) * ldr + n4) * 4u;
 #pragma unroll
             for (int i = 0; i < (RPRE ? TM : 1); ++i) {
-                const float* rbase = p.res + (img + (long)(y0 + (row0 + i * 32) / TW) * p.W + x0) * ldr;
+                const float* rbase = p.res + (img_o + (long)(y0 + (row0 + i * 32) / TW) * Wo + x0) * ldr;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     rpre[i][j][q] = f32x4{-0.f, -0.f, -0.f, -0.f};
-                    if (n4 < nlim) rpre[i][j][q] = load_s(rbase + ((8 * q / TW) * p.W + 8 * q % TW) * ldr, roff);
+                    if (n4 < nlim) rpre[i][j][q] = load_s(rbase + ((8 * q / TW) * Wo + 8 * q % TW) * ldr, roff);
                 }
             }
         }
@@ -417,7 +441,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float s1 = es1[j], t1 = et1[j], s2 = es2[j], t2 = et2[j];
-            const int nb = wn * 64 + j * 32 - (out2 ? BN / 2 : 0);   // first channel of this 32-column group in its output
+            const int nb = wn * (TN * 32) + j * 32 - (out2 ? BN / 2 : 0);   // first channel of this 32-column group in its output
             const int n4 = nb + 4 * cq;
             const bool valid = n4 < nlim;                             // Cout % 4 == 0: a lane's four channels are all in or all out
             const unsigned roff = (unsigned)((4 * fh + li) * ldr + n4) * 4u;
@@ -431,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const long pixr = img + (long)(y0 + (row0 + i * 32) / TW) * p.W + x0;   // uniform: the M tile's first pixel
+                const long pixr = img_o + (long)(y0 + (row0 + i * 32) / TW) * Wo + x0;   // uniform: the M tile's first pixel
                 const float* rbase = has_res ? p.res + pixr * ldr : nullptr;
                 float* obase = outp + pixr * ldo;
                 f32x4 rv[4];
@@ -450,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
                 } else if (has_res) {
                     if (valid) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) rv[q] = load_s(rbase + ((8 * q / TW) * p.W + 8 * q % TW) * ldr, roff);
+                        for (int q = 0; q < 4; ++q) rv[q] = load_s(rbase + ((8 * q / TW) * Wo + 8 * q % TW) * ldr, roff);
                     }
                     wait_vm<0>();
                 }
@@ -471,7 +495,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
                     }
                     quad_transpose(r, li);
                     f32x4 v = f32x4{r[0], r[1], r[2], r[3]} + rv[q];
-                    float* ob = obase + ((8 * q / TW) * p.W + 8 * q % TW) * ldo;   // rows 8q.. of the M tile: pixel (8q / TW, 8q % TW)
+                    float* ob = obase + ((8 * q / TW) * Wo + 8 * q % TW) * ldo;   // rows 8q.. of the M tile: pixel (8q / TW, 8q % TW)
                     if constexpr (!OSPLIT) {
                         if (valid) store_nt_s(ob, voff, v);
                     } else {
@@ -600,6 +624,13 @@ int launch_mode(const SepParams& q, dim3 grid, int mode, int nw, hipStream_t st)
     return emd::check_launch("sep_pipe_kernel");
 }
 
+template <int BN>
+int launch_s2(const SepParams& q, dim3 grid, int mode, hipStream_t st) {
+    if (mode == 1) hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 1, false, 8, 2>), grid, dim3(512), 0, st, q);
+    else hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 0, false, 8, 2>), grid, dim3(512), 0, st, q);
+    return emd::check_launch("sep_pipe_kernel<stride 2>");
+}
+
 template <int BN, bool DUAL>
 int launch_bn(const SepParams& q, dim3 grid, int mode, int nw, hipStream_t st) {
     if constexpr (!DUAL && BN >= 128) {
@@ -620,6 +651,9 @@ static bool use_nw4(const SepParams& p) {
 
 bool sep_pipe_covers(const SepParams& p, int precision) {
     if (!g_knobs.sep_pipe || precision != 3 || p.gen_a) return false;
+    if (p.stride == 2)   // output tiles of 4 x 16 pixels: H % 8 == 0, W % 32 == 0 (input sizes); one fp32 output of up to 256 channels
+        return p.H % 8 == 0 && p.W % 32 == 0 && p.Cin % 32 == 0 && p.Cin >= 32 && p.Cin <= 4064 && p.N2 == 0 && !p.out_split && !p.reflect &&
+               p.N <= 256;
     if (p.H % 8 != 0 || p.W % (use_nw4(p) ? 16 : 32) != 0 || p.Cin % 32 != 0 || p.Cin < 32 || p.Cin > 4064) return false;
     if (p.N2 > 0) return p.N <= 128 && p.N2 <= 128 && !p.out_split && !p.res && !p.scale2;
     if (p.out_split && p.N <= 64) return false;
@@ -628,9 +662,11 @@ bool sep_pipe_covers(const SepParams& p, int precision) {
 
 int sep_pipe_launch(const SepParams& p, int B, hipStream_t st) {
     SepParams q = p;
-    const int nw = use_nw4(p) ? 4 : 8, tw = 4 * nw;
-    const int tiles_w = p.W / tw;
-    const long wgs1 = (long)tiles_w * (p.H / 8) * B;
+    const bool s2 = p.stride == 2;
+    const int nw = (!s2 && use_nw4(p)) ? 4 : 8, tw = s2 ? 16 : 4 * nw, th = s2 ? 4 : 8;
+    const int Ho = p.H / (s2 ? 2 : 1), Wo = p.W / (s2 ? 2 : 1);
+    const int tiles_w = Wo / tw;
+    const long wgs1 = (long)tiles_w * (Ho / th) * B;
     int tpw = 1;   // several tiles per workgroup (the DMA ring runs on across them) where >= 4 workgroups per CU remain
     for (int t = 8; t >= 2; t >>= 1)
         if (tiles_w % t == 0 && wgs1 / t >= 1024 * (8 / nw)) { tpw = t; break; }
@@ -638,12 +674,13 @@ int sep_pipe_launch(const SepParams& p, int B, hipStream_t st) {
     q.tpw = tpw;
     q.stamps = g_knobs.sep_stamps;
     q.ablate = g_knobs.sep_ablate;
-    const dim3 grid(tiles_w / tpw, p.H / 8, B);
+    const dim3 grid(tiles_w / tpw, Ho / th, B);
     q.xcd = g_knobs.sep_xcd && ((long)grid.x * grid.y * grid.z) % 8 == 0;
     const bool dual = p.N2 > 0;
     // schedule (see the kernel): rule = the patch two steps ahead; one step ahead for two outputs, with a residual (its loads then
     // queue behind one DMA group instead of two) and in the 4-wave form; the dev knob sep_mode (0 / 1) overrides
     const int mode = g_knobs.sep_mode >= 0 ? g_knobs.sep_mode : ((nw == 4 || p.res) ? 1 : 0);
+    if (s2) return p.N <= 128 ? launch_s2<128>(q, grid, mode, st) : launch_s2<256>(q, grid, mode, st);
     if (dual) {
         const bool wide = p.N > 64 || p.N2 > 64;
         if (wide) return launch_bn<256, true>(q, grid, 1, 8, st);

@@ -327,12 +327,14 @@ class DenoiserEngine:
         BN x2 (+ the optional extra BN) + relu6 (+ residual) fused into its epilogue."""
         L, p = self.layers[key], self.P[key]
         Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
-        if self.fuse_sep and ops.sep_fused_supported(x, L.cout, L.stride, L.rate):
+        if (self.fuse_sep and ops.sep_fused_supported(x, L.cout, L.stride, L.rate)
+                and (L.stride == 1 or (self.precision == ops.PREC_BF16X3 and not isinstance(out, ops.SplitAct)
+                                       and os.environ.get("EMD_D_SEP_S2", "1") != "0"))):
             # one launch, the depthwise result stays in LDS (the HBM-bound single-N-tile layers)
             if out is None:
                 out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
             return ops.sep_fused(x, p["dw"], p["pw"], p["scale"], p["shift"], out, scale2=p.get("scale2"),
-                                 shift2=p.get("shift2"), res=res, precision=self.precision)
+                                 shift2=p.get("shift2"), res=res, precision=self.precision, stride=L.stride)
         if out is None:
             out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
         if self._sep_gemm_ok(x, L) and not isinstance(out, ops.SplitAct):

@@ -189,7 +189,7 @@ class GeneratorEngine:
     def _sep(self, key, x, res=None):
         L, p = self.layers[key], self.P[key]
         Ho, Wo = (x.H - 1) // L.stride + 1, (x.W - 1) // L.stride + 1
-        if ops.sep_fused_supported(x, L.cout, L.stride, 1) and x.H >= 2 and x.W >= 2:
+        if L.stride == 1 and ops.sep_fused_supported(x, L.cout, 1, 1) and x.H >= 2 and x.W >= 2:
             # one launch, the depthwise result stays in LDS (the HBM-bound <= 128-channel layers)
             out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
             return ops.sep_fused(x, p["dw"], p["pw"], p["scale"], p["shift"], out, act=ops.ACT_LEAKY, res=res,

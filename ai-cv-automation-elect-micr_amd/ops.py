@@ -131,13 +131,21 @@ def sep_fused_supported(x: Act, cout: int, stride: int, rate: int) -> bool:
 
 
 def sep_fused(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, act=True, scale2=None, shift2=None,
-              res: Act | None = None, precision=PREC_BF16X3, stream=None, reflect=False):
-    """Depthwise 3x3 (stride 1) + pointwise + epilogue in one launch (emd_sep3x3_fused_f32; reflect=True: the
-    depthwise stage reads the REFLECT-padded border, emd_sep3x3_fused_reflect_f32)."""
+              res: Act | None = None, precision=PREC_BF16X3, stream=None, reflect=False, stride=1):
+    """Depthwise 3x3 + pointwise + epilogue in one launch (emd_sep3x3_fused_f32; reflect=True: the depthwise stage reads the
+    REFLECT-padded border, emd_sep3x3_fused_reflect_f32; stride=2: emd_sep3x3_fused_s2_f32, split-bf16 only)."""
     lib = _lib.load()
-    assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, w.cout) and w.cin == x.C and w.taps == 1
+    assert (out.B, out.H, out.W, out.C) == (x.B, -(-x.H // stride), -(-x.W // stride), w.cout) and w.cin == x.C and w.taps == 1
     if res is not None:
         assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
+    if stride == 2:
+        assert not reflect and precision == PREC_BF16X3 and not isinstance(out, SplitAct)
+        rc = lib.emd_sep3x3_fused_s2_f32(x.ptr, x.ld, _p(dw_dev), _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
+                                         res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
+                                         out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, _act(act), _lib.stream_ptr(stream))
+        _lib.check(rc, "emd_sep3x3_fused_s2_f32")
+        return out
+    assert stride == 1
     if isinstance(out, SplitAct):   # split32 output for a following split32 GEMM (emd_sep3x3_fused_out_f32)
         assert not reflect and precision == PREC_BF16X3
         rc = lib.emd_sep3x3_fused_out_f32(x.ptr, x.ld, _p(dw_dev), _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),

@@ -154,6 +154,13 @@ int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, const uint16_
                          const float* scale1, const float* shift1, const float* scale2, const float* shift2,
                          const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin,
                          int Cout, int act, int precision, emd_stream_t stream);
+/* The same block with stride 2 (strided_conv_block(stride=2), machine_learning/denoiser.py:258, :273, :288), one launch (round 3): x
+ * [B,H,W,Cin] with H%8==0, W%32==0 (TF SAME on even sizes: no padding before, one pixel after), y [B,H/2,W/2,Cout], Cout <= 256,
+ * res (optional) in the output's shape.  Split-bf16.  emd_sep3x3_fused_supported(H, W, Cin, Cout, 2, 1) says where it applies. */
+int emd_sep3x3_fused_s2_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                            const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                            const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                            emd_stream_t stream);
 
 /* Depthwise 3x3, TF SAME padding, stride 1 or 2 (rate 1) or stride 1 with dilation `rate`.
  * replaces: the depthwise half of slim.separable_convolution2d (denoiser.py:113-131).

@@ -171,6 +171,95 @@ def test_sep_pipe_dual(B, H, W, ci, co, co2, tpw):
     assert rel_l2(g2, want2.torch().cpu().numpy()) < 1e-6
 
 
+S2_CASES = [
+    # B, H, W, Cin, Cout, res, extra, tpw
+    (2, 8, 32, 64, 128, False, False, 0),     # one tile per image (4 x 16 output pixels): bottom / right padding in every patch
+    (1, 16, 96, 64, 128, True, False, 0),     # left, interior and right-edge tiles, two tile rows; residual (cnn0_strided's widths)
+    (2, 24, 64, 32, 128, False, True, 2),     # one chunk, two tiles per workgroup, second affine
+    (1, 8, 256, 128, 256, True, False, 4),    # 256 columns (cnn1_strided); the pointer-increment path between interior tiles
+    (1, 16, 64, 256, 256, False, False, 0),   # 8 chunks
+    (1, 8, 64, 96, 160, True, True, 0),       # channel tail in the 256-column tile
+    (1, 8, 32, 64, 36, False, False, 0),      # channel tail in the 128-column tile
+]
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,res,extra,tpw", S2_CASES)
+@pytest.mark.parametrize("lead", [0, 1])
+def test_sep_pipe_stride2(B, H, W, ci, co, res, extra, tpw, lead):
+    """emd_sep3x3_fused_s2_f32 (strided_conv_block(stride=2), machine_learning/denoiser.py:258, :273, :288) against the oracle's TF
+    restatement (SAME on even sizes: one pixel of padding after, none before) and bit for bit against the two kernels it replaces
+    (emd_dw3x3_f32 stride 2 -> emd_conv1x1_f32: the same depthwise sums, the same products in the same order along K)."""
+    from emdenoise import _lib, ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 380, positive=True)
+    dw = rnd((3, 3, ci, 1), 381, 0.35)
+    pw = rnd((1, 1, ci, co), 382, scale=(2.0 / (ci + co)) ** 0.5)
+    s1, t1 = rnd((co,), 383, 0.2) + 1, rnd((co,), 384, 0.5)
+    s2, t2 = rnd((co,), 385, 0.2) + 1, rnd((co,), 386, 0.5)
+    Ho, Wo = H // 2, W // 2
+    r = rnd((B, Ho, Wo, co), 387, positive=True) if res else None
+    y = T.relu6_t(T.conv2d_t(T.depthwise_conv2d_t(t64(x), t64(dw), stride=2), t64(pw)) * t64(s1) + t64(t1))
+    if extra:
+        y = T.relu6_t(y * t64(s2) + t64(t2))
+    if res:
+        y = y + t64(r)
+    want = y.numpy()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    xa = to_act(x, ld=ci + 64, c0=32)
+    assert ops.sep_fused_supported(xa, co, 2, 1)
+    pk = ops.PackedWeights(pw[0], False, dev())
+    kw = dict(scale2=d(s2) if extra else None, shift2=d(t2) if extra else None, res=to_act(r, ld=co + 12, c0=8) if res else None)
+    _lib.knob("sep_mode", lead)
+    _lib.knob("sep_tpw", tpw)
+    out = out_act(B, Ho, Wo, co, ld=co + 8, c0=4)
+    ops.sep_fused(xa, d(dw[..., 0]), pk, d(s1), d(t1), out, stride=2, **kw)
+    torch.cuda.synchronize()
+    got = out.torch().cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_l2(got, want) < TOL_X3
+    full = out.buf.cpu().numpy()
+    assert np.isnan(full[..., :4]).all() and np.isnan(full[..., 4 + co:]).all()
+    tmp = ops.dw3x3(xa, d(dw[..., 0]), out_act(B, Ho, Wo, ci), stride=2)
+    two = ops.conv1x1(tmp, pk, d(s1), d(t1), out_act(B, Ho, Wo, co), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out.torch(), two.torch()), "the one-launch form and the two kernels promise the same bits"
+
+
+def test_sep_pipe_stride2_argument_checks():
+    from emdenoise import _lib, ops
+
+    d = dev()
+    pk = ops.PackedWeights(rnd((1, 64, 128), 390, 0.1), False, d)
+    one, dwv = torch.ones(128, device=d), torch.zeros(9, 64, device=d)
+    x = ops.Act(torch.zeros(1, 12, 32, 64, device=d))   # H % 8 != 0
+    assert not ops.sep_fused_supported(x, 128, 2, 1)
+    with pytest.raises(_lib.EmdError):
+        ops.sep_fused(x, dwv, pk, one, one, ops.Act.empty(1, 6, 16, 128, d), stride=2)
+    x = ops.Act(torch.zeros(1, 8, 48, 64, device=d))    # W % 32 != 0
+    assert not ops.sep_fused_supported(x, 128, 2, 1)
+    assert not ops.sep_fused_supported(ops.Act(torch.zeros(1, 8, 32, 64, device=d)), 128, 2, 2)   # no dilated stride-2 form
+
+
+def test_sep_pipe_stride2_full_size_properties():
+    """cnn0_strided at BASELINE configs[2]'s batch, [8,512,512,64] -> [8,256,256,128]: image b of the batch == the image alone, bit
+    for bit, and exact linearity of the pre-activation in the input."""
+    from emdenoise import ops
+
+    B, S, ci, co = 8, 512, 64, 128
+    g = torch.Generator(device=dev()).manual_seed(6)
+    x = torch.rand(B, S, S, ci, device=dev(), generator=g)
+    dw = (torch.rand(9, ci, device=dev(), generator=g) - 0.5)
+    pk = ops.PackedWeights(rnd((1, ci, co), 391, 0.1), False, dev())
+    s1, t0 = torch.rand(co, device=dev(), generator=g) + 0.5, torch.zeros(co, device=dev())
+    f = lambda xx: ops.sep_fused(ops.Act(xx), dw, pk, s1, t0, ops.Act.empty(xx.shape[0], S // 2, S // 2, co, dev()), act=False, stride=2).torch()
+    y, y1, y2 = f(x), f(x[5:6].contiguous()), f(2 * x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    assert torch.equal(y[5:6], y1)
+    assert torch.equal(y2, 2 * y)
+
+
 def test_sep_pipe_full_size_properties():
     """BASELINE configs[2]'s largest fused layer, [8,512,512,128] -> 64 (+ the 64-channel projection): size-independent properties --
     image b of the batch == the image alone, bit for bit (no tile or workgroup boundary depends on the batch), and linearity of the
