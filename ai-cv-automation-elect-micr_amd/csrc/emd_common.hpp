@@ -56,11 +56,12 @@ struct Knobs {
     int sep_xcd = 1;         // one contiguous run of tiles per XCD
     int sep_wide = 1;        // sep_fused 256-column single-output form: 0 never, 1 Cin <= 256, 2 whenever it fits
     int sep_wres = 1;        // sep_fused 64-column instances keep the pointwise weights resident in LDS
-    int deconv_direct = 1;   // one-launch transposed conv: 1 = epilogue straight from the accumulators (deconv4_split_kernel), 0 = LDS-staged
+    int deconv_direct = 1;   // one-launch transposed conv: 1 = epilogue straight from the accumulators (deconv4_split_kernel), 2 = the same on 128-row tiles at two workgroups per CU, 0 = LDS-staged
     int nt_mask = 7;         // non-temporal output stores: bit 0 split32 convolutions, bit 1 fused separable conv, bit 2 pointwise GEMM
     int dw_xcd = 1;          // XCD-contiguous tile order in the depthwise kernels
     int dw_th = 0;           // strip height of the rolling depthwise kernel (0 = rule)
     int split_narrow = 1;    // pointwise split32 GEMM: 128 x 64 tiles where 128 x 128 tiles leave CUs idle (0 = never)
+    int split_wide = 0;      // pointwise split32 GEMM: 256 x 192 tiles (gemm_split16_wide_kernel) where they fill the chip: 0 never (default: slower in graph D), 1 = 8 waves of 64 x 96, 2 = 4 waves of 128 x 96
     int split_variant = -1;  // pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
     long long* sep_stamps = nullptr;   // device buffer for the in-kernel phase stamps of the fused separable convs
 };

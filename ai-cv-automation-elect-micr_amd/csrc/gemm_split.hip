@@ -789,6 +789,205 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemm
     }
 }
 
+// 256 x 192 tiles of the same GEMM (round 3).  The K loop above is held at 0.83 of its MFMA issue time by the LDS pipe: a 64 x 64 wave
+// tile reads (4 + 4) x 2 fragments of 1 KB per 48 MFMAs and the workgroup's DMA writes another 48 KB per K step -- 176 KB per 1536
+// clocks, 0.9 of the 128 B/clk a CU's LDS delivers.  Here a wave owns 64 x 96 (NWM = 4: 8 waves) or 128 x 96 (NWM = 2: 4 waves):
+// (4 + 6) x 2 fragments per 72 MFMAs, and the tile's DMA (256 + 192 rows) is shared by 1.5x the MFMAs: 216 KB per 2304 clocks = 0.73
+// (0.57 with 4 waves).  N = 728 is four column tiles (768 columns, as the 128-wide tiles pad it), M = 32768 gives 512 workgroups =
+// two full rounds of one per CU.  LDS: the A ring has three stages (the activations stream from HBM: two K steps of lead), the W ring
+// two (the weights sit in L2) = 144 KB.  Same products in the same order per output element as gemm_split16_kernel: identical bits,
+// so that the choice of tile by M (the host rule) changes nothing in a result.  fp32 output, optional residual and second affine.
+// MEASURED (profiles/r03_experiments.txt 11): 414 vs 433 us on 131072 x 728 x 728 and 53.7 vs 60.6 us on 16384 x 728 x 728, but 113.7 vs
+// 101.2 us on the headline 32768 x 728 x 728 (two lockstep rounds of one workgroup per CU: every CU streams its 196 KB of output at the
+// same moment, nothing computes meanwhile) and graph D 24.9-25.1 vs 24.3-24.4 ms -- so it is OFF by default (dev knob split_wide).
+template <int NWM>
+__global__ __launch_bounds__(NWM * 128, 1) void gemm_split16_wide_kernel(const SplitGemmParams p) {
+    constexpr int BM = 256, BN = 192, NW = NWM * 2, NT = NW * 64;
+    constexpr int WROWS = BM / NWM, TI = WROWS / 16, TJ = 6;       // wave tile: TI x TJ MFMA tiles of 16 x 16
+    constexpr int PA = 32 / NW, PW = 24 / NW;                       // 1 KiB DMA pieces per wave and K step (A: 32, W: 24 per tile)
+    constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128, NSA = 3, NSW = 2;
+    constexpr int W_OFF = NSA * A_STAGE, SMEM_BYTES = W_OFF + NSW * W_STAGE;
+    constexpr int EPI_LD = BN + 4, HALF = 128;
+    static_assert(HALF * EPI_LD * 4 <= SMEM_BYTES, "staging half tile");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int nblk = p.n_mtiles * p.n_ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.n_ntiles, nt = bid % p.n_ntiles;   // the column tiles of a row tile are neighbours in one XCD: its A rows come from L2
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int drow = lane >> 3, dchunk = lane & 7;
+    const unsigned char* asrc[PA];
+    const unsigned char* wsrc[PW];
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+        const int row = (wv * PA + q) * 8 + drow;
+        const int c = dchunk ^ ((row >> 1) & 7);
+        long m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        asrc[q] = p.A + m * p.lda_bytes + c * 16;
+    }
+#pragma unroll
+    for (int q = 0; q < PW; ++q) {
+        const int row = (wv * PW + q) * 8 + drow;
+        const int c = dchunk ^ ((row >> 1) & 7);
+        const uint16_t* plane = (c & 4) ? p.Wlo : p.Whi;
+        wsrc[q] = reinterpret_cast<const unsigned char*>(plane + (long)(n0 + row) * p.Ktot + (c & 3) * 8);
+    }
+    auto issue_a = [&](int stage, int kt) {
+#pragma unroll
+        for (int q = 0; q < PA; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (long)kt * 128), (lptr_t)(smem + stage * A_STAGE + (wv * PA + q) * 1024), 16, 0, 0);
+    };
+    auto issue_w = [&](int stage, int kt) {
+#pragma unroll
+        for (int q = 0; q < PW; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[q] + (long)kt * 64), (lptr_t)(smem + W_OFF + stage * W_STAGE + (wv * PW + q) * 1024), 16, 0, 0);
+    };
+
+    f32x4v acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int sw = (r16 >> 1) & 7;
+    const int ch_hi = ((q4 ^ sw) & 7) << 4, ch_lo = (((4 + q4) ^ sw) & 7) << 4;
+    const int a_off = (wm * WROWS + r16) * 128;              // + i * 2048
+    const int w_off = W_OFF + (wn * (BN / 2) + r16) * 128;   // + j * 2048
+
+    const int nk = (p.Cin + SBK - 1) / SBK;
+    // Pipeline.  The W fragments of a step (12 x 16 bytes per lane) are read one step ahead into a second register set; the A
+    // fragments are read just in time, one row tile ahead of their MFMAs.  So at barrier kt the wave needs A(kt) and W(kt+1) in LDS:
+    // issue order A0 W0 W1 A1 | step kt: W(kt+2), A(kt+2); the only group younger than W(kt+1) at the top of step kt is A(kt+1):
+    // vmcnt(PA).  A(kt+2) goes into the stage tile kt-1 was read from (free since everybody passed barrier kt), W(kt+2) into the one
+    // the current W fragments were read from during step kt-1.  A has two K steps to land (HBM), W one (L2).
+    issue_a(0, 0);
+    issue_w(0, 0);
+    issue_w(1, 1 < nk ? 1 : nk - 1);
+    issue_a(1, 1 < nk ? 1 : nk - 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA) : "memory");
+    __builtin_amdgcn_s_barrier();
+    struct BFrags { bf16x8 h[TJ], l[TJ]; };
+    BFrags b0, b1;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        b0.h[j] = *reinterpret_cast<const bf16x8*>(smem + w_off + j * 2048 + ch_hi);
+        b0.l[j] = *reinterpret_cast<const bf16x8*>(smem + w_off + j * 2048 + ch_lo);
+    }
+    int sa = 0, sa2 = 2;
+    auto step = [&](const BFrags& cur, BFrags& nxt, int kt) {
+        // (lgkmcnt(0): this wave's reads of the stages about to be refilled have returned, not merely been issued)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_w(kt & 1, kt + 2 < nk ? kt + 2 : nk - 1);
+        issue_a(sa2, kt + 2 < nk ? kt + 2 : nk - 1);
+        const unsigned char* ab = smem + sa * A_STAGE + a_off;
+        const unsigned char* wb = smem + ((kt + 1) & 1) * W_STAGE + w_off;
+        bf16x8 ah[2], al[2];
+        ah[0] = *reinterpret_cast<const bf16x8*>(ab + ch_hi);
+        al[0] = *reinterpret_cast<const bf16x8*>(ab + ch_lo);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            if (i + 1 < TI) {
+                ah[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(ab + (i + 1) * 2048 + ch_hi);
+                al[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(ab + (i + 1) * 2048 + ch_lo);
+            }
+            // the next step's W fragments, spread over the row tiles
+#pragma unroll
+            for (int j = i * TJ / TI; j < (i + 1) * TJ / TI; ++j) {
+                nxt.h[j] = *reinterpret_cast<const bf16x8*>(wb + j * 2048 + ch_hi);
+                nxt.l[j] = *reinterpret_cast<const bf16x8*>(wb + j * 2048 + ch_lo);
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i & 1], cur.h[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], cur.l[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], cur.h[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // issue order pinned: the DMA pieces and the LDS reads sit between MFMAs, not in front of them
+        constexpr int NDS = 2 * (TI - 1) + 2 * TJ, NMF = 3 * TI * TJ;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);            // A fragments of row tile 0
+#pragma unroll
+        for (int g = 0; g < PA + PW; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < NDS; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if constexpr (NMF - 2 * (PA + PW) - 2 * NDS > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - 2 * (PA + PW) - 2 * NDS, 0);
+        sa = sa + 1 == NSA ? 0 : sa + 1;
+        sa2 = sa2 + 1 == NSA ? 0 : sa2 + 1;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(b0, b1, kt);
+        if (kt + 1 < nk) step(b1, b0, kt + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- epilogue: the tile leaves in two halves of 128 rows through a staging tile (full 768-byte row runs per 48 lanes)
+    float(*stage)[EPI_LD] = reinterpret_cast<float(*)[EPI_LD]>(smem);
+    constexpr int C4 = BN / 4;
+    const float hi = p.act == 1 ? 6.f : __builtin_inff();
+    const float hi2 = p.act == 2 ? __builtin_inff() : 6.f;
+    const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+    const bool two = p.scale2 != nullptr;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        if (wm * WROWS / HALF == h) {   // wave-uniform
+            const int rbase = wm * WROWS - h * HALF;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) stage[rbase + i * 16 + 4 * q4 + e][wn * (BN / 2) + j * 16 + r16] = acc[i][j][e];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int idx = tid; idx < HALF * C4; idx += NT) {
+            const int r = idx / C4, c = (idx - r * C4) * 4;
+            const long pix = m0 + h * HALF + r;
+            const int n = n0 + c;
+            if (pix >= p.M) break;
+            if (n >= p.N) continue;
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n), t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
+            f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+            if (two) {
+                s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n);
+                t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n);
+            }
+            f32x4 v = *reinterpret_cast<const f32x4*>(&stage[r][c]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float u = fmaf(v[k], s1[k], t1[k]);
+                u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                if (two) u = fminf(fmaxf(fmaf(u, s2[k], t2[k]), 0.f), hi2);
+                v[k] = u;
+            }
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n);
+            if (p.nt) store_nt16(p.C + pix * p.ldc + n, v);
+            else *reinterpret_cast<f32x4*>(p.C + pix * p.ldc + n) = v;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolutions from split32 activations: dense 3x3 (stride 1/2, dilation), the four output phases of the
 // 3x3 stride-2 transposed convolution, strided 1x1 -- the row map and tap list of gemm_conv.hip on the pipelined LDS-DMA
@@ -1439,7 +1638,11 @@ static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, co
     // ... and 64-column tiles (two workgroups per CU) where even the 128-row tiles leave CUs idle: a batch of 4 at 512^2 is M = 4096,
     // 192 tiles of 128 x 128 on 256 CUs, 384 of 128 x 64.  All forms give the same bits (same products, same K order).
     const bool narrow = small && !out_split && ((M + 127) / 128) * ((Cout + SBN - 1) / SBN) < 256 && emd::g_knobs.split_narrow;
-    const int bm = (v == 2 || small) ? 128 : 256, bn = narrow ? 64 : SBN;
+    // ... and 256 x 192 tiles (gemm_split16_wide_kernel) where they fill the chip and stay inside the padded weight planes (N = 728, 384, 192, ...)
+    const int n192 = (Cout + 191) / 192;
+    const int wide = (v == 5 && !stats_part && !out_split && n192 * 192 <= (Cout + SBN - 1) / SBN * SBN && ((M + 255) / 256) * n192 >= 256)
+                         ? emd::g_knobs.split_wide : 0;
+    const int bm = (v == 2 || small) ? 128 : 256, bn = wide ? 192 : (narrow ? 64 : SBN);
     p.n_mtiles = (int)((M + bm - 1) / bm);
     p.n_ntiles = (Cout + bn - 1) / bn;
     const long nblk = (long)p.n_mtiles * p.n_ntiles;
@@ -1457,6 +1660,8 @@ static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, co
         hipLaunchKernelGGL(gemm_split_persist_kernel, dim3(grid), dim3(512), 0, st, p);
     }
     else if (v == 2) hipLaunchKernelGGL((gemm_split_kernel<128, 2>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else if (wide == 2) hipLaunchKernelGGL((gemm_split16_wide_kernel<2>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else if (wide) hipLaunchKernelGGL((gemm_split16_wide_kernel<4>), dim3((unsigned)nblk), dim3(512), 0, st, p);
     else if (v == 5 && narrow) hipLaunchKernelGGL((gemm_split16_kernel<128, 64>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     else if (v == 5 && small) hipLaunchKernelGGL(gemm_split16_kernel<128>, dim3((unsigned)nblk), dim3(256), 0, st, p);
     else if (v == 5) hipLaunchKernelGGL(gemm_split16_kernel<256>, dim3((unsigned)nblk), dim3(512), 0, st, p);
@@ -1759,6 +1964,229 @@ __global__ __launch_bounds__(512, 2) void deconv4_split_kernel(const SplitConvPa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The same transposed conv on 128-row tiles, 4 waves, two LDS stages (64 KB at BN = 128): TWO workgroups per CU.  vmcnt retires in
+// order, so a workgroup's output stores (four times the bytes it reads) hold up its own next K loop whatever the issue order -- here
+// the partner workgroup's K loop runs meanwhile.  Same wave tile (64 x 64), same products in the same order along K: bit-identical
+// to deconv4_split_kernel.  One K step of DMA in flight (two stages), fragments read after the step's barrier.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void deconv4_half_kernel(const SplitConvParams cp) {
+    const SplitGemmParams& p = cp.g;
+    constexpr int BM = 128, NS = 2, WQ = BN / 32, TN = BN / 64;
+    constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128, STAGE = A_STAGE + W_STAGE;
+    constexpr int E = 8 * TN;   // stores per wave and phase
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int nblk = p.n_mtiles * p.n_ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.n_ntiles, nt = bid % p.n_ntiles;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int drow = lane >> 3, dchunk = lane & 7;
+    int pi[4], pj[4], pb[4], pc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wv * 32 + q * 8 + drow;
+        pc[q] = (dchunk ^ ((row >> 1) & 7)) * 16;
+        const long m = m0 + row;
+        if (m < p.M) {
+            const int j = (int)(m % cp.Wg);
+            const long t = m / cp.Wg;
+            pi[q] = (int)(t % cp.Hg); pj[q] = j; pb[q] = (int)(t / cp.Hg) * cp.Ha * cp.Wa;
+        } else {
+            pi[q] = -(1 << 20); pj[q] = 0; pb[q] = 0;    // beyond M: every tap reads zeros
+        }
+    }
+    const int fr = lane & 31, fh = lane >> 5;
+    const int sw = (fr >> 1) & 7;
+    const int a_off = (wm * 64 + fr) * 128;
+    const int w_off = A_STAGE + (wn * (BN / 2) + fr) * 128;
+
+    // ---- epilogue roles.  Before the transpose a lane holds channel n0 + wn BN/2 + 32 j + fr of rows (e & 3) + 8 (e >> 2) + 4 fh;
+    // after it, row 8 q + 4 fh + li and channels 4 cq .. 4 cq + 3 of the 32-column group
+    const int li = fr & 3, cq = fr >> 2;
+    long dst0[2][4];     // output pixel of phase (0, 0) for this lane's rows, -1 beyond M
+    bool full = true;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long m = m0 + wm * 64 + i * 32 + 8 * q + 4 * fh + li;
+            long d = -1;
+            if (m < p.M) {
+                const int j = (int)(m % cp.Wg);
+                const long t = m / cp.Wg;
+                d = ((t / cp.Hg) * cp.Hc + (t % cp.Hg) * 2) * (long)cp.Wc + 2 * j;
+            }
+            dst0[i][q] = d;
+            full = full && d >= 0;
+        }
+    float es1[TN], et1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + fr;
+        es1[j] = n < p.N ? p.scale1[n] : 0.f;
+        et1[j] = n < p.N ? p.shift1[n] : 0.f;
+        asm volatile("" ::"v"(es1[j]), "v"(et1[j]));   // waited for here, not behind the DMA groups in the loop
+        full = full && (n0 + wn * (BN / 2) + j * 32 + 31 < p.N);
+    }
+    full = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(!full) == 0);   // per wave: no masked store, the store count is exact
+    const float hi = p.act == 1 ? 6.f : __builtin_inff();
+    const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
+
+    // ---- per-phase state
+    const uint16_t* __restrict__ Whi = cp.Whi4[0];
+    const uint16_t* __restrict__ Wlo = cp.Wlo4[0];
+    int ntaps = cp.ntaps4[0];
+    unsigned long long dyp = cp.dyp4[0], dxp = cp.dxp4[0];
+    const unsigned char* asrc[4];
+    const unsigned char* wsrc[WQ];
+    auto set_tap = [&](int tap) {
+        const int dy = (int)((dyp >> (7 * tap)) & 127) - 64, dx = (int)((dxp >> (7 * tap)) & 127) - 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int iy = pi[q] * cp.sa + dy, ix = pj[q] * cp.sa + dx;
+            const bool ok = iy >= 0 && iy < cp.Ha && ix >= 0 && ix < cp.Wa;
+            const long pix = (long)pb[q] + (long)iy * cp.Wa + ix;
+            asrc[q] = (ok ? p.A + pix * p.lda_bytes : g_zero_buf) + pc[q];
+        }
+    };
+    auto set_phase = [&](int ph) {
+        Whi = cp.Whi4[ph]; Wlo = cp.Wlo4[ph]; ntaps = cp.ntaps4[ph]; dyp = cp.dyp4[ph]; dxp = cp.dxp4[ph];
+        const int Ktot = ntaps * cp.Cpad;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int row = wv * (WQ * 8) + q * 8 + drow;
+            const int c = dchunk ^ ((row >> 1) & 7);
+            const uint16_t* plane = (c & 4) ? Wlo : Whi;
+            wsrc[q] = reinterpret_cast<const unsigned char*>(plane + (long)(n0 + row) * Ktot + (c & 3) * 8);
+        }
+    };
+    auto issue = [&](int stage, int tap, int kc) {
+        unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (long)kc * 128), (lptr_t)(sb + (wv * 32 + q * 8) * 128), 16, 0, 0);
+        const long wk = ((long)tap * cp.Cpad + (long)kc * 32) * 2;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[q] + wk), (lptr_t)(sb + A_STAGE + (wv * (WQ * 8) + q * 8) * 128), 16, 0, 0);
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    struct Frags { bf16x8 ah[2], al[2], bh[TN], bl[TN]; };
+    auto load_frags = [&](Frags& f, const unsigned char* sb, int ks) {
+        const int ch = ((ks * 2 + fh) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + ch);
+            f.al[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 4096 + (ch ^ 64));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + ch);
+            f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 4096 + (ch ^ 64));
+        }
+    };
+    auto mfma12 = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    int total = 0, dtap = 0, dkc = 0, dstep = 0;
+    auto advance = [&]() {
+        if (dstep + 1 < total) {
+            ++dstep;
+            if (++dkc == cp.nkc) {
+                dkc = 0;
+                ++dtap;
+                set_tap(dtap);
+            }
+        }
+    };
+    auto prologue = [&](int ph) {   // the first K step of phase ph into stage 0
+        set_phase(ph);
+        total = ntaps * cp.nkc;
+        dtap = dkc = dstep = 0;
+        set_tap(0);
+        issue(0, 0, 0);
+        advance();
+    };
+    prologue(0);
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ++ph) {
+        for (int st = 0; st < total; ++st) {
+            // K step st has landed.  Older than its group: nothing but, at st == 0 of a later phase, nothing either (the previous
+            // phase's stores were issued AFTER this phase's first group) -- so the E stores may stay in flight across the first barrier
+            if (st == 0 && ph > 0 && full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(E) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // ... for every wave; and every wave is done with the other stage (step st - 1)
+            issue((st + 1) & 1, dtap, dkc);     // step st + 1 (beyond the last step: a re-read of it, so that the counts stay uniform)
+            advance();
+            Frags f0, f1;
+            const unsigned char* sb = smem + (st & 1) * STAGE;
+            load_frags(f0, sb, 0);
+            load_frags(f1, sb, 1);
+            mfma12(f0);
+            mfma12(f1);
+        }
+        // every wave's fragment reads are done and this wave's surplus DMA groups have landed: the stages are free for the next phase
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int py = ph >> 1, px = ph & 1;
+        if (ph < 3) prologue(ph + 1);
+        // ---- epilogue of phase ph, straight from the accumulators
+        const long poff = (long)py * cp.Wc + px;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n4 = n0 + wn * (BN / 2) + j * 32 + 4 * cq;
+            const bool ncol = n4 < p.N;
+            const float s1 = es1[j], t1 = et1[j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float r[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float u = fmaf(acc[i][j][4 * q + k], s1, t1);
+                        r[k] = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                    }
+                    quad_transpose4(r, li);
+                    if (ncol && dst0[i][q] >= 0) store_nt16(p.C + (dst0[i][q] + poff) * p.ldc + n4, f32x4{r[0], r[1], r[2], r[3]});
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- convolutions on split32 input
@@ -1807,6 +2235,14 @@ int launch_conv(SplitConvParams& c, hipStream_t st, bool four = false) {
     if (nblk <= 0 || nblk > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "split32 conv: grid too large");
     if (p.M > 0x7fffffffL || (!c.flat && (long)(p.M / ((long)c.Hg * c.Wg)) * c.Ha * c.Wa > 0x7fffffffL))
         return emd::fail(EMD_E_UNSUPPORTED, "split32 conv: more than 2^31 pixels");   // the kernel keeps pixel indices in 32 bits
+    if (four && !c.out_split && !p.res && !p.scale2 && emd::g_knobs.deconv_direct == 2) {   // 128-row tiles, two workgroups per CU
+        p.n_mtiles = (int)((p.M + 127) / 128);
+        const long nb2 = (long)p.n_mtiles * p.n_ntiles;
+        if (nb2 > 0x7fffffffL) return emd::fail(EMD_E_UNSUPPORTED, "split32 conv: grid too large");
+        if (bn == 64) hipLaunchKernelGGL((deconv4_half_kernel<64>), dim3((unsigned)nb2), dim3(256), 0, st, c);
+        else hipLaunchKernelGGL((deconv4_half_kernel<128>), dim3((unsigned)nb2), dim3(256), 0, st, c);
+        return emd::check_launch("deconv4_half_kernel");
+    }
     if (four && !c.out_split && !p.res && !p.scale2 && emd::g_knobs.deconv_direct) {   // round 3: epilogue from the registers, next phase's DMA first
         if (bn == 64) hipLaunchKernelGGL((deconv4_split_kernel<64>), dim3((unsigned)nblk), dim3(512), 0, st, c);
         else hipLaunchKernelGGL((deconv4_split_kernel<128>), dim3((unsigned)nblk), dim3(512), 0, st, c);

@@ -17,11 +17,14 @@
  *   sep_xcd (1)         0 = launch-order tiles instead of one contiguous run of tiles per XCD
  *   sep_wide (1)        sep_fused 256-column single-output form: 0 never, 1 Cin <= 256, 2 whenever it fits
  *   sep_wres (1)        0 = per-chunk pointwise weight loads in sep_fused's 64-column instances (default: resident in LDS)
- *   deconv_direct (1)   one-launch transposed conv: 1 = epilogue straight from the accumulators (next phase's DMA issued first), 0 = LDS-staged
+ *   deconv_direct (1)   one-launch transposed conv: 1 = epilogue straight from the accumulators (next phase's DMA issued first), 2 = the same on
+ *                       128-row tiles at two workgroups per CU, 0 = LDS-staged
  *   nt_mask (7)         non-temporal output stores: bit 0 split32 convolutions, bit 1 sep_fused, bit 2 pointwise split32 GEMM
  *   dw_xcd (1)          depthwise kernels: 0 = launch-order tiles, 1 = XCD-contiguous up to 128 x 128 maps, 2 = always
  *   dw_th (0)           strip height of the rolling depthwise kernel (0 = rule)
  *   split_narrow (1)    pointwise split32 GEMM: 128 x 64 tiles for the small batches whose 128 x 128 tiles leave CUs idle (0 = never)
+ *   split_wide (0)      pointwise split32 GEMM: 256 x 192 tiles where they fill the chip (N = 728: four column tiles, no half round): 0 never
+ *                       (default: same bits, slower inside graph D), 1 = 8 waves of 64 x 96, 2 = 4 waves of 128 x 96
  *   split_variant (-1)  pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
  */
 #ifndef EMDENOISE_DEV_H

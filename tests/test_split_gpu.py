@@ -196,6 +196,40 @@ def test_conv1x1_split32_full_size_identity():
     assert torch.equal(d4.buf, d.buf[8:12]) and torch.equal(d8.buf, d.buf[16:24]) and torch.equal(d1.buf, d.buf[31:32])
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,res,extra", [
+    (16, 32, 32, 728, 728, True, False),     # 64 x 4 tiles of 256 x 192: the smallest grid that takes the wide form; residual
+    (33, 23, 23, 728, 728, False, True),     # M = 17457: a ragged last row tile; second affine
+    (32, 32, 32, 256, 384, True, True),      # two column tiles, K = 8 steps
+    (20, 32, 32, 96, 192, False, False),     # one column tile, K = 3 steps (fewer than the A ring has stages)
+])
+@pytest.mark.parametrize("form", [1, 2])
+def test_conv1x1_split32_wide_tiles(B, H, W, ci, co, res, extra, form):
+    """gemm_split16_wide_kernel (256 x 192 tiles; dev knob split_wide: 1 = 8 waves of 64 x 96, 2 = 4 waves of 128 x 96) gives the bits of
+    gemm_split16_kernel (knob 0): same products, same order along K per output element -- so the tile the host picks by M never shows in
+    a result -- and writes nothing outside its channel slice."""
+    from emdenoise import _lib, ops
+
+    x = rnd((B, H, W, ci), 71, positive=True)
+    w = rnd((1, ci, co), 72, scale=0.04)
+    r = rnd((B, H, W, co), 73)
+    pw = ops.PackedWeights(w, False, dev())
+    s1, t1 = up(rnd((co,), 74, 0.3) + 1.0), up(rnd((co,), 75, 0.5))
+    s2, t2 = up(rnd((co,), 76, 0.2) + 1.0), up(rnd((co,), 77, 0.3))
+    kw = dict(scale2=s2 if extra else None, shift2=t2 if extra else None, res=ops.Act(up(r)) if res else None)
+    xs = ops.to_split32(ops.Act(up(x)))
+    try:
+        _lib.knob("split_wide", 0)
+        ref = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()), **kw)
+        _lib.knob("split_wide", form)
+        wide = torch.full((B, H, W, co + 8), float("nan"), dtype=torch.float32, device=dev())
+        got = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act(wide, co, 4), **kw)
+        torch.cuda.synchronize()
+    finally:
+        _lib.knob("split_wide", 0)
+    assert torch.equal(got.torch(), ref.torch())
+    assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
+
+
 def test_split32_argument_checks():
     from emdenoise import _lib, ops
 
@@ -279,11 +313,20 @@ def test_deconv3x3s2_split32_equals_deconv(B, H, W, ci, co, out_split):
         torch.cuda.synchronize()
         assert torch.equal(one.buf.view(torch.int32), got.buf.view(torch.int32))
     else:
-        wide = torch.full((B, 2 * H, 2 * W, co + 8), float("nan"), dtype=torch.float32, device=dev())
-        one = ops.deconv3x3s2_fused(xs, phases, s1, t1, ops.Act(wide, co, 4))
-        torch.cuda.synchronize()
-        assert torch.equal(one.torch(), got.torch())
-        assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
+        from emdenoise import _lib
+
+        # every form of the one-launch kernel (dev knob deconv_direct: 0 = LDS-staged epilogue, 1 = epilogue from the registers on
+        # 256-row tiles, 2 = the same on 128-row tiles at two workgroups per CU)
+        try:
+            for form in (0, 1, 2):
+                _lib.knob("deconv_direct", form)
+                wide = torch.full((B, 2 * H, 2 * W, co + 8), float("nan"), dtype=torch.float32, device=dev())
+                one = ops.deconv3x3s2_fused(xs, phases, s1, t1, ops.Act(wide, co, 4))
+                torch.cuda.synchronize()
+                assert torch.equal(one.torch(), got.torch()), form
+                assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
+        finally:
+            _lib.knob("deconv_direct", 1)
 
 
 @pytest.mark.parametrize("B,H,W,ci,co,res", [(2, 16, 16, 256, 256, True), (1, 24, 20, 728, 132, False), (1, 8, 8, 64, 36, True)])
