@@ -300,6 +300,38 @@ def gen_lq(img, select=None, seed=1, frac=1.0 / 64):
     return lq
 
 
+def spiral_mask(size, frac=1.0 / 64):
+    """NOT in the reference (its mask is the fixed Bernoulli(1/64) field of gen_lq, :1172-1175): a spiral-scan mask of our own, for
+    BASELINE configs[4]'s wording "512x512 spiral-scan masks".  An Archimedean spiral r = p theta / (2 pi) from the centre out to the
+    corners, one pixel wide, sampled more finely than a pixel so that consecutive visited pixels touch (a beam path, not a point
+    cloud); the pitch p is bisected until the number of visited pixels is frac * size**2 to within one turn's granularity.
+    Deterministic.  Returns a bool [size, size] array: True = measured.  Use as gen_lq(img, select=spiral_mask(S))."""
+    target = frac * size * size
+    c = (size - 1) / 2.0
+    rmax = c * 2.0 ** 0.5
+
+    def build(pitch):
+        turns = rmax / pitch
+        n = int(turns * 2.0 * np.pi * rmax * 2.0) + 16          # at least two samples per pixel of arc on the outermost turn
+        th = np.sqrt(np.linspace(0.0, 1.0, n)) * turns * 2.0 * np.pi   # sqrt spacing: uniform arc-length steps
+        r = pitch * th / (2.0 * np.pi)
+        y = np.rint(c + r * np.sin(th)).astype(np.int64)
+        x = np.rint(c + r * np.cos(th)).astype(np.int64)
+        ok = (y >= 0) & (y < size) & (x >= 0) & (x < size)
+        m = np.zeros((size, size), bool)
+        m[y[ok], x[ok]] = True
+        return m
+
+    lo, hi = 1.0, float(size)          # pitch in pixels: small pitch = dense mask
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        if build(mid).sum() > target:
+            lo = mid
+        else:
+            hi = mid
+    return build(0.5 * (lo + hi))
+
+
 def generator_architecture(inputs, phase=False, params=None, train_batch_norm=None, engine=None):
     """Signature of the reference's graph builder (:133); inference only."""
     if train_batch_norm:

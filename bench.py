@@ -73,6 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--train-streams", type=int, default=8, help="workload T: HIP streams the towers are issued on")
     ap.add_argument("--tower-mode", choices=["streams", "batched"], default="batched",
                     help="workload T, towers of 1: the towers on --train-streams HIP streams, or as ONE batched pass with per-image batch-norm statistics")
+    ap.add_argument("--mask", choices=["spiral", "bernoulli"], default="spiral",
+                    help="workloads G / A: which 1/64 of the pixels is given -- a spiral scan path (ours) or the reference's fixed Bernoulli field")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying captured hipGraphs (T / A / S)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-child", default=None, metavar="DIR",
@@ -423,7 +425,15 @@ def inputs_K(a, B, first):
 def inputs_G(a, B, first):
     from emdenoise import gan as GN
 
-    return GN.gen_lq(2.0 * synthetic_lq(max(B, 1), a.size, a.size, seed=77 + first)[..., 0] - 1.0)[..., None]
+    return GN.gen_lq(2.0 * synthetic_lq(max(B, 1), a.size, a.size, seed=77 + first)[..., 0] - 1.0, select=g_mask(a))[..., None]
+
+
+def g_mask(a):
+    """--mask spiral (default; BASELINE configs[4]'s wording, a generator of our own: gan.spiral_mask) or bernoulli (the reference's
+    fixed field, gan-infilling-100.py:1172-1175).  The mask is input DATA: no kernel's work depends on it."""
+    from emdenoise import gan as GN
+
+    return GN.spiral_mask(a.size) if a.mask == "spiral" else None
 
 
 def inputs_S(a, B, first):
@@ -440,7 +450,7 @@ def inputs_A(a, rank):
 
     T, S = a.gan_batch, a.size
     hq = (2.0 * synthetic_lq(T, S, S, seed=177 + rank) - 1.0).astype(np.float32)
-    lq = GN.gen_lq(hq[..., 0])[..., None]
+    lq = GN.gen_lq(hq[..., 0], select=g_mask(a))[..., None]
     rng = np.random.default_rng(5 + rank)
     pad = (3 * S) // 4
     offsets = [tuple((int(rng.integers(0, S + 2 * pad - n + 1)), int(rng.integers(0, S + 2 * pad - n + 1))) for n in (S // 4, S // 2, pad))
@@ -1050,7 +1060,7 @@ def bench_G(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
            "median_hipevent_ms": timer.median_event_ms, "steps": steps, "warmup": warmup,
            "dtype": "bf16x3 (split-bf16 MFMA inputs, fp32 accumulate and activations)",
            "config": {"workload": f"G: in-filling generator forward (misc_py/gan-infilling-100.py), [{B},{S},{S},1] fp32 per GPU, "
-                                  "1/64 of the pixels given", "precision": a.precision,
+                                  f"1/64 of the pixels given ({a.mask} mask)", "precision": a.precision,
                       "algorithmic_tflop_per_step": round(tflop, 3), "sharding": shard_note(a, world, B, total)},
            "tflops_algorithmic": round(tflop / (ms / 1e3), 1),
            "roofline": {"bound": "mfma", "kernel": "matrix-core family (sep_fused + gemm_split + gemm_conv launches of one step)",
