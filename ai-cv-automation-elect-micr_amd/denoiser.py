@@ -389,7 +389,9 @@ class DenoiserEngine:
         half = x.B // 2
         # with the depthwise stage inside the GEMM there is no bandwidth-bound kernel left for the other half's GEMM to overlap with
         fused = self._sep_gemm_ok(x, self.layers["cnn4_a"]) and os.environ.get("EMD_D_TWO_STREAMS_FUSED", "0") != "1"
-        if (self.two_streams and not fused and x.B % 2 == 0 and half >= 1 and self.precision == ops.PREC_BF16X3
+        # ... and only while a half still fills the chip: its GEMMs run on 128-row tiles below 192 tiles of 256 rows, and two half-filled
+        # launches side by side lose to one (B = 4 at 512^2: 3.84 ms as halves, 3.71 ms whole; B = 8: 6.65 vs 6.72; profiles/r03_experiments.txt 12)
+        if (self.two_streams and not fused and x.B % 2 == 0 and half * x.H * x.W >= 4096 and self.precision == ops.PREC_BF16X3
                 and ops.conv1x1_split32_supported(half * x.H * x.W, x.C, out.C)):
             return self._halves.run(x, out, self._middle_chain)
         for _ in self._middle_chain(x, out):
