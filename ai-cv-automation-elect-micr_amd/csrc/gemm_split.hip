@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "mfma_common.hpp"
+#include "conv3_params.hpp"
 
 namespace {
 
@@ -2269,6 +2270,13 @@ extern "C" int emd_conv3x3_split32_f32(const void* xs, int ldx, const uint16_t* 
     EMD_REQUIRE(rate >= 1 && rate <= 31 && (rate == 1 || stride == 1), EMD_E_UNSUPPORTED,
                 "emd_conv3x3_split32_f32: rate must be 1..31, and 1 when stride is 2");
     if (B == 0) return EMD_OK;
+    if (stride == 1 && rate == 1 && !res && H >= 8 && B <= 65535 && 9L * W * ldy < (1L << 31)) {   // round 3: the patch-resident kernel (conv3_pipe.hip)
+        emd::Conv3Params q{};
+        q.x = static_cast<const unsigned char*>(xs); q.ldx_bytes = (long)ldx * 4; q.Whi = whi; q.Wlo = wlo; q.y = static_cast<float*>(y);
+        q.scale1 = scale1; q.shift1 = shift1; q.scale2 = scale2; q.shift2 = shift2;
+        q.H = H; q.W = W; q.Cin = (Cin + 31) / 32 * 32; q.Cpad = (Cin + kBK - 1) / kBK * kBK; q.Ktot = 9 * q.Cpad; q.N = Cout; q.ldy = ldy; q.act = act;
+        if (emd::conv3_pipe_covers(q)) return emd::conv3_pipe_launch(q, B, out_split, static_cast<hipStream_t>(stream));
+    }
     SplitConvParams c{};
     SplitGemmParams& p = c.g;
     p.A = static_cast<const unsigned char*>(xs); p.Whi = whi; p.Wlo = wlo; p.C = static_cast<float*>(y); p.res = res;

@@ -404,6 +404,75 @@ def test_sep_fused_with_split32_output(B, H, W, ci, co, res):
     assert torch.equal(got.buf.view(torch.int32), ops.to_split32(want).buf.view(torch.int32))
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,tpw", [
+    (2, 8, 32, 64, 64, 0),        # one tile per image: every patch border is padding
+    (1, 16, 96, 128, 64, 0),      # left-edge, interior and right-edge tiles, two tile rows (X decoder's 128 -> 64)
+    (1, 8, 256, 32, 64, 4),       # one chunk; four tiles per workgroup: the pointer-increment path between interior tiles
+    (2, 24, 64, 96, 36, 2),       # channel tail (36 of 64 columns), three chunks, two tiles per workgroup
+    (1, 8, 64, 40, 64, 0),        # Cin not a multiple of 32: the split32 tensor's zero padding channels are read as the last chunk
+    (1, 16, 64, 192, 128, 0),     # two column tiles of 64 (X decoder's 192 -> 128)
+    (1, 8, 32, 64, 132, 0),       # three column tiles, the last with 4 live columns
+    (2, 8, 64, 96, 192, 2),       # three full column tiles, two pixel tiles per workgroup
+])
+@pytest.mark.parametrize("out_split", [False, True])
+def test_conv3_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split):
+    """csrc/conv3_pipe.hip (dense 3x3, stride 1, <= 64 output channels, the patch resident in LDS across the nine taps; reached through
+    emd_conv3x3_split32_f32): X's conv_block against the oracle (float64), against the tap-major GEMM it replaces (dev knob
+    conv3_pipe = 0; another summation order: 1e-6, not bits), fp32 output into a NaN-filled concat slice and split32 output equal to
+    emd_to_split32_f32 of the fp32 one."""
+    from emdenoise import _lib, ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 171)
+    w = rnd((3, 3, ci, co), 172, scale=(2.0 / (9 * ci + co)) ** 0.5)
+    bias, g, h = rnd((co,), 173, 0.2), rnd((co,), 174, 0.3) + 1.0, rnd((co,), 175, 0.4)
+    ref = torch.relu(torch.relu(T.conv2d_t(t64(x), t64(w), t64(bias))) * t64(g) + t64(h)).numpy()
+    pw = ops.PackedWeights(w.reshape(9, ci, co), False, dev())
+    xs = ops.to_split32(ops.Act(up(x)))
+    one = up(np.ones(co, np.float32))
+    kw = dict(act=ops.ACT_RELU, scale2=up(g), shift2=up(h))
+    try:
+        _lib.knob("sep_tpw", tpw)
+        wide = torch.full((B, H, W, co + 8), float("nan"), dtype=torch.float32, device=dev())
+        got = ops.conv3x3_split32(xs, pw, one, up(bias), ops.Act(wide, co, 4), **kw)
+        if out_split:
+            sp = ops.SplitAct(B, H, W, co, dev())
+            sp.buf.fill_(float("nan"))
+            ops.conv3x3_split32(xs, pw, one, up(bias), sp, **kw)
+        _lib.knob("conv3_pipe", 0)
+        old = ops.conv3x3_split32(xs, pw, one, up(bias), ops.Act.empty(B, H, W, co, dev()), **kw)
+        torch.cuda.synchronize()
+    finally:
+        _lib.knob("conv3_pipe", 1)
+        _lib.knob("sep_tpw", 0)
+    g_np = got.torch().cpu().numpy()
+    assert not np.isnan(g_np).any()
+    assert rel_l2(g_np, ref) < TOL_X3
+    assert float((got.torch() - old.torch()).norm() / old.torch().norm()) < 1e-6
+    assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
+    if out_split:
+        want = ops.to_split32(ops.Act(got.torch().contiguous()))
+        assert torch.equal(sp.buf.view(torch.int32), want.buf.view(torch.int32))
+
+
+def test_conv3_pipe_full_size_properties():
+    """Graph X's 64 -> 64 decoder layer at full size, [8,512,512,64]: image b of the batch == the image alone, bit for bit, and the
+    pre-activation is exactly linear in the input under powers of two."""
+    from emdenoise import ops
+
+    B, S, ci, co = 8, 512, 64, 64
+    g = torch.Generator(device=dev()).manual_seed(7)
+    x = torch.rand(B, S, S, ci, device=dev(), generator=g)
+    pw = ops.PackedWeights(rnd((9, ci, co), 181, 0.05), False, dev())
+    s1, t0 = torch.rand(co, device=dev(), generator=g) + 0.5, torch.zeros(co, device=dev())
+    f = lambda xx: ops.conv3x3_split32(ops.to_split32(ops.Act(xx)), pw, s1, t0, ops.Act.empty(xx.shape[0], S, S, co, dev()), act=ops.ACT_NONE).torch()
+    y, y1, y2 = f(x), f(x[5:6].contiguous()), f(2 * x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    assert torch.equal(y[5:6], y1)
+    assert torch.equal(y2, 2 * y)
+
+
 @pytest.mark.parametrize("B,H,W,ci,co,stride,rate", [
     (2, 16, 16, 64, 128, 1, 1), (1, 33, 21, 96, 132, 1, 1), (1, 32, 32, 728, 728, 1, 6), (2, 18, 14, 40, 128, 2, 1),
     (2, 24, 24, 64, 64, 1, 1), (1, 17, 19, 32, 36, 1, 3)])
