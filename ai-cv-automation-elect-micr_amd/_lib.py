@@ -106,6 +106,8 @@ SIGNATURES = {
                                           _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_long, C.c_int, C.c_int,
                                           C.c_int, C.c_void_p]),
     # x w9 a shift y ldy B H W Cout stride act stream
+    "emd_conv3x3_cin1_f32": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "emd_cin1_f32": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     # x ldx w scale shift y B H W Cin act stream

@@ -242,6 +242,61 @@ __global__ __launch_bounds__(256) void cin1_kernel(const float* __restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense 3x3 conv of a ONE-channel image (graph X's entry conv, misc_py/modified_Xception.py:356-364: tf.layers.conv2d(1 -> 32, k 3,
+// stride 2) + bias -> BN -> relu): 9 inputs per output pixel -- nothing for the matrix cores (the 9-tap GEMM ran it with the channel
+// padded to 64 per tap: 0.57 ms for 0.4 GB of traffic).  A thread = one output pixel x 8 output channels (fp32 FMAs); Cout / 8 lanes
+// share a pixel, so a wave's store instruction covers whole pixels' channel runs.  TF SAME.  SPLIT: the output as a split32 tensor
+// (a thread's 8 channels = 16 bytes of hi words + 16 bytes of lo words of the pixel's line).
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void conv3x3_cin1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ y, int ldy, int H, int W, int Ho, int Wo, int stride,
+                                                           int pt, int pl, int N8, int Cout, long npix, int act) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = (int)(idx % N8);
+    const long pix = idx / N8;
+    if (pix >= npix) return;
+    int ox, oy;
+    const long t = emd::divmod(pix, Wo, ox);
+    const long b = emd::divmod(t, Ho, oy);
+    const float* img = x + b * (long)H * W;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    const bool live = c8 * 8 < Cout;       // (SPLIT: the lanes of the padding channels up to a multiple of 32 store zeros)
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int iy = oy * stride - pt + i;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ix = ox * stride - pl + j;
+                const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[(long)iy * W + ix] : 0.f;
+                const float4 w0 = *reinterpret_cast<const float4*>(w + (i * 3 + j) * Cout + c8 * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(w + (i * 3 + j) * Cout + c8 * 8 + 4);
+                acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]); acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
+                acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]); acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
+            }
+        }
+        const float lo = (act == 1 || act == 2) ? 0.f : -__builtin_inff(), hi = act == 1 ? 6.f : __builtin_inff();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fminf(fmaxf(fmaf(acc[k], scale[c8 * 8 + k], shift[c8 * 8 + k]), lo), hi);
+    }
+    if (!SPLIT) {
+        if (!live) return;
+        *reinterpret_cast<float4*>(y + pix * ldy + c8 * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(y + pix * ldy + c8 * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) emd::split2(acc[2 * k], acc[2 * k + 1], h[k], l[k]);
+        unsigned char* g = reinterpret_cast<unsigned char*>(y) + pix * (long)ldy * 4 + (c8 >> 2) * 128 + (c8 & 3) * 16;
+        *reinterpret_cast<emd::u32x4*>(g) = emd::u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<emd::u32x4*>(g + 64) = emd::u32x4{l[0], l[1], l[2], l[3]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dense 3x3 conv to ONE output channel: LP = Cin/4 lanes share a pixel (each owns 4 input channels of
 // all 9 taps) and reduce their partial dot products with wave shuffles; 64/LP pixels per wave.
 __global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restrict__ x, int ldx,
@@ -805,6 +860,39 @@ extern "C" int emd_cin1_f32(const float* x, const float* w9, const float* a, con
     hipLaunchKernelGGL(cin1_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, w9, a, shift, y, ldy, H,
                        W, Ho, Wo, stride, N4, w9 ? 1 : 0, npix, act ? 1 : 0);
     return emd::check_launch("cin1_kernel");
+}
+
+extern "C" int emd_conv3x3_cin1_f32(const float* x, const float* w, const float* scale, const float* shift, void* y, int ldy, int B,
+                                    int H, int W, int Cout, int stride, int act, int out_split, emd_stream_t stream) {
+    EMD_REQUIRE(x && w && scale && shift && y, EMD_E_INVALID, "emd_conv3x3_cin1_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_conv3x3_cin1_f32: bad shape");
+    EMD_REQUIRE(stride == 1 || stride == 2, EMD_E_UNSUPPORTED, "emd_conv3x3_cin1_f32: stride must be 1 or 2");
+    EMD_REQUIRE(Cout >= 8 && Cout % 8 == 0 && Cout <= 512, EMD_E_UNSUPPORTED, "emd_conv3x3_cin1_f32: Cout a multiple of 8, <= 512");
+    EMD_REQUIRE(act == EMD_ACT_NONE || act == EMD_ACT_RELU6 || act == EMD_ACT_RELU, EMD_E_UNSUPPORTED, "emd_conv3x3_cin1_f32: act none / relu6 / relu");
+    EMD_REQUIRE(emd::aligned16(w) && emd::aligned16(scale) && emd::aligned16(shift), EMD_E_ALIGN, "emd_conv3x3_cin1_f32: w, scale, shift 16-byte aligned");
+    if (out_split)
+        EMD_REQUIRE(ldy % 32 == 0 && ldy >= (Cout + 31) / 32 * 32 && (reinterpret_cast<uintptr_t>(y) & 127u) == 0, EMD_E_ALIGN,
+                    "emd_conv3x3_cin1_f32: a split32 output needs y 128-byte aligned, ldy a multiple of 32, >= ceil32(Cout)");
+    else
+        EMD_REQUIRE(ldy % 4 == 0 && ldy >= Cout && emd::aligned16(y), EMD_E_ALIGN, "emd_conv3x3_cin1_f32: ldy a multiple of 4, >= Cout; y 16-byte aligned");
+    if (B == 0) return EMD_OK;
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    int pth = (Ho - 1) * stride + 3 - H, ptw = (Wo - 1) * stride + 3 - W;   // TF SAME: total padding, the smaller half first
+    if (pth < 0) pth = 0;
+    if (ptw < 0) ptw = 0;
+    const long npix = (long)B * Ho * Wo;
+    const int N8 = out_split ? (Cout + 31) / 32 * 4 : Cout / 8;
+    unsigned nb;
+    int rc = grid_for(npix * N8, &nb);
+    if (rc != EMD_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (out_split)
+        hipLaunchKernelGGL(conv3x3_cin1_kernel<true>, dim3(nb), dim3(256), 0, st, x, w, scale, shift, static_cast<float*>(y), ldy, H, W, Ho,
+                           Wo, stride, pth / 2, ptw / 2, N8, Cout, npix, act);
+    else
+        hipLaunchKernelGGL(conv3x3_cin1_kernel<false>, dim3(nb), dim3(256), 0, st, x, w, scale, shift, static_cast<float*>(y), ldy, H, W, Ho,
+                           Wo, stride, pth / 2, ptw / 2, N8, Cout, npix, act);
+    return emd::check_launch("conv3x3_cin1_kernel");
 }
 
 extern "C" int emd_conv3x3_cout1_f32(const float* x, int ldx, const float* w, float scale, float shift, float* y,

@@ -423,6 +423,18 @@ def conv1x1_split32(x: SplitAct, w: PackedWeights, scale1, shift1, out: Act, act
     return out
 
 
+def conv3x3_cin1(x_img, w_dev, scale, shift, out, stride=1, act=True, stream=None):
+    """Dense 3x3 conv of a 1-channel image (emd_conv3x3_cin1_f32).  x_img: torch CUDA float32 [B,H,W] or [B,H,W,1] contiguous; w_dev
+    [9, Cout]; out an Act (fp32) or a SplitAct (split32)."""
+    lib = _lib.load()
+    B, H, W = x_img.shape[0], x_img.shape[1], x_img.shape[2]
+    assert x_img.is_contiguous() and (out.B, out.H, out.W) == (B, -(-H // stride), -(-W // stride)) and w_dev.shape == (9, out.C)
+    rc = lib.emd_conv3x3_cin1_f32(_p(x_img), _p(w_dev), _p(scale), _p(shift), out.ptr, out.ld, B, H, W, out.C, stride, _act(act),
+                                  1 if isinstance(out, SplitAct) else 0, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_conv3x3_cin1_f32")
+    return out
+
+
 def cin1(x_img, w9_dev, a_dev, shift_dev, out: Act, stride=1, act=True, stream=None):
     """x_img: torch CUDA float32 [B,H,W] or [B,H,W,1] contiguous."""
     lib = _lib.load()

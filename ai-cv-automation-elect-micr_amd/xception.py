@@ -204,6 +204,7 @@ class XceptionEngine:
                 else:
                     cin = L.cin
                     if cin == 1:                                 # entry conv: the 1-channel image is zero-padded to 4 channels
+                        p["w9"] = d(wt[:, :, 0, :].reshape(9, L.cout))          # ... or goes through the 1-channel kernel (forward)
                         wt = np.concatenate([wt, np.zeros((L.k, L.k, 3, L.cout), np.float32)], axis=2)
                         cin = 4
                     p["pw"] = ops.PackedWeights(wt.reshape(L.k * L.k, cin, L.cout), False, device)
@@ -279,9 +280,27 @@ class XceptionEngine:
             return r
 
         def conv_bn_relu(a, out=None):
-            """tf.layers.conv2d (+bias) -> batch_then_activ: one GEMM launch."""
+            """tf.layers.conv2d (+bias) -> batch_then_activ: one GEMM launch.  The two entry convs (:356-372) take their own routes in
+            the split-bf16 mode: 1 -> 32 (k 3, stride 2) is nine fp32 FMAs per output on emd_conv3x3_cin1_f32, writing split32; 32 -> 64
+            (k 3) then runs on the patch-resident split32 kernel (csrc/conv3_pipe.hip) -- 0.57 + 0.65 ms on the 9-tap GEMM before."""
             L, p = next(it)
+            if L.cin == 1 and L.k == 3 and prec == ops.PREC_BF16X3 and out is None and L.cout % 32 == 0:
+                Ho, Wo = -(-S // L.stride), -(-S // L.stride)
+                r = ops.conv3x3_cin1(x, p["w9"], p["gs"], p["hs"], ops.SplitAct(B, Ho, Wo, L.cout, dev), stride=L.stride, act=RELU)
+                if trace is not None:
+                    trace.append(host(r))
+                    r = forced(r)
+                return r
             Ho, Wo = -(-a.H // L.stride), -(-a.W // L.stride)
+            if (L.k == 3 and L.stride == 1 and L.rate == 1 and out is None and prec == ops.PREC_BF16X3 and L.cin % 32 == 0
+                    and L.cout <= 192 and Ho % 8 == 0 and Wo % 32 == 0 and (isinstance(a, ops.SplitAct) or teacher is not None)):
+                r = ops.conv3x3_split32(as_split(a), p["pw"], p["gs"], p["hs"], E(Ho, Wo, L.cout), act=RELU)
+                if trace is not None:
+                    trace.append(r.torch().cpu().numpy())
+                    r = forced(r)
+                return r
+            if isinstance(a, ops.SplitAct):
+                a = ops.Act(a.to_float().contiguous())
             out = out or E(Ho, Wo, L.cout)
             if L.k == 1:
                 r = ops.conv1x1(a, p["pw"], p["gs"], p["hs"], out, stride=L.stride, act=RELU, precision=prec)
@@ -356,9 +375,12 @@ class XceptionEngine:
             return r
 
         # entry flow: the 1-channel image as a 4-channel tensor (3 zero channels) feeds the 9-tap GEMM
-        x4 = torch.zeros((B, S, S, 4), dtype=torch.float32, device=dev)
-        x4[..., 0] = x[..., 0]
-        e = conv_bn_relu(ops.Act(x4))
+        if prec == ops.PREC_BF16X3:
+            e = conv_bn_relu(None)                              # reads x itself (emd_conv3x3_cin1_f32)
+        else:
+            x4 = torch.zeros((B, S, S, 4), dtype=torch.float32, device=dev)
+            x4[..., 0] = x[..., 0]
+            e = conv_bn_relu(ops.Act(x4))
         e = conv_bn_relu(e)
         for _ in range(3):
             res = conv_bn_relu(e)

@@ -246,6 +246,13 @@ int emd_dw3x3_pre_f32(const float* x, int ldx, const float* pre_scale, const flo
 int emd_dw3x3_pre_split32_f32(const float* x, int ldx, const float* pre_scale, const float* pre_shift, const float* w,
                               void* y, int ldy, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream);
 
+/* Dense 3x3 conv of a ONE-channel image + per-channel affine + activation (graph X's entry conv: tf.layers.conv2d(1 -> 32, k 3,
+ * stride 2) + bias -> batch norm -> relu, misc_py/modified_Xception.py:356-364; the caller folds bias and norm into scale / shift):
+ * x [B,H,W] fp32 contiguous, w [9][Cout] fp32 (tap-major), y [B,Ho,Wo,Cout] fp32 (pitch ldy floats) or, out_split != 0, a split32
+ * tensor (pitch ldy 4-byte units, a multiple of 32; padding channels written as zero).  TF SAME, stride 1 or 2.  fp32 FMAs. */
+int emd_conv3x3_cin1_f32(const float* x, const float* w, const float* scale, const float* shift, void* y, int ldy, int B, int H, int W,
+                         int Cout, int stride, int act, int out_split, emd_stream_t stream);
+
 /* Layers fed by the 1-channel image: y[pix][n] = act( d[pix]*a[n] + shift[n] ).
  * w9 != NULL: d = 3x3 SAME depthwise of x with the 9 weights w9 (stride 1)  -- cnn0 (denoiser.py:252),
  *             a[n] = pointwise_weights[0][n] * folded BN scale;

@@ -504,3 +504,36 @@ def test_generated_input_entry_points_validate_and_accept_empty_batches():
     assert g(1, 1, p(a)) < 0 and b"reflect" in lib.emd_last_error()
     assert g(1, 8, C.c_void_p(a.data_ptr() + 4)) < 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,H,W,co,stride", [(2, 64, 64, 32, 2), (1, 33, 47, 32, 2), (2, 24, 40, 64, 1), (1, 16, 16, 40, 2)])
+@pytest.mark.parametrize("split", [False, True])
+def test_conv3x3_cin1(B, H, W, co, stride, split):
+    """emd_conv3x3_cin1_f32: graph X's entry conv (tf.layers.conv2d(1 -> 32, k 3, stride 2) + bias -> BN -> relu,
+    misc_py/modified_Xception.py:356-364) in fp32 FMAs, against the oracle's TF-SAME conv (float64); fp32 output into a NaN-filled concat
+    slice, split32 output == emd_to_split32_f32 of the fp32 one (padding channels zero)."""
+    from emdenoise import ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, 1), 501)
+    w = rnd((3, 3, 1, co), 502, 0.4)
+    bias, g, h = rnd((co,), 503, 0.2), rnd((co,), 504, 0.3) + 1.0, rnd((co,), 505, 0.4)
+    ref = torch.relu((T.conv2d_t(t64(x), t64(w), t64(bias), stride=stride)) * t64(g) + t64(h)).numpy()
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    xd, wd = d(x), d(w[:, :, 0, :].reshape(9, co))
+    gs, hs = d(g), d(bias.astype(np.float64) * g + h)
+    out = out_act(B, Ho, Wo, co, ld=co + 8, c0=4)
+    ops.conv3x3_cin1(xd, wd, gs, hs, out, stride=stride, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    got = out.torch().cpu().numpy()
+    assert rel_l2(got, ref) < TOL_F32
+    full = out.buf.cpu().numpy()
+    assert np.isnan(full[..., :4]).all() and np.isnan(full[..., 4 + co:]).all()
+    if split:
+        sp = ops.SplitAct(B, Ho, Wo, co, dev())
+        sp.buf.fill_(float("nan"))
+        ops.conv3x3_cin1(xd, wd, gs, hs, sp, stride=stride, act=ops.ACT_RELU)
+        want = ops.to_split32(ops.Act(out.torch().contiguous()))
+        torch.cuda.synchronize()
+        assert torch.equal(sp.buf.view(torch.int32), want.buf.view(torch.int32))
