@@ -37,6 +37,7 @@ SIGNATURES = {
                                   _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "emd_sep3x3_fused_supported": (C.c_int, [C.c_int] * 6),
+    "emd_deconv3x3s2_fused_preferred": (C.c_int, [C.c_int] * 5),
     # x ldx dw whi wlo scale1 shift1 scale2 shift2 res ldres y ldy B H W Cin Cout act precision stream
     "emd_sep3x3_fused_s2_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
                                           _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int,

@@ -20,6 +20,22 @@ struct Conv3Params {
     int n_ntiles;             // column tiles of 64 output channels
 };
 
+// the patch-resident transposed conv (deconv_pipe.hip)
+struct DeconvPipeParams {
+    const unsigned char* x;   // split32 input [B,H,W, ceil32(Cin)]
+    long ldx_bytes;
+    const uint16_t* Whi[4];   // per output phase 2 py + px: packed weights [Npad][taps of the phase: 4, 2, 2, 1][Cpad]
+    const uint16_t* Wlo[4];
+    float* y;                 // [B,2H,2W,N] fp32 (pitch ldy floats) or split32 (pitch ldy 4-byte units)
+    const float* scale1;
+    const float* shift1;
+    int H, W, Cin, Cpad, N, ldy, act;
+    int tpw, n_ntiles;
+};
+
+bool deconv_pipe_covers(const DeconvPipeParams& p);
+int deconv_pipe_launch(const DeconvPipeParams& p, int B, int out_split, hipStream_t st);
+
 bool conv3_pipe_covers(const Conv3Params& p);
 int conv3_pipe_launch(const Conv3Params& p, int B, int out_split, hipStream_t st);
 

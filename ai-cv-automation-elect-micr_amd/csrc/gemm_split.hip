@@ -2338,6 +2338,17 @@ extern "C" int emd_deconv3x3s2_split32_f32(const void* xs, int ldx, const uint16
 // The same transposed convolution as ONE launch (gemm_split_conv_kernel<BN, true>): each workgroup computes the four output
 // phases of its 256 input pixels back to back, so the input is fetched from HBM once instead of once per phase launch (the 9 taps'
 // DMA re-reads hit L2).  Same products in the same order as the four-launch form: bit-identical results.
+// Where graph hosts should take the one-launch form (emd_deconv3x3s2_fused_split32_f32) rather than the register-staged four-phase GEMM:
+// always where the patch-resident kernel covers the layer (H % 8 == 0, W % 32 == 0, Cin % 32 == 0: it sums in another order than the GEMM
+// forms, so the choice must not depend on the batch size -- image b of a batch == the image alone, bit for bit), otherwise from 192
+// row tiles on (the GEMM forms agree with each other bit for bit, there the choice is speed only).
+extern "C" int emd_deconv3x3s2_fused_preferred(int B, int H, int W, int Cin, int Cout) {
+    emd::DeconvPipeParams q{};
+    q.H = H; q.W = W; q.Cin = (Cin + 31) / 32 * 32; q.N = Cout;
+    if (Cin % 32 == 0 && H >= 8 && emd::deconv_pipe_covers(q)) return 1;
+    return (long)B * H * W >= 256L * 192 ? 1 : 0;
+}
+
 extern "C" int emd_deconv3x3s2_fused_split32_f32(const void* xs, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4],
                                                  const float* scale1, const float* shift1, void* y, int ldy, int B, int H, int W,
                                                  int Cin, int Cout, int act, int out_split, emd_stream_t stream) {
@@ -2348,6 +2359,14 @@ extern "C" int emd_deconv3x3s2_fused_split32_f32(const void* xs, int ldx, const 
     }
     EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_deconv3x3s2_fused_split32_f32: bad shape");
     if (B == 0) return EMD_OK;
+    if (H >= 8 && B <= 65535 && 36L * W * ldy < (1L << 31)) {   // the patch-resident kernel (deconv_pipe.hip), dev knob deconv_direct = 3
+        emd::DeconvPipeParams q{};
+        q.x = static_cast<const unsigned char*>(xs); q.ldx_bytes = (long)ldx * 4; q.y = static_cast<float*>(y);
+        for (int ph = 0; ph < 4; ++ph) { q.Whi[ph] = whi[ph]; q.Wlo[ph] = wlo[ph]; }
+        q.scale1 = scale1; q.shift1 = shift1;
+        q.H = H; q.W = W; q.Cin = (Cin + 31) / 32 * 32; q.Cpad = (Cin + kBK - 1) / kBK * kBK; q.N = Cout; q.ldy = ldy; q.act = act;
+        if (emd::deconv_pipe_covers(q)) return emd::deconv_pipe_launch(q, B, out_split, static_cast<hipStream_t>(stream));
+    }
     SplitConvParams c{};
     SplitGemmParams& p = c.g;
     p.A = static_cast<const unsigned char*>(xs); p.Whi = whi[0]; p.Wlo = wlo[0]; p.C = static_cast<float*>(y); p.res = nullptr;

@@ -299,7 +299,7 @@ struct Run {
     static bool split_gemm_ok(long npix, int cout, int ktot) {
         return cout >= 128 && ktot >= 512 && ((npix + 255) / 256) * ((cout + 127) / 128) >= 192;
     }
-    static bool deconv_fused_ok(long npix) { return npix >= 256L * 192; }
+    static bool deconv_fused_ok(int B, int H, int W, int cin, int cout) { return emd_deconv3x3s2_fused_preferred(B, H, W, cin, cout) != 0; }
 
     // strided_conv_block (denoiser.py:110-136); out: optional destination (a concat slice); split_out: write a split32 tensor
     T4 sep(const std::string& key, const T4& x, const T4* out_opt, const T4* res, void** split_out = nullptr) {
@@ -412,7 +412,8 @@ struct Run {
         const uint16_t* lo[4] = {p.phase[0].lo, p.phase[1].lo, p.phase[2].lo, p.phase[3].lo};
         const long npix = (long)B * H * W;
         const int ldx = emd_split32_ld(d.cin);
-        if (deconv_fused_ok(npix) || (d.cin >= 256 && split_gemm_ok(npix, d.cout, 4 * d.cin))) {
+        const bool fused = deconv_fused_ok(B, H, W, d.cin, d.cout);
+        if (fused || (d.cin >= 256 && split_gemm_ok(npix, d.cout, 4 * d.cin))) {
             void* tmp = nullptr;
             if (!xs) {
                 tmp = raw((size_t)npix * ldx * 4);
@@ -420,7 +421,7 @@ struct Run {
                 xs = tmp;
             }
             if (live()) {
-                if (deconv_fused_ok(npix))
+                if (fused)
                     call(emd_deconv3x3s2_fused_split32_f32(xs, ldx, hi, lo, p.scale, p.shift, out.ptr(), out.ld, B, H, W, d.cin, d.cout,
                                                            EMD_ACT_RELU6, 0, st));
                 else
@@ -632,7 +633,7 @@ struct Run {
         free(aspp);
         T4 residual2_d = conv1x1("residual2_d", concat2, nullptr);
         T4 d2a = sep("deconv2_a", concat2, nullptr, nullptr);
-        const bool so2 = deconv_fused_ok((long)B * S4 * S4) && S4 % 8 == 0 && S4 % 16 == 0;
+        const bool so2 = deconv_fused_ok(B, S4, S4, F2, F2) && S4 % 8 == 0 && S4 % 16 == 0;
         void* deconv2_s = nullptr;
         T4 deconv2 = sep("deconv2_b", d2a, nullptr, &residual2_d, so2 ? &deconv2_s : nullptr);
         free(d2a); free(residual2_d); free(concat2);
@@ -643,7 +644,7 @@ struct Run {
         // deconv1_a + residual1_d read concat1: one launch (128 | 128 columns) where emd_sep3x3_dual_preferred says so
         T4 residual1_d, d1a;
         sep_and_projection("deconv1_a", "residual1_d", concat1, &d1a, &residual1_d);
-        const bool so1 = deconv_fused_ok((long)B * S2 * S2) && S2 % 8 == 0 && S2 % 16 == 0;
+        const bool so1 = deconv_fused_ok(B, S2, S2, F1, F1) && S2 % 8 == 0 && S2 % 16 == 0;
         void* deconv1_s = nullptr;
         T4 deconv1 = sep("deconv1_b", d1a, nullptr, &residual1_d, so1 ? &deconv1_s : nullptr);
         free(d1a); free(residual1_d); free(concat1);

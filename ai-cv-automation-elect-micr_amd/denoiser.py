@@ -430,13 +430,16 @@ class DenoiserEngine:
             return ops.conv3x3_split32(xs, p["pw"], p["scale"], p["shift"], out, rate=L.rate)
         return ops.conv3x3(x, p["pw"], p["scale"], p["shift"], out, stride=L.stride, rate=L.rate, precision=self.precision)
 
-    def _deconv_fused_ok(self, npix):
-        return self.precision == ops.PREC_BF16X3 and os.environ.get("EMD_D_DECONV_FUSED", "1") != "0" and npix >= 256 * 192
+    def _deconv_fused_ok(self, B, H, W, cin, cout):
+        """The one-launch transposed conv for this input ([B,H,W,cin]): emd_deconv3x3s2_fused_preferred (independent of B where the
+        patch-resident kernel applies: it sums in another order than the GEMM forms)."""
+        return (self.precision == ops.PREC_BF16X3 and os.environ.get("EMD_D_DECONV_FUSED", "1") != "0"
+                and bool(_lib.load().emd_deconv3x3s2_fused_preferred(B, H, W, cin, cout)))
 
     def _split_out(self, B, H, W, Cc):
         """Output tensor of the layer in front of a transposed conv: split32 when the fused transposed conv will read it (the
         producer's epilogue splits; no fp32 tensor, no converter pass), fp32 otherwise."""
-        if (self.fuse_sep and self._deconv_fused_ok(B * H * W) and Cc % 32 == 0 and H % 8 == 0 and W % 16 == 0
+        if (self.fuse_sep and self._deconv_fused_ok(B, H, W, Cc, Cc) and Cc % 32 == 0 and H % 8 == 0 and W % 16 == 0
                 and os.environ.get("EMD_D_SPLIT_OUT", "1") != "0"):
             return ops.SplitAct(B, H, W, Cc, self.device)
         return None
@@ -445,7 +448,7 @@ class DenoiserEngine:
         L, p = self.layers[key], self.P[key]
         # measured (tools/conv_split_bench.py): converting the input (fp32 -> split32, one pass) + the LDS-DMA GEMM beats the
         # register-staged GEMM where K = taps x Cin >= 1024 per output phase (deconv2to1: 2.72 -> 0.18 + 2.17 ms)
-        if self._deconv_fused_ok(x.B * x.H * x.W):
+        if self._deconv_fused_ok(x.B, x.H, x.W, L.cin, L.cout):
             # one launch, the four output phases per workgroup: the input is read from HBM once instead of four times
             xs = x if isinstance(x, ops.SplitAct) else ops.to_split32(x)
             return ops.deconv3x3s2_fused(xs, p["phases"], p["scale"], p["shift"], out)

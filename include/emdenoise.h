@@ -231,6 +231,11 @@ int emd_sep3x3_fused_out_f32(const float* x, int ldx, const float* dw, const uin
                              const float* scale1, const float* shift1, const float* scale2, const float* shift2,
                              const float* res, int ldres, void* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
                              emd_stream_t stream);
+/* 1 where a graph host should take emd_deconv3x3s2_fused_split32_f32 for this layer ([B,H,W,Cin] input): always where its
+ * patch-resident kernel applies (H % 8 == 0, W % 32 == 0, Cin % 32 == 0 -- independent of B, because that kernel sums in another order
+ * than the GEMM forms and a result must not depend on the batch size), otherwise from B*H*W >= 49152 on (speed only). */
+int emd_deconv3x3s2_fused_preferred(int B, int H, int W, int Cin, int Cout);
+
 /* emd_deconv3x3s2_split32_f32 as ONE launch: a workgroup computes the four output phases of its 256 input pixels back to
  * back, so the input is read from HBM once instead of once per phase launch.  Same arguments, bit-identical results. */
 int emd_deconv3x3s2_fused_split32_f32(const void* xs, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4],

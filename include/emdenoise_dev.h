@@ -17,8 +17,9 @@
  *   sep_xcd (1)         0 = launch-order tiles instead of one contiguous run of tiles per XCD
  *   sep_wide (1)        sep_fused 256-column single-output form: 0 never, 1 Cin <= 256, 2 whenever it fits
  *   sep_wres (1)        0 = per-chunk pointwise weight loads in sep_fused's 64-column instances (default: resident in LDS)
- *   deconv_direct (1)   one-launch transposed conv: 1 = epilogue straight from the accumulators (next phase's DMA issued first), 2 = the same on
- *                       128-row tiles at two workgroups per CU, 0 = LDS-staged
+ *   deconv_direct (3)   one-launch transposed conv: 3 = the patch-resident kernel (csrc/deconv_pipe.hip; sums chunk-major: last-bit
+ *                       differences to the GEMM forms) where H % 8 == 0 and W % 32 == 0, else as 1; 1 = GEMM form with the epilogue straight
+ *                       from the accumulators; 2 = the same on 128-row tiles, two workgroups per CU; 0 = LDS-staged epilogue
  *   nt_mask (7)         non-temporal output stores: bit 0 split32 convolutions, bit 1 sep_fused, bit 2 pointwise split32 GEMM
  *   dw_xcd (1)          depthwise kernels: 0 = launch-order tiles, 1 = XCD-contiguous up to 128 x 128 maps, 2 = always
  *   dw_th (0)           strip height of the rolling depthwise kernel (0 = rule)

@@ -11,6 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL_X3 = 2e-5
+DECONV_DEFAULT = 3   # dev knob deconv_direct (csrc/emd_common.hpp)
 
 
 def rel_l2(a, b):
@@ -326,7 +327,52 @@ def test_deconv3x3s2_split32_equals_deconv(B, H, W, ci, co, out_split):
                 assert torch.equal(one.torch(), got.torch()), form
                 assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
         finally:
-            _lib.knob("deconv_direct", 1)
+            _lib.knob("deconv_direct", DECONV_DEFAULT)
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,tpw", [
+    (2, 8, 32, 128, 128, 0),      # one tile per image (the top / left halo is all padding), two column tiles (D's deconv1to0 widths)
+    (1, 16, 96, 64, 64, 0),       # left, interior and right tiles, two tile rows
+    (1, 8, 128, 256, 132, 2),     # three column tiles (the last: 4 live columns), 8 chunks, two tiles per workgroup
+    (2, 24, 64, 96, 36, 0),       # channel tail inside the only column tile, three chunks
+    (1, 8, 256, 32, 64, 4),       # one chunk, four tiles per workgroup (the pointer-increment path)
+])
+@pytest.mark.parametrize("out_split", [False, True])
+def test_deconv_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split):
+    """csrc/deconv_pipe.hip (dev knob deconv_direct = 3; slim.conv2d_transpose k 3 s 2, denoiser.py:138-150) through
+    emd_deconv3x3s2_fused_split32_f32: against the register-staged four-phase GEMM (which tests/test_ops_gpu.py holds to the oracle) at
+    1e-6 -- another summation order, not bits -- into a NaN-filled concat slice, and as a split32 tensor."""
+    from emdenoise import _lib, ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 261)
+    w = rnd((3, 3, co, ci), 262, scale=(2.0 / (9 * ci + co)) ** 0.5)
+    s1, t1 = up(rnd((co,), 263, 0.3) + 1.0), up(rnd((co,), 264, 0.5))
+    phases = ops.pack_deconv(w, dev())
+    xa = ops.Act(up(x))
+    want = ops.deconv3x3s2(xa, phases, s1, t1, ops.Act.empty(B, 2 * H, 2 * W, co, dev()))
+    ref = T.relu6_t(T.conv2d_transpose_s2_t(t64(x), t64(w)) * t64(s1.cpu().numpy()) + t64(t1.cpu().numpy())).numpy()
+    xs = ops.to_split32(xa)
+    try:
+        _lib.knob("deconv_direct", 3)
+        _lib.knob("sep_tpw", tpw)
+        wide = torch.full((B, 2 * H, 2 * W, co + 8), float("nan"), dtype=torch.float32, device=dev())
+        got = ops.deconv3x3s2_fused(xs, phases, s1, t1, ops.Act(wide, co, 4))
+        if out_split:
+            sp = ops.SplitAct(B, 2 * H, 2 * W, co, dev())
+            sp.buf.fill_(float("nan"))
+            ops.deconv3x3s2_fused(xs, phases, s1, t1, sp)
+        torch.cuda.synchronize()
+    finally:
+        _lib.knob("deconv_direct", DECONV_DEFAULT)
+        _lib.knob("sep_tpw", 0)
+    g_np = got.torch().cpu().numpy()
+    assert not np.isnan(g_np).any()
+    assert rel_l2(g_np, ref) < TOL_X3
+    assert float((got.torch() - want.torch()).norm() / want.torch().norm()) < 1e-6
+    assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
+    if out_split:
+        assert torch.equal(sp.buf.view(torch.int32), ops.to_split32(ops.Act(got.torch().contiguous())).buf.view(torch.int32))
 
 
 @pytest.mark.parametrize("B,H,W,ci,co,res", [(2, 16, 16, 256, 256, True), (1, 24, 20, 728, 132, False), (1, 8, 8, 64, 36, True)])
