@@ -220,13 +220,66 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
             }
         }
     };
+    // ---- epilogue of two phases, from the accumulators: phase (py, px) of input pixel (i, j) is output pixel (2 i + py, 2 j + px).
+    // The tile's stores leave in two halves -- phases 0, 1 are complete after step 1 of the last chunk, phases 2, 3 after step 2 -- so that
+    // each half has a whole step to drain before a wait has to include it (vmcnt retires in order).
+    auto epilogue_pair = [&](int ph0) {
+        int ldo = p.ldy;
+        asm volatile("" : "+s"(ldo));
+        const int li = fr & 3, cq = fr >> 2;
+        const int Wo = 2 * p.W;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int ph = ph0 + pp;
+            const long pixr = 4 * img + (long)(2 * (y0 + wv) + (ph >> 1)) * Wo + 2 * x0 + (ph & 1);
+            float* obase = p.y + pixr * ldo;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float s1 = es1[j], t1 = et1[j];
+                const int n4 = n0 + j * 32 + 4 * cq;
+                const bool valid = n4 < p.N;
+                unsigned voff;
+                if constexpr (OSPLIT) voff = (unsigned)(2 * (4 * fh + li) * ldo) * 4u + (n4 >> 5) * 128u + ((cq & 1) ? 64u : 0u) + ((n4 & 31) >> 3) * 16u;
+                else voff = (unsigned)(2 * (4 * fh + li) * ldo + n4) * 4u;
+                f32x16& a16 = ph0 == 0 ? acc[pp][j] : acc[2 + pp][j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float r[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float v = fmaf(a16[4 * q + k], s1, t1);
+                        r[k] = fminf(fmaxf(fmaxf(v, lo), slope * v), hi);
+                    }
+                    quad_transpose(r, li);
+                    f32x4 v = f32x4{r[0], r[1], r[2], r[3]};
+                    float* ob = obase + (16 * q) * ldo;
+                    if constexpr (!OSPLIT) {
+                        if (valid) store_nt_s(ob, voff, v);
+                    } else {
+                        if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        unsigned h0, l0, h1, l1;
+                        split2(v[0], v[1], h0, l0);
+                        split2(v[2], v[3], h1, l1);
+                        const bool oddq = cq & 1;
+                        const unsigned r0 = xchg4(oddq ? h0 : l0, oddq), r1 = xchg4(oddq ? h1 : l1, oddq);
+                        if (n4 < ((p.N + 31) & ~31)) store_nt_s(ob, voff, oddq ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1});
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) a16[e] = 0.f;
+            }
+        }
+    };
     using std::integral_constant;
     // one step (compile-time S = 0, 1, 2): B(g, S) -- and everything older -- has landed for this wave; younger groups that may stay in
     // flight: the next chunk's patch (issued in step 0, after B(g, 1)) at S = 1, the E stores of an epilogue before S = 0
     auto step = [&](auto S_, int g) {
         constexpr int S = decltype(S_)::value;
+        // (E / 2 stores per half epilogue: the first half is issued after step 1 of a tile's last chunk, i.e. after B(g, 2); the second
+        // after step 2, i.e. after B(g + 1, 0))
         if constexpr (S == 1) wait_vm<PP>();
-        else if (S == 0 && epi && full) wait_vm<E>();
+        else if (S == 2) { if (c + 1 == nchunks && full) wait_vm<E / 2>(); else wait_vm<0>(); }
+        else if (epi && full) wait_vm<E / 2>();
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         {
@@ -250,58 +303,12 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
         step(integral_constant<int, 0>{}, g);
         epi = false;
         step(integral_constant<int, 1>{}, g);
+        if (c + 1 == nchunks) epilogue_pair(0);     // phases (0, 0) and (0, 1) are complete
         step(integral_constant<int, 2>{}, g);
         if (++c == nchunks) {
             c = 0;
             epi = true;
-            // ---- epilogue: phase (py, px) of input pixel (i, j) is output pixel (2 i + py, 2 j + px)
-            int ldo = p.ldy;
-            asm volatile("" : "+s"(ldo));
-            const int li = fr & 3, cq = fr >> 2;
-            const int Wo = 2 * p.W;
-#pragma unroll
-            for (int ph = 0; ph < 4; ++ph) {
-                const long pixr = 4 * img + (long)(2 * (y0 + wv) + (ph >> 1)) * Wo + 2 * x0 + (ph & 1);
-                float* obase = p.y + pixr * ldo;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float s1 = es1[j], t1 = et1[j];
-                    const int n4 = n0 + j * 32 + 4 * cq;
-                    const bool valid = n4 < p.N;
-                    unsigned voff;
-                    if constexpr (OSPLIT) voff = (unsigned)(2 * (4 * fh + li) * ldo) * 4u + (n4 >> 5) * 128u + ((cq & 1) ? 64u : 0u) + ((n4 & 31) >> 3) * 16u;
-                    else voff = (unsigned)(2 * (4 * fh + li) * ldo + n4) * 4u;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float r[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float v = fmaf(acc[ph][j][4 * q + k], s1, t1);
-                            r[k] = fminf(fmaxf(fmaxf(v, lo), slope * v), hi);
-                        }
-                        quad_transpose(r, li);
-                        f32x4 v = f32x4{r[0], r[1], r[2], r[3]};
-                        float* ob = obase + (16 * q) * ldo;
-                        if constexpr (!OSPLIT) {
-                            if (valid) store_nt_s(ob, voff, v);
-                        } else {
-                            if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                            unsigned h0, l0, h1, l1;
-                            split2(v[0], v[1], h0, l0);
-                            split2(v[2], v[3], h1, l1);
-                            const bool oddq = cq & 1;
-                            const unsigned r0 = xchg4(oddq ? h0 : l0, oddq), r1 = xchg4(oddq ? h1 : l1, oddq);
-                            if (n4 < ((p.N + 31) & ~31)) store_nt_s(ob, voff, oddq ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1});
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[ph][j][e] = 0.f;
+            epilogue_pair(2);     // phases (1, 0) and (1, 1); phases (0, 0) and (0, 1) left after step 1
             x0 += TW;
         }
     }
