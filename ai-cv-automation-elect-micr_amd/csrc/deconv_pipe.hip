@@ -59,13 +59,19 @@ struct TapE { int ph, t, dy, dx; };
 __device__ constexpr TapE kTaps[9] = {{0, 0, 0, 0}, {0, 1, 0, -1}, {0, 2, -1, 0}, {0, 3, -1, -1}, {1, 0, 0, 0}, {1, 1, -1, 0},
                                       {2, 0, 0, 0}, {2, 1, 0, -1}, {3, 0, 0, 0}};
 
-template <bool OSPLIT>
-__global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipeParams p) {
-    constexpr int BN = 64, NW = 8, TW = 32, TH = 8;
-    constexpr int PW = TW + 1, PH = TH + 1, PWS = 33, NPATCH = PH * PWS;   // 297 slots: one halo row above, one halo column to the left
-    constexpr int NPIECE = (NPATCH + 7) / 8, PP = (NPIECE + NW - 1) / NW;  // 38 pieces of 1 KiB, 5 per wave (waves 6, 7 repeat one)
-    constexpr int STAGE = NPIECE * 1024;                                   // 38912
-    constexpr int B_ONE = 3 * BN * 128, PB = 3 * BN / 8 / NW;              // 24576 B per step: 24 pieces, 3 per wave
+// NW = 8: 8 x 32 input pixels per tile, three taps per step, one workgroup per CU (124 KB of LDS).  NW = 4: 4 x 32 pixels, two taps per
+// step (five steps per chunk, the last with one tap), 75 KB: TWO workgroups per CU -- a transposed conv writes four times what it reads
+// (deconv1to0: 262 KB of stores per 256 input pixels against 27.6 k clocks of MFMA issue), the stores retire in order with the loads
+// behind them, and a workgroup waiting for its stores to drain leaves the matrix cores to its neighbour.
+template <bool OSPLIT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void deconv_pipe_kernel(const DeconvPipeParams p) {
+    constexpr int BN = 64, TW = 32, TH = NW;
+    constexpr int TPS = NW == 8 ? 3 : 2, NSTEP = (9 + TPS - 1) / TPS;       // taps per step, steps per chunk
+    constexpr int H1 = NW == 8 ? 1 : 2;                                     // phases 0 and 1 are complete after this step of the last chunk
+    constexpr int PW = TW + 1, PH = TH + 1, PWS = 33, NPATCH = PH * PWS;   // one halo row above, one halo column to the left
+    constexpr int NPIECE = (NPATCH + 7) / 8, PP = (NPIECE + NW - 1) / NW;  // 1 KiB pieces; surplus pieces of the last round repeat one
+    constexpr int STAGE = NPIECE * 1024;
+    constexpr int B_ONE = TPS * BN * 128, PB = TPS * BN / 8 / NW;           // weight tiles of a step: 8 pieces per tap
     constexpr int B_OFF = 2 * STAGE;
     constexpr int TN = 2, E = 4 * 4 * TN;                                  // stores per wave and tile: 4 phases x 4 row groups x TN
     __shared__ __attribute__((aligned(1024))) unsigned char smem[B_OFF + 2 * B_ONE];
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
     bool blo[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
-        const int row = (wv * PB + j) * 8 + drow;     // 0 .. 191; (wv * PB + j) / 8 = the table entry inside the step: wave-uniform
+        const int row = (wv * PB + j) * 8 + drow;     // (wv * PB + j) / 8 = the table entry inside the step: wave-uniform
         const int c = dk ^ ((row >> 1) & 7);
         brow_n[j] = n0 + (row & 63);
         bcol[j] = (c & 3) * 8;
@@ -131,7 +137,8 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
     auto issue_B = [&](int buf, int c, int s) {
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
-            const int e = s * 3 + (wv * PB + j) / 8;          // scalar
+            int e = s * TPS + (wv * PB + j) / 8;              // scalar
+            if (e > 8) e = 8;                                 // (NW = 4: the fifth step has one tap; its second tile is a copy nobody reads)
             const int ph = e < 4 ? 0 : (e < 6 ? 1 : (e < 8 ? 2 : 3)), t = e < 4 ? e : (e < 6 ? e - 4 : (e < 8 ? e - 6 : 0));
             const int nt = ph == 0 ? 4 : (ph == 3 ? 1 : 2);
             const uint16_t* hi_p = ph == 0 ? p.Whi[0] : (ph == 1 ? p.Whi[1] : (ph == 2 ? p.Whi[2] : p.Whi[3]));
@@ -271,22 +278,23 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
         }
     };
     using std::integral_constant;
-    // one step (compile-time S = 0, 1, 2): B(g, S) -- and everything older -- has landed for this wave; younger groups that may stay in
-    // flight: the next chunk's patch (issued in step 0, after B(g, 1)) at S = 1, the E stores of an epilogue before S = 0
+    // one step (compile-time S): B(g, S) -- and everything older -- has landed for this wave; younger groups that may stay in flight:
+    // the next chunk's patch (issued in step 0, after B(g, 1)) at S = 1; the E / 2 stores of a half epilogue at the step after it
+    // (the first half is issued after step H1 of a tile's last chunk, i.e. after B(g, H1 + 1); the second after the last step, i.e.
+    // after B(g + 1, 0))
     auto step = [&](auto S_, int g) {
         constexpr int S = decltype(S_)::value;
-        // (E / 2 stores per half epilogue: the first half is issued after step 1 of a tile's last chunk, i.e. after B(g, 2); the second
-        // after step 2, i.e. after B(g + 1, 0))
         if constexpr (S == 1) wait_vm<PP>();
-        else if (S == 2) { if (c + 1 == nchunks && full) wait_vm<E / 2>(); else wait_vm<0>(); }
-        else if (epi && full) wait_vm<E / 2>();
+        else if (S == H1 + 1) { if (c + 1 == nchunks && full) wait_vm<E / 2>(); else wait_vm<0>(); }
+        else if (S == 0) { if (epi && full) wait_vm<E / 2>(); else wait_vm<0>(); }
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
+        const int u = g * NSTEP + S;             // weight buffer u & 1
         {
             int cn = c, sn = S + 1;
-            if (sn == 3) { sn = 0; cn = c + 1 == nchunks ? 0 : c + 1; }
-            if (S == 2 && g + 1 >= ngroups) { cn = c; sn = S; }
-            issue_B((S + 1) & 1 ^ (g & 1), cn, sn);
+            if (sn == NSTEP) { sn = 0; cn = c + 1 == nchunks ? 0 : c + 1; }
+            if (S == NSTEP - 1 && g + 1 >= ngroups) { cn = c; sn = S; }
+            issue_B((u + 1) & 1, cn, sn);
         }
         if constexpr (S == 0) {
             const bool more = ichunk + 1 < tchunks;
@@ -294,21 +302,26 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
             issue_patch(more ? (ichunk & 1) : ((ichunk + 1) & 1), ic);
         }
         const unsigned char* stg = smem + (g & 1) * STAGE;
-        const int bbase = ((S & 1) ^ (g & 1)) * B_ONE + b_off;     // step u = 3 g + S uses weight buffer u & 1
-        tap(stg, bbase, integral_constant<int, 3 * S>{}, 0);
-        tap(stg, bbase, integral_constant<int, 3 * S + 1>{}, 1);
-        tap(stg, bbase, integral_constant<int, 3 * S + 2>{}, 2);
+        const int bbase = (u & 1) * B_ONE + b_off;
+        tap(stg, bbase, integral_constant<int, TPS * S>{}, 0);
+        if constexpr (TPS * S + 1 < 9) tap(stg, bbase, integral_constant<int, TPS * S + 1>{}, 1);
+        if constexpr (TPS == 3 && TPS * S + 2 < 9) tap(stg, bbase, integral_constant<int, (TPS * S + 2 < 9 ? TPS * S + 2 : 8)>{}, 2);
     };
     for (int g = 0; g < ngroups; ++g) {
         step(integral_constant<int, 0>{}, g);
         epi = false;
         step(integral_constant<int, 1>{}, g);
-        if (c + 1 == nchunks) epilogue_pair(0);     // phases (0, 0) and (0, 1) are complete
+        if constexpr (H1 == 1) { if (c + 1 == nchunks) epilogue_pair(0); }     // phases (0, 0) and (0, 1) are complete
         step(integral_constant<int, 2>{}, g);
+        if constexpr (NSTEP == 5) {
+            if (c + 1 == nchunks) epilogue_pair(0);
+            step(integral_constant<int, 3>{}, g);
+            step(integral_constant<int, 4>{}, g);
+        }
         if (++c == nchunks) {
             c = 0;
             epi = true;
-            epilogue_pair(2);     // phases (1, 0) and (1, 1); phases (0, 0) and (0, 1) left after step 1
+            epilogue_pair(2);     // phases (1, 0) and (1, 1)
             x0 += TW;
         }
     }
@@ -335,8 +348,20 @@ int deconv_pipe_launch(const DeconvPipeParams& p, int B, int out_split, hipStrea
     if (g_knobs.sep_tpw > 0 && tiles_w % g_knobs.sep_tpw == 0) tpw = g_knobs.sep_tpw;
     q.tpw = tpw;
     const dim3 grid(tiles_w / tpw * q.n_ntiles, p.H / 8, B);
-    if (out_split) hipLaunchKernelGGL((deconv_pipe_kernel<true>), grid, dim3(512), 0, st, q);
-    else hipLaunchKernelGGL((deconv_pipe_kernel<false>), grid, dim3(512), 0, st, q);
+    if (g_knobs.deconv_nw == 4 && p.H % 4 == 0) {     // 4 x 32 tiles, two workgroups per CU
+        const long wgs4 = (long)tiles_w * (p.H / 4) * B * q.n_ntiles;
+        int t4 = 1;
+        for (int t : {8, 4, 2})
+            if (tiles_w % t == 0 && wgs4 / t >= 2048) { t4 = t; break; }
+        if (g_knobs.sep_tpw > 0 && tiles_w % g_knobs.sep_tpw == 0) t4 = g_knobs.sep_tpw;
+        q.tpw = t4;
+        const dim3 grid4(tiles_w / t4 * q.n_ntiles, p.H / 4, B);
+        if (out_split) hipLaunchKernelGGL((deconv_pipe_kernel<true, 4>), grid4, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((deconv_pipe_kernel<false, 4>), grid4, dim3(256), 0, st, q);
+        return emd::check_launch("deconv_pipe_kernel<4 waves>");
+    }
+    if (out_split) hipLaunchKernelGGL((deconv_pipe_kernel<true, 8>), grid, dim3(512), 0, st, q);
+    else hipLaunchKernelGGL((deconv_pipe_kernel<false, 8>), grid, dim3(512), 0, st, q);
     return emd::check_launch("deconv_pipe_kernel");
 }
 
