@@ -20,6 +20,7 @@ from __future__ import annotations
 from collections import OrderedDict
 
 import os
+import types
 
 import numpy as np
 
@@ -440,136 +441,196 @@ class DenoiserTrainer:
         depthwise convs, resampling and every parameter gradient are per-pixel or sums over pixels, so they need no change.
         Same arithmetic per image as B separate towers (the moving statistics follow image 0), B times the GEMM M, B times
         fewer launches.  result3 is then [B, 3].
-        wgrad_stream=True: the weight-gradient launches of the backward pass go to a side stream (see _wg); same arithmetic."""
+        wgrad_stream=True: the weight-gradient launches of the backward pass go to a side stream (see _wg); same arithmetic.
+
+        The pass is six segments (_enc_fwd, _mid_fwd, _dec_fwd, _dec_bwd, _mid_bwd, _enc_bwd) so that towers_merged can run the
+        1/16-resolution part of several groups of images as ONE pass; here they simply follow each other."""
+        import torch
+
+        self._update_moving = update_moving
+        self._per_image = bool(per_image)
+        self._wg_side = self._side_streams(1)[0] if wgrad_stream else None
+        st = self._enc_fwd(lq)
+        ms = self._mid_fwd(st.cnn3_strided)
+        self._dec_fwd(st, ms.aspp, truth, grad_scale)
+        daspp = self._E(ms.aspp.B, ms.aspp.H, ms.aspp.W, ms.aspp.C)
+        self._dec_bwd(st, ms.aspp, daspp)
+        dx = self._mid_bwd(ms, daspp)
+        self._enc_bwd(st, dx)
+        if self._wg_side is not None:   # join: the gradient vector is complete, the tensors the side stream read may go
+            torch.cuda.current_stream().wait_stream(self._wg_side)
+            self._wg_side, self._wg_keep = None, []
+        self.last = {"out": st.out, "result": st.result}
+        return st.out, st.result
+
+    @staticmethod
+    def _gkey(a):
+        return id(a.buf), a.c0, a.C
+
+    def _enc_fwd(self, lq, mid_out=None):
+        """Encoder down to the input of the 1/16-resolution flow (cnn3_strided; written into ``mid_out`` when given)."""
         import torch
 
         assert lq.is_cuda and lq.dtype == torch.float32 and lq.is_contiguous() and lq.dim() == 4 and lq.shape[3] == 1
-        assert truth.shape == lq.shape and truth.is_contiguous() and truth.dtype == torch.float32
         B, S = lq.shape[0], lq.shape[1]
         assert lq.shape[2] == S and S % 32 == 0, "square crops with side a multiple of 32"
-        self._update_moving = update_moving
-        self._per_image = bool(per_image)
+        st = types.SimpleNamespace(B=B, S=S, C={})
         E = lambda H, Cc: self._E(B, H, H, Cc)
-        S2, S4, S8, S16 = S // 2, S // 4, S // 8, S // 16
-        f0, f1, f2, f3, f4, af = features0, features1, features2, features3, features4, aspp_filters
-        C = {}   # layer key -> saved context
-
-        # ---------------- forward
+        S2, S4 = S // 2, S // 4
+        f1, f2 = features1, features2
+        C = st.C
         x4 = torch.zeros((B, S, S, 4), dtype=torch.float32, device=self.device)
         x4[..., 0:1].copy_(lq)
         x = ops.Act(x4)
         cnn0, C["cnn0"] = self._sep_fwd("cnn0", x)
         cnn0_last, C["cnn0_last"] = self._sep_fwd("cnn0_last", cnn0)
         residual0, C["residual0"] = self._conv_fwd("residual0", x)
-        concat1 = E(S2, f2 + f1)
-        cnn0_strided, C["cnn0_strided"] = self._sep_fwd("cnn0_strided", cnn0_last, out=concat1.slice(f2, f1), res=residual0)
-        cnn1, C["cnn1"] = self._sep_fwd("cnn1", cnn0_strided)
+        st.concat1 = E(S2, f2 + f1)
+        st.cnn0_strided, C["cnn0_strided"] = self._sep_fwd("cnn0_strided", cnn0_last, out=st.concat1.slice(f2, f1), res=residual0)
+        cnn1, C["cnn1"] = self._sep_fwd("cnn1", st.cnn0_strided)
         cnn1_last, C["cnn1_last"] = self._sep_fwd("cnn1_last", cnn1)
-        residual1, C["residual1"] = self._conv_fwd("residual1", cnn0_strided)
-        concat2 = E(S4, aspp_output + f1)
-        cnn1_strided, C["cnn1_strided"] = self._sep_fwd("cnn1_strided", cnn1_last, out=concat2.slice(aspp_output, f1), res=residual1)
-        cnn2, C["cnn2"] = self._sep_fwd("cnn2", cnn1_strided)
+        residual1, C["residual1"] = self._conv_fwd("residual1", st.cnn0_strided)
+        st.concat2 = E(S4, aspp_output + f1)
+        st.cnn1_strided, C["cnn1_strided"] = self._sep_fwd("cnn1_strided", cnn1_last, out=st.concat2.slice(aspp_output, f1), res=residual1)
+        cnn2, C["cnn2"] = self._sep_fwd("cnn2", st.cnn1_strided)
         cnn2_last, C["cnn2_last"] = self._sep_fwd("cnn2_last", cnn2)
-        residual2, C["residual2"] = self._conv_fwd("residual2", cnn1_strided)
-        cnn2_strided, C["cnn2_strided"] = self._sep_fwd("cnn2_strided", cnn2_last, res=residual2)
-        cnn3, C["cnn3"] = self._sep_fwd("cnn3", cnn2_strided)
+        residual2, C["residual2"] = self._conv_fwd("residual2", st.cnn1_strided)
+        st.cnn2_strided, C["cnn2_strided"] = self._sep_fwd("cnn2_strided", cnn2_last, res=residual2)
+        cnn3, C["cnn3"] = self._sep_fwd("cnn3", st.cnn2_strided)
         cnn3_last, C["cnn3_last"] = self._sep_fwd("cnn3_last", cnn3)
-        residual3, C["residual3"] = self._conv_fwd("residual3", cnn2_strided)
-        cnn3_strided, C["cnn3_strided"] = self._sep_fwd("cnn3_strided", cnn3_last, res=residual3)
-        t, C["cnn4_a"] = self._sep_fwd("cnn4_a", cnn3_strided)
+        residual3, C["residual3"] = self._conv_fwd("residual3", st.cnn2_strided)
+        st.cnn3_strided, C["cnn3_strided"] = self._sep_fwd("cnn3_strided", cnn3_last, out=mid_out, res=residual3)
+        return st
+
+    def _mid_fwd(self, x):
+        """The 1/16-resolution part: encoder 4, the middle flow and ASPP -> the 256-channel ASPP output (x: [B,S/16,S/16,728])."""
+        B, S16 = x.B, x.H
+        ms = types.SimpleNamespace(B=B, C={}, x=x)
+        E = lambda H, Cc: self._E(B, H, H, Cc)
+        af = aspp_filters
+        C = ms.C
+        t, C["cnn4_a"] = self._sep_fwd("cnn4_a", x)
         t, C["cnn4_b"] = self._sep_fwd("cnn4_b", t)
-        cur, C["cnn4_last"] = self._sep_fwd("cnn4_last", t, res=cnn3_strided)
+        cur, C["cnn4_last"] = self._sep_fwd("cnn4_last", t, res=x)
         for i in range(num_extra_blocks):
             t, C[f"middle{i}_0"] = self._sep_fwd(f"middle{i}_0", cur)
             t, C[f"middle{i}_1"] = self._sep_fwd(f"middle{i}_1", t)
             cur, C[f"middle{i}_2"] = self._sep_fwd(f"middle{i}_2", t, res=cur)
-        cat = E(S16, 5 * af)
+        ms.cur = cur
+        ms.cat = cat = E(S16, 5 * af)
         _, C["aspp_conv1x1"] = self._conv_fwd("aspp_conv1x1", cur, out=cat.slice(0, af))
         _, C["aspp_small"] = self._conv_fwd("aspp_small", cur, out=cat.slice(af, af))
         _, C["aspp_medium"] = self._conv_fwd("aspp_medium", cur, out=cat.slice(2 * af, af))
         _, C["aspp_large"] = self._conv_fwd("aspp_large", cur, out=cat.slice(3 * af, af))
-        pooled = ops.avgpool2x2(cur, self._E(B, S16 // 2, S16 // 2, af))
-        img_lvl, C["aspp_image_conv"] = self._conv_fwd("aspp_image_conv", pooled)
-        up = ops.resize_bilinear(img_lvl, E(S16, af))
-        Lp = self.layers["aspp_pooling_bn"]
-        fold_p = self._bn("aspp_pooling_bn", up)
-        self._affine(up, fold_p, cat.slice(4 * af, af), ops.ACT_RELU6)
-        C["aspp_pooling_bn"] = {"r": up, "fold": fold_p}
-        aspp, C["aspp_reduce"] = self._conv_fwd("aspp_reduce", cat)
-        ops.resize_bilinear(aspp, concat2.slice(0, aspp_output))
-        t, C["deconv2_a"] = self._sep_fwd("deconv2_a", concat2)
-        residual2_d, C["residual2_d"] = self._conv_fwd("residual2_d", concat2)
-        deconv2, C["deconv2_b"] = self._sep_fwd("deconv2_b", t, res=residual2_d)
-        _, C["deconv2to1"] = self._deconv_fwd("deconv2to1", deconv2, concat1.slice(0, f2))
-        t, C["deconv1_a"] = self._sep_fwd("deconv1_a", concat1)
-        residual1_d, C["residual1_d"] = self._conv_fwd("residual1_d", concat1)
-        deconv1, C["deconv1_b"] = self._sep_fwd("deconv1_b", t, res=residual1_d)
-        deconv1to0, C["deconv1to0"] = self._deconv_fwd("deconv1to0", deconv1, E(S, f1))
-        t, C["deconv0_a"] = self._sep_fwd("deconv0_a", deconv1to0)
-        residual0_d, C["residual0_d"] = self._conv_fwd("residual0_d", deconv1to0)
-        deconv0, C["deconv0_b"] = self._sep_fwd("deconv0_b", t, res=residual0_d)
+        ms.pooled = ops.avgpool2x2(cur, self._E(B, S16 // 2, S16 // 2, af))
+        ms.img_lvl, C["aspp_image_conv"] = self._conv_fwd("aspp_image_conv", ms.pooled)
+        ms.up = ops.resize_bilinear(ms.img_lvl, E(S16, af))
+        ms.fold_p = self._bn("aspp_pooling_bn", ms.up)
+        self._affine(ms.up, ms.fold_p, cat.slice(4 * af, af), ops.ACT_RELU6)
+        C["aspp_pooling_bn"] = {"r": ms.up, "fold": ms.fold_p}
+        ms.aspp, C["aspp_reduce"] = self._conv_fwd("aspp_reduce", cat)
+        return ms
+
+    def _dec_fwd(self, st, aspp, truth, grad_scale=1.0):
+        """Decoder from the ASPP output (``aspp``: this tower's images) to the output, and the loss."""
+        import torch
+
+        B, S, C = st.B, st.S, st.C
+        assert truth.shape == (B, S, S, 1) and truth.is_contiguous() and truth.dtype == torch.float32
+        E = lambda H, Cc: self._E(B, H, H, Cc)
+        f0, f1, f2 = features0, features1, features2
+        ops.resize_bilinear(aspp, st.concat2.slice(0, aspp_output))
+        t, C["deconv2_a"] = self._sep_fwd("deconv2_a", st.concat2)
+        residual2_d, C["residual2_d"] = self._conv_fwd("residual2_d", st.concat2)
+        st.deconv2, C["deconv2_b"] = self._sep_fwd("deconv2_b", t, res=residual2_d)
+        _, C["deconv2to1"] = self._deconv_fwd("deconv2to1", st.deconv2, st.concat1.slice(0, f2))
+        t, C["deconv1_a"] = self._sep_fwd("deconv1_a", st.concat1)
+        residual1_d, C["residual1_d"] = self._conv_fwd("residual1_d", st.concat1)
+        st.deconv1, C["deconv1_b"] = self._sep_fwd("deconv1_b", t, res=residual1_d)
+        st.deconv1to0, C["deconv1to0"] = self._deconv_fwd("deconv1to0", st.deconv1, E(S, f1))
+        t, C["deconv0_a"] = self._sep_fwd("deconv0_a", st.deconv1to0)
+        residual0_d, C["residual0_d"] = self._conv_fwd("residual0_d", st.deconv1to0)
+        st.deconv0, C["deconv0_b"] = self._sep_fwd("deconv0_b", t, res=residual0_d)
         # final 3x3 conv to one channel (+ bias) -> BN -> relu6 -> clip [0,1]  (:528-538)
         Lf = self.layers["deconv_final"]
-        wf = self.v[Lf.scope + "/" + Lf.wname].view(9, f0)
+        st.wf = self.v[Lf.scope + "/" + Lf.wname].view(9, f0)
         rf = torch.empty((B, S, S, 1), dtype=torch.float32, device=self.device)
-        ops.conv3x3_cout1(deconv0, wf, 1.0, 0.0, rf, act=0)
-        rfa = ops.Act(rf)
-        self._force(rfa, Lf.scope, "r")
-        fold_f = self._bn("deconv_final", rfa, Lf.scope + "/" + Lf.bname)
+        ops.conv3x3_cout1(st.deconv0, st.wf, 1.0, 0.0, rf, act=0)
+        st.rfa = ops.Act(rf)
+        self._force(st.rfa, Lf.scope, "r")
+        st.fold_f = fold_f = self._bn("deconv_final", st.rfa, Lf.scope + "/" + Lf.bname)
         out = torch.empty_like(rf)
         # one channel: run the per-channel affine over a [.., 4] view with the scalar replicated
-        if per_image:
+        if self._per_image:
             sc4 = fold_f["scale"].view(B, 1).expand(B, 4).contiguous().view(-1)
             sh4 = fold_f["shift"].view(B, 1).expand(B, 4).contiguous().view(-1)
             ops.affine_act_images(ops.Act(rf.view(B, S, S // 4, 4)), sc4, sh4, ops.Act(out.view(B, S, S // 4, 4)), act=ops.ACT_RELU6_CLIP01)
         else:
             sc4, sh4 = fold_f["scale"].expand(4).contiguous(), fold_f["shift"].expand(4).contiguous()
             ops.affine_act(ops.Act(rf.view(B, S, S // 4, 4)), sc4, sh4, ops.Act(out.view(B, S, S // 4, 4)), act=ops.ACT_RELU6_CLIP01)
-
         # ---------------- loss (:768-775)
-        dout = torch.empty_like(out)
-        if per_image:   # every image is its own tower: its own mse, loss and dloss/dout (:763, :768-775)
+        st.dout = dout = torch.empty_like(out)
+        if self._per_image:   # every image is its own tower: its own mse, loss and dloss/dout (:763, :768-775)
             result = torch.stack([TO.denoise_loss(out[b:b + 1], truth[b:b + 1], dout[b:b + 1], grad_scale=grad_scale) for b in range(B)])
         else:
             result = TO.denoise_loss(out, truth, dout, grad_scale=grad_scale)
+        st.out, st.result = out, result
 
-        # ---------------- backward: reverse order; gslot holds the gradients that exist so far
-        self._wg_side = self._side_streams(1)[0] if wgrad_stream else None
-        G = {}
-        gconcat1, gconcat2, gcat = E(S2, f2 + f1), E(S4, aspp_output + f1), E(S16, 5 * af)
-        self._gparent = {id(concat1.buf): gconcat1, id(concat2.buf): gconcat2, id(cat.buf): gcat}
-        grad = lambda a: G[(id(a.buf), a.c0, a.C)]
-
-        drf = TO.bn_backward(ops.Act(dout), rfa, fold_f, self.v[Lf.bn[0] + "/gamma"], self.g[Lf.bn[0] + "/gamma"],
-                             self.g[Lf.bn[0] + "/beta"], rfa, mask=TO.MASK_RELU6_CLIP)
+    def _dec_bwd(self, st, aspp, daspp):
+        """Backward through the decoder; the gradient w.r.t. the ASPP output lands in ``daspp`` (this tower's images)."""
+        B, S, C = st.B, st.S, st.C
+        E = lambda H, Cc: self._E(B, H, H, Cc)
+        S2, S4 = S // 2, S // 4
+        f0, f1, f2 = features0, features1, features2
+        st.G = G = {}
+        st.gconcat1, st.gconcat2 = E(S2, f2 + f1), E(S4, aspp_output + f1)
+        self._gparent = {id(st.concat1.buf): st.gconcat1, id(st.concat2.buf): st.gconcat2, id(aspp.buf): daspp}
+        grad = lambda a: G[self._gkey(a)]
+        Lf = self.layers["deconv_final"]
+        drf = TO.bn_backward(ops.Act(st.dout), st.rfa, st.fold_f, self.v[Lf.bn[0] + "/gamma"], self.g[Lf.bn[0] + "/gamma"],
+                             self.g[Lf.bn[0] + "/beta"], st.rfa, mask=TO.MASK_RELU6_CLIP)
+        deconv0 = st.deconv0
         self._wg(lambda: TO.conv3x3_cout1_wgrad(deconv0, drf.buf, self.g[Lf.scope + "/" + Lf.wname].view(9, f0)))
-        self._put(G, deconv0, lambda dst: TO.conv3x3_cout1_bwd_data(drf.buf, wf, dst))
+        self._put(G, deconv0, lambda dst: TO.conv3x3_cout1_bwd_data(drf.buf, st.wf, dst))
         # decoder 0: deconv0 = sep_b(sep_a(deconv1to0)) + residual0_d(deconv1to0)
         g = grad(deconv0)
         self._sep_bwd("deconv0_b", g, C["deconv0_b"], G)
         self._sep_bwd("deconv0_a", grad(C["deconv0_b"]["x"]), C["deconv0_a"], G)
         self._conv_bwd("residual0_d", g, C["residual0_d"], G)   # after the separable branch: a GEMM can ADD its data gradient, a depthwise kernel cannot
-        self._deconv_bwd("deconv1to0", grad(deconv1to0), C["deconv1to0"], G)
+        self._deconv_bwd("deconv1to0", grad(st.deconv1to0), C["deconv1to0"], G)
         # decoder 1
-        g = grad(deconv1)
+        g = grad(st.deconv1)
         self._sep_bwd("deconv1_b", g, C["deconv1_b"], G)
         self._sep_bwd("deconv1_a", grad(C["deconv1_b"]["x"]), C["deconv1_a"], G)
         self._conv_bwd("residual1_d", g, C["residual1_d"], G)   # after the separable branch: a GEMM can ADD its data gradient, a depthwise kernel cannot
-        self._deconv_bwd("deconv2to1", gconcat1.slice(0, f2), C["deconv2to1"], G)
+        self._deconv_bwd("deconv2to1", st.gconcat1.slice(0, f2), C["deconv2to1"], G)
         # decoder 2
-        g = grad(deconv2)
+        g = grad(st.deconv2)
         self._sep_bwd("deconv2_b", g, C["deconv2_b"], G)
         self._sep_bwd("deconv2_a", grad(C["deconv2_b"]["x"]), C["deconv2_a"], G)
         self._conv_bwd("residual2_d", g, C["residual2_d"], G)   # after the separable branch: a GEMM can ADD its data gradient, a depthwise kernel cannot
-        self._put(G, aspp, lambda dst: TO.resize_bilinear_bwd(gconcat2.slice(0, aspp_output), dst))
+        self._put(G, aspp, lambda dst: TO.resize_bilinear_bwd(st.gconcat2.slice(0, aspp_output), dst))
+        self._gparent = {}
+
+    def _mid_bwd(self, ms, daspp):
+        """Backward through ASPP, the middle flow and encoder 4: ``daspp`` = gradient w.r.t. the ASPP output (all images of the
+        pass) -> the gradient w.r.t. the part's input."""
+        B, C = ms.B, ms.C
+        S16 = ms.x.H
+        af = aspp_filters
+        G = {self._gkey(ms.aspp): daspp}
+        gcat = self._E(B, S16, S16, 5 * af)
+        self._gparent = {id(ms.cat.buf): gcat}
+        grad = lambda a: G[self._gkey(a)]
+        cur = ms.cur
         # ASPP
-        self._conv_bwd("aspp_reduce", grad(aspp), C["aspp_reduce"], G)          # writes gcat (all five slices)
+        self._conv_bwd("aspp_reduce", grad(ms.aspp), C["aspp_reduce"], G)          # writes gcat (all five slices)
         Lp = self.layers["aspp_pooling_bn"]
-        dup = TO.bn_backward(gcat.slice(4 * af, af), up, fold_p, self.v[Lp.bn[0] + "/gamma"], self.g[Lp.bn[0] + "/gamma"],
-                             self.g[Lp.bn[0] + "/beta"], up, mask=TO.MASK_RELU6)
-        self._put(G, img_lvl, lambda dst: TO.resize_bilinear_bwd(dup, dst))
-        self._conv_bwd("aspp_image_conv", grad(img_lvl), C["aspp_image_conv"], G)
-        self._put(G, cur, lambda dst: TO.avgpool2x2_bwd(grad(pooled), dst))
+        dup = TO.bn_backward(gcat.slice(4 * af, af), ms.up, ms.fold_p, self.v[Lp.bn[0] + "/gamma"], self.g[Lp.bn[0] + "/gamma"],
+                             self.g[Lp.bn[0] + "/beta"], ms.up, mask=TO.MASK_RELU6)
+        self._put(G, ms.img_lvl, lambda dst: TO.resize_bilinear_bwd(dup, dst))
+        self._conv_bwd("aspp_image_conv", grad(ms.img_lvl), C["aspp_image_conv"], G)
+        self._put(G, cur, lambda dst: TO.avgpool2x2_bwd(grad(ms.pooled), dst))
         self._conv_bwd("aspp_large", gcat.slice(3 * af, af), C["aspp_large"], G)
         self._conv_bwd("aspp_medium", gcat.slice(2 * af, af), C["aspp_medium"], G)
         self._conv_bwd("aspp_small", gcat.slice(af, af), C["aspp_small"], G)
@@ -581,7 +642,7 @@ class DenoiserTrainer:
             self._sep_bwd(keys[2], gy, C[keys[2]], G)
             self._sep_bwd(keys[1], grad(C[keys[2]]["x"]), C[keys[1]], G)
             xin = C[keys[0]]["x"]
-            G[(id(xin.buf), xin.c0, xin.C)] = gy
+            G[self._gkey(xin)] = gy
             self._sep_bwd(keys[0], grad(C[keys[1]]["x"]), C[keys[0]], G)
 
         y = cur
@@ -589,7 +650,17 @@ class DenoiserTrainer:
             residual_block([f"middle{i}_{j}" for j in range(3)], y)
             y = C[f"middle{i}_0"]["x"]
         residual_block(["cnn4_a", "cnn4_b", "cnn4_last"], y)
-        # encoders 3..0: y = sep_strided(sep_last(sep(x))) + residual_conv(x)
+        self._gparent = {}
+        return grad(ms.x)
+
+    def _enc_bwd(self, st, dx):
+        """Backward through encoders 3..0: y = sep_strided(sep_last(sep(x))) + residual_conv(x); ``dx`` = gradient w.r.t.
+        cnn3_strided (this tower's images)."""
+        C, G = st.C, st.G
+        f1 = features1
+        self._gparent = {id(st.concat1.buf): st.gconcat1, id(st.concat2.buf): st.gconcat2}
+        grad = lambda a: G[self._gkey(a)]
+
         def encoder(keys, res_key, y, need_dx=True):
             gy = grad(y)
             self._sep_bwd(keys[2], gy, C[keys[2]], G)
@@ -599,18 +670,69 @@ class DenoiserTrainer:
 
         # cnn1_strided / cnn0_strided live in concat2 / concat1: their gradients started in the decoder (the slices of
         # gconcat2 / gconcat1 written above); the encoder-side consumers below add into them
-        G[(id(cnn1_strided.buf), cnn1_strided.c0, cnn1_strided.C)] = gconcat2.slice(aspp_output, f1)
-        G[(id(cnn0_strided.buf), cnn0_strided.c0, cnn0_strided.C)] = gconcat1.slice(f2, f1)
-        encoder(["cnn3", "cnn3_last", "cnn3_strided"], "residual3", cnn3_strided)
-        encoder(["cnn2", "cnn2_last", "cnn2_strided"], "residual2", cnn2_strided)
-        encoder(["cnn1", "cnn1_last", "cnn1_strided"], "residual1", cnn1_strided)
-        encoder(["cnn0", "cnn0_last", "cnn0_strided"], "residual0", cnn0_strided, need_dx=False)
+        G[self._gkey(st.cnn3_strided)] = dx
+        G[self._gkey(st.cnn1_strided)] = st.gconcat2.slice(aspp_output, f1)
+        G[self._gkey(st.cnn0_strided)] = st.gconcat1.slice(features2, f1)
+        encoder(["cnn3", "cnn3_last", "cnn3_strided"], "residual3", st.cnn3_strided)
+        encoder(["cnn2", "cnn2_last", "cnn2_strided"], "residual2", st.cnn2_strided)
+        encoder(["cnn1", "cnn1_last", "cnn1_strided"], "residual1", st.cnn1_strided)
+        encoder(["cnn0", "cnn0_last", "cnn0_strided"], "residual0", st.cnn0_strided, need_dx=False)
         self._gparent = {}
-        if self._wg_side is not None:   # join: the gradient vector is complete, the tensors the side stream read may go
-            torch.cuda.current_stream().wait_stream(self._wg_side)
-            self._wg_side, self._wg_keep = None, []
-        self.last = {"out": out, "result": result}
-        return out, result
+
+    def towers_merged(self, lq, truth, groups):
+        """The B one-image towers of a rank as ``groups`` batched passes on as many streams through encoder and decoder (the
+        full-resolution levels fill the chip with a few images), MERGED into one pass of all B images through the 1/16-resolution
+        part (encoder 4, the middle flow, ASPP: 36 of the 60 layers, where even B images leave CUs idle): every batch norm takes
+        per-image statistics, so which images share a launch changes no value.  Returns the [B, 3] results."""
+        import torch
+
+        B, S = lq.shape[0], lq.shape[1]
+        per = B // groups
+        S16 = S // 16
+        self._per_image = True
+        self._wg_side = None
+        main = torch.cuda.current_stream()
+        side = self._side_streams(groups)
+        mid_in = self._E(B, S16, S16, features3)
+        mid_slices = [mid_in.images(k * per, (k + 1) * per) for k in range(groups)]
+        states = []
+        for s in side:
+            s.wait_stream(main)
+        for k, s in enumerate(side):
+            with torch.cuda.stream(s):
+                self._update_moving = k == 0
+                states.append(self._enc_fwd(lq[k * per:(k + 1) * per].contiguous(), mid_out=mid_slices[k]))
+        for s in side:
+            main.wait_stream(s)
+        self._update_moving = True          # image 0 of the merged pass = image 0 of the rank
+        ms = self._mid_fwd(mid_in)
+        daspp = self._E(B, S16, S16, aspp_output)
+        aspp_slices = [ms.aspp.images(k * per, (k + 1) * per) for k in range(groups)]
+        daspp_slices = [daspp.images(k * per, (k + 1) * per) for k in range(groups)]
+        for s in side:
+            s.wait_stream(main)
+        for k, s in enumerate(side):
+            with torch.cuda.stream(s):
+                self._update_moving = k == 0
+                self._dec_fwd(states[k], aspp_slices[k], truth[k * per:(k + 1) * per].contiguous())
+                self._dec_bwd(states[k], aspp_slices[k], daspp_slices[k])
+        for s in side:
+            main.wait_stream(s)
+        dx = self._mid_bwd(ms, daspp)
+        dx_slices = [dx.images(k * per, (k + 1) * per) for k in range(groups)]
+        for s in side:
+            s.wait_stream(main)
+        outs = []
+        for k, s in enumerate(side):
+            with torch.cuda.stream(s):
+                self._enc_bwd(states[k], dx_slices[k])
+                states[k].result.record_stream(main)
+            outs.append(states[k].result)
+        for s in side:
+            main.wait_stream(s)
+        self.last = {"out": states[0].out, "result": states[0].result}
+        self._keep = (states, ms, mid_in, daspp, dx)     # (alive until the next call: the side streams may still be reading)
+        return torch.cat(outs)
 
     # ---- one training step -----------------------------------------------------------------------------------------
     def _side_streams(self, n):
@@ -646,6 +768,13 @@ class DenoiserTrainer:
         if batched and tower_batch == 1 and B > 1:
             # the B one-image towers as ONE batched pass with per-image batch-norm statistics (see tower): same arithmetic per image
             groups = self.batched_groups(B)
+            # (towers_merged: the groups' 1/16-resolution parts as ONE pass of all B images -- measured 51.0 ms against 47.5 ms for the
+            # groups side by side all the way, profiles/r03_experiments.txt 15: four streams of small kernels fill the chip better than
+            # one stream of four-times larger ones; opt-in)
+            if groups > 1 and os.environ.get("EMD_T_MERGE", "0") == "1":
+                res = self.towers_merged(lq, truth, groups)
+                self._unpad_grads()
+                return res
             if groups > 1:
                 # ... as `groups` such passes on as many streams: at 8 images the 32 x 32 and 64 x 64 levels' kernels leave most CUs
                 # idle, two-image passes side by side fill them (8 pairs of 512^2: 50.9 ms as one pass, 48.5 as two, 47.1-47.8 as
