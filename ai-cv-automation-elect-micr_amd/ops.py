@@ -362,7 +362,8 @@ def deconv3x3s2_split32(x: SplitAct, w_phases, scale1, shift1, out, act=True, st
 
 def deconv3x3s2_fused(x: SplitAct, w_phases, scale1, shift1, out, act=True, stream=None):
     """The transposed conv as one launch (emd_deconv3x3s2_fused_split32_f32): every workgroup runs the four output phases of its
-    input pixels back to back -- the input comes from HBM once; bit-identical to deconv3x3s2_split32."""
+    input pixels -- the input comes from HBM once.  Where H % 8 == 0 and W % 32 == 0 the patch-resident kernel (csrc/deconv_pipe.hip;
+    chunk-major sums: last-bit differences to the GEMM forms), otherwise the GEMM form, bit-identical to deconv3x3s2_split32."""
     lib = _lib.load()
     assert len(w_phases) == 4 and (out.B, out.H, out.W) == (x.B, 2 * x.H, 2 * x.W) and out.C == w_phases[0].cout
     hi = (C.c_void_p * 4)(*[w.hi.data_ptr() for w in w_phases])

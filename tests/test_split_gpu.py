@@ -379,6 +379,29 @@ def test_deconv_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split, nw):
         assert torch.equal(sp.buf.view(torch.int32), ops.to_split32(ops.Act(got.torch().contiguous())).buf.view(torch.int32))
 
 
+def test_deconv_pipe_full_size_properties_and_route():
+    """Graph D's deconv1to0 at [8,256,256,128] -> [8,512,512,128] on the patch-resident kernel: image b of the batch == the image alone,
+    bit for bit; the pre-activation is exactly linear under powers of two; and the host-side route query is independent of the batch size
+    wherever that kernel applies (it sums in another order than the GEMM forms: an M-dependent choice would show in the bits)."""
+    from emdenoise import _lib, ops
+
+    lib = _lib.load()
+    B, S, c = 8, 256, 128
+    g = torch.Generator(device=dev()).manual_seed(9)
+    x = torch.rand(B, S, S, c, device=dev(), generator=g)
+    phases = ops.pack_deconv(rnd((3, 3, c, c), 271, 0.03), dev())
+    s1, t0 = torch.rand(c, device=dev(), generator=g) + 0.5, torch.zeros(c, device=dev())
+    f = lambda xx: ops.deconv3x3s2_fused(ops.to_split32(ops.Act(xx)), phases, s1, t0, ops.Act.empty(xx.shape[0], 2 * S, 2 * S, c, dev()), act=False).torch()
+    y, y1, y2 = f(x), f(x[5:6].contiguous()), f(2 * x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    assert torch.equal(y[5:6], y1)
+    assert torch.equal(y2, 2 * y)
+    for (H, W, ci) in ((256, 256, 128), (128, 128, 256), (8, 32, 32)):
+        assert {lib.emd_deconv3x3s2_fused_preferred(b, H, W, ci, ci) for b in (1, 2, 4, 32)} == {1}
+    assert lib.emd_deconv3x3s2_fused_preferred(1, 20, 20, 128, 128) == 0 and lib.emd_deconv3x3s2_fused_preferred(256, 20, 20, 128, 128) == 1
+
+
 @pytest.mark.parametrize("B,H,W,ci,co,res", [(2, 16, 16, 256, 256, True), (1, 24, 20, 728, 132, False), (1, 8, 8, 64, 36, True)])
 def test_conv1x1_split32_with_split32_output(B, H, W, ci, co, res):
     """emd_conv1x1_split32_out_f32: the split32 tensor it writes == emd_to_split32_f32 of what emd_conv1x1_split32_f32 writes
