@@ -42,6 +42,9 @@ SIGNATURES = {
     "emd_sep3x3_fused_s2_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
                                           _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "emd_sep3x3_fused_s2_reflect_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
+                                          _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "emd_sep3x3_fused_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p,
                                        _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

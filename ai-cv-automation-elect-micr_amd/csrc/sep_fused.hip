@@ -599,10 +599,30 @@ extern "C" int emd_sep3x3_fused_f32(const float* x, int ldx, const float* dw, co
 // The stride-2 separable block (strided_conv_block(stride=2), machine_learning/denoiser.py:258, :273, :288) in one launch: x [B,H,W,Cin]
 // (H, W even; TF SAME = no padding before, one pixel after) -> y [B,H/2,W/2,Cout].  Split-bf16.  Same arithmetic as emd_dw3x3_f32(stride 2)
 // followed by emd_conv1x1_f32; the depthwise result never exists in memory.
+static int sep_s2_entry(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                        const float* shift1, const float* scale2, const float* shift2, const float* res, int ldres, float* y, int ldy,
+                        int B, int H, int W, int Cin, int Cout, int act, int reflect, emd_stream_t stream);
+
 extern "C" int emd_sep3x3_fused_s2_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
                                        const float* scale1, const float* shift1, const float* scale2, const float* shift2,
                                        const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
                                        emd_stream_t stream) {
+    return sep_s2_entry(x, ldx, dw, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, B, H, W, Cin, Cout, act, 0, stream);
+}
+
+// The same with the depthwise stage on the tf.pad(REFLECT, 1) image and VALID padding: graph G's strided_conv_block(stride 2,
+// pad_size = (1, 1)) (misc_py/gan-infilling-100.py:205-243, the down-sampling layers :345-352): output pixel (i, j) reads input rows
+// 2 i - 1 .. 2 i + 1 (row -1 = row 1); on even sizes nothing is read beyond the last row / column.
+extern "C" int emd_sep3x3_fused_s2_reflect_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                                               const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                                               const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout,
+                                               int act, emd_stream_t stream) {
+    return sep_s2_entry(x, ldx, dw, whi, wlo, scale1, shift1, scale2, shift2, res, ldres, y, ldy, B, H, W, Cin, Cout, act, 1, stream);
+}
+
+static int sep_s2_entry(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo, const float* scale1,
+                        const float* shift1, const float* scale2, const float* shift2, const float* res, int ldres, float* y, int ldy,
+                        int B, int H, int W, int Cin, int Cout, int act, int reflect, emd_stream_t stream) {
     EMD_REQUIRE(x && dw && whi && wlo && scale1 && shift1 && y, EMD_E_INVALID, "emd_sep3x3_fused_s2_f32: null pointer");
     EMD_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), EMD_E_INVALID, "emd_sep3x3_fused_s2_f32: scale2/shift2 pair");
     EMD_REQUIRE(B >= 0 && H >= 2 && W >= 2, EMD_E_INVALID, "emd_sep3x3_fused_s2_f32: bad shape");
@@ -622,7 +642,7 @@ extern "C" int emd_sep3x3_fused_s2_f32(const float* x, int ldx, const float* dw,
     p.x = x; p.dw = dw; p.Whi = whi; p.Wlo = wlo; p.y = y; p.res = res;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.H = H; p.W = W; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.N = Cout;
-    p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act; p.stride = 2;
+    p.ldx = ldx; p.ldy = ldy; p.ldres = ldres; p.act = act; p.stride = 2; p.reflect = reflect ? 1 : 0;
     EMD_REQUIRE(emd::sep_pipe_covers(p, 3), EMD_E_UNSUPPORTED, "emd_sep3x3_fused_s2_f32: the pipelined kernel is switched off (dev knob sep_pipe)");
     return emd::sep_pipe_launch(p, B, static_cast<hipStream_t>(stream));
 }

@@ -151,7 +151,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
             if (q >= NPIECE) q -= NW;
             const int slot = q * 8 + drow;
             const int py = slot / PWS, px = slot - py * PWS;
-            int gy = STRIDE * y0 - (STRIDE == 1) + py, gx = STRIDE * xt - (STRIDE == 1) + px;
+            // patch origin: one pixel up / left of the tile for stride 1 and for the REFLECT-padded stride 2 (tf.pad(1) then VALID), at the
+            // tile for TF SAME stride 2 on even sizes (which pads after only)
+            const int org = (STRIDE == 1 || p.reflect) ? 1 : 0;
+            int gy = STRIDE * y0 - org + py, gx = STRIDE * xt - org + px;
             if (p.reflect) {   // tf.pad(REFLECT, 1): -1 -> 1, H -> H - 2
                 gy = gy < 0 ? -gy : (gy >= p.H ? 2 * p.H - 2 - gy : gy);
                 gx = gx < 0 ? -gx : (gx >= p.W ? 2 * p.W - 2 - gx : gx);
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
         if (++ic == nchunks) {
             ic = 0;
             const int xn = ixt + TW;
-            if ((STRIDE == 2 || ixt >= 1) && STRIDE * (xn + TW) + 1 <= p.W) {   // both tiles clear of the left / right image edges: every real
+            if (((STRIDE == 2 && !p.reflect) || ixt >= 1) && STRIDE * (xn + TW) + 1 <= p.W) {   // both tiles clear of the left / right image edges: every real
                 const long step = (long)STRIDE * TW * p.ldx;                     // pixel moves one tile on
 #pragma unroll
                 for (int j = 0; j < PP; ++j) psrc[j] += ((pmove >> j) & 1) ? step : 0;
@@ -652,8 +655,7 @@ static bool use_nw4(const SepParams& p) {
 bool sep_pipe_covers(const SepParams& p, int precision) {
     if (!g_knobs.sep_pipe || precision != 3 || p.gen_a) return false;
     if (p.stride == 2)   // output tiles of 4 x 16 pixels: H % 8 == 0, W % 32 == 0 (input sizes); one fp32 output of up to 256 channels
-        return p.H % 8 == 0 && p.W % 32 == 0 && p.Cin % 32 == 0 && p.Cin >= 32 && p.Cin <= 4064 && p.N2 == 0 && !p.out_split && !p.reflect &&
-               p.N <= 256;
+        return p.H % 8 == 0 && p.W % 32 == 0 && p.Cin % 32 == 0 && p.Cin >= 32 && p.Cin <= 4064 && p.N2 == 0 && !p.out_split && p.N <= 256;
     if (p.H % 8 != 0 || p.W % (use_nw4(p) ? 16 : 32) != 0 || p.Cin % 32 != 0 || p.Cin < 32 || p.Cin > 4064) return false;
     if (p.N2 > 0) return p.N <= 128 && p.N2 <= 128 && !p.out_split && !p.res && !p.scale2;
     if (p.out_split && p.N <= 64) return false;

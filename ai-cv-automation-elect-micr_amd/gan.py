@@ -194,6 +194,11 @@ class GeneratorEngine:
             out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
             return ops.sep_fused(x, p["dw"], p["pw"], p["scale"], p["shift"], out, act=ops.ACT_LEAKY, res=res,
                                  precision=self.precision, reflect=L.reflect)
+        if (L.stride == 2 and L.reflect and self.precision == ops.PREC_BF16X3 and x.H % 2 == 0 and x.W % 2 == 0
+                and os.environ.get("EMD_G_SEP_S2", "1") != "0" and ops.sep_fused_supported(x, L.cout, 2, 1)):
+            # the down-sampling layers (:345-352) in one launch too (round 3: sep_pipe's stride-2 form on the REFLECT-padded image)
+            out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
+            return ops.sep_fused(x, p["dw"], p["pw"], p["scale"], p["shift"], out, act=ops.ACT_LEAKY, res=res, reflect=True, stride=2)
         if self.precision == ops.PREC_BF16X3 and ops.conv1x1_split32_supported(x.B * Ho * Wo, L.cin, L.cout):
             out = ops.Act.empty(x.B, Ho, Wo, L.cout, self.device)
             return ops.sep_split32(x, p["dw"], p["pw"], p["scale"], p["shift"], out, stride=L.stride, act=ops.ACT_LEAKY,

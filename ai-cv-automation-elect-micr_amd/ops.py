@@ -139,8 +139,8 @@ def sep_fused(x: Act, dw_dev, w: PackedWeights, scale1, shift1, out: Act, act=Tr
     if res is not None:
         assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
     if stride == 2:
-        assert not reflect and precision == PREC_BF16X3 and not isinstance(out, SplitAct)
-        rc = lib.emd_sep3x3_fused_s2_f32(x.ptr, x.ld, _p(dw_dev), _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
+        assert precision == PREC_BF16X3 and not isinstance(out, SplitAct)
+        rc = (lib.emd_sep3x3_fused_s2_reflect_f32 if reflect else lib.emd_sep3x3_fused_s2_f32)(x.ptr, x.ld, _p(dw_dev), _p(w.hi), _p(w.lo), _p(scale1), _p(shift1), _p(scale2), _p(shift2),
                                          res.ptr if res is not None else C.c_void_p(0), res.ld if res is not None else 0,
                                          out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, _act(act), _lib.stream_ptr(stream))
         _lib.check(rc, "emd_sep3x3_fused_s2_f32")

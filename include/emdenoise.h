@@ -161,6 +161,12 @@ int emd_sep3x3_fused_s2_f32(const float* x, int ldx, const float* dw, const uint
                             const float* scale1, const float* shift1, const float* scale2, const float* shift2,
                             const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
                             emd_stream_t stream);
+/* The same on the tf.pad(REFLECT, 1) image with VALID padding: graph G's down-sampling strided_conv_block(stride 2, pad_size = (1, 1))
+ * (misc_py/gan-infilling-100.py:205-243, :345-352).  Same shape rules (emd_sep3x3_fused_supported(H, W, Cin, Cout, 2, 1)). */
+int emd_sep3x3_fused_s2_reflect_f32(const float* x, int ldx, const float* dw, const uint16_t* whi, const uint16_t* wlo,
+                                    const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                                    const float* res, int ldres, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int act,
+                                    emd_stream_t stream);
 
 /* Depthwise 3x3, TF SAME padding, stride 1 or 2 (rate 1) or stride 1 with dilation `rate`.
  * replaces: the depthwise half of slim.separable_convolution2d (denoiser.py:113-131).

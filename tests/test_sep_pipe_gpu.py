@@ -226,6 +226,42 @@ def test_sep_pipe_stride2(B, H, W, ci, co, res, extra, tpw, lead):
     assert torch.equal(out.torch(), two.torch()), "the one-launch form and the two kernels promise the same bits"
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,tpw", [(2, 8, 32, 32, 64, 0), (1, 16, 96, 64, 128, 0), (1, 8, 256, 128, 256, 4), (1, 24, 64, 96, 36, 2)])
+@pytest.mark.parametrize("lead", [0, 1])
+def test_sep_pipe_stride2_reflect(B, H, W, ci, co, tpw, lead):
+    """emd_sep3x3_fused_s2_reflect_f32: graph G's down-sampling strided_conv_block(stride 2, pad_size = (1, 1))
+    (misc_py/gan-infilling-100.py:205-243, :345-352: tf.pad(REFLECT, 1), depthwise VALID stride 2, pointwise, BN x2, leaky relu) against
+    the oracle and bit for bit against emd_dw3x3_reflect_f32(stride 2) -> emd_conv1x1_f32."""
+    from emdenoise import _lib, ops
+    from oracle import tf_ops as T
+
+    x = rnd((B, H, W, ci), 480)
+    dw = rnd((3, 3, ci, 1), 481, 0.35)
+    pw = rnd((1, 1, ci, co), 482, scale=(2.0 / (ci + co)) ** 0.5)
+    s1, t1 = rnd((co,), 483, 0.2) + 1, rnd((co,), 484, 0.5)
+    xp = torch.from_numpy(np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)), mode="reflect"))
+    d64 = T.depthwise_conv2d_t(xp, t64(dw))[:, 1:-1, 1:-1, :][:, ::2, ::2, :]       # VALID stride 2 on the padded image
+    y = T.conv2d_t(d64, t64(pw)) * t64(s1) + t64(t1)
+    want = torch.where(y > 0, y, 0.2 * y).numpy()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    xa = to_act(x, ld=ci + 64, c0=32)
+    pk = ops.PackedWeights(pw[0], False, dev())
+    _lib.knob("sep_mode", lead)
+    _lib.knob("sep_tpw", tpw)
+    out = out_act(B, H // 2, W // 2, co, ld=co + 8, c0=4)
+    ops.sep_fused(xa, d(dw[..., 0]), pk, d(s1), d(t1), out, act=ops.ACT_LEAKY, reflect=True, stride=2)
+    torch.cuda.synchronize()
+    got = out.torch().cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_l2(got, want) < TOL_X3
+    full = out.buf.cpu().numpy()
+    assert np.isnan(full[..., :4]).all() and np.isnan(full[..., 4 + co:]).all()
+    tmp = ops.dw3x3_reflect(xa, d(dw[..., 0]), out_act(B, H // 2, W // 2, ci), stride=2)
+    two = ops.conv1x1(tmp, pk, d(s1), d(t1), out_act(B, H // 2, W // 2, co), act=ops.ACT_LEAKY)
+    torch.cuda.synchronize()
+    assert torch.equal(out.torch(), two.torch())
+
+
 def test_sep_pipe_stride2_argument_checks():
     from emdenoise import _lib, ops
 
