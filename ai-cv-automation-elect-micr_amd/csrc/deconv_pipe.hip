@@ -68,7 +68,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void deconv_pipe_kernel(c
     constexpr int BN = 64, TW = 32, TH = NW;
     constexpr int TPS = NW == 8 ? 3 : 2, NSTEP = (9 + TPS - 1) / TPS;       // taps per step, steps per chunk
     constexpr int H1 = NW == 8 ? 1 : 2;                                     // phases 0 and 1 are complete after this step of the last chunk
-    constexpr int PW = TW + 1, PH = TH + 1, PWS = 33, NPATCH = PH * PWS;   // one halo row above, one halo column to the left
+    constexpr int PH = TH + 1, PWS = TW + 1, NPATCH = PH * PWS;            // one halo row above, one halo column to the left (33 slots per patch row)
     constexpr int NPIECE = (NPATCH + 7) / 8, PP = (NPIECE + NW - 1) / NW;  // 1 KiB pieces; surplus pieces of the last round repeat one
     constexpr int STAGE = NPIECE * 1024;
     constexpr int B_ONE = TPS * BN * 128, PB = TPS * BN / 8 / NW;           // weight tiles of a step: 8 pieces per tap

@@ -15,7 +15,7 @@
 #include <string>
 #include <vector>
 
-#include "mfma_common.hpp"
+#include "graph_common.hpp"
 
 namespace {
 
@@ -114,10 +114,7 @@ std::vector<LayerDecl> declare_layers(bool twin) {
 }
 
 
-struct Packed {   // bf16 hi / lo planes on the device (one allocation, lo behind hi)
-    uint16_t* hi = nullptr;
-    uint16_t* lo = nullptr;
-};
+using emd::gx::Packed;
 
 struct LayerParams {
     LayerDecl d;
@@ -140,6 +137,7 @@ struct emd_graph {   // the handle behind emd_graph_t
     std::string error;
     // the two side streams of the 1/16-resolution flow (Run::middle_two_streams) and their fork / join events; made on first use
     bool twin = false;          // variant 1: graph D' (the training twin's inference graph)
+    emd::gx::XGraph* x = nullptr;   // variant 2: graph X (graph_exec_x.hip)
     bool two_streams = false;   // emd_graph_set_two_streams
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
@@ -156,61 +154,19 @@ struct emd_graph {   // the handle behind emd_graph_t
 
 namespace {
 
-typedef std::map<std::string, std::pair<const float*, long>> WeightMap;
-
-bool fetch(const WeightMap& w, const std::string& name, long count, const float** out, std::string* err) {
-    auto it = w.find(name);
-    if (it == w.end()) {
-        *err = "emd_graph_create: missing variable " + name;
-        return false;
-    }
-    if (it->second.second != count) {
-        *err = "emd_graph_create: " + name + ": " + std::to_string(it->second.second) + " elements, expected " + std::to_string(count);
-        return false;
-    }
-    *out = it->second.first;
-    return true;
-}
+using emd::gx::WeightMap;
+using emd::gx::fetch;
+using emd::gx::Arena;
+using emd::gx::T4;
 
 template <typename T>
-T* upload(emd_graph* g, const T* host, size_t n) {
-    void* d = nullptr;
-    if (hipMalloc(&d, n * sizeof(T) < 16 ? 16 : n * sizeof(T)) != hipSuccess) return nullptr;
-    g->allocs.push_back(d);
-    if (hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    return static_cast<T*>(d);
-}
-
-float* upload_f(emd_graph* g, const std::vector<double>& v) {
-    std::vector<float> f(v.begin(), v.end());
-    return upload(g, f.data(), f.size());
-}
-
-// host weights [taps][a][b] -> packed planes on the device
+T* upload(emd_graph* g, const T* host, size_t n) { return emd::gx::upload(g->allocs, host, n); }
+float* upload_f(emd_graph* g, const std::vector<double>& v) { return emd::gx::upload_f(g->allocs, v); }
 bool pack(emd_graph* g, const float* w, int taps, int cin, int cout, int cout_major, Packed* out) {
-    const size_t n = emd_packed_weight_elems(taps, cin, cout), npad = (n + 63) / 64 * 64;
-    std::vector<uint16_t> both(2 * npad, 0);
-    if (emd_pack_weights_bf16(w, taps, cin, cout, cout_major, both.data(), both.data() + npad) != EMD_OK) return false;
-    uint16_t* d = upload(g, both.data(), both.size());
-    if (!d) return false;
-    out->hi = d;
-    out->lo = d + npad;
-    return true;
+    return emd::gx::pack(g->allocs, w, taps, cin, cout, cout_major, out);
 }
-
-// inference batch norm as y = x * gs + hs (float64)
 bool bn_affine(const WeightMap& w, const std::string& scope, int C, std::vector<double>* gs, std::vector<double>* hs, std::string* err) {
-    const float *gamma, *beta, *mean, *var;
-    if (!fetch(w, scope + "/gamma", C, &gamma, err) || !fetch(w, scope + "/beta", C, &beta, err) ||
-        !fetch(w, scope + "/moving_mean", C, &mean, err) || !fetch(w, scope + "/moving_variance", C, &var, err))
-        return false;
-    gs->resize(C);
-    hs->resize(C);
-    for (int c = 0; c < C; ++c) {
-        (*gs)[c] = (double)gamma[c] / std::sqrt((double)var[c] + BN_EPS);
-        (*hs)[c] = (double)beta[c] - (double)mean[c] * (*gs)[c];
-    }
-    return true;
+    return emd::gx::bn_affine(w, scope, C, BN_EPS, gs, hs, err);
 }
 
 // bias + the layer's consecutive batch norms -> one affine (scale, shift)
@@ -230,43 +186,6 @@ bool fold(const WeightMap& w, const LayerDecl& d, const float* bias, std::vector
     }
     return true;
 }
-
-// ---- workspace: a first-fit free-list allocator over the caller's buffer; in measuring mode it only tracks the peak
-struct Arena {
-    unsigned char* base = nullptr;
-    size_t cap = 0, peak = 0;
-    bool measuring = false;
-    std::map<size_t, size_t> live;   // offset -> size
-    void* alloc(size_t bytes) {
-        bytes = (bytes + 255) & ~(size_t)255;
-        size_t off = 0;
-        for (auto& kv : live) {   // ordered by offset: first gap that fits
-            if (kv.first - off >= bytes) break;
-            off = kv.first + kv.second;
-        }
-        if (!measuring && off + bytes > cap) return nullptr;
-        live[off] = bytes;
-        if (off + bytes > peak) peak = off + bytes;
-        return measuring ? reinterpret_cast<void*>(off + 4096) : static_cast<void*>(base + off);   // measuring: a fake non-null address
-    }
-    void release(void* p) {
-        if (!p) return;
-        const size_t off = measuring ? reinterpret_cast<size_t>(p) - 4096 : static_cast<size_t>(static_cast<unsigned char*>(p) - base);
-        live.erase(off);
-    }
-};
-
-struct T4 {   // an activation: channels [c0, c0 + C) of a [B,H,W,ld] fp32 buffer
-    float* buf = nullptr;
-    int B = 0, H = 0, W = 0, C = 0, ld = 0, c0 = 0;
-    float* ptr() const { return buf + c0; }
-    T4 slice(int off, int n) const {
-        T4 t = *this;
-        t.c0 = c0 + off;
-        t.C = n;
-        return t;
-    }
-};
 
 struct Run {
     emd_graph* g;
@@ -669,8 +588,8 @@ struct Run {
 extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const char* const* names, const float* const* data,
                                 const long* counts) {
     EMD_REQUIRE(out && names && data && counts && n_vars > 0, EMD_E_INVALID, "emd_graph_create: null argument");
-    EMD_REQUIRE(variant == 0 || variant == 1, EMD_E_UNSUPPORTED,
-                "emd_graph_create: variant 0 (graph D, machine_learning/denoiser.py) or 1 (graph D', misc_py/denoiser-multi-gpu.py, phase=False)");
+    EMD_REQUIRE(variant >= 0 && variant <= 2, EMD_E_UNSUPPORTED,
+                "emd_graph_create: variant 0 (graph D, machine_learning/denoiser.py), 1 (graph D', misc_py/denoiser-multi-gpu.py, phase=False) or 2 (graph X, misc_py/modified_Xception.py)");
     *out = nullptr;
     WeightMap w;
     for (int i = 0; i < n_vars; ++i) {
@@ -681,6 +600,18 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
     g->twin = variant == 1;
     std::string err;
     bool ok = true;
+    if (variant == 2) {   // graph X: its own layer table, parameters and launch sequence (graph_exec_x.hip)
+        g->x = emd::gx::x_create(w, g->allocs, &err);
+        if (!g->x) {
+            const bool dev_failure = err.find("device allocation") != std::string::npos || err.find("upload") != std::string::npos;
+            emd::set_error("%s", err.c_str());
+            for (void* q : g->allocs) (void)hipFree(q);
+            delete g;
+            return dev_failure ? EMD_E_ALLOC : EMD_E_INVALID;
+        }
+        *out = g;
+        return EMD_OK;
+    }
     const float u4[4] = {1.f, 0.f, 0.f, 0.f}, z4[4] = {0.f, 0.f, 0.f, 0.f};
     g->unit4 = upload(g, u4, 4);
     g->zero4 = upload(g, z4, 4);
@@ -783,6 +714,13 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
 
 extern "C" size_t emd_graph_workspace_bytes(emd_graph* g, int B, int S) {
     if (!g || B < 1 || S < 16 || S % 16) return 0;
+    if (g->x) {
+        if (S % 64) return 0;
+        Arena ar;
+        ar.measuring = true;
+        if (emd::gx::x_forward(g->x, &ar, nullptr, true, nullptr, nullptr, B, S) != EMD_OK) return 0;
+        return ar.peak + 256;
+    }
     // the larger of the two launch forms: a size asked for before emd_graph_set_two_streams stays valid after it
     size_t need = 0;
     const bool keep = g->two_streams;
@@ -809,6 +747,10 @@ extern "C" int emd_graph_run(emd_graph* g, const float* x, float* y, int B, int 
     Arena ar;
     ar.base = base + skew;
     ar.cap = workspace_bytes - skew;
+    if (g->x) {
+        EMD_REQUIRE(S % 64 == 0, EMD_E_INVALID, "emd_graph_run: graph X takes square crops with side a multiple of 64");
+        return emd::gx::x_forward(g->x, &ar, static_cast<hipStream_t>(stream), false, x, y, B, S);
+    }
     Run r{g, &ar, static_cast<hipStream_t>(stream), false};
     r.forward(x, y, B, S);
     return r.rc;
@@ -828,5 +770,6 @@ extern "C" void emd_graph_destroy(emd_graph* g) {
         if (g->side[0] && g->side[h]) (void)hipStreamDestroy(g->side[h]);
     }
     if (g->fork) (void)hipEventDestroy(g->fork);
+    if (g->x) emd::gx::x_destroy(g->x);
     delete g;
 }

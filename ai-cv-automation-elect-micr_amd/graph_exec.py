@@ -15,12 +15,13 @@ from . import _lib
 
 class NativeGraph:
     """architecture() behind the C ABI: variant "D" = machine_learning/denoiser.py:58-398, "Dprime" = the training twin
-    misc_py/denoiser-multi-gpu.py:200-540 run with phase=False (the graph a trained checkpoint of that script serves)."""
+    misc_py/denoiser-multi-gpu.py:200-540 run with phase=False (the graph a trained checkpoint of that script serves), "X" = the
+    Xception autoencoder misc_py/modified_Xception.py:194-654 (csrc/graph_exec_x.hip; side a multiple of 64, output in [0,1])."""
 
     def __init__(self, weights, device, variant="D"):
         import torch
 
-        code = {"D": 0, "Dprime": 1}[variant]
+        code = {"D": 0, "Dprime": 1, "X": 2}[variant]
 
         self.lib = _lib.load()
         self.device = device
@@ -51,7 +52,7 @@ class NativeGraph:
         B, S = x.shape[0], x.shape[1]
         need = self.workspace_bytes(B, S)
         if need == 0:
-            raise ValueError("square crops with side a multiple of 16")
+            raise ValueError("square crops with side a multiple of 16 (graph X: 64)")
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         y = torch.empty_like(x)

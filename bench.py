@@ -1015,6 +1015,27 @@ def bench_X(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
                         "algorithmic_flops_per_step": dec_fl, "kernel_ms_per_step": round(dec_ms, 3),
                         "how": "HIP events around every launch of the family in one extra step; flops from the launch arguments"},
            "kernel_family_ms": fam.table()}
+    if B and rank == 0 and H == W and H % 64 == 0 and a.precision == "bf16x3":
+        # the same graph through the library's native executor (csrc/graph_exec_x.hip, emd_graph_create variant 2)
+        try:
+            from emdenoise.graph_exec import NativeGraph
+
+            nat = NativeGraph(weights, dev, variant="X")
+            yn = nat.forward(x)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(yn, box[0]))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                nat.forward(x)
+            e1.record()
+            torch.cuda.synchronize()
+            out["native_executor"] = {"ms_per_step": round(e0.elapsed_time(e1) / 3, 3), "bit_identical_to_python_engine": same,
+                                      "workspace_GiB": round(nat.workspace_bytes(B, H) / 2 ** 30, 2)}
+            nat.close()
+            del nat, yn
+        except Exception as e:
+            out["native_executor"] = {"error": f"{type(e).__name__}: {e}"}
     if B and cpu and "X" in cpu and "error" not in cpu["X"]:
         # X normalises with the statistics of the batch it is given, so parity is defined per batch: the GPU runs the SAME
         # sub-batch the CPU leg ran (2 images: ~25 s of CPU work), and that pair is what rel_l2_vs_oracle compares

@@ -20,9 +20,9 @@ def test_create_reports_a_missing_or_misshapen_variable():
     names = [n for n in w if not n.endswith("/gamma")][:5]
     arrays = [np.ascontiguousarray(w[n], np.float32) for n in names]
     h = C.c_void_p()
-    rc = lib.emd_graph_create(C.byref(h), 2, len(names), (C.c_char_p * 5)(*[n.encode() for n in names]),
+    rc = lib.emd_graph_create(C.byref(h), 3, len(names), (C.c_char_p * 5)(*[n.encode() for n in names]),
                               (C.c_void_p * 5)(*[a.ctypes.data for a in arrays]), (C.c_long * 5)(*[a.size for a in arrays]))
-    assert rc == -2 and b"variant" in lib.emd_last_error()          # 0 = graph D, 1 = graph D' 
+    assert rc == -2 and b"variant" in lib.emd_last_error()          # 0 = graph D, 1 = graph D', 2 = graph X
     assert lib.emd_graph_workspace_bytes(None, 1, 64) == 0
 
 
@@ -98,4 +98,37 @@ def test_native_graph_dprime_equals_the_python_engine(B, S):
     torch.cuda.synchronize()
     assert torch.equal(got, want)
     assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+    nat.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S", [(2, 128), (1, 64), (4, 512)])
+def test_native_graph_x_equals_the_python_engine(B, S):
+    """emd_graph_create(variant 2): graph X (misc_py/modified_Xception.py:194-654) from C -- layer table under scope "pellet", folded
+    moving-statistics norms, packed weights, the per-layer choice between the fp32 / split32 / patch-resident kernels with its
+    look-ahead, batch-statistics norms folded on the device, workspace planning -- bit-identical to XceptionEngine (split-bf16 mode),
+    and a workspace that is too small is reported."""
+    from emdenoise import _lib, xception
+    from emdenoise.graph_exec import NativeGraph
+
+    dev = torch.device("cuda", 0)
+    w = xception.synthetic_weights()
+    eng = xception.XceptionEngine(w, dev, "bf16x3")
+    nat = NativeGraph(w, dev, variant="X")
+    x = torch.from_numpy(synthetic_lq(B, S, S, seed=90 + S)).to(dev)
+    want = eng.forward(x)
+    got = nat.forward(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+    assert torch.equal(got, want)
+    again = nat.forward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(again, want)
+    need = nat.workspace_bytes(B, S)
+    assert need > 0 and nat.workspace_bytes(B, 48) == 0            # graph X: side a multiple of 64
+    small = torch.empty(need // 2, dtype=torch.uint8, device=dev)
+    y = torch.empty_like(x)
+    rc = nat.lib.emd_graph_run(nat._h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), B, S, C.c_void_p(small.data_ptr()),
+                               C.c_size_t(small.numel()), None)
+    assert rc != 0 and b"workspace" in _lib.load().emd_last_error()
     nat.close()
