@@ -119,5 +119,11 @@ void x_destroy(XGraph* x);
 // launches (dry = false) or only plans the workspace (dry = true: ar in measuring mode); returns an EMD_* code
 int x_forward(XGraph* x, Arena* ar, hipStream_t st, bool dry, const float* in, float* out, int B, int S);
 
+// ---- graph G's generator (graph_exec_g.hip): misc_py/gan-infilling-100.py:133-374, inference
+struct GGraph;
+GGraph* g_create(const WeightMap& w, std::vector<void*>& allocs, std::string* err);
+void g_destroy(GGraph* g);
+int g_forward(GGraph* g, Arena* ar, hipStream_t st, bool dry, const float* in, float* out, int B, int S);
+
 }  // namespace gx
 }  // namespace emd

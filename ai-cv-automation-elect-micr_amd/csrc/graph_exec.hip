@@ -138,6 +138,7 @@ struct emd_graph {   // the handle behind emd_graph_t
     // the two side streams of the 1/16-resolution flow (Run::middle_two_streams) and their fork / join events; made on first use
     bool twin = false;          // variant 1: graph D' (the training twin's inference graph)
     emd::gx::XGraph* x = nullptr;   // variant 2: graph X (graph_exec_x.hip)
+    emd::gx::GGraph* gen = nullptr; // variant 3: graph G's generator (graph_exec_g.hip)
     bool two_streams = false;   // emd_graph_set_two_streams
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
@@ -588,8 +589,8 @@ struct Run {
 extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const char* const* names, const float* const* data,
                                 const long* counts) {
     EMD_REQUIRE(out && names && data && counts && n_vars > 0, EMD_E_INVALID, "emd_graph_create: null argument");
-    EMD_REQUIRE(variant >= 0 && variant <= 2, EMD_E_UNSUPPORTED,
-                "emd_graph_create: variant 0 (graph D, machine_learning/denoiser.py), 1 (graph D', misc_py/denoiser-multi-gpu.py, phase=False) or 2 (graph X, misc_py/modified_Xception.py)");
+    EMD_REQUIRE(variant >= 0 && variant <= 3, EMD_E_UNSUPPORTED,
+                "emd_graph_create: variant 0 (graph D, machine_learning/denoiser.py), 1 (graph D', misc_py/denoiser-multi-gpu.py, phase=False) , 2 (graph X, misc_py/modified_Xception.py) or 3 (graph G's generator, misc_py/gan-infilling-100.py)");
     *out = nullptr;
     WeightMap w;
     for (int i = 0; i < n_vars; ++i) {
@@ -600,9 +601,10 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
     g->twin = variant == 1;
     std::string err;
     bool ok = true;
-    if (variant == 2) {   // graph X: its own layer table, parameters and launch sequence (graph_exec_x.hip)
-        g->x = emd::gx::x_create(w, g->allocs, &err);
-        if (!g->x) {
+    if (variant >= 2) {   // graphs X / G: their own layer tables, parameters and launch sequences (graph_exec_x.hip, graph_exec_g.hip)
+        if (variant == 2) g->x = emd::gx::x_create(w, g->allocs, &err);
+        else g->gen = emd::gx::g_create(w, g->allocs, &err);
+        if (!g->x && !g->gen) {
             const bool dev_failure = err.find("device allocation") != std::string::npos || err.find("upload") != std::string::npos;
             emd::set_error("%s", err.c_str());
             for (void* q : g->allocs) (void)hipFree(q);
@@ -714,12 +716,13 @@ extern "C" int emd_graph_create(emd_graph** out, int variant, int n_vars, const 
 
 extern "C" size_t emd_graph_workspace_bytes(emd_graph* g, int B, int S) {
     if (!g || B < 1 || S < 16 || S % 16) return 0;
-    if (g->x) {
-        if (S % 64) return 0;
+    if (g->x || g->gen) {
+        if ((g->x && S % 64) || (g->gen && S < 32)) return 0;
         Arena ar;
         ar.measuring = true;
-        if (emd::gx::x_forward(g->x, &ar, nullptr, true, nullptr, nullptr, B, S) != EMD_OK) return 0;
-        return ar.peak + 256;
+        const int rc = g->x ? emd::gx::x_forward(g->x, &ar, nullptr, true, nullptr, nullptr, B, S)
+                            : emd::gx::g_forward(g->gen, &ar, nullptr, true, nullptr, nullptr, B, S);
+        return rc == EMD_OK ? ar.peak + 256 : 0;
     }
     // the larger of the two launch forms: a size asked for before emd_graph_set_two_streams stays valid after it
     size_t need = 0;
@@ -751,6 +754,10 @@ extern "C" int emd_graph_run(emd_graph* g, const float* x, float* y, int B, int 
         EMD_REQUIRE(S % 64 == 0, EMD_E_INVALID, "emd_graph_run: graph X takes square crops with side a multiple of 64");
         return emd::gx::x_forward(g->x, &ar, static_cast<hipStream_t>(stream), false, x, y, B, S);
     }
+    if (g->gen) {
+        EMD_REQUIRE(S >= 32, EMD_E_INVALID, "emd_graph_run: graph G takes square crops with side a multiple of 16, >= 32");
+        return emd::gx::g_forward(g->gen, &ar, static_cast<hipStream_t>(stream), false, x, y, B, S);
+    }
     Run r{g, &ar, static_cast<hipStream_t>(stream), false};
     r.forward(x, y, B, S);
     return r.rc;
@@ -771,5 +778,6 @@ extern "C" void emd_graph_destroy(emd_graph* g) {
     }
     if (g->fork) (void)hipEventDestroy(g->fork);
     if (g->x) emd::gx::x_destroy(g->x);
+    if (g->gen) emd::gx::g_destroy(g->gen);
     delete g;
 }

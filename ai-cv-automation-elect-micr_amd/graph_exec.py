@@ -16,12 +16,13 @@ from . import _lib
 class NativeGraph:
     """architecture() behind the C ABI: variant "D" = machine_learning/denoiser.py:58-398, "Dprime" = the training twin
     misc_py/denoiser-multi-gpu.py:200-540 run with phase=False (the graph a trained checkpoint of that script serves), "X" = the
-    Xception autoencoder misc_py/modified_Xception.py:194-654 (csrc/graph_exec_x.hip; side a multiple of 64, output in [0,1])."""
+    Xception autoencoder misc_py/modified_Xception.py:194-654 (csrc/graph_exec_x.hip; side a multiple of 64, output in [0,1]), "G" = the
+    in-filling generator misc_py/gan-infilling-100.py:133-374 (csrc/graph_exec_g.hip; side a multiple of 16, >= 32, output in (-1,1))."""
 
     def __init__(self, weights, device, variant="D"):
         import torch
 
-        code = {"D": 0, "Dprime": 1, "X": 2}[variant]
+        code = {"D": 0, "Dprime": 1, "X": 2, "G": 3}[variant]
 
         self.lib = _lib.load()
         self.device = device

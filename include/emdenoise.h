@@ -636,7 +636,13 @@ int emd_gen_lq_f32(const float* img, const float* scale, float* lq, float* truth
  * bit-identical results.  variant: 0 = graph D; 1 = graph D', the inference graph of the training twin
  * misc_py/denoiser-multi-gpu.py:200-540 (phase=False): tf.layers variable names (nn/conv2d[_k]/{kernel,bias}, nn/conv2d_transpose[_k]/...,
  * the ASPP convs nn/{1x1,lowRate,mediumRate,highRate,imageLevel,pellet}), dense dilated 3x3 ASPP branches, a real image-level
- * branch, output clipped to [0,1] (:534-538).
+ * branch, output clipped to [0,1] (:534-538); 2 = graph X, the Xception autoencoder misc_py/modified_Xception.py:194-654 (variables under
+ * scope "pellet": pellet/conv2d[_k]/{kernel,bias}, pellet/SeparableConv2d[_k]/{depthwise_weights,pointwise_weights,BatchNorm/...},
+ * pellet/conv2d_transpose[_k]/..., pellet/{1x1,lowRate,mediumRate,highRate,imageLevel}/..., pellet/BatchNorm[_k]/...; S a multiple of 64;
+ * the separable convs' norms run on the statistics of the batch handed to emd_graph_run; output clipped to [0,1]), same kernels as
+ * emdenoise.xception.XceptionEngine, bit-identical; 3 = graph G's generator misc_py/gan-infilling-100.py:133-374 (variables under
+ * "GAN/Gen" and "GAN/Gen/reg"; x = the 1/64-sampled image with missing pixels -1, S a multiple of 16, >= 32; y in (-1,1)), same kernels
+ * as emdenoise.gan.GeneratorEngine, bit-identical.
  * A handle is NOT re-entrant: emd_graph_run calls on one handle must be serialised by the caller (one stream, one thread at a
  * time) -- the fork / join events and the side streams of the two-streams form belong to the handle; use one handle per
  * concurrent stream (the weights are ~100 MB).  emd_graph_workspace_bytes returns the larger of the two launch forms' needs, so a

@@ -20,9 +20,9 @@ def test_create_reports_a_missing_or_misshapen_variable():
     names = [n for n in w if not n.endswith("/gamma")][:5]
     arrays = [np.ascontiguousarray(w[n], np.float32) for n in names]
     h = C.c_void_p()
-    rc = lib.emd_graph_create(C.byref(h), 3, len(names), (C.c_char_p * 5)(*[n.encode() for n in names]),
+    rc = lib.emd_graph_create(C.byref(h), 4, len(names), (C.c_char_p * 5)(*[n.encode() for n in names]),
                               (C.c_void_p * 5)(*[a.ctypes.data for a in arrays]), (C.c_long * 5)(*[a.size for a in arrays]))
-    assert rc == -2 and b"variant" in lib.emd_last_error()          # 0 = graph D, 1 = graph D', 2 = graph X
+    assert rc == -2 and b"variant" in lib.emd_last_error()          # 0 = graph D, 1 = graph D', 2 = graph X, 3 = graph G's generator
     assert lib.emd_graph_workspace_bytes(None, 1, 64) == 0
 
 
@@ -131,4 +131,29 @@ def test_native_graph_x_equals_the_python_engine(B, S):
     rc = nat.lib.emd_graph_run(nat._h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), B, S, C.c_void_p(small.data_ptr()),
                                C.c_size_t(small.numel()), None)
     assert rc != 0 and b"workspace" in _lib.load().emd_last_error()
+    nat.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S", [(2, 64), (1, 96), (4, 512)])
+def test_native_graph_g_equals_the_python_engine(B, S):
+    """emd_graph_create(variant 3): the in-filling generator (misc_py/gan-infilling-100.py:133-374) from C -- layer table under
+    "GAN/Gen" / "GAN/Gen/reg", both norms of every separable conv folded, the four routes of a separable block (fused, fused stride 2 on
+    the REFLECT-padded image, split32 pair, register-staged pair), the generated-input first layers, resizes, the reflect-padded last
+    conv and the instance norm -- bit-identical to GeneratorEngine (split-bf16 mode; its two-halves streams give the same bits)."""
+    from emdenoise import gan
+    from emdenoise.graph_exec import NativeGraph
+
+    dev = torch.device("cuda", 0)
+    w = gan.synthetic_weights()
+    eng = gan.GeneratorEngine(w, dev, "bf16x3")
+    nat = NativeGraph(w, dev, variant="G")
+    hq = 2.0 * synthetic_lq(B, S, S, seed=95 + S)[..., 0] - 1.0
+    x = torch.from_numpy(gan.gen_lq(hq, select=gan.spiral_mask(S))[..., None]).to(dev)
+    want = eng.forward(x)
+    got = nat.forward(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and float(got.abs().max()) <= 1.0
+    assert torch.equal(got, want)
+    assert torch.equal(nat.forward(x), want)
     nat.close()
