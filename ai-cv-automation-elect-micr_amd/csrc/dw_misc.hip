@@ -741,7 +741,10 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
         // strip height: 16 rows (input re-read factor 18/16) measured 1-4 % faster than 8 on the 256^2/512^2 layers;
         // short images keep 8 so that small maps still spread over the chip
         const int th_force = emd::g_knobs.dw_th;
-        int TH = th_force == 4 || th_force == 8 || th_force == 16 || th_force == 32 ? th_force : (H >= 64 ? 16 : 8);
+        // (round 3: 16 rows also on the short maps while that still leaves >= 1024 workgroups -- 32 x 32 x 728 at a batch of 32: 1536
+        // workgroups, 2.38 -> 2.28 ms over graph D's 43 standalone launches)
+        const long wg16 = (long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((C4t + 15) / 16);
+        int TH = th_force == 4 || th_force == 8 || th_force == 16 || th_force == 32 ? th_force : ((H >= 64 || (H >= 16 && wg16 >= 1024)) ? 16 : 8);
         // small batches of small maps (4 images of 32 x 32 x 728: 384 workgroups of 8 rows): a thread's 10 dependent row loads are the
         // kernel's whole life and most CUs hold one workgroup -- 4-row strips double the workgroups and halve the chain (same bits:
         // the three row contributions of an output are added in the same order at every strip height)
