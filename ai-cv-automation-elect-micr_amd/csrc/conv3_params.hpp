@@ -31,6 +31,7 @@ struct DeconvPipeParams {
     const float* shift1;
     int H, W, Cin, Cpad, N, ldy, act;
     int tpw, n_ntiles;
+    int ablate;               // dev (knob sep_ablate; results wrong on purpose): 2 no MFMAs, 4 no stores, 8 no patch DMA, 16 no weight DMA
 };
 
 bool deconv_pipe_covers(const DeconvPipeParams& p);

@@ -19,6 +19,8 @@
 // Summation order per output element: chunk-major, taps inside -- NOT the order of gemm_split_conv_kernel (tap-major): same error
 // class (split-bf16, fp32 accumulate), different last bits; the dispatch depends on the layer's shape only.
 // Epilogue from the accumulators (quad transpose, 16-byte non-temporal stores), fp32 or split32 output, two-stage affine.
+#include <type_traits>
+
 #include "conv3_params.hpp"
 
 namespace {
@@ -33,6 +35,9 @@ __device__ __attribute__((aligned(128))) unsigned char g_zero_c3[16384];   // pa
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
+}
+__device__ __forceinline__ void store_nt_d(const void* sbase, unsigned voff, unsigned v) {
+    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void store_nt_s(const void* sbase, unsigned voff, f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
@@ -64,7 +69,7 @@ __device__ __forceinline__ unsigned xchg4(unsigned v, bool oddq) {
     return oddq ? dn : up;
 }
 
-template <bool OSPLIT>
+template <bool OSPLIT, int EPI>      // EPI: dwords a lane stores at a time (1; 4 behind dev knob epi_width)
 __global__ __launch_bounds__(512, 1) void conv3_pipe_kernel(const Conv3Params p) {
     constexpr int BN = 64, NW = 8, TW = 32, TH = 8;
     constexpr int PW = TW + 2, PH = TH + 2, PWS = 35, NPATCH = PH * PWS;   // 350 slots, 2 spare
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(512, 1) void conv3_pipe_kernel(const Conv3Params p)
     constexpr int STAGE = NPIECE * 1024;                                   // 45056
     constexpr int B_ONE = 3 * BN * 128, PB = 3 * BN / 8 / NW;              // 24576 B per (chunk, tap row): 24 pieces, 3 per wave
     constexpr int B_OFF = 2 * STAGE;
-    constexpr int TN = 2, E = 4 * TN;                                      // 32-column MFMA tiles / stores per wave and tile
+    constexpr int TN = 2, E = 16 * TN / EPI;                               // 32-column MFMA tiles / stores per wave and tile
     __shared__ __attribute__((aligned(1024))) unsigned char smem[B_OFF + 2 * B_ONE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -254,46 +259,95 @@ __global__ __launch_bounds__(512, 1) void conv3_pipe_kernel(const Conv3Params p)
             if (++c == nchunks) {
                 c = 0;
                 epi = true;
-                // ---- epilogue from the accumulators: C/D layout col = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) = pixel of the tile row
+                // ---- epilogue from the accumulators: C/D layout col = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) = pixel
+                // of the tile row.  A lane stores its channel's sixteen pixels as they are, one dword each: the 32 lanes of a half wave write
+                // the 128 contiguous bytes of a pixel's channel group (see deconv_pipe.hip; EPI = 4 behind dev knob epi_width is the older
+                // form -- a 4 x 4 transpose inside lane quads, then 16 bytes per lane).  split32 output: two pixels are split together,
+                // the (even, odd) channel pair trades halves, the even lane stores hi (c, c + 1), the odd lane lo (c - 1, c).
                 int ldo = p.ldy;
                 asm volatile("" : "+s"(ldo));
-                const int li = fr & 3, cq = fr >> 2;
                 const long pixr = img + (long)(y0 + wv) * p.W + x0;
                 float* obase = p.y + pixr * ldo;
+                auto body = [&](auto LEAKY_, auto TWO_) {
+                    constexpr bool LEAKY = decltype(LEAKY_)::value, TWO = decltype(TWO_)::value;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float s1 = es1[j], t1 = et1[j], s2 = es2[j], t2 = et2[j];
-                    const int n4 = n0 + j * 32 + 4 * cq;
-                    const bool valid = n4 < p.N;
-                    unsigned voff;
-                    if constexpr (OSPLIT) voff = (unsigned)((4 * fh + li) * ldo) * 4u + (n4 >> 5) * 128u + ((cq & 1) ? 64u : 0u) + ((n4 & 31) >> 3) * 16u;
-                    else voff = (unsigned)((4 * fh + li) * ldo + n4) * 4u;
+                    for (int j = 0; j < TN; ++j) {
+                        const float s1 = es1[j], t1 = et1[j], s2 = es2[j], t2 = et2[j];
+                        auto act = [&](float a) {
+                            float v = fmaf(a, s1, t1);
+                            if constexpr (LEAKY) v = fmaxf(v, slope * v);
+                            v = __builtin_amdgcn_fmed3f(v, lo, hi);
+                            if constexpr (TWO) v = __builtin_amdgcn_fmed3f(fmaf(v, s2, t2), 0.f, hi2);
+                            return v;
+                        };
+                        if constexpr (EPI == 1) {
+                            const int n = n0 + j * 32 + fr;
+                            const bool odd = fr & 1;
+                            unsigned voff;
+                            bool live;
+                            if constexpr (OSPLIT) {
+                                voff = (unsigned)(4 * fh * ldo) * 4u + (n >> 5) * 128u + (odd ? 64u + 2u * ((n & 31) - 1) : 2u * (n & 31));
+                                live = n < ((p.N + 31) & ~31);     // (scale = shift = 0 past N: the padding of the last channel group is zeros)
+                            } else {
+                                voff = (unsigned)(4 * fh * ldo + n) * 4u;
+                                live = n < p.N;
+                            }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float r[4];
+                            for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float v = fmaf(acc[j][4 * q + k], s1, t1);
-                            v = fminf(fmaxf(fmaxf(v, lo), slope * v), hi);
-                            const float v2 = fminf(fmaxf(fmaf(v, s2, t2), 0.f), hi2);
-                            r[k] = two ? v2 : v;
-                        }
-                        quad_transpose(r, li);
-                        f32x4 v = f32x4{r[0], r[1], r[2], r[3]};
-                        float* ob = obase + (8 * q) * ldo;
-                        if constexpr (!OSPLIT) {
-                            if (valid) store_nt_s(ob, voff, v);
+                                for (int k = 0; k < 4; k += 2) {
+                                    const float r0 = act(acc[j][4 * q + k]), r1 = act(acc[j][4 * q + k + 1]);
+                                    float* ob0 = obase + (8 * q + k) * ldo;
+                                    float* ob1 = ob0 + ldo;
+                                    if constexpr (!OSPLIT) {
+                                        if (live) {
+                                            store_nt_d(ob0, voff, __builtin_bit_cast(unsigned, r0));
+                                            store_nt_d(ob1, voff, __builtin_bit_cast(unsigned, r1));
+                                        }
+                                    } else {
+                                        unsigned h, l;                                 // (pixel k | pixel k + 1) halves of this channel
+                                        split2(r0, r1, h, l);
+                                        const unsigned got = swap_pair(odd ? h : l);   // even lane: the odd channel's hi pair; odd lane: the even channel's lo pair
+                                        const unsigned first = odd ? got : h, second = odd ? l : got;
+                                        if (live) {
+                                            store_nt_d(ob0, voff, __builtin_amdgcn_perm(second, first, 0x05040100u));
+                                            store_nt_d(ob1, voff, __builtin_amdgcn_perm(second, first, 0x07060302u));
+                                        }
+                                    }
+                                }
+                            }
                         } else {
-                            if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                            unsigned h0, l0, h1, l1;
-                            split2(v[0], v[1], h0, l0);
-                            split2(v[2], v[3], h1, l1);
-                            const bool oddq = cq & 1;
-                            const unsigned r0 = xchg4(oddq ? h0 : l0, oddq), r1 = xchg4(oddq ? h1 : l1, oddq);
-                            if (n4 < ((p.N + 31) & ~31)) store_nt_s(ob, voff, oddq ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1});
+                            const int li = fr & 3, cq = fr >> 2;
+                            const int n4 = n0 + j * 32 + 4 * cq;
+                            const bool valid = n4 < p.N;
+                            unsigned voff;
+                            if constexpr (OSPLIT) voff = (unsigned)((4 * fh + li) * ldo) * 4u + (n4 >> 5) * 128u + ((cq & 1) ? 64u : 0u) + ((n4 & 31) >> 3) * 16u;
+                            else voff = (unsigned)((4 * fh + li) * ldo + n4) * 4u;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float r[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) r[k] = act(acc[j][4 * q + k]);
+                                quad_transpose(r, li);
+                                f32x4 v = f32x4{r[0], r[1], r[2], r[3]};
+                                float* ob = obase + (8 * q) * ldo;
+                                if constexpr (!OSPLIT) {
+                                    if (valid) store_nt_s(ob, voff, v);
+                                } else {
+                                    if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                                    unsigned h0, l0, h1, l1;
+                                    split2(v[0], v[1], h0, l0);
+                                    split2(v[2], v[3], h1, l1);
+                                    const bool oddq = cq & 1;
+                                    const unsigned r0 = xchg4(oddq ? h0 : l0, oddq), r1 = xchg4(oddq ? h1 : l1, oddq);
+                                    if (n4 < ((p.N + 31) & ~31)) store_nt_s(ob, voff, oddq ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1});
+                                }
+                            }
                         }
                     }
-                }
+                };
+                if (p.act == 4) { if (two) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+                else { if (two) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -326,8 +380,13 @@ int conv3_pipe_launch(const Conv3Params& p, int B, int out_split, hipStream_t st
     if (g_knobs.sep_tpw > 0 && tiles_w % g_knobs.sep_tpw == 0) tpw = g_knobs.sep_tpw;   // dev knob (shared with the separable kernels)
     q.tpw = tpw;
     const dim3 grid(tiles_w / tpw * q.n_ntiles, p.H / 8, B);
-    if (out_split) hipLaunchKernelGGL((conv3_pipe_kernel<true>), grid, dim3(512), 0, st, q);
-    else hipLaunchKernelGGL((conv3_pipe_kernel<false>), grid, dim3(512), 0, st, q);
+    if (g_knobs.epi_width == 4) {
+        if (out_split) hipLaunchKernelGGL((conv3_pipe_kernel<true, 4>), grid, dim3(512), 0, st, q);
+        else hipLaunchKernelGGL((conv3_pipe_kernel<false, 4>), grid, dim3(512), 0, st, q);
+    } else {
+        if (out_split) hipLaunchKernelGGL((conv3_pipe_kernel<true, 1>), grid, dim3(512), 0, st, q);
+        else hipLaunchKernelGGL((conv3_pipe_kernel<false, 1>), grid, dim3(512), 0, st, q);
+    }
     return emd::check_launch("conv3_pipe_kernel");
 }
 

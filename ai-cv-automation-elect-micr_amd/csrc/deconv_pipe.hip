@@ -27,6 +27,9 @@ __device__ __forceinline__ void store_nt_s(const void* sbase, unsigned voff, f32
 __device__ __forceinline__ void store_nt_s(const void* sbase, unsigned voff, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
+__device__ __forceinline__ void store_nt_d(const void* sbase, unsigned voff, unsigned v) {
+    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 __device__ __forceinline__ float dpp_f(float v, int xor2) {
     return xor2 ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true))
                 : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -54,27 +57,27 @@ __device__ __forceinline__ unsigned xchg4(unsigned v, bool oddq) {
 // Tap table of slim.conv2d_transpose(k = 3, s = 2, SAME) in the order the nine (phase, tap) weight tiles are brought in, three per step.
 // Phase = 2 py + px of the output pixel (2 i + py, 2 j + px); emd_deconv_phase_taps (gemm_conv.hip) fixes the tap order inside a phase:
 // phase 0: kernel (0,0) (0,2) (2,0) (2,2) reading input (i,j) (i,j-1) (i-1,j) (i-1,j-1); phase 1: (0,1) (2,1) reading (i,j) (i-1,j);
-// phase 2: (1,0) (1,2) reading (i,j) (i,j-1); phase 3: (1,1) reading (i,j).
+// phase 2: (1,0) (1,2) reading (i,j) (i,j-1); phase 3: (1,1) reading (i,j).  The phases are ordered SHORTEST FIRST -- 3, 1, 2, 0 -- so
+// that in a tile's last chunk phases 3 and 1 are complete after step 0, phase 2 after step 1 and phase 0 after step 2: the tile's stores
+// (four times what it read) leave in three instalments spread over the chunk instead of one burst behind it.
 struct TapE { int ph, t, dy, dx; };
-__device__ constexpr TapE kTaps[9] = {{0, 0, 0, 0}, {0, 1, 0, -1}, {0, 2, -1, 0}, {0, 3, -1, -1}, {1, 0, 0, 0}, {1, 1, -1, 0},
-                                      {2, 0, 0, 0}, {2, 1, 0, -1}, {3, 0, 0, 0}};
+__device__ constexpr TapE kTaps[9] = {{3, 0, 0, 0}, {1, 0, 0, 0}, {1, 1, -1, 0}, {2, 0, 0, 0}, {2, 1, 0, -1},
+                                      {0, 0, 0, 0}, {0, 1, 0, -1}, {0, 2, -1, 0}, {0, 3, -1, -1}};
 
-// NW = 8: 8 x 32 input pixels per tile, three taps per step, one workgroup per CU (124 KB of LDS).  NW = 4: 4 x 32 pixels, two taps per
-// step (five steps per chunk, the last with one tap), 75 KB: TWO workgroups per CU -- a transposed conv writes four times what it reads
-// (deconv1to0: 262 KB of stores per 256 input pixels against 27.6 k clocks of MFMA issue), the stores retire in order with the loads
-// behind them, and a workgroup waiting for its stores to drain leaves the matrix cores to its neighbour.
-template <bool OSPLIT, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void deconv_pipe_kernel(const DeconvPipeParams p) {
-    constexpr int BN = 64, TW = 32, TH = NW;
-    constexpr int TPS = NW == 8 ? 3 : 2, NSTEP = (9 + TPS - 1) / TPS;       // taps per step, steps per chunk
-    constexpr int H1 = NW == 8 ? 1 : 2;                                     // phases 0 and 1 are complete after this step of the last chunk
+// 8 x 32 input pixels per tile, three taps per step, one workgroup of eight waves per CU: 76 KB of patch ring (two chunks) + 72 KB of
+// weight ring (THREE steps: the tile of step u + 2 is issued in step u, so that a store instalment has two whole steps to drain before
+// a wait has to include it -- vmcnt retires loads and stores in order).
+template <bool OSPLIT, bool ABL, int EPI>     // EPI: dwords a lane stores at a time (1, or 4 behind dev knob epi_width: see the epilogue).  ABL: the dev build with the ablation switches (knob sep_ablate; tools/deconv_ablate.py)
+__global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipeParams p) {
+    constexpr int NW = 8, BN = 64, TW = 32, TH = NW;
+    constexpr int TPS = 3, NSTEP = 3;                                       // taps per step, steps per chunk
     constexpr int PH = TH + 1, PWS = TW + 1, NPATCH = PH * PWS;            // one halo row above, one halo column to the left (33 slots per patch row)
     constexpr int NPIECE = (NPATCH + 7) / 8, PP = (NPIECE + NW - 1) / NW;  // 1 KiB pieces; surplus pieces of the last round repeat one
     constexpr int STAGE = NPIECE * 1024;
     constexpr int B_ONE = TPS * BN * 128, PB = TPS * BN / 8 / NW;           // weight tiles of a step: 8 pieces per tap
     constexpr int B_OFF = 2 * STAGE;
-    constexpr int TN = 2, E = 4 * 4 * TN;                                  // stores per wave and tile: 4 phases x 4 row groups x TN
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[B_OFF + 2 * B_ONE];
+    constexpr int TN = 2, EP = 16 * TN / EPI;                              // stores per wave, tile and phase
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[B_OFF + 3 * B_ONE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,7 +98,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void deconv_pipe_kernel(c
     const long img = (long)bz * p.H * p.W;
 
     const int drow = lane >> 3, dk = lane & 7;
-    const unsigned char* psrc[PP];
+    // patch sources: 32-bit offsets from the image (real pixels) or from the zero page (padding); bit j of pmove tells which
+    const unsigned char* const ximg = p.x + img * p.ldx_bytes;
+    unsigned psrc[PP];
     unsigned pmove = 0;
     auto set_tile = [&](int xt) {
         pmove = 0;
@@ -108,42 +113,38 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void deconv_pipe_kernel(c
             const int gy = y0 - 1 + py, gx = xt - 1 + px;
             const bool real = slot < NPATCH && gy >= 0 && gx >= 0;      // (gy < H, gx < W by construction: H % 8 == 0, W % 32 == 0)
             const int kk = dk ^ ((slot >> 1) & 7);
-            const unsigned char* o = g_zero_dc + kk * 16;
-            const unsigned char* o_px = p.x + (img + (long)gy * p.W + gx) * p.ldx_bytes + kk * 16;
-            psrc[j] = real ? o_px : o;
+            psrc[j] = (real ? (unsigned)(gy * p.W + gx) * (unsigned)p.ldx_bytes : 0u) + kk * 16;
             pmove |= real ? 1u << j : 0u;
         }
     };
+    const int abl = ABL ? p.ablate : 0;
+    bool primed = false;
     auto issue_patch = [&](int stage, int c) {
+        if constexpr (ABL) { if ((abl & 8) && primed) return; }
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
             int q = wv + NW * j;
             if (q >= NPIECE) q -= NW;
-            __builtin_amdgcn_global_load_lds((gptr_t)(psrc[j] + c * 128), (lptr_t)(smem + stage * STAGE + q * 1024), 16, 0, 0);
+            const unsigned char* base = ((pmove >> j) & 1) ? ximg : g_zero_dc;
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + (psrc[j] + c * 128)), (lptr_t)(smem + stage * STAGE + q * 1024), 16, 0, 0);
         }
     };
     // weight rows of step s: row = k * 64 + output channel for the step's three table entries k; pieces XOR-swizzled by (row >> 1) & 7.
     // The sources are rebuilt at issue time from lane constants (a dozen VALU operations per step) rather than kept in 18 registers.
-    int brow_n[PB], bcol[PB];
-    bool blo[PB];
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-        const int row = (wv * PB + j) * 8 + drow;     // (wv * PB + j) / 8 = the table entry inside the step: wave-uniform
-        const int c = dk ^ ((row >> 1) & 7);
-        brow_n[j] = n0 + (row & 63);
-        bcol[j] = (c & 3) * 8;
-        blo[j] = (c & 4) != 0;
-    }
+    // piece q = wv * PB + j (scalar) holds rows q * 8 + drow: entry q / 8 of the step, output channel n0 + (q & 7) * 8 + drow, 16-byte
+    // column dk ^ (4 (q & 1) + (drow >> 1))
+    const int bc0 = dk ^ (drow >> 1);
     auto issue_B = [&](int buf, int c, int s) {
+        if constexpr (ABL) { if ((abl & 16) && primed) return; }
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
-            int e = s * TPS + (wv * PB + j) / 8;              // scalar
-            if (e > 8) e = 8;                                 // (NW = 4: the fifth step has one tap; its second tile is a copy nobody reads)
-            const int ph = e < 4 ? 0 : (e < 6 ? 1 : (e < 8 ? 2 : 3)), t = e < 4 ? e : (e < 6 ? e - 4 : (e < 8 ? e - 6 : 0));
+            const int e = s * TPS + (wv * PB + j) / 8;        // scalar: entry of kTaps
+            const int ph = e == 0 ? 3 : (e < 3 ? 1 : (e < 5 ? 2 : 0)), t = e == 0 ? 0 : (e < 3 ? e - 1 : (e < 5 ? e - 3 : e - 5));
             const int nt = ph == 0 ? 4 : (ph == 3 ? 1 : 2);
             const uint16_t* hi_p = ph == 0 ? p.Whi[0] : (ph == 1 ? p.Whi[1] : (ph == 2 ? p.Whi[2] : p.Whi[3]));
             const uint16_t* lo_p = ph == 0 ? p.Wlo[0] : (ph == 1 ? p.Wlo[1] : (ph == 2 ? p.Wlo[2] : p.Wlo[3]));
-            const uint16_t* src = (blo[j] ? lo_p : hi_p) + (long)brow_n[j] * (nt * p.Cpad) + t * p.Cpad + bcol[j] + c * 32;
+            const int q = wv * PB + j, cc = bc0 ^ ((q & 1) << 2);
+            const uint16_t* src = ((cc & 4) ? lo_p : hi_p) + (long)(n0 + (q & 7) * 8 + drow) * (nt * p.Cpad) + t * p.Cpad + (cc & 3) * 8 + c * 32;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + B_OFF + buf * B_ONE + (wv * PB + j) * 1024), 16, 0, 0);
         }
     };
@@ -157,10 +158,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void deconv_pipe_kernel(c
         a_off[o] = slot * 128 + ((fh ^ ((slot >> 1) & 7)) << 4);
     }
     const int sw = (fr >> 1) & 7;
-    const int b_off = B_OFF + fr * 128 + ((fh ^ sw) << 4);
+    // the four (ks, hi / lo) variants of the lane's weight-fragment address (bits 5 and 6): everything else a step adds is a multiple of
+    // 4 KiB known at compile time and rides in the read's offset field (two bases: the field holds 16 bits)
+    const unsigned char* b_var[2][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        b_var[0][v] = smem + ((B_OFF + fr * 128 + ((fh ^ sw) << 4)) ^ (v << 5));
+        b_var[1][v] = b_var[0][v] + 2 * B_ONE;
+    }
 
     float es1[TN], et1[TN];
-    const bool full = n0 + BN <= p.N;
+    const bool full = n0 + BN <= p.N && !(ABL && (abl & 28));     // (the counts hold while every load and store is issued)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + fr;
@@ -191,9 +199,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void deconv_pipe_kernel(c
             ic = 0;
             const int xn = ixt + TW;
             if (ixt >= 1) {     // both tiles clear of the left image edge (there is no right halo): every real pixel moves one tile on
-                const long step = (long)TW * p.ldx_bytes;
+                const unsigned step = (unsigned)(TW * p.ldx_bytes);
 #pragma unroll
-                for (int j = 0; j < PP; ++j) psrc[j] += ((pmove >> j) & 1) ? step : 0;
+                for (int j = 0; j < PP; ++j) psrc[j] += ((pmove >> j) & 1) ? step : 0u;
             } else {
                 set_tile(xn);
             }
@@ -201,16 +209,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void deconv_pipe_kernel(c
         }
     };
 
+    const int ngroups = p.tpw * nchunks;      // (chunk, tile) pairs of this workgroup: three steps each
     issue_patch(0, 0);
     issue_B(0, 0, 0);
+    issue_B(1, 0, 1);
+    primed = true;
 
     int x0 = xbase;
     int c = 0;
-    bool epi = false;
-    const int ngroups = p.tpw * nchunks;      // (chunk, tile) pairs of this workgroup: three steps each
-    auto tap = [&](const unsigned char* stg, int bbase, auto E_, int k) {
-        constexpr int e = decltype(E_)::value;
+    bool prev_last = false;                   // the group before this one closed a tile (its stores may still be in flight)
+    auto tap = [&](const unsigned char* stg, auto E_) {
+        constexpr int e = decltype(E_)::value, S = e / TPS, k = e % TPS;
         constexpr TapE te = kTaps[e];
+        if constexpr (ABL) { if (abl & 2) return; }
         const int ao = a_off[2 * (te.dy < 0) + (te.dx < 0)];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -218,83 +229,137 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void deconv_pipe_kernel(c
             const bf16x8 al = *reinterpret_cast<const bf16x8*>(stg + (ao ^ (ks << 5) ^ 64));
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int bo = bbase + k * (BN * 128) + j * 4096;
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(smem + (bo ^ (ks << 5)));
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(smem + (bo ^ (ks << 5) ^ 64));
+                const int bo = (S & 1) * B_ONE + k * (BN * 128) + j * 4096;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_var[S >> 1][ks] + bo);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_var[S >> 1][ks + 2] + bo);
                 acc[te.ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[te.ph][j], 0, 0, 0);
                 acc[te.ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[te.ph][j], 0, 0, 0);
                 acc[te.ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[te.ph][j], 0, 0, 0);
             }
         }
     };
-    // ---- epilogue of two phases, from the accumulators: phase (py, px) of input pixel (i, j) is output pixel (2 i + py, 2 j + px).
-    // The tile's stores leave in two halves -- phases 0, 1 are complete after step 1 of the last chunk, phases 2, 3 after step 2 -- so that
-    // each half has a whole step to drain before a wait has to include it (vmcnt retires in order).
-    auto epilogue_pair = [&](int ph0) {
+    // ---- epilogue of one phase, from the accumulators: phase (py, px) of input pixel (i, j) is output pixel (2 i + py, 2 j + px).
+    // A lane holds ONE output channel (n0 + 32 j + fr) of sixteen pixels (8 q + 4 fh + k): it stores them as they are, one dword per
+    // pixel -- the 32 lanes of a half wave write the 128 contiguous bytes of a pixel's channel group, every store instruction two whole
+    // lines -- instead of gathering four channels per lane first (EPI = 4: a 4 x 4 transpose inside lane quads, then 16-byte stores;
+    // measured 6-8 % slower here although a pure store stream prefers 16 bytes per lane, profiles/r03_experiments.txt item 18).
+    // split32 output: two pixels are split together (packed
+    // conversions), the (even, odd) channel pair trades halves, the even lane stores hi (c, c + 1), the odd lane lo (c - 1, c).
+    auto epilogue = [&](auto PH_) {
+        constexpr int ph = decltype(PH_)::value;
+        if constexpr (ABL) { if (abl & 4) return; }
         int ldo = p.ldy;
         asm volatile("" : "+s"(ldo));
-        const int li = fr & 3, cq = fr >> 2;
         const int Wo = 2 * p.W;
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const int ph = ph0 + pp;
-            const long pixr = 4 * img + (long)(2 * (y0 + wv) + (ph >> 1)) * Wo + 2 * x0 + (ph & 1);
-            float* obase = p.y + pixr * ldo;
+        const long pixr = 4 * img + (long)(2 * (y0 + wv) + (ph >> 1)) * Wo + 2 * x0 + (ph & 1);
+        float* obase = p.y + pixr * ldo;
+        const bool odd = fr & 1;
+        auto body = [&](auto LEAKY_) {
+            constexpr bool LEAKY = decltype(LEAKY_)::value;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const float s1 = es1[j], t1 = et1[j];
-                const int n4 = n0 + j * 32 + 4 * cq;
-                const bool valid = n4 < p.N;
-                unsigned voff;
-                if constexpr (OSPLIT) voff = (unsigned)(2 * (4 * fh + li) * ldo) * 4u + (n4 >> 5) * 128u + ((cq & 1) ? 64u : 0u) + ((n4 & 31) >> 3) * 16u;
-                else voff = (unsigned)(2 * (4 * fh + li) * ldo + n4) * 4u;
-                f32x16& a16 = ph0 == 0 ? acc[pp][j] : acc[2 + pp][j];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float r[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float v = fmaf(a16[4 * q + k], s1, t1);
-                        r[k] = fminf(fmaxf(fmaxf(v, lo), slope * v), hi);
-                    }
-                    quad_transpose(r, li);
-                    f32x4 v = f32x4{r[0], r[1], r[2], r[3]};
-                    float* ob = obase + (16 * q) * ldo;
-                    if constexpr (!OSPLIT) {
-                        if (valid) store_nt_s(ob, voff, v);
+                const int n = n0 + j * 32 + fr;
+                f32x16& a16 = acc[ph][j];
+                auto act = [&](float a) {
+                    float v = fmaf(a, s1, t1);
+                    if constexpr (LEAKY) v = fmaxf(v, slope * v);
+                    return __builtin_amdgcn_fmed3f(v, lo, hi);
+                };
+                if constexpr (EPI == 1) {
+                    unsigned voff;
+                    bool live;
+                    if constexpr (OSPLIT) {
+                        voff = (unsigned)(8 * fh * ldo) * 4u + (n >> 5) * 128u + (odd ? 64u + 2u * ((n & 31) - 1) : 2u * (n & 31));
+                        live = n < ((p.N + 31) & ~31);     // (es1 = et1 = 0 past N: the padding of the last channel group is written as zeros)
                     } else {
-                        if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                        unsigned h0, l0, h1, l1;
-                        split2(v[0], v[1], h0, l0);
-                        split2(v[2], v[3], h1, l1);
-                        const bool oddq = cq & 1;
-                        const unsigned r0 = xchg4(oddq ? h0 : l0, oddq), r1 = xchg4(oddq ? h1 : l1, oddq);
-                        if (n4 < ((p.N + 31) & ~31)) store_nt_s(ob, voff, oddq ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1});
+                        voff = (unsigned)(8 * fh * ldo + n) * 4u;
+                        live = n < p.N;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int k = 0; k < 4; k += 2) {
+                            const float r0 = act(a16[4 * q + k]), r1 = act(a16[4 * q + k + 1]);
+                            float* ob0 = obase + (16 * q + 2 * k) * ldo;
+                            float* ob1 = ob0 + 2 * ldo;
+                            if constexpr (!OSPLIT) {
+                                if (live) {
+                                    store_nt_d(ob0, voff, __builtin_bit_cast(unsigned, r0));
+                                    store_nt_d(ob1, voff, __builtin_bit_cast(unsigned, r1));
+                                }
+                            } else {
+                                unsigned h, l;                                 // (pixel k | pixel k + 1) halves of this channel
+                                split2(r0, r1, h, l);
+                                const unsigned got = swap_pair(odd ? h : l);   // even lane: the odd channel's hi pair; odd lane: the even channel's lo pair
+                                const unsigned first = odd ? got : h, second = odd ? l : got;      // channel order inside the stored dword
+                                if (live) {
+                                    store_nt_d(ob0, voff, __builtin_amdgcn_perm(second, first, 0x05040100u));
+                                    store_nt_d(ob1, voff, __builtin_amdgcn_perm(second, first, 0x07060302u));
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    const int li = fr & 3, cq = fr >> 2;
+                    const int n4 = n0 + j * 32 + 4 * cq;
+                    const bool valid = n4 < p.N;
+                    unsigned voff;
+                    if constexpr (OSPLIT) voff = (unsigned)(2 * (4 * fh + li) * ldo) * 4u + (n4 >> 5) * 128u + ((cq & 1) ? 64u : 0u) + ((n4 & 31) >> 3) * 16u;
+                    else voff = (unsigned)(2 * (4 * fh + li) * ldo + n4) * 4u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float r[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) r[k] = act(a16[4 * q + k]);
+                        quad_transpose(r, li);
+                        f32x4 v = f32x4{r[0], r[1], r[2], r[3]};
+                        float* ob = obase + (16 * q) * ldo;
+                        if constexpr (!OSPLIT) {
+                            if (valid) store_nt_s(ob, voff, v);
+                        } else {
+                            if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                            unsigned h0, l0, h1, l1;
+                            split2(v[0], v[1], h0, l0);
+                            split2(v[2], v[3], h1, l1);
+                            const bool oddq = cq & 1;
+                            const unsigned r0 = xchg4(oddq ? h0 : l0, oddq), r1 = xchg4(oddq ? h1 : l1, oddq);
+                            if (n4 < ((p.N + 31) & ~31)) store_nt_s(ob, voff, oddq ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1});
+                        }
                     }
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) a16[e] = 0.f;
             }
-        }
+        };
+        if (p.act == 4) body(std::true_type{});
+        else body(std::false_type{});
     };
     using std::integral_constant;
-    // one step (compile-time S): B(g, S) -- and everything older -- has landed for this wave; younger groups that may stay in flight:
-    // the next chunk's patch (issued in step 0, after B(g, 1)) at S = 1; the E / 2 stores of a half epilogue at the step after it
-    // (the first half is issued after step H1 of a tile's last chunk, i.e. after B(g, H1 + 1); the second after the last step, i.e.
-    // after B(g + 1, 0))
+    // One step (compile-time S) of group g, global step u = 3 g + S.  Issue order of a step: [barrier] B(u + 2); at S = 0 the next
+    // group's patch (PP pieces); the taps; in a tile's last chunk the store instalment (S = 0: phases 3 and 1, 2 EP stores; S = 1: phase 2,
+    // EP; S = 2: phase 0, EP).  The wait before the barrier needs B(u) -- issued in step u - 2 -- and everything older; what may stay in
+    // flight is what was issued after it: the rest of step u - 2 and all of step u - 1.  (A tile whose columns are partly masked issues an
+    // unknown number of stores: it counts none, which only waits longer.)
     auto step = [&](auto S_, int g) {
         constexpr int S = decltype(S_)::value;
-        if constexpr (S == 1) wait_vm<PP>();
-        else if (S == H1 + 1) { if (c + 1 == nchunks && full) wait_vm<E / 2>(); else wait_vm<0>(); }
-        else if (S == 0) { if (epi && full) wait_vm<E / 2>(); else wait_vm<0>(); }
-        else wait_vm<0>();
+        const bool this_last = c + 1 == nchunks;
+        if constexpr (S == 0) {            // step u - 2 = S 1, u - 1 = S 2 of the previous group
+            if (prev_last && full) wait_vm<PB + 2 * EP>(); else wait_vm<PB>();
+        } else if constexpr (S == 1) {     // u - 2 = S 2 of the previous group, u - 1 = S 0 of this one
+            if (!full || (!prev_last && !this_last)) wait_vm<PB + PP>();
+            else if (prev_last && this_last) wait_vm<PB + PP + 3 * EP>();
+            else if (this_last) wait_vm<PB + PP + 2 * EP>();
+            else wait_vm<PB + PP + EP>();
+        } else {                           // u - 2 = S 0, u - 1 = S 1 of this group
+            if (this_last && full) wait_vm<PB + PP + 3 * EP>(); else wait_vm<PB + PP>();
+        }
         __builtin_amdgcn_s_barrier();
-        const int u = g * NSTEP + S;             // weight buffer u & 1
         {
-            int cn = c, sn = S + 1;
-            if (sn == NSTEP) { sn = 0; cn = c + 1 == nchunks ? 0 : c + 1; }
-            if (S == NSTEP - 1 && g + 1 >= ngroups) { cn = c; sn = S; }
-            issue_B((u + 1) & 1, cn, sn);
+            int cn = c, sn = S + 2;
+            if (sn >= NSTEP) { sn -= NSTEP; cn = this_last ? 0 : c + 1; }
+            if (g * NSTEP + S + 2 >= ngroups * NSTEP) { cn = c; sn = S; }     // past the end: a copy nobody reads keeps the counts uniform
+            issue_B((S + 2) % 3, cn, sn);
         }
         if constexpr (S == 0) {
             const bool more = ichunk + 1 < tchunks;
@@ -302,26 +367,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void deconv_pipe_kernel(c
             issue_patch(more ? (ichunk & 1) : ((ichunk + 1) & 1), ic);
         }
         const unsigned char* stg = smem + (g & 1) * STAGE;
-        const int bbase = (u & 1) * B_ONE + b_off;
-        tap(stg, bbase, integral_constant<int, TPS * S>{}, 0);
-        if constexpr (TPS * S + 1 < 9) tap(stg, bbase, integral_constant<int, TPS * S + 1>{}, 1);
-        if constexpr (TPS == 3 && TPS * S + 2 < 9) tap(stg, bbase, integral_constant<int, (TPS * S + 2 < 9 ? TPS * S + 2 : 8)>{}, 2);
+        tap(stg, integral_constant<int, TPS * S>{});
+        tap(stg, integral_constant<int, TPS * S + 1>{});
+        tap(stg, integral_constant<int, TPS * S + 2>{});
+        if (this_last) {
+            if constexpr (S == 0) { epilogue(integral_constant<int, 3>{}); epilogue(integral_constant<int, 1>{}); }
+            if constexpr (S == 1) epilogue(integral_constant<int, 2>{});
+            if constexpr (S == 2) epilogue(integral_constant<int, 0>{});
+        }
     };
     for (int g = 0; g < ngroups; ++g) {
         step(integral_constant<int, 0>{}, g);
-        epi = false;
         step(integral_constant<int, 1>{}, g);
-        if constexpr (H1 == 1) { if (c + 1 == nchunks) epilogue_pair(0); }     // phases (0, 0) and (0, 1) are complete
+        prev_last = false;
         step(integral_constant<int, 2>{}, g);
-        if constexpr (NSTEP == 5) {
-            if (c + 1 == nchunks) epilogue_pair(0);
-            step(integral_constant<int, 3>{}, g);
-            step(integral_constant<int, 4>{}, g);
-        }
         if (++c == nchunks) {
             c = 0;
-            epi = true;
-            epilogue_pair(2);     // phases (1, 0) and (1, 1)
+            prev_last = true;
             x0 += TW;
         }
     }
@@ -334,11 +396,12 @@ namespace emd {
 
 bool deconv_pipe_covers(const DeconvPipeParams& p) {
     return g_knobs.deconv_direct == 3 && p.H % 8 == 0 && p.W % 32 == 0 && p.Cin % 32 == 0 && p.Cin >= 32 && p.Cin <= 4064 && p.N % 4 == 0 &&
-           p.N <= 1024;
+           p.N <= 1024 && (long)p.H * p.W * p.ldx_bytes < (1L << 32);     // (patch sources are 32-bit offsets inside an image)
 }
 
 int deconv_pipe_launch(const DeconvPipeParams& p, int B, int out_split, hipStream_t st) {
     DeconvPipeParams q = p;
+    q.ablate = g_knobs.sep_ablate;
     const int tiles_w = p.W / 32;
     q.n_ntiles = (p.N + 63) / 64;
     const long wgs1 = (long)tiles_w * (p.H / 8) * B * q.n_ntiles;
@@ -348,20 +411,15 @@ int deconv_pipe_launch(const DeconvPipeParams& p, int B, int out_split, hipStrea
     if (g_knobs.sep_tpw > 0 && tiles_w % g_knobs.sep_tpw == 0) tpw = g_knobs.sep_tpw;
     q.tpw = tpw;
     const dim3 grid(tiles_w / tpw * q.n_ntiles, p.H / 8, B);
-    if (g_knobs.deconv_nw == 4 && p.H % 4 == 0) {     // 4 x 32 tiles, two workgroups per CU
-        const long wgs4 = (long)tiles_w * (p.H / 4) * B * q.n_ntiles;
-        int t4 = 1;
-        for (int t : {8, 4, 2})
-            if (tiles_w % t == 0 && wgs4 / t >= 2048) { t4 = t; break; }
-        if (g_knobs.sep_tpw > 0 && tiles_w % g_knobs.sep_tpw == 0) t4 = g_knobs.sep_tpw;
-        q.tpw = t4;
-        const dim3 grid4(tiles_w / t4 * q.n_ntiles, p.H / 4, B);
-        if (out_split) hipLaunchKernelGGL((deconv_pipe_kernel<true, 4>), grid4, dim3(256), 0, st, q);
-        else hipLaunchKernelGGL((deconv_pipe_kernel<false, 4>), grid4, dim3(256), 0, st, q);
-        return emd::check_launch("deconv_pipe_kernel<4 waves>");
+    const int epi = g_knobs.epi_width;
+    if (q.ablate) hipLaunchKernelGGL((deconv_pipe_kernel<false, true, 1>), grid, dim3(512), 0, st, q);
+    else if (out_split) {
+        if (epi == 1) hipLaunchKernelGGL((deconv_pipe_kernel<true, false, 1>), grid, dim3(512), 0, st, q);
+        else hipLaunchKernelGGL((deconv_pipe_kernel<true, false, 4>), grid, dim3(512), 0, st, q);
+    } else {
+        if (epi == 1) hipLaunchKernelGGL((deconv_pipe_kernel<false, false, 1>), grid, dim3(512), 0, st, q);
+        else hipLaunchKernelGGL((deconv_pipe_kernel<false, false, 4>), grid, dim3(512), 0, st, q);
     }
-    if (out_split) hipLaunchKernelGGL((deconv_pipe_kernel<true, 8>), grid, dim3(512), 0, st, q);
-    else hipLaunchKernelGGL((deconv_pipe_kernel<false, 8>), grid, dim3(512), 0, st, q);
     return emd::check_launch("deconv_pipe_kernel");
 }
 

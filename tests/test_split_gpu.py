@@ -12,7 +12,6 @@ pytestmark = pytest.mark.gpu
 
 TOL_X3 = 2e-5
 DECONV_DEFAULT = 3   # dev knob deconv_direct (csrc/emd_common.hpp)
-DECONV_NW_DEFAULT = 8
 
 
 def rel_l2(a, b):
@@ -339,8 +338,8 @@ def test_deconv3x3s2_split32_equals_deconv(B, H, W, ci, co, out_split):
     (1, 8, 256, 32, 64, 4),       # one chunk, four tiles per workgroup (the pointer-increment path)
 ])
 @pytest.mark.parametrize("out_split", [False, True])
-@pytest.mark.parametrize("nw", [8, 4])
-def test_deconv_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split, nw):
+@pytest.mark.parametrize("epi", [1, 2, 4])
+def test_deconv_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split, epi):
     """csrc/deconv_pipe.hip (dev knob deconv_direct = 3; slim.conv2d_transpose k 3 s 2, denoiser.py:138-150) through
     emd_deconv3x3s2_fused_split32_f32: against the register-staged four-phase GEMM (which tests/test_ops_gpu.py holds to the oracle) at
     1e-6 -- another summation order, not bits -- into a NaN-filled concat slice, and as a split32 tensor."""
@@ -357,7 +356,7 @@ def test_deconv_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split, nw):
     xs = ops.to_split32(xa)
     try:
         _lib.knob("deconv_direct", 3)
-        _lib.knob("deconv_nw", nw)       # 8 waves on 8 x 32 tiles, or 4 waves on 4 x 32 tiles (two workgroups per CU)
+        _lib.knob("epi_width", epi)      # dwords a lane stores at a time (dev knob)
         _lib.knob("sep_tpw", tpw)
         wide = torch.full((B, 2 * H, 2 * W, co + 8), float("nan"), dtype=torch.float32, device=dev())
         got = ops.deconv3x3s2_fused(xs, phases, s1, t1, ops.Act(wide, co, 4))
@@ -368,7 +367,7 @@ def test_deconv_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split, nw):
         torch.cuda.synchronize()
     finally:
         _lib.knob("deconv_direct", DECONV_DEFAULT)
-        _lib.knob("deconv_nw", DECONV_NW_DEFAULT)
+        _lib.knob("epi_width", 1)
         _lib.knob("sep_tpw", 0)
     g_np = got.torch().cpu().numpy()
     assert not np.isnan(g_np).any()

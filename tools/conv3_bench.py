@@ -32,15 +32,17 @@ for nm, (B, H, W, ci, co) in SHAPES.items():
     x = ops.to_split32(ops.Act(torch.rand(B, H, W, ci, device=dev)))
     w = ops.PackedWeights((np.random.default_rng(0).standard_normal((9, ci, co)) * 0.03).astype(np.float32), False, dev)
     s, t = torch.ones(co, device=dev), torch.zeros(co, device=dev)
-    outs = {k: ops.Act.empty(B, H, W, co, dev) for k in (0, 1)}
+    outs = {k: ops.Act.empty(B, H, W, co, dev) for k in (0, 1, 4)}
 
     def mk(k):
         def f():
             _lib.knob("conv3_pipe", WIDE if k else 0)
+            _lib.knob("epi_width", 4 if k == 4 else 1)       # k = 4: the patch-resident kernel with the older 16-byte epilogue
             ops.conv3x3_split32(x, w, s, t, outs[k], act=ops.ACT_RELU, scale2=s, shift2=t)
+            _lib.knob("epi_width", 1)
         return f
 
-    fns = {k: mk(k) for k in (0, 1)}
+    fns = {k: mk(k) for k in (0, 1, 4)}
     for f in fns.values():
         f(); f()
     torch.cuda.synchronize()

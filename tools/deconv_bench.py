@@ -30,16 +30,24 @@ for nm, (B, H, W, ci, co) in SHAPES.items():
     x = ops.to_split32(ops.Act(torch.rand(B, H, W, ci, device=dev)))
     w = ops.pack_deconv((np.random.default_rng(0).standard_normal((3, 3, co, ci)) * 0.03).astype(np.float32), dev)
     s, t = torch.ones(co, device=dev), torch.zeros(co, device=dev)
-    outs = {k: ops.Act.empty(B, 2 * H, 2 * W, co, dev) for k in (1, 3, 4)}
+    outs = {k: ops.Act.empty(B, 2 * H, 2 * W, co, dev) for k in (1, 3)}
 
     def mk(k):
         def f():
-            _lib.knob("deconv_direct", min(k, 3))        # "4" = the patch-resident kernel on 4-wave workgroups (knob deconv_nw = 4)
-            _lib.knob("deconv_nw", 4 if k == 4 else 8)
+            _lib.knob("deconv_direct", k)
             ops.deconv3x3s2_fused(x, w, s, t, outs[k])
         return f
 
-    fns = {k: mk(k) for k in (1, 3, 4)}
+    fns = {k: mk(k) for k in (1, 3)}
+    for ew in (3, 4):
+        def mke(ew=ew):
+            def f():
+                _lib.knob("deconv_direct", 3)
+                _lib.knob("epi_width", ew)
+                ops.deconv3x3s2_fused(x, w, s, t, outs[3])
+                _lib.knob("epi_width", 1)
+            return f
+        fns[f"3/epi{ew}"] = mke()
     for f in fns.values():
         f(); f()
     torch.cuda.synchronize()
@@ -51,4 +59,3 @@ for nm, (B, H, W, ci, co) in SHAPES.items():
     fl = 6.0 * B * H * W * 9 * ci * co
     print(f"{nm:14s} rel diff(3 vs 1) {rel:.1e}: " + "  ".join(f"deconv_direct={k} {np.median(T[k]):8.1f} us ({fl / np.median(T[k]) / 1e6 / 25:4.1f}%)" for k in fns), flush=True)
 _lib.knob("deconv_direct", 3)
-_lib.knob("deconv_nw", 8)
