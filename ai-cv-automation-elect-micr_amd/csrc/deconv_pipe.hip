@@ -411,7 +411,7 @@ int deconv_pipe_launch(const DeconvPipeParams& p, int B, int out_split, hipStrea
     if (g_knobs.sep_tpw > 0 && tiles_w % g_knobs.sep_tpw == 0) tpw = g_knobs.sep_tpw;
     q.tpw = tpw;
     const dim3 grid(tiles_w / tpw * q.n_ntiles, p.H / 8, B);
-    const int epi = g_knobs.epi_width;
+    const int epi = g_knobs.epi_width ? g_knobs.epi_width : 1;
     if (q.ablate) hipLaunchKernelGGL((deconv_pipe_kernel<false, true, 1>), grid, dim3(512), 0, st, q);
     else if (out_split) {
         if (epi == 1) hipLaunchKernelGGL((deconv_pipe_kernel<true, false, 1>), grid, dim3(512), 0, st, q);

@@ -56,7 +56,7 @@ struct Knobs {
     int sep_xcd = 1;         // one contiguous run of tiles per XCD
     int sep_wide = 1;        // sep_fused 256-column single-output form: 0 never, 1 Cin <= 256, 2 whenever it fits
     int sep_wres = 1;        // sep_fused 64-column instances keep the pointwise weights resident in LDS
-    int epi_width = 1;       // dev: dwords a lane stores at a time in the patch-resident kernels' epilogue: 1 (a lane = one channel, as the MFMA leaves it) or 4 (after a 4 x 4 transpose inside lane quads)
+    int epi_width = 0;       // dev: dwords a lane stores at a time in the patch-resident kernels' epilogue: 1 (a lane = one channel, as the MFMA leaves it) or 4 (after a 4 x 4 transpose inside lane quads); 0 = the kernel's rule (1, except sep_pipe with a residual on > 128 columns)
     int deconv_direct = 3;   // one-launch transposed conv: 3 = the patch-resident kernel (deconv_pipe.hip) where it covers the shape (H % 8 == 0, W % 32 == 0), else as 1; 1 = GEMM form, epilogue from the accumulators (deconv4_split_kernel); 2 = the same on 128-row tiles, two workgroups per CU; 0 = LDS-staged epilogue
     int nt_mask = 7;         // non-temporal output stores: bit 0 split32 convolutions, bit 1 fused separable conv, bit 2 pointwise GEMM
     int dw_xcd = 1;          // XCD-contiguous tile order in the depthwise kernels

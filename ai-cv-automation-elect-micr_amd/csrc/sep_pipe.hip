@@ -66,6 +66,15 @@ __device__ __forceinline__ f32x4 load_s(const void* sbase, unsigned voff) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
     return v;
 }
+__device__ __forceinline__ float load_s1(const void* sbase, unsigned voff) {
+    float v;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+    return v;
+}
+// One dword per lane (EPI = 1: a lane = one channel, the layout the MFMA leaves): no data hazard to cover, no transpose before it.
+__device__ __forceinline__ void store_nt_d(const void* sbase, unsigned voff, unsigned v) {
+    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 __device__ __forceinline__ float dpp_f(float v, int ctrl_is_xor2) {
     return ctrl_is_xor2 ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true))
                         : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -98,7 +107,7 @@ __device__ __forceinline__ unsigned xchg4(unsigned v, bool oddq) {
 // before, one pixel after): output tile 4 x 16 pixels (64 GEMM rows) from a 9 x 33 pixel patch, a thread one output pixel x 4 channels
 // in stage 1 (9 patch + 9 weight reads), every wave one 32 x (BN / 4) accumulator block -- the depthwise result of the strided
 // blocks no longer goes through HBM (cnn0_strided: 0.54 GB written and read back per batch).
-template <int BN, bool DUAL, int MODE, bool OSPLIT, int NW = 8, int STRIDE = 1>
+template <int BN, bool DUAL, int MODE, bool OSPLIT, int NW = 8, int STRIDE = 1, int EPI = 1>     // EPI: dwords a lane stores at a time (epilogue)
 __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p) {
     constexpr int TW = STRIDE == 2 ? 16 : 4 * NW, TH = STRIDE == 2 ? 4 : 8, BM = TH * TW;
     constexpr int PW = STRIDE * TW + 3 - STRIDE, PH = STRIDE * TH + 3 - STRIDE, PWS = PW | 1;   // patch pixels per row; slot pitch odd (see above): 34 -> 35, 18 -> 19, 33
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
     constexpr int A_OFF = 2 * STAGE, B_OFF = A_OFF + A_BYTES;
     constexpr int SMEM = B_OFF + B_ONE * (BDBL ? 2 : 1);
     constexpr bool SWZ = DUAL;                                // patch chunks XORed with (pixel >> 1) & 3: the projection's centre reads
-    constexpr int E = 4 * TM * TN;                            // stores per wave and tile (exact when no lane is masked: full tiles)
+    constexpr int E = 16 / EPI * TM * TN;                     // stores per wave and tile (exact when no lane is masked: full tiles)
     static_assert(!(DUAL && MODE != 1), "the two-output instances read the patch in stage 2");
     static_assert(!(DUAL && OSPLIT), "split32 output: one-output instances only");
     static_assert(PP >= 2 && PB >= 1 && SMEM <= (NW == 8 ? 160 : 80) * 1024, "shape");
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
     // Residual values of the tile, requested after stage 1 of the tile's last step (TM <= 2: 16 TM TN registers, free once stage 1's
     // are dead): they land under stage 2 instead of stalling the epilogue behind every older DMA piece (vmcnt is in order).
     constexpr bool RPRE = TM <= 2 && !DUAL;
-    constexpr int R = RPRE ? 4 * TM * TN : 0;                // residual loads per wave and tile
+    constexpr int R = RPRE ? 16 / EPI * TM * TN : 0;         // residual loads per wave and tile
     f32x4 rpre[RPRE ? TM : 1][TN][4];
     const bool res_on = p.res != nullptr && !out2 && !(abl & 32);
     auto res_prefetch = [&](int x0) {
@@ -339,15 +348,23 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
         const int li = fr & 3, cq = fr >> 2;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n4 = wn * (TN * 32) + j * 32 + 4 * cq;
-            const unsigned roff = (unsigned)((4 * fh + li) * ldr + n4) * 4u;
+            const int n4 = wn * (TN * 32) + j * 32 + 4 * cq, n1 = wn * (TN * 32) + j * 32 + fr;
+            const unsigned roff = EPI == 1 ? (unsigned)(4 * fh * ldr + n1) * 4u : (unsigned)((4 * fh + li) * ldr + n4) * 4u;
 #pragma unroll
             for (int i = 0; i < (RPRE ? TM : 1); ++i) {
                 const float* rbase = p.res + (img_o + (long)(y0 + (row0 + i * 32) / TW) * Wo + x0) * ldr;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     rpre[i][j][q] = f32x4{-0.f, -0.f, -0.f, -0.f};
-                    if (n4 < nlim) rpre[i][j][q] = load_s(rbase + ((8 * q / TW) * Wo + 8 * q % TW) * ldr, roff);
+                    const float* rb = rbase + ((8 * q / TW) * Wo + 8 * q % TW) * ldr;
+                    if constexpr (EPI == 1) {      // element k = this lane's channel at pixel 8 q + 4 fh + k
+                        if (n1 < nlim) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) rpre[i][j][q][k] = load_s1(rb + k * ldr, roff);
+                        }
+                    } else {
+                        if (n4 < nlim) rpre[i][j][q] = load_s(rb, roff);
+                    }
                 }
             }
         }
@@ -440,76 +457,162 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
         int ldo = out2 ? p.ldy2 : p.ldy, ldr = p.ldres;
         asm volatile("" : "+s"(ldo), "+s"(ldr));   // opaque: the per-pixel bases below are recomputed per tile, not hoisted out of the
                                                   // step loop into (spilled) SGPRs
-        const int li = fr & 3, cq = fr >> 2;       // after the transpose: lane = pixel (e >> 2) * 8 + 4 fh + li, channels 4 cq .. 4 cq + 3
+        if constexpr (EPI == 1) {
+            // a lane keeps its channel (nb + fr) and stores the sixteen pixels of an accumulator one dword each: the 32 lanes of a half
+            // wave write a pixel's 128 contiguous bytes.  split32: two pixels are split together, the (even, odd) channel pair trades
+            // halves, the even lane stores hi (c, c + 1), the odd lane lo (c - 1, c).
+            const bool odd = fr & 1;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float s1 = es1[j], t1 = et1[j], s2 = es2[j], t2 = et2[j];
-            const int nb = wn * (TN * 32) + j * 32 - (out2 ? BN / 2 : 0);   // first channel of this 32-column group in its output
-            const int n4 = nb + 4 * cq;
-            const bool valid = n4 < nlim;                             // Cout % 4 == 0: a lane's four channels are all in or all out
-            const unsigned roff = (unsigned)((4 * fh + li) * ldr + n4) * 4u;
-            unsigned voff;
-            if constexpr (OSPLIT) {
-                // split32 output: the lanes of an (even, odd) pair of channel quads swap halves -- the even one stores both quads' hi
-                // words (16 bytes of the channel group's 128-byte line), the odd one both quads' lo words (64 bytes further on)
-                voff = (unsigned)((4 * fh + li) * ldo) * 4u + (n4 >> 5) * 128u + ((cq & 1) ? 64u : 0u) + ((n4 & 31) >> 3) * 16u;
-            } else {
-                voff = (unsigned)((4 * fh + li) * ldo + n4) * 4u;
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const long pixr = img_o + (long)(y0 + (row0 + i * 32) / TW) * Wo + x0;   // uniform: the M tile's first pixel
-                const float* rbase = has_res ? p.res + pixr * ldr : nullptr;
-                float* obase = outp + pixr * ldo;
-                f32x4 rv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rv[q] = f32x4{-0.f, -0.f, -0.f, -0.f};   // x + (-0) == x for every x
-                if constexpr (RPRE) {
-                    if (has_res) {
-                        if (i == 0 && j == 0) {   // requested by res_prefetch; younger than them: the DMA groups issued after barrier B
-                            if (!full) wait_vm<0>();
-                            else if constexpr (LEAD2) wait_vm<(BDBL ? PB : 0) + PP>();
-                            else wait_vm<0>();
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) rv[q] = rpre[i][j][q];
-                    }
-                } else if (has_res) {
-                    if (valid) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) rv[q] = load_s(rbase + ((8 * q / TW) * Wo + 8 * q % TW) * ldr, roff);
-                    }
-                    wait_vm<0>();
+            for (int j = 0; j < TN; ++j) {
+                const float s1 = es1[j], t1 = et1[j], s2 = es2[j], t2 = et2[j];
+                const int n = wn * (TN * 32) + j * 32 - (out2 ? BN / 2 : 0) + fr;
+                unsigned voff;
+                bool live;
+                if constexpr (OSPLIT) {
+                    voff = (unsigned)(4 * fh * ldo) * 4u + (n >> 5) * 128u + (odd ? 64u + 2u * ((n & 31) - 1) : 2u * (n & 31));
+                    live = n < ((nlim + 31) & ~31);     // (scales and shifts are 0 / 1 / 0 past N: the padding is written as zeros)
+                } else {
+                    voff = (unsigned)(4 * fh * ldo + n) * 4u;
+                    live = n < nlim;
                 }
+                const unsigned roff = (unsigned)(4 * fh * ldr + n) * 4u;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float r[4];
-                    if (simple) {
+                for (int i = 0; i < TM; ++i) {
+                    const long pixr = img_o + (long)(y0 + (row0 + i * 32) / TW) * Wo + x0;   // uniform: the M tile's first pixel
+                    const float* rbase = has_res ? p.res + pixr * ldr : nullptr;
+                    float* obase = outp + pixr * ldo;
+                    f32x4 rv[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) r[k] = fminf(fmaxf(fmaf(acc[i][j][4 * q + k], s1, t1), 0.f), 6.f);
-                    } else {
+                    for (int q = 0; q < 4; ++q) rv[q] = f32x4{-0.f, -0.f, -0.f, -0.f};   // x + (-0) == x for every x
+                    if constexpr (RPRE) {
+                        if (has_res) {
+                            if (i == 0 && j == 0) {   // requested by res_prefetch; younger than them: the DMA groups issued after barrier B
+                                if (!full) wait_vm<0>();
+                                else if constexpr (LEAD2) wait_vm<(BDBL ? PB : 0) + PP>();
+                                else wait_vm<0>();
+                            }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float u = fmaf(acc[i][j][4 * q + k], s1, t1);
-                            u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
-                            const float u2 = fminf(fmaxf(fmaf(u, s2, t2), 0.f), hi2);
-                            r[k] = two ? u2 : u;
+                            for (int q = 0; q < 4; ++q) rv[q] = rpre[i][j][q];
+                        }
+                    } else if (has_res) {
+                        if (n < nlim) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) rv[q][k] = load_s1(rbase + ((8 * q / TW) * Wo + 8 * q % TW + k) * ldr, roff);
+                        }
+                        wait_vm<0>();
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float r[4];
+                        if (simple) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) r[k] = __builtin_amdgcn_fmed3f(fmaf(acc[i][j][4 * q + k], s1, t1), 0.f, 6.f) + rv[q][k];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float u = fmaf(acc[i][j][4 * q + k], s1, t1);
+                                u = __builtin_amdgcn_fmed3f(fmaxf(u, slope * u), lo, hi);
+                                const float u2 = __builtin_amdgcn_fmed3f(fmaf(u, s2, t2), 0.f, hi2);
+                                r[k] = (two ? u2 : u) + rv[q][k];
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k += 2) {
+                            float* ob0 = obase + ((8 * q / TW) * Wo + 8 * q % TW + k) * ldo;   // rows 8q + k.. of the M tile
+                            float* ob1 = ob0 + ldo;
+                            if constexpr (!OSPLIT) {
+                                if (live) {
+                                    store_nt_d(ob0, voff, __builtin_bit_cast(unsigned, r[k]));
+                                    store_nt_d(ob1, voff, __builtin_bit_cast(unsigned, r[k + 1]));
+                                }
+                            } else {
+                                unsigned h, l;                                 // (pixel k | pixel k + 1) halves of this channel
+                                split2(r[k], r[k + 1], h, l);
+                                const unsigned got = swap_pair(odd ? h : l);   // even lane: the odd channel's hi pair; odd lane: the even channel's lo pair
+                                const unsigned first = odd ? got : h, second = odd ? l : got;
+                                if (live) {
+                                    store_nt_d(ob0, voff, __builtin_amdgcn_perm(second, first, 0x05040100u));
+                                    store_nt_d(ob1, voff, __builtin_amdgcn_perm(second, first, 0x07060302u));
+                                }
+                            }
                         }
                     }
-                    quad_transpose(r, li);
-                    f32x4 v = f32x4{r[0], r[1], r[2], r[3]} + rv[q];
-                    float* ob = obase + ((8 * q / TW) * Wo + 8 * q % TW) * ldo;   // rows 8q.. of the M tile: pixel (8q / TW, 8q % TW)
-                    if constexpr (!OSPLIT) {
-                        if (valid) store_nt_s(ob, voff, v);
-                    } else {
-                        if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};   // the padding channels of a split32 tensor (up to a multiple of 32) are zero
-                        unsigned h0, l0, h1, l1;
-                        split2(v[0], v[1], h0, l0);
-                        split2(v[2], v[3], h1, l1);
-                        const bool oddq = cq & 1;
-                        const unsigned r0 = xchg4(oddq ? h0 : l0, oddq), r1 = xchg4(oddq ? h1 : l1, oddq);
-                        if (n4 < ((nlim + 31) & ~31))   // nothing lies beyond the padding (both lanes of a pair agree: the bound is a multiple of 8)
-                            store_nt_s(ob, voff, oddq ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1});
+                }
+            }
+        } else {
+            const int li = fr & 3, cq = fr >> 2;       // after the transpose: lane = pixel (e >> 2) * 8 + 4 fh + li, channels 4 cq .. 4 cq + 3
+    #pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float s1 = es1[j], t1 = et1[j], s2 = es2[j], t2 = et2[j];
+                const int nb = wn * (TN * 32) + j * 32 - (out2 ? BN / 2 : 0);   // first channel of this 32-column group in its output
+                const int n4 = nb + 4 * cq;
+                const bool valid = n4 < nlim;                             // Cout % 4 == 0: a lane's four channels are all in or all out
+                const unsigned roff = (unsigned)((4 * fh + li) * ldr + n4) * 4u;
+                unsigned voff;
+                if constexpr (OSPLIT) {
+                    // split32 output: the lanes of an (even, odd) pair of channel quads swap halves -- the even one stores both quads' hi
+                    // words (16 bytes of the channel group's 128-byte line), the odd one both quads' lo words (64 bytes further on)
+                    voff = (unsigned)((4 * fh + li) * ldo) * 4u + (n4 >> 5) * 128u + ((cq & 1) ? 64u : 0u) + ((n4 & 31) >> 3) * 16u;
+                } else {
+                    voff = (unsigned)((4 * fh + li) * ldo + n4) * 4u;
+                }
+    #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const long pixr = img_o + (long)(y0 + (row0 + i * 32) / TW) * Wo + x0;   // uniform: the M tile's first pixel
+                    const float* rbase = has_res ? p.res + pixr * ldr : nullptr;
+                    float* obase = outp + pixr * ldo;
+                    f32x4 rv[4];
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) rv[q] = f32x4{-0.f, -0.f, -0.f, -0.f};   // x + (-0) == x for every x
+                    if constexpr (RPRE) {
+                        if (has_res) {
+                            if (i == 0 && j == 0) {   // requested by res_prefetch; younger than them: the DMA groups issued after barrier B
+                                if (!full) wait_vm<0>();
+                                else if constexpr (LEAD2) wait_vm<(BDBL ? PB : 0) + PP>();
+                                else wait_vm<0>();
+                            }
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q) rv[q] = rpre[i][j][q];
+                        }
+                    } else if (has_res) {
+                        if (valid) {
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q) rv[q] = load_s(rbase + ((8 * q / TW) * Wo + 8 * q % TW) * ldr, roff);
+                        }
+                        wait_vm<0>();
+                    }
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float r[4];
+                        if (simple) {
+    #pragma unroll
+                            for (int k = 0; k < 4; ++k) r[k] = fminf(fmaxf(fmaf(acc[i][j][4 * q + k], s1, t1), 0.f), 6.f);
+                        } else {
+    #pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float u = fmaf(acc[i][j][4 * q + k], s1, t1);
+                                u = fminf(fmaxf(fmaxf(u, lo), slope * u), hi);
+                                const float u2 = fminf(fmaxf(fmaf(u, s2, t2), 0.f), hi2);
+                                r[k] = two ? u2 : u;
+                            }
+                        }
+                        quad_transpose(r, li);
+                        f32x4 v = f32x4{r[0], r[1], r[2], r[3]} + rv[q];
+                        float* ob = obase + ((8 * q / TW) * Wo + 8 * q % TW) * ldo;   // rows 8q.. of the M tile: pixel (8q / TW, 8q % TW)
+                        if constexpr (!OSPLIT) {
+                            if (valid) store_nt_s(ob, voff, v);
+                        } else {
+                            if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};   // the padding channels of a split32 tensor (up to a multiple of 32) are zero
+                            unsigned h0, l0, h1, l1;
+                            split2(v[0], v[1], h0, l0);
+                            split2(v[2], v[3], h1, l1);
+                            const bool oddq = cq & 1;
+                            const unsigned r0 = xchg4(oddq ? h0 : l0, oddq), r1 = xchg4(oddq ? h1 : l1, oddq);
+                            if (n4 < ((nlim + 31) & ~31))   // nothing lies beyond the padding (both lanes of a pair agree: the bound is a multiple of 8)
+                                store_nt_s(ob, voff, oddq ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1});
+                        }
                     }
                 }
             }
@@ -606,40 +709,53 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
 #undef PIPE_STAMP
 }
 
-template <int BN, bool DUAL, bool OSPLIT>
+template <int BN, bool DUAL, bool OSPLIT, int EPI>
 int launch_mode(const SepParams& q, dim3 grid, int mode, int nw, hipStream_t st) {
     if constexpr (DUAL) {
-        hipLaunchKernelGGL((sep_pipe_kernel<BN, true, 1, false>), grid, dim3(512), 0, st, q);
+        hipLaunchKernelGGL((sep_pipe_kernel<BN, true, 1, false, 8, 1, EPI>), grid, dim3(512), 0, st, q);
     } else {
         if constexpr (BN == 64 && !OSPLIT) {
             if (nw == 4) {
-                if (mode == 1) hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 1, false, 4>), grid, dim3(256), 0, st, q);
-                else hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 0, false, 4>), grid, dim3(256), 0, st, q);
+                if (mode == 1) hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 1, false, 4, 1, EPI>), grid, dim3(256), 0, st, q);
+                else hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 0, false, 4, 1, EPI>), grid, dim3(256), 0, st, q);
                 return emd::check_launch("sep_pipe_kernel<4 waves>");
             }
         }
         if (mode == 1) {
-            hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 1, OSPLIT>), grid, dim3(512), 0, st, q);
+            hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 1, OSPLIT, 8, 1, EPI>), grid, dim3(512), 0, st, q);
         } else {
-            hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 0, OSPLIT>), grid, dim3(512), 0, st, q);
+            hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 0, OSPLIT, 8, 1, EPI>), grid, dim3(512), 0, st, q);
         }
     }
     return emd::check_launch("sep_pipe_kernel");
 }
 
-template <int BN>
+template <int BN, int EPI>
 int launch_s2(const SepParams& q, dim3 grid, int mode, hipStream_t st) {
-    if (mode == 1) hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 1, false, 8, 2>), grid, dim3(512), 0, st, q);
-    else hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 0, false, 8, 2>), grid, dim3(512), 0, st, q);
+    if (mode == 1) hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 1, false, 8, 2, EPI>), grid, dim3(512), 0, st, q);
+    else hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 0, false, 8, 2, EPI>), grid, dim3(512), 0, st, q);
     return emd::check_launch("sep_pipe_kernel<stride 2>");
 }
 
-template <int BN, bool DUAL>
+template <int BN, bool DUAL, int EPI>
 int launch_bn(const SepParams& q, dim3 grid, int mode, int nw, hipStream_t st) {
     if constexpr (!DUAL && BN >= 128) {
-        if (q.out_split) return launch_mode<BN, false, true>(q, grid, mode, nw, st);
+        if (q.out_split) return launch_mode<BN, false, true, EPI>(q, grid, mode, nw, st);
     }
-    return launch_mode<BN, DUAL, false>(q, grid, mode, nw, st);
+    return launch_mode<BN, DUAL, false, EPI>(q, grid, mode, nw, st);
+}
+
+template <int EPI>
+int launch_epi(const SepParams& p, const SepParams& q, dim3 grid, int mode, int nw, hipStream_t st) {
+    if (p.stride == 2) return p.N <= 128 ? launch_s2<128, EPI>(q, grid, mode, st) : launch_s2<256, EPI>(q, grid, mode, st);
+    if (p.N2 > 0) {
+        const bool wide = p.N > 64 || p.N2 > 64;
+        if (wide) return launch_bn<256, true, EPI>(q, grid, 1, 8, st);
+        return launch_bn<128, true, EPI>(q, grid, 1, 8, st);
+    }
+    if (p.N <= 64) return launch_bn<64, false, EPI>(q, grid, mode, nw, st);
+    if (p.N <= 128) return launch_bn<128, false, EPI>(q, grid, mode, nw, st);
+    return launch_bn<256, false, EPI>(q, grid, mode, nw, st);
 }
 
 }  // namespace
@@ -678,19 +794,13 @@ int sep_pipe_launch(const SepParams& p, int B, hipStream_t st) {
     q.ablate = g_knobs.sep_ablate;
     const dim3 grid(tiles_w / tpw, Ho / th, B);
     q.xcd = g_knobs.sep_xcd && ((long)grid.x * grid.y * grid.z) % 8 == 0;
-    const bool dual = p.N2 > 0;
     // schedule (see the kernel): rule = the patch two steps ahead; one step ahead for two outputs, with a residual (its loads then
     // queue behind one DMA group instead of two) and in the 4-wave form; the dev knob sep_mode (0 / 1) overrides
     const int mode = g_knobs.sep_mode >= 0 ? g_knobs.sep_mode : ((nw == 4 || p.res) ? 1 : 0);
-    if (s2) return p.N <= 128 ? launch_s2<128>(q, grid, mode, st) : launch_s2<256>(q, grid, mode, st);
-    if (dual) {
-        const bool wide = p.N > 64 || p.N2 > 64;
-        if (wide) return launch_bn<256, true>(q, grid, 1, 8, st);
-        return launch_bn<128, true>(q, grid, 1, 8, st);
-    }
-    if (p.N <= 64) return launch_bn<64, false>(q, grid, mode, nw, st);
-    if (p.N <= 128) return launch_bn<128, false>(q, grid, mode, nw, st);
-    return launch_bn<256, false>(q, grid, mode, nw, st);
+    // epilogue (see the kernel): per-channel dword stores, 2.7 % over graph D's twelve shapes (tools/sep_epi_bench.py; the two-output
+    // launches 5 %) -- except with a residual on more than 128 columns (cnn2_last: 445 against 430 us for the transposed 16-byte form)
+    const int epi = g_knobs.epi_width ? g_knobs.epi_width : ((p.res && p.N > 128) ? 4 : 1);
+    return epi == 4 ? launch_epi<4>(p, q, grid, mode, nw, st) : launch_epi<1>(p, q, grid, mode, nw, st);
 }
 
 }  // namespace emd

@@ -19,12 +19,15 @@ from tests.test_ops_gpu import TOL_X3, dev, out_act, rel_l2, rnd, t64, to_act
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _restore_knobs():
+@pytest.fixture(autouse=True, params=[0, 4], ids=["epi_rule", "epi_16B"])
+def _restore_knobs(request):
+    """Every test runs with the epilogue the kernel's rule picks (per-channel dword stores, mostly) and with the transposed 16-byte form
+    forced (dev knob epi_width = 4): same values, other lanes."""
     from emdenoise import _lib
 
+    _lib.knob("epi_width", request.param)
     yield
-    for k, v in (("sep_pipe", 1), ("sep_mode", -1), ("sep_tpw", 0), ("sep_nw", 8)):
+    for k, v in (("sep_pipe", 1), ("sep_mode", -1), ("sep_tpw", 0), ("sep_nw", 8), ("epi_width", 0)):
         _lib.knob(k, v)
 
 

@@ -338,7 +338,7 @@ def test_deconv3x3s2_split32_equals_deconv(B, H, W, ci, co, out_split):
     (1, 8, 256, 32, 64, 4),       # one chunk, four tiles per workgroup (the pointer-increment path)
 ])
 @pytest.mark.parametrize("out_split", [False, True])
-@pytest.mark.parametrize("epi", [1, 2, 4])
+@pytest.mark.parametrize("epi", [0, 4])
 def test_deconv_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split, epi):
     """csrc/deconv_pipe.hip (dev knob deconv_direct = 3; slim.conv2d_transpose k 3 s 2, denoiser.py:138-150) through
     emd_deconv3x3s2_fused_split32_f32: against the register-staged four-phase GEMM (which tests/test_ops_gpu.py holds to the oracle) at
@@ -367,7 +367,7 @@ def test_deconv_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split, epi)
         torch.cuda.synchronize()
     finally:
         _lib.knob("deconv_direct", DECONV_DEFAULT)
-        _lib.knob("epi_width", 1)
+        _lib.knob("epi_width", 0)
         _lib.knob("sep_tpw", 0)
     g_np = got.torch().cpu().numpy()
     assert not np.isnan(g_np).any()
@@ -487,11 +487,13 @@ def test_sep_fused_with_split32_output(B, H, W, ci, co, res):
     (2, 8, 64, 96, 192, 2),       # three full column tiles, two pixel tiles per workgroup
 ])
 @pytest.mark.parametrize("out_split", [False, True])
-def test_conv3_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split):
+@pytest.mark.parametrize("epi", [0, 4])
+def test_conv3_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split, epi):
     """csrc/conv3_pipe.hip (dense 3x3, stride 1, <= 64 output channels, the patch resident in LDS across the nine taps; reached through
     emd_conv3x3_split32_f32): X's conv_block against the oracle (float64), against the tap-major GEMM it replaces (dev knob
     conv3_pipe = 0; another summation order: 1e-6, not bits), fp32 output into a NaN-filled concat slice and split32 output equal to
-    emd_to_split32_f32 of the fp32 one."""
+    emd_to_split32_f32 of the fp32 one; with the per-channel dword epilogue (epi = 0: the kernel's rule) and the transposed 16-byte one
+    (dev knob epi_width = 4)."""
     from emdenoise import _lib, ops
     from oracle import tf_ops as T
 
@@ -505,6 +507,7 @@ def test_conv3_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split):
     kw = dict(act=ops.ACT_RELU, scale2=up(g), shift2=up(h))
     try:
         _lib.knob("sep_tpw", tpw)
+        _lib.knob("epi_width", epi)
         wide = torch.full((B, H, W, co + 8), float("nan"), dtype=torch.float32, device=dev())
         got = ops.conv3x3_split32(xs, pw, one, up(bias), ops.Act(wide, co, 4), **kw)
         if out_split:
@@ -517,6 +520,7 @@ def test_conv3_pipe_patch_resident_kernel(B, H, W, ci, co, tpw, out_split):
     finally:
         _lib.knob("conv3_pipe", 1)
         _lib.knob("sep_tpw", 0)
+        _lib.knob("epi_width", 0)
     g_np = got.torch().cpu().numpy()
     assert not np.isnan(g_np).any()
     assert rel_l2(g_np, ref) < TOL_X3

@@ -39,7 +39,7 @@ for nm, (B, H, W, ci, co) in SHAPES.items():
             _lib.knob("conv3_pipe", WIDE if k else 0)
             _lib.knob("epi_width", 4 if k == 4 else 1)       # k = 4: the patch-resident kernel with the older 16-byte epilogue
             ops.conv3x3_split32(x, w, s, t, outs[k], act=ops.ACT_RELU, scale2=s, shift2=t)
-            _lib.knob("epi_width", 1)
+            _lib.knob("epi_width", 0)
         return f
 
     fns = {k: mk(k) for k in (0, 1, 4)}

@@ -1,0 +1,73 @@
+"""Dev tool: the fused separable conv (sep_pipe.hip) on graph D's shapes with the per-channel dword epilogue (dev knob epi_width = 1)
+against the older one (4: a 4 x 4 transpose inside lane quads, 16-byte stores), with a bit-identity check between them."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from emdenoise import _lib, ops
+
+# name: (S, Cin, Cout, residual, Cout2 (dual) or 0, split32 output, stride)
+SHAPES = {
+    "cnn0_last": (512, 64, 64, 0, 0, 0, 1), "deconv0_b": (512, 64, 64, 1, 0, 0, 1), "deconv0_a": (512, 128, 64, 0, 0, 0, 1),
+    "deconv0_dual": (512, 128, 64, 0, 64, 0, 1), "cnn1": (256, 128, 128, 0, 0, 0, 1), "deconv1_b": (256, 128, 128, 1, 0, 1, 1),
+    "deconv1_a": (256, 384, 128, 0, 0, 0, 1), "deconv1_dual": (256, 384, 128, 0, 128, 0, 1), "cnn2": (128, 128, 256, 0, 0, 0, 1),
+    "cnn2_last": (128, 256, 256, 1, 0, 0, 1), "cnn0_strided": (512, 64, 128, 0, 0, 0, 2), "cnn1_strided": (256, 128, 256, 0, 0, 0, 2)}
+dev = torch.device("cuda", 0)
+B = int(os.environ.get("SB_B", "32"))
+REP, ROUNDS = 5, 3
+_lib.load()
+
+
+def timed(fn):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REP):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000.0 / REP
+
+
+tot = {1: 0.0, 4: 0.0}
+for nm, (S, ci, co, res, co2, osplit, stride) in SHAPES.items():
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = ops.Act(torch.rand(B, S, S, ci, device=dev, generator=g))
+    w = torch.rand(9, ci, device=dev, generator=g) - 0.5
+    rng = np.random.default_rng(0)
+    pw = ops.PackedWeights(rng.standard_normal((1, ci, co)).astype(np.float32) * 0.1, False, dev)
+    s1, t1 = torch.rand(co, device=dev) + 0.5, torch.rand(co, device=dev) - 0.5
+    So = S // stride
+    r = ops.Act(torch.rand(B, So, So, co, device=dev)) if res else None
+    if co2:
+        pw2 = ops.PackedWeights(rng.standard_normal((1, ci, co2)).astype(np.float32) * 0.1, False, dev)
+        sb, tb = torch.rand(co2, device=dev) + 0.5, torch.rand(co2, device=dev) - 0.5
+    outs, fns = {}, {}
+    for ew in (1, 4):
+        out = ops.SplitAct(B, So, So, co, dev) if osplit else ops.Act.empty(B, So, So, co, dev)
+        out.buf.fill_(float("nan"))
+        out2 = ops.Act.empty(B, So, So, co2, dev) if co2 else None
+        outs[ew] = (out, out2)
+
+        def fn(ew=ew, out=out, out2=out2):
+            _lib.knob("epi_width", ew)
+            if co2:
+                ops.sep_dual(x, w, pw, pw2, s1, t1, out, sb, tb, out2)
+            else:
+                ops.sep_fused(x, w, pw, s1, t1, out, res=r, stride=stride)
+            _lib.knob("epi_width", 0)
+        fns[ew] = fn
+    for f in fns.values():
+        f(); f()
+    torch.cuda.synchronize()
+    same = torch.equal(outs[1][0].buf, outs[4][0].buf) and (not co2 or torch.equal(outs[1][1].buf, outs[4][1].buf))
+    T = {k: [] for k in fns}
+    for _ in range(ROUNDS):
+        for k, f in fns.items():
+            T[k].append(timed(f))
+    for k in T:
+        tot[k] += float(np.median(T[k]))
+    print(f"{nm:13s} same bits {same}: " + "  ".join(f"epi_width={k} {np.median(T[k]):8.1f} us" for k in T), flush=True)
+print("sum: " + "  ".join(f"epi_width={k} {v:8.1f} us" for k, v in tot.items()))
