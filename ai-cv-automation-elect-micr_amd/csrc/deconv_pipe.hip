@@ -27,6 +27,14 @@ __device__ __forceinline__ void store_nt_s(const void* sbase, unsigned voff, f32
 __device__ __forceinline__ void store_nt_s(const void* sbase, unsigned voff, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
+// Fragment reads by hand: the compiler neither sees them nor waits for them (it would wait with lgkmcnt(0), i.e. also for the NEXT
+// unit's reads issued behind them); wait_frags<N> lets the N youngest LDS reads stay in flight and ties the registers to the wait.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read16(const unsigned char* p) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((lptr_t)p), "n"(OFF) : "memory");
+    return v;
+}
 __device__ __forceinline__ void store_nt_d(const void* sbase, unsigned voff, unsigned v) {
     asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
@@ -100,6 +108,8 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
     const int drow = lane >> 3, dk = lane & 7;
     // patch sources: 32-bit offsets from the image (real pixels) or from the zero page (padding); bit j of pmove tells which
     const unsigned char* const ximg = p.x + img * p.ldx_bytes;
+    const unsigned char* zpage = g_zero_dc;
+    asm volatile("" : "+s"(zpage));      // (taken once: otherwise a GOT load per group)
     unsigned psrc[PP];
     unsigned pmove = 0;
     auto set_tile = [&](int xt) {
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
         for (int j = 0; j < PP; ++j) {
             int q = wv + NW * j;
             if (q >= NPIECE) q -= NW;
-            const unsigned char* base = ((pmove >> j) & 1) ? ximg : g_zero_dc;
+            const unsigned char* base = ((pmove >> j) & 1) ? ximg : zpage;
             __builtin_amdgcn_global_load_lds((gptr_t)(base + (psrc[j] + c * 128)), (lptr_t)(smem + stage * STAGE + q * 1024), 16, 0, 0);
         }
     };
@@ -218,25 +228,60 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
     int x0 = xbase;
     int c = 0;
     bool prev_last = false;                   // the group before this one closed a tile (its stores may still be in flight)
-    auto tap = [&](const unsigned char* stg, auto E_) {
-        constexpr int e = decltype(E_)::value, S = e / TPS, k = e % TPS;
+    // A step's 36 MFMAs run as six units (tap, K half) of six; the twelve fragment registers of unit i + 1 are read from LDS BEFORE the
+    // MFMAs of unit i are issued (two register sets), so that a read's latency passes under matrix work instead of in front of every
+    // MFMA -- left to itself the compiler puts each ds_read next to its first use (25 exposed waits per step).  Only a step's first
+    // unit waits in the open (its weights land with the barrier).
+    struct Frag { bf16x8 ah, al, bh[TN], bl[TN]; };
+    auto load_unit = [&](const unsigned char* stg, auto U_) {
+        constexpr int u = decltype(U_)::value, e = u / 2, ks = u % 2, S = e / TPS, k = e % TPS;
         constexpr TapE te = kTaps[e];
-        if constexpr (ABL) { if (abl & 2) return; }
         const int ao = a_off[2 * (te.dy < 0) + (te.dx < 0)];
+        constexpr int bo = (S & 1) * B_ONE + k * (BN * 128);
+        static_assert(TN == 2, "two column tiles per wave");
+        Frag f;
+        f.ah = lds_read16<0>(stg + (ao ^ (ks << 5)));
+        f.al = lds_read16<0>(stg + (ao ^ (ks << 5) ^ 64));
+        f.bh[0] = lds_read16<bo>(b_var[S >> 1][ks]);
+        f.bl[0] = lds_read16<bo>(b_var[S >> 1][ks + 2]);
+        f.bh[1] = lds_read16<bo + 4096>(b_var[S >> 1][ks]);
+        f.bl[1] = lds_read16<bo + 4096>(b_var[S >> 1][ks + 2]);
+        return f;
+    };
+    auto mma_unit = [&](Frag& f, auto U_, auto YOUNGER_) {      // YOUNGER: LDS reads issued after this unit's six
+        constexpr int ph = kTaps[decltype(U_)::value / 2].ph;
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.ah), "+v"(f.al), "+v"(f.bh[0]), "+v"(f.bl[0]), "+v"(f.bh[1]), "+v"(f.bl[1]) : "n"(decltype(YOUNGER_)::value));
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(stg + (ao ^ (ks << 5)));
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(stg + (ao ^ (ks << 5) ^ 64));
+        for (int j = 0; j < TN; ++j) acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[j], acc[ph][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int bo = (S & 1) * B_ONE + k * (BN * 128) + j * 4096;
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_var[S >> 1][ks] + bo);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_var[S >> 1][ks + 2] + bo);
-                acc[te.ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[te.ph][j], 0, 0, 0);
-                acc[te.ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[te.ph][j], 0, 0, 0);
-                acc[te.ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[te.ph][j], 0, 0, 0);
-            }
-        }
+        for (int j = 0; j < TN; ++j) acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[j], acc[ph][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[j], acc[ph][j], 0, 0, 0);
+    };
+    auto taps_of_step = [&](const unsigned char* stg, auto S_) {
+        constexpr int S = decltype(S_)::value, U0 = 2 * TPS * S;
+        using std::integral_constant;
+        typedef integral_constant<int, 6> Six;
+        typedef integral_constant<int, 0> Zero;
+        if constexpr (ABL) { if (abl & 2) return; }
+        Frag f0 = load_unit(stg, integral_constant<int, U0>{}), f1;
+        f1 = load_unit(stg, integral_constant<int, U0 + 1>{});
+        mma_unit(f0, integral_constant<int, U0>{}, Six{});
+        __builtin_amdgcn_sched_barrier(0);
+        f0 = load_unit(stg, integral_constant<int, U0 + 2>{});
+        mma_unit(f1, integral_constant<int, U0 + 1>{}, Six{});
+        __builtin_amdgcn_sched_barrier(0);
+        f1 = load_unit(stg, integral_constant<int, U0 + 3>{});
+        mma_unit(f0, integral_constant<int, U0 + 2>{}, Six{});
+        __builtin_amdgcn_sched_barrier(0);
+        f0 = load_unit(stg, integral_constant<int, U0 + 4>{});
+        mma_unit(f1, integral_constant<int, U0 + 3>{}, Six{});
+        __builtin_amdgcn_sched_barrier(0);
+        f1 = load_unit(stg, integral_constant<int, U0 + 5>{});
+        mma_unit(f0, integral_constant<int, U0 + 4>{}, Six{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma_unit(f1, integral_constant<int, U0 + 5>{}, Zero{});
+        __builtin_amdgcn_sched_barrier(0);
     };
     // ---- epilogue of one phase, from the accumulators: phase (py, px) of input pixel (i, j) is output pixel (2 i + py, 2 j + px).
     // A lane holds ONE output channel (n0 + 32 j + fr) of sixteen pixels (8 q + 4 fh + k): it stores them as they are, one dword per
@@ -367,9 +412,7 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
             issue_patch(more ? (ichunk & 1) : ((ichunk + 1) & 1), ic);
         }
         const unsigned char* stg = smem + (g & 1) * STAGE;
-        tap(stg, integral_constant<int, TPS * S>{});
-        tap(stg, integral_constant<int, TPS * S + 1>{});
-        tap(stg, integral_constant<int, TPS * S + 2>{});
+        taps_of_step(stg, S_);
         if (this_last) {
             if constexpr (S == 0) { epilogue(integral_constant<int, 3>{}); epilogue(integral_constant<int, 1>{}); }
             if constexpr (S == 1) epilogue(integral_constant<int, 2>{});
