@@ -65,14 +65,27 @@ __device__ __forceinline__ unsigned xchg4(unsigned v, bool oddq) {
 // Tap table of slim.conv2d_transpose(k = 3, s = 2, SAME) in the order the nine (phase, tap) weight tiles are brought in, three per step.
 // Phase = 2 py + px of the output pixel (2 i + py, 2 j + px); emd_deconv_phase_taps (gemm_conv.hip) fixes the tap order inside a phase:
 // phase 0: kernel (0,0) (0,2) (2,0) (2,2) reading input (i,j) (i,j-1) (i-1,j) (i-1,j-1); phase 1: (0,1) (2,1) reading (i,j) (i-1,j);
-// phase 2: (1,0) (1,2) reading (i,j) (i,j-1); phase 3: (1,1) reading (i,j).  The phases are ordered SHORTEST FIRST -- 3, 1, 2, 0 -- so
-// that in a tile's last chunk phases 3 and 1 are complete after step 0, phase 2 after step 1 and phase 0 after step 2: the tile's stores
-// (four times what it read) leave in three instalments spread over the chunk instead of one burst behind it.
-struct TapE { int ph, t, dy, dx; };
-__device__ constexpr TapE kTaps[9] = {{3, 0, 0, 0}, {1, 0, 0, 0}, {1, 1, -1, 0}, {2, 0, 0, 0}, {2, 1, 0, -1},
-                                      {0, 0, 0, 0}, {0, 1, 0, -1}, {0, 2, -1, 0}, {0, 3, -1, -1}};
+// phase 2: (1,0) (1,2) reading (i,j) (i,j-1); phase 3: (1,1) reading (i,j).  The nine entries are ordered BY INPUT OFFSET -- (0,0) x 4,
+// (0,-1) x 2, (-1,0) x 2, (-1,-1) -- so that the taps of one offset share their A fragments (the four phases read the same input
+// pixels: 10 fragment loads per chunk instead of 18), every phase still taking its taps in its own order.  Phase 3 is complete after
+// step 0 of a tile's last chunk, phase 2 after step 1, phases 1 and 0 after step 2: the tile's stores (four times what it read) leave
+// in three instalments.
+struct TapE { int ph, t, o; };      // o = 2 (dy == -1) + (dx == -1)
+__device__ constexpr TapE kTaps[9] = {{3, 0, 0}, {1, 0, 0}, {2, 0, 0}, {0, 0, 0}, {2, 1, 1}, {0, 1, 1}, {1, 1, 2}, {0, 2, 2}, {0, 3, 3}};
+// A step's 36 MFMAs per wave as six units of six: (tap entry, K half, A fragments loaded with it or kept from the unit before)
+struct UnitE { int e, ks, la; };
+__device__ constexpr UnitE kUnits[3][6] = {{{0, 0, 1}, {1, 0, 0}, {2, 0, 0}, {0, 1, 1}, {1, 1, 0}, {2, 1, 0}},
+                                           {{3, 0, 1}, {3, 1, 1}, {4, 0, 1}, {5, 0, 0}, {4, 1, 1}, {5, 1, 0}},
+                                           {{6, 0, 1}, {7, 0, 0}, {6, 1, 1}, {7, 1, 0}, {8, 0, 1}, {8, 1, 1}}};
+__device__ constexpr int unit_abuf(int S, int I) {      // which of the two A register sets unit I of step S reads
+    int n = 0;
+    for (int i = 0; i <= I; ++i) n += kUnits[S][i].la;
+    return (n - 1) & 1;
+}
+__device__ constexpr int unit_reads(int S, int I) { return I > 5 ? 0 : 2 + 4 * kUnits[S][I].la; }
 
-// 8 x 32 input pixels per tile, three taps per step, one workgroup of eight waves per CU: 76 KB of patch ring (two chunks) + 72 KB of
+// 8 x 32 input pixels x 64 columns per tile, three taps per step, one workgroup of eight waves per CU, a wave = two tile rows (64
+// pixels) x 32 columns per phase (with the shared A fragments: 0.7 KB of LDS reads per MFMA; one row x 64 columns moved 1.0): 76 KB of patch ring (two chunks) + 72 KB of
 // weight ring (THREE steps: the tile of step u + 2 is issued in step u, so that a store instalment has two whole steps to drain before
 // a wait has to include it -- vmcnt retires loads and stores in order).
 template <bool OSPLIT, bool ABL, int EPI>     // EPI: dwords a lane stores at a time (1, or 4 behind dev knob epi_width: see the epilogue).  ABL: the dev build with the ablation switches (knob sep_ablate; tools/deconv_ablate.py)
@@ -84,11 +97,12 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
     constexpr int STAGE = NPIECE * 1024;
     constexpr int B_ONE = TPS * BN * 128, PB = TPS * BN / 8 / NW;           // weight tiles of a step: 8 pieces per tap
     constexpr int B_OFF = 2 * STAGE;
-    constexpr int TN = 2, EP = 16 * TN / EPI;                              // stores per wave, tile and phase
+    constexpr int TM = 2, EP = 16 * TM / EPI;                              // 32-pixel MFMA tiles per wave / stores per wave, tile and phase
     __shared__ __attribute__((aligned(1024))) unsigned char smem[B_OFF + 3 * B_ONE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;      // tile rows 2 wm, 2 wm + 1; columns 32 wn ..
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     {   // XCD k takes the k-th contiguous eighth of the tile list
         const unsigned total = gridDim.x * gridDim.y * gridDim.z;
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
             const int e = s * TPS + (wv * PB + j) / 8;        // scalar: entry of kTaps
-            const int ph = e == 0 ? 3 : (e < 3 ? 1 : (e < 5 ? 2 : 0)), t = e == 0 ? 0 : (e < 3 ? e - 1 : (e < 5 ? e - 3 : e - 5));
+            const int ph = (0x001020213ull >> (4 * e)) & 15, t = (0x321110000ull >> (4 * e)) & 15;      // kTaps[e] as nibble tables
             const int nt = ph == 0 ? 4 : (ph == 3 ? 1 : 2);
             const uint16_t* hi_p = ph == 0 ? p.Whi[0] : (ph == 1 ? p.Whi[1] : (ph == 2 ? p.Whi[2] : p.Whi[3]));
             const uint16_t* lo_p = ph == 0 ? p.Wlo[0] : (ph == 1 ? p.Wlo[1] : (ph == 2 ? p.Wlo[2] : p.Wlo[3]));
@@ -159,44 +173,40 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
         }
     };
 
-    // A fragments: lane fr = input pixel fr of the wave's tile row; the four input offsets (dy, dx) in {0, -1}^2
+    // A fragments: lane fr = input pixel fr of the wave's tile rows 2 wm + i; the four input offsets (dy, dx) in {0, -1}^2
     const int fr = lane & 31, fh = lane >> 5;
-    int a_off[4];   // index 2 * (dy == -1) + (dx == -1)
+    int a_off[TM][4];   // second index 2 * (dy == -1) + (dx == -1)
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        const int slot = (wv + 1 - (o >> 1)) * PWS + fr + 1 - (o & 1);
-        a_off[o] = slot * 128 + ((fh ^ ((slot >> 1) & 7)) << 4);
-    }
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int slot = (2 * wm + i + 1 - (o >> 1)) * PWS + fr + 1 - (o & 1);
+            a_off[i][o] = slot * 128 + ((fh ^ ((slot >> 1) & 7)) << 4);
+        }
     const int sw = (fr >> 1) & 7;
-    // the four (ks, hi / lo) variants of the lane's weight-fragment address (bits 5 and 6): everything else a step adds is a multiple of
-    // 4 KiB known at compile time and rides in the read's offset field (two bases: the field holds 16 bits)
+    // the four (ks, hi / lo) variants of the lane's weight-fragment address (bits 5 and 6; row 32 wn + fr of a tap's 64): everything else
+    // a step adds is a multiple of 8 KiB known at compile time and rides in the read's offset field (two bases: the field holds 16 bits)
     const unsigned char* b_var[2][4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        b_var[0][v] = smem + ((B_OFF + fr * 128 + ((fh ^ sw) << 4)) ^ (v << 5));
+        b_var[0][v] = smem + ((B_OFF + (wn * 32 + fr) * 128 + ((fh ^ sw) << 4)) ^ (v << 5));
         b_var[1][v] = b_var[0][v] + 2 * B_ONE;
     }
 
-    float es1[TN], et1[TN];
+    const int nch = n0 + wn * 32 + fr;          // this lane's output channel
     const bool full = n0 + BN <= p.N && !(ABL && (abl & 28));     // (the counts hold while every load and store is issued)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + j * 32 + fr;
-        const bool valid = n < p.N;
-        es1[j] = valid ? p.scale1[n] : 0.f;
-        et1[j] = valid ? p.shift1[n] : 0.f;
-        asm volatile("" ::"v"(es1[j]), "v"(et1[j]));
-    }
+    float es1 = nch < p.N ? p.scale1[nch] : 0.f, et1 = nch < p.N ? p.shift1[nch] : 0.f;
+    asm volatile("" ::"v"(es1), "v"(et1));
     const float hi = p.act == 1 ? 6.f : __builtin_inff();
     const float slope = p.act == 4 ? 0.2f : 1.f, lo = (p.act == 1 || p.act == 2) ? 0.f : -__builtin_inff();
 
-    f32x16 acc[4][TN];
+    f32x16 acc[4][TM];
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[ph][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[ph][i][e] = 0.f;
 
     const int nchunks = p.Cin / 32;
     int ic = 0, ixt = xbase, ichunk = 0;
@@ -228,59 +238,62 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
     int x0 = xbase;
     int c = 0;
     bool prev_last = false;                   // the group before this one closed a tile (its stores may still be in flight)
-    // A step's 36 MFMAs run as six units (tap, K half) of six; the twelve fragment registers of unit i + 1 are read from LDS BEFORE the
-    // MFMAs of unit i are issued (two register sets), so that a read's latency passes under matrix work instead of in front of every
-    // MFMA -- left to itself the compiler puts each ds_read next to its first use (25 exposed waits per step).  Only a step's first
+    // A step's 36 MFMAs run as six units (tap, K half) of six; the fragment registers of unit i + 1 are read from LDS BEFORE the MFMAs
+    // of unit i are issued (two register sets each for A and B), so that a read's latency passes under matrix work.  Only a step's first
     // unit waits in the open (its weights land with the barrier).
-    struct Frag { bf16x8 ah, al, bh[TN], bl[TN]; };
-    auto load_unit = [&](const unsigned char* stg, auto U_) {
-        constexpr int u = decltype(U_)::value, e = u / 2, ks = u % 2, S = e / TPS, k = e % TPS;
-        constexpr TapE te = kTaps[e];
-        const int ao = a_off[2 * (te.dy < 0) + (te.dx < 0)];
+    struct AFrag { bf16x8 h[TM], l[TM]; };
+    struct BFrag { bf16x8 h, l; };
+    AFrag fa[2];
+    BFrag fb[2];
+    auto load_unit = [&](const unsigned char* stg, auto S_, auto I_) {
+        constexpr int S = decltype(S_)::value, I = decltype(I_)::value;
+        constexpr UnitE u = kUnits[S][I];
+        constexpr int ks = u.ks, k = u.e % TPS, o = kTaps[u.e].o, ab = unit_abuf(S, I), bb = I & 1;
+        static_assert(u.e / TPS == S && TM == 2, "unit table");
+        if constexpr (u.la) {
+            fa[ab].h[0] = lds_read16<0>(stg + (a_off[0][o] ^ (ks << 5)));
+            fa[ab].l[0] = lds_read16<0>(stg + (a_off[0][o] ^ (ks << 5) ^ 64));
+            fa[ab].h[1] = lds_read16<0>(stg + (a_off[1][o] ^ (ks << 5)));
+            fa[ab].l[1] = lds_read16<0>(stg + (a_off[1][o] ^ (ks << 5) ^ 64));
+        }
         constexpr int bo = (S & 1) * B_ONE + k * (BN * 128);
-        static_assert(TN == 2, "two column tiles per wave");
-        Frag f;
-        f.ah = lds_read16<0>(stg + (ao ^ (ks << 5)));
-        f.al = lds_read16<0>(stg + (ao ^ (ks << 5) ^ 64));
-        f.bh[0] = lds_read16<bo>(b_var[S >> 1][ks]);
-        f.bl[0] = lds_read16<bo>(b_var[S >> 1][ks + 2]);
-        f.bh[1] = lds_read16<bo + 4096>(b_var[S >> 1][ks]);
-        f.bl[1] = lds_read16<bo + 4096>(b_var[S >> 1][ks + 2]);
-        return f;
+        fb[bb].h = lds_read16<bo>(b_var[S >> 1][ks]);
+        fb[bb].l = lds_read16<bo>(b_var[S >> 1][ks + 2]);
     };
-    auto mma_unit = [&](Frag& f, auto U_, auto YOUNGER_) {      // YOUNGER: LDS reads issued after this unit's six
-        constexpr int ph = kTaps[decltype(U_)::value / 2].ph;
-        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.ah), "+v"(f.al), "+v"(f.bh[0]), "+v"(f.bl[0]), "+v"(f.bh[1]), "+v"(f.bl[1]) : "n"(decltype(YOUNGER_)::value));
+    auto mma_unit = [&](auto S_, auto I_) {
+        constexpr int S = decltype(S_)::value, I = decltype(I_)::value;
+        constexpr int ph = kTaps[kUnits[S][I].e].ph, ab = unit_abuf(S, I), bb = I & 1;
+        AFrag& a = fa[ab];
+        BFrag& b = fb[bb];
+        // the reads of the next unit (issued after this one's) may stay in flight; the registers are tied to the wait
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a.h[0]), "+v"(a.l[0]), "+v"(a.h[1]), "+v"(a.l[1]), "+v"(b.h), "+v"(b.l) : "n"(unit_reads(S, I + 1)));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[j], acc[ph][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) acc[ph][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[i], b.h, acc[ph][i], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[j], acc[ph][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) acc[ph][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[i], b.l, acc[ph][i], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[j], acc[ph][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) acc[ph][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[i], b.h, acc[ph][i], 0, 0, 0);
     };
     auto taps_of_step = [&](const unsigned char* stg, auto S_) {
-        constexpr int S = decltype(S_)::value, U0 = 2 * TPS * S;
         using std::integral_constant;
-        typedef integral_constant<int, 6> Six;
-        typedef integral_constant<int, 0> Zero;
         if constexpr (ABL) { if (abl & 2) return; }
-        Frag f0 = load_unit(stg, integral_constant<int, U0>{}), f1;
-        f1 = load_unit(stg, integral_constant<int, U0 + 1>{});
-        mma_unit(f0, integral_constant<int, U0>{}, Six{});
+        load_unit(stg, S_, integral_constant<int, 0>{});
+        load_unit(stg, S_, integral_constant<int, 1>{});
+        mma_unit(S_, integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
-        f0 = load_unit(stg, integral_constant<int, U0 + 2>{});
-        mma_unit(f1, integral_constant<int, U0 + 1>{}, Six{});
+        load_unit(stg, S_, integral_constant<int, 2>{});
+        mma_unit(S_, integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        f1 = load_unit(stg, integral_constant<int, U0 + 3>{});
-        mma_unit(f0, integral_constant<int, U0 + 2>{}, Six{});
+        load_unit(stg, S_, integral_constant<int, 3>{});
+        mma_unit(S_, integral_constant<int, 2>{});
         __builtin_amdgcn_sched_barrier(0);
-        f0 = load_unit(stg, integral_constant<int, U0 + 4>{});
-        mma_unit(f1, integral_constant<int, U0 + 3>{}, Six{});
+        load_unit(stg, S_, integral_constant<int, 4>{});
+        mma_unit(S_, integral_constant<int, 3>{});
         __builtin_amdgcn_sched_barrier(0);
-        f1 = load_unit(stg, integral_constant<int, U0 + 5>{});
-        mma_unit(f0, integral_constant<int, U0 + 4>{}, Six{});
+        load_unit(stg, S_, integral_constant<int, 5>{});
+        mma_unit(S_, integral_constant<int, 4>{});
         __builtin_amdgcn_sched_barrier(0);
-        mma_unit(f1, integral_constant<int, U0 + 5>{}, Zero{});
+        mma_unit(S_, integral_constant<int, 5>{});
         __builtin_amdgcn_sched_barrier(0);
     };
     // ---- epilogue of one phase, from the accumulators: phase (py, px) of input pixel (i, j) is output pixel (2 i + py, 2 j + px).
@@ -296,15 +309,15 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
         int ldo = p.ldy;
         asm volatile("" : "+s"(ldo));
         const int Wo = 2 * p.W;
-        const long pixr = 4 * img + (long)(2 * (y0 + wv) + (ph >> 1)) * Wo + 2 * x0 + (ph & 1);
-        float* obase = p.y + pixr * ldo;
         const bool odd = fr & 1;
         auto body = [&](auto LEAKY_) {
             constexpr bool LEAKY = decltype(LEAKY_)::value;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float s1 = es1[j], t1 = et1[j];
-                const int n = n0 + j * 32 + fr;
+            for (int j = 0; j < TM; ++j) {      // the wave's two tile rows
+                const long pixr = 4 * img + (long)(2 * (y0 + 2 * wm + j) + (ph >> 1)) * Wo + 2 * x0 + (ph & 1);
+                float* obase = p.y + pixr * ldo;
+                const float s1 = es1, t1 = et1;
+                const int n = nch;
                 f32x16& a16 = acc[ph][j];
                 auto act = [&](float a) {
                     float v = fmaf(a, s1, t1);
@@ -347,7 +360,7 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
                     }
                 } else {
                     const int li = fr & 3, cq = fr >> 2;
-                    const int n4 = n0 + j * 32 + 4 * cq;
+                    const int n4 = n0 + wn * 32 + 4 * cq;
                     const bool valid = n4 < p.N;
                     unsigned voff;
                     if constexpr (OSPLIT) voff = (unsigned)(2 * (4 * fh + li) * ldo) * 4u + (n4 >> 5) * 128u + ((cq & 1) ? 64u : 0u) + ((n4 & 31) >> 3) * 16u;
@@ -382,22 +395,22 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
     };
     using std::integral_constant;
     // One step (compile-time S) of group g, global step u = 3 g + S.  Issue order of a step: [barrier] B(u + 2); at S = 0 the next
-    // group's patch (PP pieces); the taps; in a tile's last chunk the store instalment (S = 0: phases 3 and 1, 2 EP stores; S = 1: phase 2,
-    // EP; S = 2: phase 0, EP).  The wait before the barrier needs B(u) -- issued in step u - 2 -- and everything older; what may stay in
+    // group's patch (PP pieces); the taps; in a tile's last chunk the store instalment (S = 0: phase 3, EP stores; S = 1: phase 2, EP;
+    // S = 2: phases 1 and 0, 2 EP).  The wait before the barrier needs B(u) -- issued in step u - 2 -- and everything older; what may stay in
     // flight is what was issued after it: the rest of step u - 2 and all of step u - 1.  (A tile whose columns are partly masked issues an
     // unknown number of stores: it counts none, which only waits longer.)
     auto step = [&](auto S_, int g) {
         constexpr int S = decltype(S_)::value;
         const bool this_last = c + 1 == nchunks;
-        if constexpr (S == 0) {            // step u - 2 = S 1, u - 1 = S 2 of the previous group
-            if (prev_last && full) wait_vm<PB + 2 * EP>(); else wait_vm<PB>();
-        } else if constexpr (S == 1) {     // u - 2 = S 2 of the previous group, u - 1 = S 0 of this one
+        if constexpr (S == 0) {            // step u - 2 = S 1 (EP stores), u - 1 = S 2 (2 EP) of the previous group
+            if (prev_last && full) wait_vm<PB + 3 * EP>(); else wait_vm<PB>();
+        } else if constexpr (S == 1) {     // u - 2 = S 2 of the previous group (2 EP), u - 1 = S 0 of this one (patch, EP)
             if (!full || (!prev_last && !this_last)) wait_vm<PB + PP>();
             else if (prev_last && this_last) wait_vm<PB + PP + 3 * EP>();
-            else if (this_last) wait_vm<PB + PP + 2 * EP>();
-            else wait_vm<PB + PP + EP>();
-        } else {                           // u - 2 = S 0, u - 1 = S 1 of this group
-            if (this_last && full) wait_vm<PB + PP + 3 * EP>(); else wait_vm<PB + PP>();
+            else if (this_last) wait_vm<PB + PP + EP>();
+            else wait_vm<PB + PP + 2 * EP>();
+        } else {                           // u - 2 = S 0 (patch, EP), u - 1 = S 1 (EP) of this group
+            if (this_last && full) wait_vm<PB + PP + 2 * EP>(); else wait_vm<PB + PP>();
         }
         __builtin_amdgcn_s_barrier();
         {
@@ -414,9 +427,9 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
         const unsigned char* stg = smem + (g & 1) * STAGE;
         taps_of_step(stg, S_);
         if (this_last) {
-            if constexpr (S == 0) { epilogue(integral_constant<int, 3>{}); epilogue(integral_constant<int, 1>{}); }
+            if constexpr (S == 0) epilogue(integral_constant<int, 3>{});
             if constexpr (S == 1) epilogue(integral_constant<int, 2>{});
-            if constexpr (S == 2) epilogue(integral_constant<int, 0>{});
+            if constexpr (S == 2) { epilogue(integral_constant<int, 1>{}); epilogue(integral_constant<int, 0>{}); }
         }
     };
     for (int g = 0; g < ngroups; ++g) {
