@@ -36,6 +36,14 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
 }
+// Fragment reads by hand: the compiler neither sees them nor waits for them (it would wait with lgkmcnt(0), i.e. also for the NEXT
+// unit's reads issued behind them); the wait in front of a unit's MFMAs lets the younger reads stay in flight and ties the registers.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read16(const unsigned char* p) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((lptr_t)p), "n"(OFF) : "memory");
+    return v;
+}
 __device__ __forceinline__ void store_nt_d(const void* sbase, unsigned voff, unsigned v) {
     asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
@@ -157,7 +165,11 @@ __global__ __launch_bounds__(512, 1) void conv3_pipe_kernel(const Conv3Params p)
         a_off[t] = slot * 128 + ((fh ^ ((slot >> 1) & 7)) << 4);
     }
     const int sw = (fr >> 1) & 7;
-    const int b_off = B_OFF + fr * 128 + ((fh ^ sw) << 4);   // + kx * 8192 + j * 4096; K half / lo: XOR below
+    // the four (K half, hi / lo) variants of the lane's weight-fragment address (bits 5 and 6); + buffer; kx * 8192 + j * 4096 ride in the
+    // read's offset field
+    const unsigned char* b_var[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) b_var[v] = smem + ((B_OFF + fr * 128 + ((fh ^ sw) << 4)) ^ (v << 5));
 
     // ---- epilogue constants: before the transpose a lane holds channel j * 32 + fr
     float es1[TN], et1[TN], es2[TN], et2[TN];
@@ -234,24 +246,56 @@ __global__ __launch_bounds__(512, 1) void conv3_pipe_kernel(const Conv3Params p)
             issue_patch(more ? (ichunk & 1) : ((ichunk + 1) & 1), ic);
         }
         const unsigned char* stg = smem + ((u / 3) & 1) * STAGE;
-        const int bbase = (u & 1) * B_ONE + b_off;
+        {   // the step's 36 MFMAs as six units (kx, K half) of six; unit i + 1's twelve fragment registers are read BEFORE unit i's MFMAs
+            // are issued (two register sets): a read's latency passes under matrix work instead of in front of every MFMA
+            const unsigned char* bv[4];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ao = ky == 0 ? a_off[kx] : (ky == 1 ? a_off[3 + kx] : a_off[6 + kx]);
+            for (int v = 0; v < 4; ++v) bv[v] = b_var[v] + (u & 1) * B_ONE;
+            int ao3[3];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(stg + (ao ^ (ks << 5)));
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(stg + (ao ^ (ks << 5) ^ 64));
+            for (int kx = 0; kx < 3; ++kx) ao3[kx] = ky == 0 ? a_off[kx] : (ky == 1 ? a_off[3 + kx] : a_off[6 + kx]);
+            struct Frag { bf16x8 ah, al, bh[TN], bl[TN]; };
+            static_assert(TN == 2, "two column tiles per wave");
+            auto load_unit = [&](auto U_) {
+                constexpr int kx = decltype(U_)::value / 2, ks = decltype(U_)::value % 2;
+                Frag f;
+                f.ah = lds_read16<0>(stg + (ao3[kx] ^ (ks << 5)));
+                f.al = lds_read16<0>(stg + (ao3[kx] ^ (ks << 5) ^ 64));
+                f.bh[0] = lds_read16<kx * (BN * 128)>(bv[ks]);
+                f.bl[0] = lds_read16<kx * (BN * 128)>(bv[ks + 2]);
+                f.bh[1] = lds_read16<kx * (BN * 128) + 4096>(bv[ks]);
+                f.bl[1] = lds_read16<kx * (BN * 128) + 4096>(bv[ks + 2]);
+                return f;
+            };
+            auto mma_unit = [&](Frag& f, auto YOUNGER_) {
+                asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.ah), "+v"(f.al), "+v"(f.bh[0]), "+v"(f.bl[0]), "+v"(f.bh[1]), "+v"(f.bl[1]) : "n"(decltype(YOUNGER_)::value));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int bo = bbase + kx * (BN * 128) + j * 4096;
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(smem + (bo ^ (ks << 5)));
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(smem + (bo ^ (ks << 5) ^ 64));
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
-                }
-            }
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[j], acc[j], 0, 0, 0);
+            };
+            using std::integral_constant;
+            typedef integral_constant<int, 6> Six;
+            Frag f0 = load_unit(integral_constant<int, 0>{}), f1;
+            f1 = load_unit(integral_constant<int, 1>{});
+            mma_unit(f0, Six{});
+            __builtin_amdgcn_sched_barrier(0);
+            f0 = load_unit(integral_constant<int, 2>{});
+            mma_unit(f1, Six{});
+            __builtin_amdgcn_sched_barrier(0);
+            f1 = load_unit(integral_constant<int, 3>{});
+            mma_unit(f0, Six{});
+            __builtin_amdgcn_sched_barrier(0);
+            f0 = load_unit(integral_constant<int, 4>{});
+            mma_unit(f1, Six{});
+            __builtin_amdgcn_sched_barrier(0);
+            f1 = load_unit(integral_constant<int, 5>{});
+            mma_unit(f0, Six{});
+            __builtin_amdgcn_sched_barrier(0);
+            mma_unit(f1, integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
         }
         epi = false;
         if (++ky == 3) {
@@ -366,7 +410,7 @@ namespace emd {
 bool conv3_pipe_covers(const Conv3Params& p) {
     // (column tiles of 64: the packed weight planes are padded to a multiple of 128 rows, so a last partial tile stays inside them)
     return g_knobs.conv3_pipe && p.H % 8 == 0 && p.W % 32 == 0 && p.Cin % 32 == 0 && p.Cin >= 32 && p.Cin <= 4064 && p.N % 4 == 0 &&
-           p.N <= (g_knobs.conv3_pipe >= 2 ? 1024 : 192);   // measured: faster up to 192 columns, level with the 128-wide GEMM tiles at 256
+           p.N <= (g_knobs.conv3_pipe >= 2 ? 1024 : 256);   // measured (tools/conv3_bench.py): faster up to 192 columns, 3-4 % at 256
 }
 
 int conv3_pipe_launch(const Conv3Params& p, int B, int out_split, hipStream_t st) {
@@ -380,7 +424,8 @@ int conv3_pipe_launch(const Conv3Params& p, int B, int out_split, hipStream_t st
     if (g_knobs.sep_tpw > 0 && tiles_w % g_knobs.sep_tpw == 0) tpw = g_knobs.sep_tpw;   // dev knob (shared with the separable kernels)
     q.tpw = tpw;
     const dim3 grid(tiles_w / tpw * q.n_ntiles, p.H / 8, B);
-    if (g_knobs.epi_width == 4) {
+    // epilogue: per-channel dword stores; four or more column tiles (>= 256 columns) do better with the transposed 16-byte form
+    if (g_knobs.epi_width ? g_knobs.epi_width == 4 : q.n_ntiles >= 4) {
         if (out_split) hipLaunchKernelGGL((conv3_pipe_kernel<true, 4>), grid, dim3(512), 0, st, q);
         else hipLaunchKernelGGL((conv3_pipe_kernel<false, 4>), grid, dim3(512), 0, st, q);
     } else {

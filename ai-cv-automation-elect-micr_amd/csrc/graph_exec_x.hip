@@ -292,7 +292,7 @@ struct XRun {
         }
         const int H = a.t.H, W = a.t.W;
         const int Ho = (H + d.stride - 1) / d.stride, Wo = (W + d.stride - 1) / d.stride;
-        if (d.k == 3 && d.stride == 1 && d.rate == 1 && !out_opt && d.cin % 32 == 0 && d.cout <= 192 && Ho % 8 == 0 && Wo % 32 == 0 && a.split) {
+        if (d.k == 3 && d.stride == 1 && d.rate == 1 && !out_opt && d.cin % 32 == 0 && d.cout <= 256 && Ho % 8 == 0 && Wo % 32 == 0 && a.split) {
             XT r = F(Ho, Wo, d.cout);
             if (live())
                 call(emd_conv3x3_split32_f32(a.sp, a.ld, p.pw.hi, p.pw.lo, p.gs, p.hs, nullptr, nullptr, nullptr, 0, r.t.ptr(), r.t.ld, B, H, W,

@@ -293,7 +293,7 @@ class XceptionEngine:
                 return r
             Ho, Wo = -(-a.H // L.stride), -(-a.W // L.stride)
             if (L.k == 3 and L.stride == 1 and L.rate == 1 and out is None and prec == ops.PREC_BF16X3 and L.cin % 32 == 0
-                    and L.cout <= 192 and Ho % 8 == 0 and Wo % 32 == 0 and (isinstance(a, ops.SplitAct) or teacher is not None)):
+                    and L.cout <= 256 and Ho % 8 == 0 and Wo % 32 == 0 and (isinstance(a, ops.SplitAct) or teacher is not None)):
                 r = ops.conv3x3_split32(as_split(a), p["pw"], p["gs"], p["hs"], E(Ho, Wo, L.cout), act=RELU)
                 if trace is not None:
                     trace.append(r.torch().cpu().numpy())

@@ -24,7 +24,7 @@
  *   dw_xcd (1)          depthwise kernels: 0 = launch-order tiles, 1 = XCD-contiguous up to 128 x 128 maps, 2 = always
  *   dw_th (0)           strip height of the rolling depthwise kernel (0 = rule)
  *   split_narrow (1)    pointwise split32 GEMM: 128 x 64 tiles for the small batches whose 128 x 128 tiles leave CUs idle (0 = never)
- *   conv3_pipe (1)      dense 3x3 conv, stride 1, rate 1, H % 8 == 0, W % 32 == 0, <= 192 output channels (2: any width): the patch-resident kernel
+ *   conv3_pipe (1)      dense 3x3 conv, stride 1, rate 1, H % 8 == 0, W % 32 == 0, <= 256 output channels (2: any width): the patch-resident kernel
  *                       (conv3_pipe.hip; sums chunk-major, taps inside: last-bit differences to the tap-major GEMM), 0 = gemm_split_conv_kernel
  *   split_wide (0)      pointwise split32 GEMM: 256 x 192 tiles where they fill the chip (N = 728: four column tiles, no half round): 0 never
  *                       (default: same bits, slower inside graph D), 1 = 8 waves of 64 x 96, 2 = 4 waves of 128 x 96

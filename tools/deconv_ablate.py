@@ -15,7 +15,7 @@ for nm, (B, H, W, ci, co) in {"deconv1to0": (32, 256, 256, 128, 128), "deconv2to
     w = ops.pack_deconv((np.random.default_rng(0).standard_normal((3, 3, co, ci)) * 0.03).astype(np.float32), dev)
     s, t = torch.ones(co, device=dev), torch.zeros(co, device=dev)
     out = ops.Act.empty(B, 2 * H, 2 * W, co, dev)
-    for label, bits in (("full", 1), ("raw stores (no activation, no transpose)", 33), ("-mfma", 2), ("-stores", 4), ("-mfma-stores", 6), ("-patch DMA", 8), ("-weight DMA", 16), ("-all DMA", 24),
+    for label, bits in (("full (product build)", 0), ("full (ablation build)", 1), ("-mfma", 2), ("-stores", 4), ("-mfma-stores", 6), ("-patch DMA", 8), ("-weight DMA", 16), ("-all DMA", 24),
                         ("DMA + barriers only", 6), ("nothing but barriers", 30)):
         _lib.knob("sep_ablate", bits)
         for _ in range(2):
