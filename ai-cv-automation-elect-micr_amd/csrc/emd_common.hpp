@@ -50,7 +50,7 @@ constexpr int kWave = 64;  // CDNA4 wavefront
 struct Knobs {
     int sep_pipe = 1;        // 1: the LDS-DMA pipelined fused separable conv (sep_pipe.hip) where it covers the shape; 0: sep_fused.hip
     int sep_mode = -1;       // sep_pipe schedule of the one-output instances: -1 = rule, 0 / 1 = the patch two / one steps ahead
-    int sep_nw = 0;          // sep_pipe waves per workgroup: 0 = rule, 8 (8 x 32 tiles, one workgroup per CU) or 4 (8 x 16 tiles, two per CU; <= 64 output channels)
+    int sep_nw = 0;          // sep_pipe waves per workgroup: 0 = rule (4 wherever there is an instance), 8 (8 x 32 tiles, one workgroup per CU) or 4 (8 x 16 tiles, two per CU; <= 128 output channels, 64 | 64 for two outputs)
     int sep_ablate = 0;      // sep_pipe phase ablation bits for timing experiments (results are wrong when non-zero)
     int sep_tpw = 0;         // tiles per workgroup of the fused separable convs (0 = rule)
     int sep_xcd = 1;         // one contiguous run of tiles per XCD

@@ -111,8 +111,13 @@ template <int BN, bool DUAL, int MODE, bool OSPLIT, int NW = 8, int STRIDE = 1, 
 __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p) {
     constexpr int TW = STRIDE == 2 ? 16 : 4 * NW, TH = STRIDE == 2 ? 4 : 8, BM = TH * TW;
     constexpr int PW = STRIDE * TW + 3 - STRIDE, PH = STRIDE * TH + 3 - STRIDE, PWS = PW | 1;   // patch pixels per row; slot pitch odd (see above): 34 -> 35, 18 -> 19, 33
-    constexpr int NPATCH = PH * PWS, NSLOT = NPATCH + 9;      // + 9 slots of depthwise weights (one tap's 32 channels = 128 B)
-    constexpr int NPIECE = (NSLOT + 7) / 8;                   // 45 DMA pieces of 8 slots
+    // The chunk's depthwise weights (nine taps x 32 channels = nine 128-byte slots) ride in the PAD column of the patch rows where there
+    // is one (stride 1: 34 -> 35, 18 -> 19; tap t in row t), else in nine slots behind the patch: one KiB less per stage, which is what
+    // lets the 4-wave form with 128 columns fit two workgroups per CU (2 x 24 + 16 + 16 = 80 KiB).
+    constexpr bool WPAD = PWS > PW && PH >= 9;
+    constexpr int NPATCH = PH * PWS, NSLOT = WPAD ? NPATCH : NPATCH + 9;
+    constexpr int WK0 = WPAD ? PW : NPATCH, WKS = WPAD ? PWS : 1;    // slot of tap t: WK0 + t * WKS
+    constexpr int NPIECE = (NSLOT + 7) / 8;                   // DMA pieces of 8 slots (8 x 32 tiles: 44)
     constexpr int PP = (NPIECE + NW - 1) / NW;                // 6 per wave (the surplus ones repeat the wave's previous piece)
     constexpr int STAGE = NPIECE * 1024;
     constexpr int A_BYTES = BM * 128, B_ONE = BN * 128;
@@ -169,11 +174,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
                 gx = gx < 0 ? -gx : (gx >= p.W ? 2 * p.W - 2 - gx : gx);
             }
             const bool real = slot < NPATCH && px < PW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            const bool wk = slot >= NPATCH && slot < NSLOT;
+            const bool wk = WPAD ? (slot < NPATCH && px == PW && py < 9) : (slot >= NPATCH && slot < NSLOT);
+            const int tap = WPAD ? py : slot - NPATCH;
             const int kk = SWZ ? (dk ^ ((px >> 1) & 3)) : dk;
             const float* o = g_zero_pipe + dk * 4;                                  // padding pixels, unused slots
             const float* o_px = p.x + (img + (long)gy * p.W + gx) * p.ldx + kk * 4;
-            const float* o_wk = p.dw + (long)(slot - NPATCH) * p.Cin + dk * 4;     // the chunk's depthwise weights, one tap per slot
+            const float* o_wk = p.dw + (long)tap * p.Cin + dk * 4;                 // the chunk's depthwise weights, one tap per slot
             o = real ? o_px : o;
             o = wk ? o_wk : o;
             psrc[j] = o;
@@ -295,13 +301,13 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
     auto stage1 = [&](const unsigned char* stg) {   // depthwise 3x3 from the patch -> bf16 hi / lo A rows
         if (abl & 1) return;
         if constexpr (STRIDE == 2) {
-            const unsigned char* wkp = stg + NPATCH * 128 + c4 * 16;
+            const unsigned char* wkp = stg + WK0 * 128 + c4 * 16;
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
-                    o += *reinterpret_cast<const f32x4*>(wkp + (i * 3 + d) * 128) *
+                    o += *reinterpret_cast<const f32x4*>(wkp + (i * 3 + d) * (WKS * 128)) *
                          *reinterpret_cast<const f32x4*>(stg + rd_base + (i * PWS + d) * 128 + c4 * 16);
             unsigned h0, l0, h1, l1;
             split2(o[0], o[1], h0, l0);
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
             *reinterpret_cast<u32x2*>(smem + (a_wr[0] ^ 64)) = u32x2{l0, l1};
             return;
         }
-            const unsigned char* wkp = stg + NPATCH * 128 + c4 * 16;
+            const unsigned char* wkp = stg + WK0 * 128 + c4 * 16;
             f32x4 o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
             for (int i = 0; i < 3; ++i) {
                 f32x4 wk[3], pr[6];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) wk[d] = *reinterpret_cast<const f32x4*>(wkp + (i * 3 + d) * 128);
+                for (int d = 0; d < 3; ++d) wk[d] = *reinterpret_cast<const f32x4*>(wkp + (i * 3 + d) * (WKS * 128));
 #pragma unroll
                 for (int d = 0; d < 6; ++d)
                     pr[d] = *reinterpret_cast<const f32x4*>(stg + rd_base + (i * PWS + d) * 128 + rd_k[d >> 1]);
@@ -712,12 +718,18 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
 template <int BN, bool DUAL, bool OSPLIT, int EPI>
 int launch_mode(const SepParams& q, dim3 grid, int mode, int nw, hipStream_t st) {
     if constexpr (DUAL) {
+        if constexpr (BN == 128) {
+            if (nw == 4) {
+                hipLaunchKernelGGL((sep_pipe_kernel<BN, true, 1, false, 4, 1, EPI>), grid, dim3(256), 0, st, q);
+                return emd::check_launch("sep_pipe_kernel<4 waves, two outputs>");
+            }
+        }
         hipLaunchKernelGGL((sep_pipe_kernel<BN, true, 1, false, 8, 1, EPI>), grid, dim3(512), 0, st, q);
     } else {
-        if constexpr (BN == 64 && !OSPLIT) {
+        if constexpr (BN <= 128) {
             if (nw == 4) {
-                if (mode == 1) hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 1, false, 4, 1, EPI>), grid, dim3(256), 0, st, q);
-                else hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 0, false, 4, 1, EPI>), grid, dim3(256), 0, st, q);
+                if (mode == 1) hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 1, OSPLIT, 4, 1, EPI>), grid, dim3(256), 0, st, q);
+                else hipLaunchKernelGGL((sep_pipe_kernel<BN, false, 0, OSPLIT, 4, 1, EPI>), grid, dim3(256), 0, st, q);
                 return emd::check_launch("sep_pipe_kernel<4 waves>");
             }
         }
@@ -751,7 +763,7 @@ int launch_epi(const SepParams& p, const SepParams& q, dim3 grid, int mode, int 
     if (p.N2 > 0) {
         const bool wide = p.N > 64 || p.N2 > 64;
         if (wide) return launch_bn<256, true, EPI>(q, grid, 1, 8, st);
-        return launch_bn<128, true, EPI>(q, grid, 1, 8, st);
+        return launch_bn<128, true, EPI>(q, grid, 1, nw, st);
     }
     if (p.N <= 64) return launch_bn<64, false, EPI>(q, grid, mode, nw, st);
     if (p.N <= 128) return launch_bn<128, false, EPI>(q, grid, mode, nw, st);
@@ -762,10 +774,15 @@ int launch_epi(const SepParams& p, const SepParams& q, dim3 grid, int mode, int 
 
 namespace emd {
 
-// 4-wave form (8 x 16 tiles, two workgroups per CU): one fp32 output of up to 64 channels.  Rule (profiles/r03_sep_ab.txt): wherever it
-// applies -- 512^2 x 128 -> 64: 1.43 ms against 1.46 for the 8-wave form, 64 -> 64: 0.88 against 1.00; dev knob sep_nw = 8 / 4 forces.
+// 4-wave form (8 x 16 tiles, 80 KiB of LDS or less: two workgroups per CU, whose phases -- DMA wait, depthwise stage, MFMAs, epilogue --
+// interleave): instances up to 128 output columns (one output, fp32 or split32) and 64 | 64 (two outputs).  Rule: wherever there is an
+// instance.  Measured on graph D's shapes (tools/sep_epi_bench.py with SEB_KNOB=sep_nw, [32, ., ., .], two boxes): the two-output launch
+// 512^2 x 128 -> 64 | 64 2078 -> 1892 us, 2084 -> 1921; 64 -> 64 961 -> 859, 943 -> 873; 128 -> 64 1382 -> 1354; 64 -> 64 with a
+// residual 1161 / 1288 -> 1212 / 1210; 256^2 x 128 -> 128 480 -> 467, 486 -> 469; with residual and split32 output 669 -> 647 / 653;
+// 384 -> 128 1155 -> 1144; the whole D step 23.36 -> 23.24 ms in one process (tools/d_knob_ab.py).  Dev knob sep_nw = 8 / 4 forces.
 static bool use_nw4(const SepParams& p) {
-    return g_knobs.sep_nw != 8 && p.N2 == 0 && p.N <= 64 && !p.out_split;
+    if (g_knobs.sep_nw == 8 || p.stride == 2) return false;
+    return p.N2 > 0 ? (p.N <= 64 && p.N2 <= 64) : (p.N <= 128 && !(p.out_split && p.N <= 64));    // instances: launch_mode
 }
 
 bool sep_pipe_covers(const SepParams& p, int precision) {

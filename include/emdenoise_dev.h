@@ -10,13 +10,16 @@
  * set by name through emd_debug_knob; defaults = the measured-best path:
  *   sep_pipe (1)        1: the LDS-DMA pipelined fused separable conv (csrc/sep_pipe.hip) where it covers the shape, 0: csrc/sep_fused.hip
  *   sep_mode (-1)       sep_pipe schedule of the one-output instances: -1 = rule, 0 / 1 = the patch requested two / one steps ahead
- *   sep_nw (0)          sep_pipe waves per workgroup: 0 = rule, 8 (8 x 32 pixel tiles, one workgroup per CU) or 4 (8 x 16 tiles, two per CU)
+ *   sep_nw (0)          sep_pipe waves per workgroup: 0 = rule (4 wherever there is an instance), 8 (8 x 32 pixel tiles, one workgroup per CU)
+ *                       or 4 (8 x 16 tiles, two per CU: up to 128 output columns, 64 | 64 for two outputs)
  *   sep_ablate (0)      sep_pipe timing experiments: bit 0 no depthwise stage, 1 no MFMA stage, 2 no epilogue, 3 no patch DMA after the
  *                       prologue, 4 no weight DMA after it, 5 no residual loads -- RESULTS ARE WRONG when non-zero
  *   sep_tpw (0)         tiles per workgroup of the fused separable convs (0 = rule)
  *   sep_xcd (1)         0 = launch-order tiles instead of one contiguous run of tiles per XCD
  *   sep_wide (1)        sep_fused 256-column single-output form: 0 never, 1 Cin <= 256, 2 whenever it fits
  *   sep_wres (1)        0 = per-chunk pointwise weight loads in sep_fused's 64-column instances (default: resident in LDS)
+ *   epi_width (0)       epilogue of sep_pipe / conv3_pipe / deconv_pipe: 1 = a lane keeps its channel and stores one dword per pixel, 4 = 4 x 4 transpose
+ *                       inside lane quads, then 16 bytes per lane; 0 = the kernel's rule (same values either way)
  *   deconv_direct (3)   one-launch transposed conv: 3 = the patch-resident kernel (csrc/deconv_pipe.hip; sums chunk-major: last-bit
  *                       differences to the GEMM forms) where H % 8 == 0 and W % 32 == 0, else as 1; 1 = GEMM form with the epilogue straight
  *                       from the accumulators; 2 = the same on 128-row tiles, two workgroups per CU; 0 = LDS-staged epilogue

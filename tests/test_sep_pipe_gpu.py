@@ -27,7 +27,7 @@ def _restore_knobs(request):
 
     _lib.knob("epi_width", request.param)
     yield
-    for k, v in (("sep_pipe", 1), ("sep_mode", -1), ("sep_tpw", 0), ("sep_nw", 8), ("epi_width", 0)):
+    for k, v in (("sep_pipe", 1), ("sep_mode", -1), ("sep_tpw", 0), ("sep_nw", 0), ("epi_width", 0)):
         _lib.knob(k, v)
 
 
@@ -69,8 +69,8 @@ CASES = [
 def test_sep_pipe_vs_oracle_and_register_staged_kernel(B, H, W, ci, co, res, extra, act, reflect, tpw, lead, nw):
     from emdenoise import _lib, ops
 
-    if nw == 4 and co > 64:
-        pytest.skip("the 4-wave form (8 x 16 tiles, two workgroups per CU) covers up to 64 output channels")
+    if nw == 4 and co > 128:
+        pytest.skip("the 4-wave form (8 x 16 tiles, two workgroups per CU) covers up to 128 output channels")
 
     x = rnd((B, H, W, ci), 340, positive=not reflect)
     dw = rnd((3, 3, ci, 1), 341, 0.35)
@@ -106,7 +106,8 @@ def test_sep_pipe_vs_oracle_and_register_staged_kernel(B, H, W, ci, co, res, ext
 
 @pytest.mark.parametrize("B,H,W,ci,co,res", [(1, 16, 64, 128, 128, True), (2, 8, 32, 256, 256, True), (1, 8, 96, 64, 224, False)])
 @pytest.mark.parametrize("lead", [0, 1])
-def test_sep_pipe_split32_output(B, H, W, ci, co, res, lead):
+@pytest.mark.parametrize("nw", [8, 4])
+def test_sep_pipe_split32_output(B, H, W, ci, co, res, lead, nw):
     """emd_sep3x3_fused_out_f32 (the producer of a split32 convolution's input: deconv1_b / deconv2_b, denoiser.py:357, :369) ==
     emd_to_split32_f32 of the fp32 output, padding channels zero."""
     from emdenoise import _lib, ops
@@ -119,7 +120,10 @@ def test_sep_pipe_split32_output(B, H, W, ci, co, res, lead):
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
     xa, pk = to_act(x), ops.PackedWeights(pw, False, dev())
     kw = dict(res=to_act(r) if res else None)
+    if nw == 4 and co > 128:
+        pytest.skip("the 4-wave form covers up to 128 output channels")
     _lib.knob("sep_mode", lead)
+    _lib.knob("sep_nw", nw)
     out = out_act(B, H, W, co)
     ops.sep_fused(xa, d(dw), pk, d(s1), d(t1), out, **kw)
     sp = ops.SplitAct(B, H, W, co, dev())
@@ -136,7 +140,8 @@ def test_sep_pipe_split32_output(B, H, W, ci, co, res, lead):
     (1, 24, 64, 96, 128, 32, 2),        # unequal widths, two tiles per workgroup
     (2, 8, 64, 32, 36, 64, 0),          # channel tail in the separable output, one chunk
 ])
-def test_sep_pipe_dual(B, H, W, ci, co, co2, tpw):
+@pytest.mark.parametrize("nw", [8, 4])
+def test_sep_pipe_dual(B, H, W, ci, co, co2, tpw, nw):
     """emd_sep3x3_dual_f32 through sep_pipe: output 1 == the separable block, output 2 == conv 1x1 + bias + BN + relu6 of the same
     input (denoiser.py:356-359 / :368-371 / :380-383), against the oracle and against the two kernels it replaces."""
     from emdenoise import _lib, ops
@@ -157,7 +162,10 @@ def test_sep_pipe_dual(B, H, W, ci, co, co2, tpw):
     out, out2 = out_act(B, H, W, co, ld=co + 8, c0=4), out_act(B, H, W, co2, ld=co2 + 12, c0=8)
     p1, p2 = ops.PackedWeights(pw[0], False, dev()), ops.PackedWeights(w2[0], False, dev())
     shift_b = (bias2.astype(np.float64) * sb + tb).astype(np.float32)
+    if nw == 4 and (co > 64 or co2 > 64):
+        pytest.skip("the 4-wave two-output form: 64 | 64 columns")
     _lib.knob("sep_tpw", tpw)
+    _lib.knob("sep_nw", nw)       # 4: 8 x 16 tiles, two workgroups per CU
     ops.sep_dual(xa, d(dw[..., 0]), p1, p2, d(s1), d(t1), out, d(sb), d(shift_b), out2)
     torch.cuda.synchronize()
     g1, g2 = out.torch().cpu().numpy(), out2.torch().cpu().numpy()

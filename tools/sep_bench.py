@@ -99,4 +99,4 @@ for nm in names:
             print(f"{nm:13s} {label} bit-identical to old: {same and same2}", flush=True)
     _lib.knob("sep_pipe", 1)
     _lib.knob("sep_mode", -1)
-    _lib.knob("sep_nw", 8)
+    _lib.knob("sep_nw", 0)

@@ -1,5 +1,6 @@
-"""Dev tool: the fused separable conv (sep_pipe.hip) on graph D's shapes with the per-channel dword epilogue (dev knob epi_width = 1)
-against the older one (4: a 4 x 4 transpose inside lane quads, 16-byte stores), with a bit-identity check between them."""
+"""Dev tool: the fused separable conv (sep_pipe.hip) on graph D's shapes, A/B of one dev knob (SEB_KNOB=epi_width: per-channel dword
+epilogue 1 against the transposed 16-byte one 4; SEB_KNOB=sep_nw: 8-wave workgroups on 8 x 32 tiles, one per CU, against 4-wave ones on
+8 x 16 tiles, two per CU), with a bit-identity check between the two."""
 import os
 import sys
 
@@ -18,6 +19,8 @@ SHAPES = {
 dev = torch.device("cuda", 0)
 B = int(os.environ.get("SB_B", "32"))
 REP, ROUNDS = 5, 3
+KNOB = os.environ.get("SEB_KNOB", "epi_width")
+VALS = (1, 4) if KNOB == "epi_width" else (8, 4)
 _lib.load()
 
 
@@ -31,7 +34,7 @@ def timed(fn):
     return e0.elapsed_time(e1) * 1000.0 / REP
 
 
-tot = {1: 0.0, 4: 0.0}
+tot = {v: 0.0 for v in VALS}
 for nm, (S, ci, co, res, co2, osplit, stride) in SHAPES.items():
     g = torch.Generator(device=dev).manual_seed(1)
     x = ops.Act(torch.rand(B, S, S, ci, device=dev, generator=g))
@@ -45,29 +48,30 @@ for nm, (S, ci, co, res, co2, osplit, stride) in SHAPES.items():
         pw2 = ops.PackedWeights(rng.standard_normal((1, ci, co2)).astype(np.float32) * 0.1, False, dev)
         sb, tb = torch.rand(co2, device=dev) + 0.5, torch.rand(co2, device=dev) - 0.5
     outs, fns = {}, {}
-    for ew in (1, 4):
+    for ew in VALS:
         out = ops.SplitAct(B, So, So, co, dev) if osplit else ops.Act.empty(B, So, So, co, dev)
         out.buf.fill_(float("nan"))
         out2 = ops.Act.empty(B, So, So, co2, dev) if co2 else None
         outs[ew] = (out, out2)
 
         def fn(ew=ew, out=out, out2=out2):
-            _lib.knob("epi_width", ew)
+            _lib.knob(KNOB, ew)
             if co2:
                 ops.sep_dual(x, w, pw, pw2, s1, t1, out, sb, tb, out2)
             else:
                 ops.sep_fused(x, w, pw, s1, t1, out, res=r, stride=stride)
-            _lib.knob("epi_width", 0)
+            _lib.knob(KNOB, 0)
         fns[ew] = fn
     for f in fns.values():
         f(); f()
     torch.cuda.synchronize()
-    same = torch.equal(outs[1][0].buf, outs[4][0].buf) and (not co2 or torch.equal(outs[1][1].buf, outs[4][1].buf))
+    a, b = VALS
+    same = torch.equal(outs[a][0].buf, outs[b][0].buf) and (not co2 or torch.equal(outs[a][1].buf, outs[b][1].buf))
     T = {k: [] for k in fns}
     for _ in range(ROUNDS):
         for k, f in fns.items():
             T[k].append(timed(f))
     for k in T:
         tot[k] += float(np.median(T[k]))
-    print(f"{nm:13s} same bits {same}: " + "  ".join(f"epi_width={k} {np.median(T[k]):8.1f} us" for k in T), flush=True)
-print("sum: " + "  ".join(f"epi_width={k} {v:8.1f} us" for k, v in tot.items()))
+    print(f"{nm:13s} same bits {same}: " + "  ".join(f"{KNOB}={k} {np.median(T[k]):8.1f} us" for k in T), flush=True)
+print("sum: " + "  ".join(f"{KNOB}={k} {v:8.1f} us" for k, v in tot.items()))
