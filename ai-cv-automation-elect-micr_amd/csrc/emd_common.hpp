@@ -62,6 +62,7 @@ struct Knobs {
     int dw_xcd = 1;          // XCD-contiguous tile order in the depthwise kernels
     int dw_th = 0;           // strip height of the rolling depthwise kernel (0 = rule)
     int split_narrow = 1;    // pointwise split32 GEMM: 128 x 64 tiles where 128 x 128 tiles leave CUs idle (0 = never)
+    int split_lead = 2;      // pointwise split32 GEMM (16x16x32 form): DMA issued 2 (default) or 1 K steps ahead on the same three stages (same bits)
     int split_wide = 0;      // pointwise split32 GEMM: 256 x 192 tiles (gemm_split16_wide_kernel) where they fill the chip: 0 never (default: slower in graph D), 1 = 8 waves of 64 x 96, 2 = 4 waves of 128 x 96
     int conv3_pipe = 1;      // dense 3x3 conv (stride 1, rate 1, H % 8 == 0, W % 32 == 0) on the patch-resident kernel (conv3_pipe.hip): 1 = up to 192 output channels, 2 = any width, 0 = never
     int split_variant = -1;  // pointwise split32 GEMM pipeline variant (-1 = dispatch rule)

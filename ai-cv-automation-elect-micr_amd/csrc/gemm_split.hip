@@ -511,7 +511,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 // whose 256-row tiles would leave most CUs idle (M = 4096: 96 workgroups of 256 rows, 192 of 128).  Same products in the same order:
 // the two forms are bit-identical, so a result does not depend on the batch size that selected one of them.
 // BN = 64 (with BM = 128): 128 x 64 tiles, two workgroups per CU -- the batch-of-4 shapes (M = 4096) then run as 384 workgroups instead of 192.
-template <int BM, int BN = SBN>
+// LEAD2: the DMA of tile kt + 3 is issued in step kt into the stage of tile kt itself -- whose fragments are in registers since step
+// kt - 1 -- so that TWO tiles are in flight on the same three stages and a tile has two steps to land instead of one (the wait is
+// vmcnt(pieces of one tile), not vmcnt(0)).  A K step of a small-M launch is shorter than an L2 round trip: M = 4096 x 728 x 728 ran
+// 23 steps of 0.8 us.
+template <int BM, int BN = SBN, bool LEAD2 = false>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemmParams p) {
     constexpr int NS = 3, NT = BM * 2, WQ = BN / (BM / 32) / 8, TJ = BN / 32;   // TJ 16-column MFMA tiles per wave
     constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128, STAGE = A_STAGE + W_STAGE;
@@ -602,20 +606,34 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_split16_kernel(const SplitGemm
     const int nk = (p.Cin + SBK - 1) / SBK;
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, r0 = 0;
     if (p.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    constexpr int P = 4 + WQ;      // DMA pieces per wave and tile
     issue(0, 0);
     issue(1, 1 < nk ? 1 : nk - 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (LEAD2) {
+        issue(2, 2 < nk ? 2 : nk - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
     Frags f0, f1;
     load_frags(f0, smem);
     int s0 = 0, s1 = 1, s2 = 2;
     auto step = [&](Frags& cur, Frags& nxt, int kt) {
-        if (kt > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (LEAD2) {
+            // tile kt + 1 has landed (tile kt + 2 may still fly); this wave's reads of stage s0 (tile kt: issued a step ago) are over --
+            // with everybody's, behind the barrier, the stage can take tile kt + 3
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
             __builtin_amdgcn_s_barrier();
+            issue(s0, kt + 3 < nk ? kt + 3 : nk - 1);
+        } else {
+            if (kt > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            issue(s2, kt + 2 < nk ? kt + 2 : nk - 1);
         }
-        issue(s2, kt + 2 < nk ? kt + 2 : nk - 1);
         load_frags(nxt, smem + s1 * STAGE);      // tile kt+1: certified by this step's barrier
         mfma48(cur);
         if constexpr (TJ == 4) {
@@ -1663,6 +1681,11 @@ static int conv1x1_split32_impl(const void* xs, int ldx, const uint16_t* whi, co
     else if (v == 2) hipLaunchKernelGGL((gemm_split_kernel<128, 2>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     else if (wide == 2) hipLaunchKernelGGL((gemm_split16_wide_kernel<2>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     else if (wide) hipLaunchKernelGGL((gemm_split16_wide_kernel<4>), dim3((unsigned)nblk), dim3(512), 0, st, p);
+    else if (v == 5 && emd::g_knobs.split_lead == 2) {
+        if (narrow) hipLaunchKernelGGL((gemm_split16_kernel<128, 64, true>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+        else if (small) hipLaunchKernelGGL((gemm_split16_kernel<128, SBN, true>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_split16_kernel<256, SBN, true>), dim3((unsigned)nblk), dim3(512), 0, st, p);
+    }
     else if (v == 5 && narrow) hipLaunchKernelGGL((gemm_split16_kernel<128, 64>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     else if (v == 5 && small) hipLaunchKernelGGL(gemm_split16_kernel<128>, dim3((unsigned)nblk), dim3(256), 0, st, p);
     else if (v == 5) hipLaunchKernelGGL(gemm_split16_kernel<256>, dim3((unsigned)nblk), dim3(512), 0, st, p);

@@ -32,6 +32,8 @@
  *   split_wide (0)      pointwise split32 GEMM: 256 x 192 tiles where they fill the chip (N = 728: four column tiles, no half round): 0 never
  *                       (default: same bits, slower inside graph D), 1 = 8 waves of 64 x 96, 2 = 4 waves of 128 x 96
  *   split_variant (-1)  pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
+ *   split_lead (2)      pointwise split32 GEMM, 16x16x32 form: the DMA of tile kt + 3 issued in step kt into the stage of tile kt (whose fragments
+ *                       are in registers): two tiles in flight on three stages; 1 = one step ahead (round 2's schedule; same bits)
  */
 #ifndef EMDENOISE_DEV_H
 #define EMDENOISE_DEV_H

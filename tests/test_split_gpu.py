@@ -231,6 +231,39 @@ def test_conv1x1_split32_wide_tiles(B, H, W, ci, co, res, extra, form):
     assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,res", [
+    (16, 32, 32, 728, 728, True),      # 256 x 128 tiles, 23 K steps, residual
+    (4, 32, 32, 728, 728, False),      # 128 x 64 tiles (the small-batch form)
+    (2, 32, 32, 96, 192, False),       # 128 x 128 tiles, K = 3 steps: as many as the ring has stages
+    (1, 16, 16, 32, 64, True),         # one K step: every younger DMA group is a surplus re-read of it
+    (3, 23, 23, 64, 40, False),        # two K steps, ragged M, channel tail
+])
+def test_conv1x1_split32_two_steps_ahead(B, H, W, ci, co, res):
+    """gemm_split16_kernel with the DMA of tile kt + 3 issued in step kt into the stage of tile kt (dev knob split_lead = 2, the default)
+    gives the bits of the one-step-ahead schedule (1) at every tile form and K depth, and writes nothing outside its channel slice."""
+    from emdenoise import _lib, ops
+
+    x = rnd((B, H, W, ci), 81, positive=True)
+    w = rnd((1, ci, co), 82, scale=0.04)
+    r = rnd((B, H, W, co), 83)
+    pw = ops.PackedWeights(w, False, dev())
+    s1, t1 = up(rnd((co,), 84, 0.3) + 1.0), up(rnd((co,), 85, 0.5))
+    kw = dict(res=ops.Act(up(r)) if res else None)
+    xs = ops.to_split32(ops.Act(up(x)))
+    try:
+        _lib.knob("split_lead", 1)
+        ref = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act.empty(B, H, W, co, dev()), **kw)
+        _lib.knob("split_lead", 2)
+        wide = torch.full((B, H, W, co + 8), float("nan"), dtype=torch.float32, device=dev())
+        got = ops.conv1x1_split32(xs, pw, s1, t1, ops.Act(wide, co, 4), **kw)
+        torch.cuda.synchronize()
+    finally:
+        _lib.knob("split_lead", 2)
+    assert not torch.isnan(got.torch()).any()
+    assert torch.equal(got.torch(), ref.torch())
+    assert torch.isnan(wide[..., :4]).all() and torch.isnan(wide[..., 4 + co:]).all()
+
+
 def test_split32_argument_checks():
     from emdenoise import _lib, ops
 
