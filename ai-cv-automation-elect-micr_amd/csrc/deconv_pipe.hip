@@ -143,25 +143,31 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
     };
     const int abl = ABL ? p.ablate : 0;
     bool primed = false;
-    auto issue_patch = [&](int stage, int c) {
+    auto issue_patch_piece = [&](int stage, int c, auto J_) {
+        constexpr int j = decltype(J_)::value;
         if constexpr (ABL) { if ((abl & 8) && primed) return; }
-#pragma unroll
-        for (int j = 0; j < PP; ++j) {
-            int q = wv + NW * j;
-            if (q >= NPIECE) q -= NW;
-            const unsigned char* base = ((pmove >> j) & 1) ? ximg : zpage;
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + (psrc[j] + c * 128)), (lptr_t)(smem + stage * STAGE + q * 1024), 16, 0, 0);
-        }
+        int q = wv + NW * j;
+        if (q >= NPIECE) q -= NW;
+        const unsigned char* base = ((pmove >> j) & 1) ? ximg : zpage;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + (psrc[j] + c * 128)), (lptr_t)(smem + stage * STAGE + q * 1024), 16, 0, 0);
+    };
+    auto issue_patch = [&](int stage, int c) {
+        static_assert(PP == 5, "pieces per wave");
+        issue_patch_piece(stage, c, std::integral_constant<int, 0>{});
+        issue_patch_piece(stage, c, std::integral_constant<int, 1>{});
+        issue_patch_piece(stage, c, std::integral_constant<int, 2>{});
+        issue_patch_piece(stage, c, std::integral_constant<int, 3>{});
+        issue_patch_piece(stage, c, std::integral_constant<int, 4>{});
     };
     // weight rows of step s: row = k * 64 + output channel for the step's three table entries k; pieces XOR-swizzled by (row >> 1) & 7.
     // The sources are rebuilt at issue time from lane constants (a dozen VALU operations per step) rather than kept in 18 registers.
     // piece q = wv * PB + j (scalar) holds rows q * 8 + drow: entry q / 8 of the step, output channel n0 + (q & 7) * 8 + drow, 16-byte
     // column dk ^ (4 (q & 1) + (drow >> 1))
     const int bc0 = dk ^ (drow >> 1);
-    auto issue_B = [&](int buf, int c, int s) {
+    auto issue_B_piece = [&](int buf, int c, int s, auto J_) {
+        constexpr int j = decltype(J_)::value;
         if constexpr (ABL) { if ((abl & 16) && primed) return; }
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
+        {
             const int e = s * TPS + (wv * PB + j) / 8;        // scalar: entry of kTaps
             const int ph = (0x001020213ull >> (4 * e)) & 15, t = (0x321110000ull >> (4 * e)) & 15;      // kTaps[e] as nibble tables
             const int nt = ph == 0 ? 4 : (ph == 3 ? 1 : 2);
@@ -171,6 +177,12 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
             const uint16_t* src = ((cc & 4) ? lo_p : hi_p) + (long)(n0 + (q & 7) * 8 + drow) * (nt * p.Cpad) + t * p.Cpad + (cc & 3) * 8 + c * 32;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + B_OFF + buf * B_ONE + (wv * PB + j) * 1024), 16, 0, 0);
         }
+    };
+    auto issue_B = [&](int buf, int c, int s) {
+        static_assert(PB == 3, "pieces per wave");
+        issue_B_piece(buf, c, s, std::integral_constant<int, 0>{});
+        issue_B_piece(buf, c, s, std::integral_constant<int, 1>{});
+        issue_B_piece(buf, c, s, std::integral_constant<int, 2>{});
     };
 
     // A fragments: lane fr = input pixel fr of the wave's tile rows 2 wm + i; the four input offsets (dy, dx) in {0, -1}^2
@@ -274,26 +286,41 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[ph][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[i], b.h, acc[ph][i], 0, 0, 0);
     };
-    auto taps_of_step = [&](const unsigned char* stg, auto S_) {
+    // between(slot) runs after unit `slot`'s MFMAs are issued: the step's DMA pieces go there, one or two per slot, instead of in one
+    // block behind the barrier -- an LDS-DMA piece costs its wave 60-180 issue clocks (MI355X_MICROARCH.md), and with every wave of the
+    // workgroup at the same point behind a barrier nobody feeds the matrix cores meanwhile.
+    auto taps_of_step = [&](const unsigned char* stg, auto S_, auto&& between) {
         using std::integral_constant;
-        if constexpr (ABL) { if (abl & 2) return; }
+        if constexpr (ABL) {
+            if (abl & 2) {
+                between(integral_constant<int, 0>{}); between(integral_constant<int, 1>{}); between(integral_constant<int, 2>{});
+                between(integral_constant<int, 3>{}); between(integral_constant<int, 4>{}); between(integral_constant<int, 5>{});
+                return;
+            }
+        }
         load_unit(stg, S_, integral_constant<int, 0>{});
         load_unit(stg, S_, integral_constant<int, 1>{});
         mma_unit(S_, integral_constant<int, 0>{});
+        between(integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
         load_unit(stg, S_, integral_constant<int, 2>{});
         mma_unit(S_, integral_constant<int, 1>{});
+        between(integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
         load_unit(stg, S_, integral_constant<int, 3>{});
         mma_unit(S_, integral_constant<int, 2>{});
+        between(integral_constant<int, 2>{});
         __builtin_amdgcn_sched_barrier(0);
         load_unit(stg, S_, integral_constant<int, 4>{});
         mma_unit(S_, integral_constant<int, 3>{});
+        between(integral_constant<int, 3>{});
         __builtin_amdgcn_sched_barrier(0);
         load_unit(stg, S_, integral_constant<int, 5>{});
         mma_unit(S_, integral_constant<int, 4>{});
+        between(integral_constant<int, 4>{});
         __builtin_amdgcn_sched_barrier(0);
         mma_unit(S_, integral_constant<int, 5>{});
+        between(integral_constant<int, 5>{});
         __builtin_amdgcn_sched_barrier(0);
     };
     // ---- epilogue of one phase, from the accumulators: phase (py, px) of input pixel (i, j) is output pixel (2 i + py, 2 j + px).
@@ -413,19 +440,26 @@ __global__ __launch_bounds__(512, 1) void deconv_pipe_kernel(const DeconvPipePar
             if (this_last && full) wait_vm<PB + PP + 2 * EP>(); else wait_vm<PB + PP>();
         }
         __builtin_amdgcn_s_barrier();
-        {
-            int cn = c, sn = S + 2;
-            if (sn >= NSTEP) { sn -= NSTEP; cn = this_last ? 0 : c + 1; }
-            if (g * NSTEP + S + 2 >= ngroups * NSTEP) { cn = c; sn = S; }     // past the end: a copy nobody reads keeps the counts uniform
-            issue_B((S + 2) % 3, cn, sn);
-        }
+        int cn = c, sn = S + 2;
+        if (sn >= NSTEP) { sn -= NSTEP; cn = this_last ? 0 : c + 1; }
+        if (g * NSTEP + S + 2 >= ngroups * NSTEP) { cn = c; sn = S; }     // past the end: a copy nobody reads keeps the counts uniform
+        int pstage = 0;
         if constexpr (S == 0) {
             const bool more = ichunk + 1 < tchunks;
             advance_patch();
-            issue_patch(more ? (ichunk & 1) : ((ichunk + 1) & 1), ic);
+            pstage = more ? (ichunk & 1) : ((ichunk + 1) & 1);
         }
         const unsigned char* stg = smem + (g & 1) * STAGE;
-        taps_of_step(stg, S_);
+        // issue order of the step (what the waits above count on): B(u + 2)'s three pieces, then the patch's five, then the stores
+        taps_of_step(stg, S_, [&](auto SLOT_) {
+            constexpr int slot = decltype(SLOT_)::value;
+            if constexpr (slot < PB) issue_B_piece((S + 2) % 3, cn, sn, SLOT_);
+            if constexpr (S == 0 && slot >= PB - 1) {      // slots 2, 3, 4: one piece each; slot 5: the last two
+                constexpr int j = slot - (PB - 1);
+                if constexpr (j < 3) issue_patch_piece(pstage, ic, integral_constant<int, j>{});
+                if constexpr (j == 3) { issue_patch_piece(pstage, ic, integral_constant<int, 3>{}); issue_patch_piece(pstage, ic, integral_constant<int, 4>{}); }
+            }
+        });
         if (this_last) {
             if constexpr (S == 0) epilogue(integral_constant<int, 3>{});
             if constexpr (S == 1) epilogue(integral_constant<int, 2>{});
