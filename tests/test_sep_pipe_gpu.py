@@ -59,6 +59,7 @@ CASES = [
     (1, 8, 32, 64, 36, False, False, 0, False, 0),       # channel tail in a 64-column tile, no activation
     (1, 8, 64, 64, 160, True, False, 1, False, 0),       # channel tail in a 256-column tile
     (1, 16, 48, 64, 64, True, False, 1, False, 0),       # W % 32 != 0: only the 4-wave form (8 x 16 tiles) covers it
+    (2, 8, 80, 96, 128, True, True, 1, False, 0),        # the same with 128 columns (five tiles of 16, three chunks)
     (2, 16, 32, 64, 32, False, False, 4, True, 0),       # graph G: REFLECT border, leaky relu
     (1, 8, 64, 32, 128, True, True, 4, True, 2),
 ]
@@ -104,7 +105,8 @@ def test_sep_pipe_vs_oracle_and_register_staged_kernel(B, H, W, ci, co, res, ext
     assert torch.equal(new.torch(), old.torch()), "sep_pipe and sep_fused promise the same bits"
 
 
-@pytest.mark.parametrize("B,H,W,ci,co,res", [(1, 16, 64, 128, 128, True), (2, 8, 32, 256, 256, True), (1, 8, 96, 64, 224, False)])
+@pytest.mark.parametrize("B,H,W,ci,co,res", [(1, 16, 64, 128, 128, True), (2, 8, 32, 256, 256, True), (1, 8, 96, 64, 224, False),
+                                             (1, 8, 48, 64, 96, True)])      # W % 32 != 0: 4-wave form only
 @pytest.mark.parametrize("lead", [0, 1])
 @pytest.mark.parametrize("nw", [8, 4])
 def test_sep_pipe_split32_output(B, H, W, ci, co, res, lead, nw):
@@ -139,6 +141,7 @@ def test_sep_pipe_split32_output(B, H, W, ci, co, res, lead, nw):
     (1, 8, 96, 384, 128, 128, 0),       # deconv1_a + residual1_d: 128 | 128 columns on the same 8 x 32 tile
     (1, 24, 64, 96, 128, 32, 2),        # unequal widths, two tiles per workgroup
     (2, 8, 64, 32, 36, 64, 0),          # channel tail in the separable output, one chunk
+    (1, 16, 48, 64, 64, 64, 0),         # W % 32 != 0: the 4-wave two-output form on 8 x 16 tiles
 ])
 @pytest.mark.parametrize("nw", [8, 4])
 def test_sep_pipe_dual(B, H, W, ci, co, co2, tpw, nw):
