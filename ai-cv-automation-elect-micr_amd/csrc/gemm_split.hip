@@ -2365,10 +2365,20 @@ extern "C" int emd_deconv3x3s2_split32_f32(const void* xs, int ldx, const uint16
 // always where the patch-resident kernel covers the layer (H % 8 == 0, W % 32 == 0, Cin % 32 == 0: it sums in another order than the GEMM
 // forms, so the choice must not depend on the batch size -- image b of a batch == the image alone, bit for bit), otherwise from 192
 // row tiles on (the GEMM forms agree with each other bit for bit, there the choice is speed only).
-extern "C" int emd_deconv3x3s2_fused_preferred(int B, int H, int W, int Cin, int Cout) {
+// ONE predicate for "this layer runs on the patch-resident kernel" (deconv_pipe.hip), used by emd_deconv3x3s2_fused_preferred and by the
+// entry point alike, and a function of the LAYER only (H, W, Cin, Cout) -- never of the batch size or of the pitches: the kernel sums in
+// another order than the GEMM forms, so a route that flipped with B (or with the buffer a tensor happens to live in) would break "image b
+// of a batch == the image alone, bit for bit".  What the kernel additionally needs of a call (32-bit in-image offsets: H * W * ldx_bytes <
+// 2^32, 36 * W * ldy < 2^31) is checked by the entry point and REPORTED (EMD_E_UNSUPPORTED) instead of silently falling back to a kernel
+// with other bits; batches beyond the grid's 65535 images are cut into launches of the same kernel.
+static bool deconv_patch_route(int H, int W, int Cin, int Cout) {
     emd::DeconvPipeParams q{};
-    q.H = H; q.W = W; q.Cin = (Cin + 31) / 32 * 32; q.N = Cout;
-    if (Cin % 32 == 0 && H >= 8 && emd::deconv_pipe_covers(q)) return 1;
+    q.H = H; q.W = W; q.Cin = (Cin + 31) / 32 * 32; q.N = Cout;   // (ldx_bytes = 0: the offset bound is the entry point's to check)
+    return Cin % 32 == 0 && H >= 8 && emd::deconv_pipe_covers(q);
+}
+
+extern "C" int emd_deconv3x3s2_fused_preferred(int B, int H, int W, int Cin, int Cout) {
+    if (deconv_patch_route(H, W, Cin, Cout)) return 1;
     return (long)B * H * W >= 256L * 192 ? 1 : 0;
 }
 
@@ -2382,13 +2392,24 @@ extern "C" int emd_deconv3x3s2_fused_split32_f32(const void* xs, int ldx, const 
     }
     EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_deconv3x3s2_fused_split32_f32: bad shape");
     if (B == 0) return EMD_OK;
-    if (H >= 8 && B <= 65535 && 36L * W * ldy < (1L << 31)) {   // the patch-resident kernel (deconv_pipe.hip), dev knob deconv_direct = 3
+    if (Cin % 32 == 0 && deconv_patch_route(H, W, Cin, Cout)) {   // the patch-resident kernel (deconv_pipe.hip), dev knob deconv_direct = 3
         emd::DeconvPipeParams q{};
         q.x = static_cast<const unsigned char*>(xs); q.ldx_bytes = (long)ldx * 4; q.y = static_cast<float*>(y);
         for (int ph = 0; ph < 4; ++ph) { q.Whi[ph] = whi[ph]; q.Wlo[ph] = wlo[ph]; }
         q.scale1 = scale1; q.shift1 = shift1;
         q.H = H; q.W = W; q.Cin = (Cin + 31) / 32 * 32; q.Cpad = (Cin + kBK - 1) / kBK * kBK; q.N = Cout; q.ldy = ldy; q.act = act;
-        if (emd::deconv_pipe_covers(q)) return emd::deconv_pipe_launch(q, B, out_split, static_cast<hipStream_t>(stream));
+        EMD_REQUIRE(emd::deconv_pipe_covers(q) && 36L * W * ldy < (1L << 31), EMD_E_UNSUPPORTED,
+                    "emd_deconv3x3s2_fused_split32_f32: this layer runs on the patch-resident kernel, whose in-image offsets are 32-bit "
+                    "(H * W * ldx * 4 < 2^32, 36 * W * ldy < 2^31): pitch too large (a fallback would change the summation order)");
+        const long in_img = (long)H * W * q.ldx_bytes, out_img = 4L * H * W * ldy * (long)sizeof(float);
+        for (int b0 = 0; b0 < B; b0 += 65535) {   // grid.z <= 65535: the same kernel on slices of the batch
+            const int nb = B - b0 < 65535 ? B - b0 : 65535;
+            q.x = static_cast<const unsigned char*>(xs) + (long)b0 * in_img;
+            q.y = reinterpret_cast<float*>(static_cast<unsigned char*>(y) + (long)b0 * out_img);
+            int rc = emd::deconv_pipe_launch(q, nb, out_split, static_cast<hipStream_t>(stream));
+            if (rc != EMD_OK) return rc;
+        }
+        return EMD_OK;
     }
     SplitConvParams c{};
     SplitGemmParams& p = c.g;

@@ -142,13 +142,27 @@ struct emd_graph {   // the handle behind emd_graph_t
     bool two_streams = false;   // emd_graph_set_two_streams
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+    bool streams_failed = false;   // creation failed once: later runs go straight to the single-stream sequence (no retry, no second leak)
+    void drop_streams() {
+        for (int h = 0; h < 2; ++h) {
+            if (join[h]) (void)hipEventDestroy(join[h]);
+            if (side[h]) (void)hipStreamDestroy(side[h]);
+            join[h] = nullptr; side[h] = nullptr;
+        }
+        if (fork) (void)hipEventDestroy(fork);
+        fork = nullptr;
+    }
     bool streams_ok() {
-        if (side[0]) return true;
+        if (streams_failed) return false;
+        if (side[0] && side[1]) return true;
         bool ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
         for (int h = 0; h < 2 && ok; ++h)
             ok = hipStreamCreateWithFlags(&side[h], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&join[h], hipEventDisableTiming) == hipSuccess;
-        if (!ok) side[0] = nullptr;   // single-stream launch sequence instead
+        if (!ok) {   // single-stream launch sequence instead; whatever was created goes
+            drop_streams();
+            streams_failed = true;
+        }
         return ok;
     }
 };
@@ -772,11 +786,7 @@ extern "C" int emd_graph_set_two_streams(emd_graph* g, int on) {
 extern "C" void emd_graph_destroy(emd_graph* g) {
     if (!g) return;
     for (void* q : g->allocs) (void)hipFree(q);
-    for (int h = 0; h < 2; ++h) {
-        if (g->join[h]) (void)hipEventDestroy(g->join[h]);
-        if (g->side[0] && g->side[h]) (void)hipStreamDestroy(g->side[h]);
-    }
-    if (g->fork) (void)hipEventDestroy(g->fork);
+    g->drop_streams();
     if (g->x) emd::gx::x_destroy(g->x);
     if (g->gen) emd::gx::g_destroy(g->gen);
     delete g;

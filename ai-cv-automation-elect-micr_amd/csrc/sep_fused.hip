@@ -526,7 +526,10 @@ inline int sep_wide() { return g_knobs.sep_wide; }
 // stride 2 (round 3): only the LDS-DMA pipelined kernel has the form (csrc/sep_pipe.hip, STRIDE = 2) -- even sizes with H % 8 == 0,
 // W % 32 == 0 (output tiles of 4 x 16 pixels), Cout <= 256; emd_sep3x3_fused_s2_f32
 static bool sep_s2_supported(int H, int W, int Cin, int Cout) {
-    return H % 8 == 0 && W % 32 == 0 && Cin % 32 == 0 && Cin >= 32 && Cin <= 4064 && Cout % 4 == 0 && Cout >= 4 && Cout <= 256;
+    // ask the kernel that has the form (its dev knob sep_pipe = 0 switches it off: hosts then take depthwise + pointwise, they do not get an error)
+    emd::SepParams q{};
+    q.H = H; q.W = W; q.Cin = Cin; q.N = Cout; q.stride = 2;
+    return Cout % 4 == 0 && Cout >= 4 && emd::sep_pipe_covers(q, 3);
 }
 
 extern "C" int emd_sep3x3_fused_supported(int H, int W, int Cin, int Cout, int stride, int rate) {

@@ -716,11 +716,26 @@ class Denoiser(object):
         return denoised.clip(0.0, 1.0) if postprocess else denoised
 
 
-def architecture(inputs, ground_truth=None, phase=False, params=None, engine=None):
-    """Signature of the reference's graph builder (denoiser.py:58-61).  ``phase`` must be False
-    (inference); ``params`` may carry {'weights': dict} or an engine is passed directly."""
+def architecture(inputs, ground_truth=None, phase=False, params=None, engine=None, trainer=None):
+    """Signature of the reference's graph builder (machine_learning/denoiser.py:58-61, misc_py/denoiser-multi-gpu.py:200-203):
+    ``architecture(inputs, ground_truth, phase, params) -> output``.  The graph itself is a launch sequence of an engine, so the
+    object that owns the device weights is passed too (or in ``params``: {'engine': ...} / {'trainer': ...}):
+
+    * ``phase=False`` -- inference batch norms (moving statistics, folded): ``engine`` = DenoiserEngine, -> engine.forward(inputs);
+    * ``phase=True``  -- the tower's training-mode graph (batch statistics in every norm, in-graph clip; graph D',
+      misc_py/denoiser-multi-gpu.py:200-540): ``trainer`` = trainer.DenoiserTrainer, -> DenoiserTrainer.forward_train(inputs).
+      Like the reference's builder it only builds/evaluates the forward graph: the moving-statistics updates are the train op's
+      UPDATE_OPS (get_model_fn / train_step), not a side effect of this call.
+
+    ``ground_truth`` is accepted and unused, as in the reference (the loss lives in _tower_fn)."""
+    params = params or {}
+    if isinstance(params, dict):
+        engine = engine if engine is not None else params.get("engine")
+        trainer = trainer if trainer is not None else params.get("trainer")
     if phase:
-        raise NotImplementedError("training-mode batch norm is the D' path (not in this round)")
+        if trainer is None:
+            raise ValueError("phase=True evaluates the training-mode graph: pass trainer=DenoiserTrainer(...)")
+        return trainer.forward_train(inputs)
     if engine is None:
         raise ValueError("pass engine=DenoiserEngine(...)")
     return engine.forward(inputs)

@@ -337,10 +337,26 @@ def spiral_mask(size, frac=1.0 / 64):
     return build(0.5 * (lo + hi))
 
 
-def generator_architecture(inputs, phase=False, params=None, train_batch_norm=None, engine=None):
-    """Signature of the reference's graph builder (:133); inference only."""
+def generator_architecture(inputs, phase=False, params=None, train_batch_norm=None, engine=None, trainer=None):
+    """Signature of the reference's graph builder (misc_py/gan-infilling-100.py:133).
+
+    * ``train_batch_norm`` falsy -- every batch norm on its MOVING statistics (``batch_norm_on_ph: False``, what the reference feeds
+      whenever it evaluates outputs, losses or gradients, :1668): ``engine`` = GeneratorEngine, -> engine.forward(inputs);
+    * ``train_batch_norm`` true  -- ``is_training=True`` in every norm (:164-174): the forward pass on BATCH statistics, and the norms'
+      update ops (moving <- moving - (moving - batch) * (1 - 0.9997), :866-871) applied, which is what the reference's generator train op
+      runs while counter < 250 000 (:1644, :1708-1712): ``trainer`` = gan_trainer.GeneratorTrainer, ->
+      GeneratorTrainer.update_moving_statistics(inputs) (its output; the inference folds are rebuilt).  The reference's batch is one
+      image (:74), and so is this call's."""
+    params = params or {}
+    if isinstance(params, dict):
+        engine = engine if engine is not None else params.get("engine")
+        trainer = trainer if trainer is not None else params.get("trainer")
     if train_batch_norm:
-        raise NotImplementedError("training-mode batch norm of graph G is not built yet")
+        if trainer is None:
+            raise ValueError("train_batch_norm=True runs the batch-statistics phase: pass trainer=GeneratorTrainer(...)")
+        if inputs.shape[0] != 1:
+            raise ValueError("the batch-statistics phase takes ONE image (batch_size = 1, gan-infilling-100.py:74)")
+        return trainer.update_moving_statistics(inputs)
     if engine is None:
         raise ValueError("pass engine=GeneratorEngine(...)")
     return engine.forward(inputs)

@@ -443,7 +443,7 @@ class DenoiserTrainer:
         fewer launches.  result3 is then [B, 3].
         wgrad_stream=True: the weight-gradient launches of the backward pass go to a side stream (see _wg); same arithmetic.
 
-        The pass is six segments (_enc_fwd, _mid_fwd, _dec_fwd, _dec_bwd, _mid_bwd, _enc_bwd) so that towers_merged can run the
+        The pass is six segments (_enc_fwd, _mid_fwd, _dec_fwd, _dec_bwd, _mid_bwd, _enc_bwd) so that the 1/16-resolution part can be driven on its own (round 3 ran it for several groups as ONE pass: slower, removed);
         1/16-resolution part of several groups of images as ONE pass; here they simply follow each other."""
         import torch
 
@@ -462,6 +462,21 @@ class DenoiserTrainer:
             self._wg_side, self._wg_keep = None, []
         self.last = {"out": st.out, "result": st.result}
         return st.out, st.result
+
+    def forward_train(self, lq, truth=None, update_moving=False, per_image=False):
+        """``architecture(inputs, ground_truth, phase=True)`` (misc_py/denoiser-multi-gpu.py:200-540): the training-mode forward
+        graph alone -- batch statistics in every norm, relu6, the in-graph clip -- on [B,S,S,1]; no loss gradient, no parameter
+        gradient, and (default) no moving-statistics update, which in the reference is an UPDATE_OP of the train op, not of the
+        builder.  Returns the output tensor [B,S,S,1]."""
+        import torch
+
+        self._update_moving = update_moving
+        self._per_image = bool(per_image)
+        self._wg_side = None
+        st = self._enc_fwd(lq)
+        ms = self._mid_fwd(st.cnn3_strided)
+        self._dec_fwd(st, ms.aspp, torch.zeros_like(lq) if truth is None else truth)
+        return st.out
 
     @staticmethod
     def _gkey(a):
@@ -679,62 +694,6 @@ class DenoiserTrainer:
         encoder(["cnn0", "cnn0_last", "cnn0_strided"], "residual0", st.cnn0_strided, need_dx=False)
         self._gparent = {}
 
-    def towers_merged(self, lq, truth, groups):
-        """The B one-image towers of a rank as ``groups`` batched passes on as many streams through encoder and decoder (the
-        full-resolution levels fill the chip with a few images), MERGED into one pass of all B images through the 1/16-resolution
-        part (encoder 4, the middle flow, ASPP: 36 of the 60 layers, where even B images leave CUs idle): every batch norm takes
-        per-image statistics, so which images share a launch changes no value.  Returns the [B, 3] results."""
-        import torch
-
-        B, S = lq.shape[0], lq.shape[1]
-        per = B // groups
-        S16 = S // 16
-        self._per_image = True
-        self._wg_side = None
-        main = torch.cuda.current_stream()
-        side = self._side_streams(groups)
-        mid_in = self._E(B, S16, S16, features3)
-        mid_slices = [mid_in.images(k * per, (k + 1) * per) for k in range(groups)]
-        states = []
-        for s in side:
-            s.wait_stream(main)
-        for k, s in enumerate(side):
-            with torch.cuda.stream(s):
-                self._update_moving = k == 0
-                states.append(self._enc_fwd(lq[k * per:(k + 1) * per].contiguous(), mid_out=mid_slices[k]))
-        for s in side:
-            main.wait_stream(s)
-        self._update_moving = True          # image 0 of the merged pass = image 0 of the rank
-        ms = self._mid_fwd(mid_in)
-        daspp = self._E(B, S16, S16, aspp_output)
-        aspp_slices = [ms.aspp.images(k * per, (k + 1) * per) for k in range(groups)]
-        daspp_slices = [daspp.images(k * per, (k + 1) * per) for k in range(groups)]
-        for s in side:
-            s.wait_stream(main)
-        for k, s in enumerate(side):
-            with torch.cuda.stream(s):
-                self._update_moving = k == 0
-                self._dec_fwd(states[k], aspp_slices[k], truth[k * per:(k + 1) * per].contiguous())
-                self._dec_bwd(states[k], aspp_slices[k], daspp_slices[k])
-        for s in side:
-            main.wait_stream(s)
-        dx = self._mid_bwd(ms, daspp)
-        dx_slices = [dx.images(k * per, (k + 1) * per) for k in range(groups)]
-        for s in side:
-            s.wait_stream(main)
-        outs = []
-        for k, s in enumerate(side):
-            with torch.cuda.stream(s):
-                self._enc_bwd(states[k], dx_slices[k])
-                states[k].result.record_stream(main)
-            outs.append(states[k].result)
-        for s in side:
-            main.wait_stream(s)
-        self.last = {"out": states[0].out, "result": states[0].result}
-        self._keep = (states, ms, mid_in, daspp, dx)     # (alive until the next call: the side streams may still be reading)
-        return torch.cat(outs)
-
-    # ---- one training step -----------------------------------------------------------------------------------------
     def _side_streams(self, n):
         import torch
 
@@ -768,13 +727,8 @@ class DenoiserTrainer:
         if batched and tower_batch == 1 and B > 1:
             # the B one-image towers as ONE batched pass with per-image batch-norm statistics (see tower): same arithmetic per image
             groups = self.batched_groups(B)
-            # (towers_merged: the groups' 1/16-resolution parts as ONE pass of all B images -- measured 51.0 ms against 47.5 ms for the
-            # groups side by side all the way, profiles/r03_experiments.txt 15: four streams of small kernels fill the chip better than
-            # one stream of four-times larger ones; opt-in)
-            if groups > 1 and os.environ.get("EMD_T_MERGE", "0") == "1":
-                res = self.towers_merged(lq, truth, groups)
-                self._unpad_grads()
-                return res
+            # (the groups' 1/16-resolution parts merged into ONE pass of all B images was measured slower -- 51.0 ms against 47.5 ms for the
+            # groups side by side all the way, profiles/r03_experiments.txt 15 -- and removed in round 4; the six-segment tower stays)
             if groups > 1:
                 # ... as `groups` such passes on as many streams: at 8 images the 32 x 32 and 64 x 64 levels' kernels leave most CUs
                 # idle, two-image passes side by side fill them (8 pairs of 512^2: 50.9 ms as one pass, 48.5 as two, 47.1-47.8 as
@@ -888,3 +842,58 @@ class DenoiserTrainer:
         world = sync_gradients(self.grads, self.moving, group)
         self.apply_gradients(n_local * world, learning_rate)
         return results
+
+
+def get_model_fn(num_gpus, variable_strategy="GPU", num_workers=1, trainer=None):
+    """The reference's model-function factory (misc_py/denoiser-multi-gpu.py:634-717; machine_learning/denoiser.py:463-539):
+    ``get_model_fn(num_gpus, variable_strategy, num_workers)`` -> ``_model_fn(features, labels, mode, params)`` ->
+    ``[tower_losses, tower_preds, tower_mses, update_ops] + tower_grads``.
+
+    Here one process drives ONE GPU (the towers of a rank; the reference's in-graph towers across GPUs are ranks under
+    torch.distributed), so ``num_gpus`` is the number of towers this call evaluates -- ``len(features)`` must equal
+    ``max(num_gpus, 1)`` -- and ``variable_strategy`` / ``num_workers`` (where TensorFlow placed the variables) are accepted and have
+    nothing to decide: the variables live on the trainer's device.  ``trainer`` (or ``params['trainer']`` / ``params.trainer``) is the
+    DenoiserTrainer that owns weights, gradient vector and moving statistics.
+
+    _model_fn follows the reference line by line:
+    * tower i = ``_tower_fn(is_training, features[i], labels[i])`` (:752-782), which uses ONLY image 0 of the tower's shard
+      (``feature[0]``, :763): forward in training mode, mse, the Huberised loss (:772-773), ``tf.gradients`` w.r.t. every trainable;
+    * ``tower_grads[i]`` = list of that tower's gradients in ``tf.trainable_variables()`` order (= DenoiserTrainer.trainable's);
+      they are SEPARATE sets (copies of the trainer's gradient vector, which is zeroed between towers);
+    * ``update_ops`` = the moving-statistics assignments of tower 0 only (:701-707): here a dict name -> new value, already applied to
+      the trainer (the reference applies them when the train op runs, :1074);
+    * ``_tower_preds = tf.stack(preds)`` stacks the LAST tower's prediction only (:711 -- the loop variable, not the list); reproduced.
+    ``mode`` falsy (is_training False) would differentiate the inference-mode graph, which the reference never runs and which is not
+    built: ValueError."""
+
+    def _model_fn(features, labels=None, mode=None, params=None):
+        import torch
+
+        tr = trainer
+        if tr is None and params is not None:
+            tr = params.get("trainer") if isinstance(params, dict) else getattr(params, "trainer", None)
+        if tr is None:
+            raise ValueError("pass trainer=DenoiserTrainer(...) to get_model_fn, or params['trainer']")
+        if not mode:
+            raise ValueError("mode must be true (training): the reference's train loop never evaluates the towers with is_training False")
+        num_devices = max(int(num_gpus), 1)
+        if len(features) != num_devices or labels is None or len(labels) != num_devices:
+            raise ValueError(f"features / labels must be lists of {num_devices} per-tower tensors (input_fn's shard lists)")
+        tower_losses, tower_grads, tower_mses, preds, update_ops = [], [], [], None, {}
+        for i in range(num_devices):
+            f0 = features[i][0:1].contiguous()        # feature[0] (:763)
+            t0 = labels[i][0:1].contiguous()
+            tr.zero_grad()
+            before = tr.moving.clone() if i == 0 else None
+            preds, res = tr.tower(f0, t0, update_moving=(i == 0))
+            tr._unpad_grads()
+            tower_mses.append(res[0])
+            tower_losses.append(res[1])
+            tower_grads.append([g.clone() for g in tr.g.values()])
+            if i == 0:
+                changed = (tr.moving != before)
+                update_ops = {n: t.clone() for n, t in tr.m.items()}
+                update_ops["__changed__"] = bool(changed.any().item())
+        return [tuple(tower_losses), torch.stack([preds]), tuple(tower_mses), update_ops] + tower_grads
+
+    return _model_fn

@@ -85,7 +85,11 @@ def parse_args(argv=None):
     ap.add_argument("--profile-clean", action="store_true",
                     help="for rocprofv3: the primary workload's timed steps and NOTHING else in the process (no per-family attribution pass, no "
                          "isolated-GEMM / peak micro-benchmarks, no native executor, no pinned-host pass, no CPU legs): per-kernel averages of "
-                         "the trace then mean one thing")
+                         "the trace then mean one thing.  SINGLE stream by default (full-batch launches back to back: avg us x launches of a "
+                         "kernel family reproduces depthwise_frac / pointwise_frac by hand); --profile-streams two = the timed step's own form")
+    ap.add_argument("--profile-streams", choices=["single", "two"], default="single",
+                    help="with --profile-clean: single = DenoiserEngine.two_streams / .pipeline off (every launch is a full batch and runs alone); "
+                         "two = the two-half-batch form the headline step runs (a kernel's average then means 'beside the other half's kernels')")
     ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3",
                     help="matrix-core mode: bf16x3 = split-bf16 parity mode (default), bf16 = fast mode (never reported as parity)")
     return ap.parse_args(argv)
@@ -780,6 +784,8 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
         if B:
             box[0] = eng.forward(x)
 
+    if a.profile_clean and a.profile_streams == "single":
+        eng.two_streams = eng.pipeline = False
     ms = timer.run(step, steps, warmup)
     med = timer.median_event_ms
     if a.profile_clean:
@@ -997,6 +1003,9 @@ def bench_X(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
             box[0] = eng.forward(x)
 
     ms = timer.run(step, steps, warmup)
+    if a.profile_clean:   # for rocprofv3: the timed steps and nothing else (graph X is single stream by construction)
+        return {"value": round(total * H * W / 1e6 / (ms / 1e3), 1), "unit": "MPx/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+                "dtype": "bf16x3", "config": {"workload": f"X: [{B},{H},{W},1] fp32 per GPU", "profile_clean": True}, "roofline": None}
     with FamilyTimer(torch, ops) as fam:
         step()
     scale = (B / 32.0) * (H * W) / (512.0 * 512.0)
@@ -1189,6 +1198,10 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
         box[0] = tr.train_step(x, t, tower_batch=tb, streams=a.train_streams, graph=not a.no_graph, batched=a.tower_mode == "batched")
 
     ms = timer.run(step, steps, warmup)
+    if a.profile_clean:   # for rocprofv3: run with --no-graph so that the trace names every kernel of the step
+        return {"value": round(B * S * S / 1e6 * world / (ms / 1e3), 2), "unit": "MPx/s trained", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+                "dtype": "bf16x3", "config": {"workload": f"T: [{B},{S},{S},1] pairs per GPU, towers of {tb}, {a.tower_mode}", "profile_clean": True,
+                                              "hip_graph": not a.no_graph}, "roofline": None}
     tflop = 3 * 5.38 / 32.0 * B * (S * S) / (512.0 * 512.0)   # forward + data gradient + weight gradient
     out = {"value": round(B * S * S / 1e6 * world / (ms / 1e3), 2), "unit": "MPx/s trained", "ms_per_step": round(ms, 3),
            "median_hipevent_ms": timer.median_event_ms,

@@ -193,3 +193,45 @@ def test_two_stream_halves_are_the_same_bits(weights):
         one = eng.forward(x[5:6].contiguous())
         torch.cuda.synchronize()
         assert torch.equal(both, single) and torch.equal(both[5], one[0])
+
+
+@pytest.mark.gpu
+def test_headline_config_batch_32_at_512(engine, weights):
+    """BASELINE configs[2] itself, graph D at [32,512,512,1] (the bench line's shape): a batch of 32 sends halves of
+    16 images (M = 16 384 rows at 1/16 resolution) through gemm_split16_kernel<256,128>, which no smaller batch does.  Checks:
+    (1) the committed float64-oracle probes of tests/golden/d_graph_512.json on the first two images (the batch starts with the golden's
+    two inputs); (2) image b of the batch == the image run alone, bit for bit, for two b in different halves; (3) the two-stream
+    pipeline, the single-stream sequence and the library's native executor (csrc/graph_exec.hip) produce the same bits."""
+    from emdenoise.graph_exec import NativeGraph
+
+    meta = json.load(open(os.path.join(GOLDEN, "d_graph_512.json")))
+    assert meta["B"] == 2
+    x0 = synthetic_lq(2, 512, 512, seed=meta["seed"])
+    assert hashlib.sha256(x0.tobytes()).hexdigest() == meta["x_sha256"], "synthetic input generator changed"
+    x = np.concatenate([x0, synthetic_lq(30, 512, 512, seed=4321)])
+    xd = torch.from_numpy(x).cuda()
+    assert engine.two_streams
+    yd = engine.forward(xd).clone()
+    y = yd.cpu().numpy()
+    assert y.shape == (32, 512, 512, 1) and np.isfinite(y).all()
+    pr = np.array(meta["probes"])       # [n,3] = b, row, col with b in {0, 1}
+    ref = np.array(meta["values"], np.float64)
+    r = rel_l2(y[pr[:, 0], pr[:, 1], pr[:, 2], 0], ref)
+    print(f"D graph [32,512,512,1]: golden probes of images 0, 1: rel L2 {r:.2e}")
+    assert r < 3e-4
+    for b in (1, 21):                   # one image of each half batch
+        one = engine.forward(xd[b:b + 1].contiguous())
+        assert torch.equal(one[0], yd[b]), f"image {b} of the batch differs from the image alone"
+    two, pipe = engine.two_streams, engine.pipeline
+    try:
+        engine.two_streams = engine.pipeline = False
+        assert torch.equal(engine.forward(xd), yd), "single-stream sequence != two-stream pipeline"
+    finally:
+        engine.two_streams, engine.pipeline = two, pipe
+    nat = NativeGraph(weights, torch.device("cuda", 0))
+    try:
+        got = nat.forward(xd)
+        torch.cuda.synchronize()
+        assert torch.equal(got, yd), "native executor != Python engine at [32,512,512,1]"
+    finally:
+        nat.close()
