@@ -46,5 +46,8 @@ struct SepParams {
 bool sep_pipe_covers(const SepParams& p, int precision);
 // sep_pipe.hip: launches it; p.N2 > 0 selects the two-output (DUAL) instances
 int sep_pipe_launch(const SepParams& p, int B, hipStream_t st);
+// sep_pipe2.hip: the software-pipelined form (8 x 32 tiles, stride 1): sep_pipe_launch hands it the shapes the rule below gives it
+bool sep_pipe2_covers(const SepParams& p);
+int sep_pipe2_launch(const SepParams& p, int B, hipStream_t st);
 
 }  // namespace emd

@@ -443,8 +443,9 @@ class DenoiserTrainer:
         fewer launches.  result3 is then [B, 3].
         wgrad_stream=True: the weight-gradient launches of the backward pass go to a side stream (see _wg); same arithmetic.
 
-        The pass is six segments (_enc_fwd, _mid_fwd, _dec_fwd, _dec_bwd, _mid_bwd, _enc_bwd) so that the 1/16-resolution part can be driven on its own (round 3 ran it for several groups as ONE pass: slower, removed);
-        1/16-resolution part of several groups of images as ONE pass; here they simply follow each other."""
+        The pass is six segments (_enc_fwd, _mid_fwd, _dec_fwd, _dec_bwd, _mid_bwd, _enc_bwd) so that the
+        1/16-resolution part can be driven on its own (round 3 ran it for several groups as ONE pass: slower, removed in round 4); here
+        they simply follow each other."""
         import torch
 
         self._update_moving = update_moving

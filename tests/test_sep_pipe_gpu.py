@@ -1,4 +1,4 @@
-"""GPU parity tests of the LDS-DMA pipelined fused separable conv (csrc/sep_pipe.hip), reached through the same C-ABI entry points
+"""GPU parity tests of the LDS-DMA pipelined fused separable convs (csrc/sep_pipe.hip and, round 4, csrc/sep_pipe2.hip), reached through the same C-ABI entry points
 as the register-staged kernel it replaces for W % 32 == 0 (emd_sep3x3_fused_f32 / _out_f32 / _reflect_f32 / emd_sep3x3_dual_f32):
 
   * against the oracle's TF-op restatement (oracle/tf_ops.py, float64): machine_learning/denoiser.py:110-136 (the separable block),
@@ -19,15 +19,19 @@ from tests.test_ops_gpu import TOL_X3, dev, out_act, rel_l2, rnd, t64, to_act
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[0, 4], ids=["epi_rule", "epi_16B"])
+@pytest.fixture(autouse=True, params=[(0, 2), (4, 2), (0, 0)], ids=["epi_rule", "epi_16B", "lockstep"])
 def _restore_knobs(request):
-    """Every test runs with the epilogue the kernel's rule picks (per-channel dword stores, mostly) and with the transposed 16-byte form
-    forced (dev knob epi_width = 4): same values, other lanes."""
+    """Every test runs (a) on the software-pipelined kernel (csrc/sep_pipe2.hip, round 4) wherever it has an instance -- dev knob sep_pipe2
+    = 2; the product rule, 1, leaves some residual shapes to sep_pipe.hip -- with the epilogue its rule picks (per-channel dword
+    stores, mostly), (b) the same with the transposed 16-byte epilogue forced (dev knob epi_width = 4): same values, other lanes, and
+    (c) with sep_pipe2 = 0: the lockstep kernel (csrc/sep_pipe.hip) alone, as in round 3.  sep_nw = 4 always means sep_pipe.hip's
+    4-wave form."""
     from emdenoise import _lib
 
-    _lib.knob("epi_width", request.param)
+    _lib.knob("epi_width", request.param[0])
+    _lib.knob("sep_pipe2", request.param[1])
     yield
-    for k, v in (("sep_pipe", 1), ("sep_mode", -1), ("sep_tpw", 0), ("sep_nw", 0), ("epi_width", 0)):
+    for k, v in (("sep_pipe", 1), ("sep_pipe2", 1), ("sep_mode", -1), ("sep_tpw", 0), ("sep_nw", 0), ("epi_width", 0)):
         _lib.knob(k, v)
 
 

@@ -85,9 +85,11 @@ def test_model_fn_returns_the_reference_list():
     from emdenoise import denoiser as D, trainer as TR
     from oracle import denoiser_graph as G
 
+    from tests.test_train_gpu import weights as train_weights
+
     dev = torch.device("cuda", 0)
     S = 64
-    w = D.synthetic_weights(variant="Dprime")
+    w = train_weights(smooth=True)      # no relu6 / clip unit near a kink: the whole reverse pass compares tightly (tests/test_train_gpu.py)
     lq, hq = synthetic_pair(4, S, S, seed=12)
     tr = TR.DenoiserTrainer(w, dev)
     fn = TR.get_model_fn(2, "GPU", 1, trainer=tr)
@@ -106,7 +108,7 @@ def test_model_fn_returns_the_reference_list():
         a = np.concatenate([grads[i][k].cpu().numpy().astype(np.float64).ravel() for k in nz])
         b = np.concatenate([np.asarray(ref["grads"][names[k]], np.float64).ravel() for k in nz])
         cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
-        assert cos > 0.998 and rel_l2(a, b) < 6e-2, (i, cos)       # reference regime: relu6 mask flips (tests/test_train_gpu.py)
+        assert cos > 0.99999 and rel_l2(a, b) < 2e-3, (i, cos, rel_l2(a, b))
         if i == 1:
             assert rel_l2(preds[0].cpu().numpy(), ref["out"].numpy()) < 1e-3      # the LAST tower's prediction
         if i == 0:

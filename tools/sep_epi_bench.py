@@ -20,7 +20,9 @@ dev = torch.device("cuda", 0)
 B = int(os.environ.get("SB_B", "32"))
 REP, ROUNDS = 5, 3
 KNOB = os.environ.get("SEB_KNOB", "epi_width")
-VALS = (1, 4) if KNOB == "epi_width" else (8, 4)
+VALS = tuple(int(v) for v in os.environ["SEB_VALS"].split(",")) if "SEB_VALS" in os.environ else ((1, 4) if KNOB == "epi_width" else (0, 2) if KNOB == "sep_pipe2" else (8, 4))
+RESET = 1 if KNOB == "sep_pipe2" else 0
+ONLY = os.environ.get("SEB_ONLY", "")
 _lib.load()
 
 
@@ -36,6 +38,8 @@ def timed(fn):
 
 tot = {v: 0.0 for v in VALS}
 for nm, (S, ci, co, res, co2, osplit, stride) in SHAPES.items():
+    if ONLY and nm not in ONLY.split(","):
+        continue
     g = torch.Generator(device=dev).manual_seed(1)
     x = ops.Act(torch.rand(B, S, S, ci, device=dev, generator=g))
     w = torch.rand(9, ci, device=dev, generator=g) - 0.5
@@ -60,7 +64,7 @@ for nm, (S, ci, co, res, co2, osplit, stride) in SHAPES.items():
                 ops.sep_dual(x, w, pw, pw2, s1, t1, out, sb, tb, out2)
             else:
                 ops.sep_fused(x, w, pw, s1, t1, out, res=r, stride=stride)
-            _lib.knob(KNOB, 0)
+            _lib.knob(KNOB, RESET)
         fns[ew] = fn
     for f in fns.values():
         f(); f()
@@ -73,5 +77,6 @@ for nm, (S, ci, co, res, co2, osplit, stride) in SHAPES.items():
             T[k].append(timed(f))
     for k in T:
         tot[k] += float(np.median(T[k]))
-    print(f"{nm:13s} same bits {same}: " + "  ".join(f"{KNOB}={k} {np.median(T[k]):8.1f} us" for k in T), flush=True)
+    gb = 4.0 * B * (S * S * ci + So * So * (co + co2 + (co if res else 0))) / 1e9      # algorithmic bytes: input + outputs (+ residual)
+    print(f"{nm:13s} same bits {same}: " + "  ".join(f"{KNOB}={k} {np.median(T[k]):8.1f} us ({gb / np.median(T[k]) * 1e3:5.2f} TB/s)" for k in T), flush=True)
 print("sum: " + "  ".join(f"{KNOB}={k} {v:8.1f} us" for k, v in tot.items()))
