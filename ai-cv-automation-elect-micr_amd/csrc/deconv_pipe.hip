@@ -22,10 +22,10 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
 }
 __device__ __forceinline__ void store_nt_s(const void* sbase, unsigned voff, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 3" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void store_nt_s(const void* sbase, unsigned voff, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 3" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 // Fragment reads by hand: the compiler neither sees them nor waits for them (it would wait with lgkmcnt(0), i.e. also for the NEXT
 // unit's reads issued behind them); wait_frags<N> lets the N youngest LDS reads stay in flight and ties the registers to the wait.

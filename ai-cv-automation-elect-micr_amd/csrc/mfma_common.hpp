@@ -16,10 +16,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // HIP's float4/ui
 // else plain store" is merged into ONE plain store by the optimizer (the merged store keeps only the metadata both sides share).
 // The s_nop covers the store-data hazard the compiler cannot see inside the asm.
 __device__ __forceinline__ void store_nt16(void* dst, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" ::"v"(dst), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 3" ::"v"(dst), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_nt16(void* dst, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" ::"v"(dst), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 3" ::"v"(dst), "v"(v) : "memory");
 }
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 

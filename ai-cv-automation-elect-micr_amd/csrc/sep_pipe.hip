@@ -735,14 +735,17 @@ bool sep_pipe_covers(const SepParams& p, int precision) {
     return p.N <= 256;
 }
 
-// Which launches go to the software-pipelined kernel (sep_pipe2.hip; same bits).  Dev knob sep_pipe2: 0 none, 2 everything it has an
-// instance for, 1 (default) the rule: everything except a residual on more than 64 columns (those instances fetch the residual values
-// inside the epilogue -- holding them in registers one slot early, as the 64-column instance does, spills beside 64+ accumulators).
-// A forced 4-wave form (dev knob sep_nw = 4) always means this file's kernel.
+// Which launches go to the software-pipelined kernel (sep_pipe2.hip; same bits).  Dev knob sep_pipe2: 0 (default) none, 1 the two-output
+// launches with more than 64 columns per output (deconv1_a + residual1_d, 384 -> 128 | 128: the one shape whose slots are matrix-core
+// bound), 2 everything it has an instance for (the parity tests).  Measured (profiles/r04_experiments.txt 3): standalone at parity on
+// that shape (2034 / 2070 us against 2059 / 2004 on two boxes), 5-50 % SLOWER on every one-output shape -- where this file's 4-wave
+// two-workgroups-per-CU form wins: both kernels are bound by instruction issue and by phases no other wave fills, and the pipelined one
+// issues ~1.9 x the instructions per chunk -- and graph D 22.10 ms with 0, 22.26 with 1, 23.07 with 2 in one process.  A forced 4-wave
+// form (dev knob sep_nw = 4) always means this file's kernel.
 static bool use_pipe2(const SepParams& p) {
     if (!g_knobs.sep_pipe2 || g_knobs.sep_ablate || g_knobs.sep_nw == 4 || !sep_pipe2_covers(p)) return false;
     if (g_knobs.sep_pipe2 == 2) return true;
-    return !(p.res && p.N > 64);
+    return p.N2 > 0 && (p.N > 64 || p.N2 > 64);
 }
 
 int sep_pipe_launch(const SepParams& p, int B, hipStream_t st) {

@@ -118,9 +118,9 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
             pmove |= real ? 1u << j : 0u;
         }
     };
-    auto issue_patch = [&](int stage, int coff) {   // coff: channel offset of the chunk (floats)
+    auto issue_patch = [&](int stage, int coff, int j0 = 0, int j1 = PP) {   // coff: channel offset of the chunk (floats); pieces j0 .. j1-1 of this wave
 #pragma unroll
-        for (int j = 0; j < PP; ++j) {
+        for (int j = j0; j < j1; ++j) {
             int q = wv + NW * j;
             if (q >= NPIECE) q -= NW;
             __builtin_amdgcn_global_load_lds((gptr_t)(psrc[j] + coff), (lptr_t)(smem + stage * STAGE + q * 1024), 16, 0, 0);
@@ -156,9 +156,12 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
     // {g, g + 2} x 8 channel pairs (conflict-free 8-byte reads under the patch swizzle, see the header)
     const int c2 = lane & 7, pgi = (lane >> 3) & 3, q16 = 2 * wv + (lane >> 5);
     const int xpair = q16 & 3, dy = 2 * (q16 >> 2) + (pgi >> 1), dx = 4 * ((xpair & 1) + 4 * (xpair >> 1) + 2 * (pgi & 1));
-    int rd0[3];       // byte offset inside a stage of this thread's 8 bytes of patch pixel (dy, dx + 2 m [+ 1]), K half 0 (half 1: ^ 64)
+    int rdv[2][3];    // byte offset inside a stage of this thread's 8 bytes of patch pixel (dy, dx + 2 m [+ 1]), K half h
 #pragma unroll
-    for (int m = 0; m < 3; ++m) rd0[m] = (dy * PWS + dx) * 128 + ((((c2 >> 1)) ^ (((dx >> 1) + m) & 7)) << 4) + (c2 & 1) * 8;
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            rdv[h][m] = (dy * PWS + dx) * 128 + (((h * 4 + (c2 >> 1)) ^ (((dx >> 1) + m) & 7)) << 4) + (c2 & 1) * 8;
     const int wk_off = WK0 * 128 + c2 * 8;                       // + h * 64 + tap * WKS * 128
     const int ga_w = (dx >> 2) & 3;
     const int a_wr = A_OFF + (dy * TW + dx) * 64 + (((c2 >> 2) ^ ga_w) << 4) + (c2 & 3) * 4;   // hi dword of pixel j: + 64 j; lo: ^ 32; half: + A_HALF
@@ -170,10 +173,14 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
     //   projection : fp32 centre pixels of the patch, chunks (2 fh, 2 fh + 1) of K half h: stage + (cen ^ 64 h) + 35 * 128 i, and ^ 16
     const int a_rd = A_OFF + (row0 + fr) * 64 + ((fh ^ gf) << 4);
     const int cen = ((row0 / TW + 1) * PWS + fr + 1) * 128 + (((fh * 2) ^ (((fr + 1) >> 1) & 7)) << 4);
-    const int fa0 = out2 ? cen : a_rd;                           // K half 0 ...
-    const int fa1 = out2 ? (cen ^ 64) : a_rd + A_HALF;           // ... and 1
-    const int fstride = out2 ? PWS * 128 : 2048, fxor = out2 ? 16 : 32;
-    const int b_rd = B_OFF + (wn * 64 + fr) * 64 + ((fh ^ gf) << 4);              // N tile j: + 2048 j; lo: ^ 32; K half: + B_HALF
+    int fav[2][2];                                               // [K half][first / second 16-byte read]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) fav[h][e] = out2 ? (cen ^ (h * 64) ^ (e * 16)) : ((a_rd + h * A_HALF) ^ (e * 32));
+    const int fstride = (DUAL && out2) ? PWS * 128 : 2048;       // (a compile-time 2048 in the one-output instances: immediates)
+    const int b_rd = B_OFF + (wn * 64 + fr) * 64 + ((fh ^ gf) << 4);              // N tile j: + 2048 j; K half: + B_HALF
+    const int b_rd2 = b_rd ^ 32;                                                   // the lo fragment
 
     // ---- epilogue constants: lane = output channel.  The per-channel affines are fetched IN the epilogue (once per tile, L2 hits): held
     // in registers across the slots they were 8 of the 256 a lane has, and the slots spill without them
@@ -442,17 +449,18 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
     // Issue order: [MFMAs of a quarter | FMAs of one patch row | the reads the next quarter needs] x 3, then [MFMAs | hi / lo split + A
     // writes]: the MFMAs between a read and its use hide the LDS latency, only ONE row of the 3 x 6 window is live at a time, and
     // sched_barrier pins the segments (inside one the hardware interleaves: an MFMA holds the vector issue for 8 of its 32 cycles).
-    auto slot_body = [&](int odd, int stg) {
+    struct SlotDma { int hm, cm, hp, cp, patch, pstage, pcoff, rp, x; };   // what a slot requests (see the loop); patch / rp: flags
+    auto slot_body = [&](const int odd, const int stg, const bool DIN, const SlotDma& dq) {   // DIN: the slot's DMA pieces go out between the segments
         const int hs = 1 - odd;                          // K half the depthwise stage produces
         const int hm = out2 ? 1 - odd : odd;             // K half of this wave's MFMAs
         // every LDS access is smem + an integer byte offset (a pointer that went through an integer XOR loses its address space: flat loads)
-        const int fa = (out2 ? stg : 0) + (hm ? fa1 : fa0);
-        const int fb = b_rd + hm * B_HALF;
+        const int fa_1 = (out2 ? stg : 0) + (hm ? fav[1][0] : fav[0][0]), fa_2 = (out2 ? stg : 0) + (hm ? fav[1][1] : fav[0][1]);
+        const int fb = b_rd + hm * B_HALF, fb2 = b_rd2 + hm * B_HALF;
         const int swk = stg + wk_off + hs * 64;
+        const int aw = a_wr + hs * A_HALF;
         int srd[3];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) srd[m] = stg + (rd0[m] ^ (hs * 64));
-        const int aw = a_wr + hs * A_HALF;
+        for (int m = 0; m < 3; ++m) srd[m] = stg + (hs ? rdv[1][m] : rdv[0][m]);
         f32x2v wk[3], pr[6], o[4];
         auto rd_row = [&](int i) {
 #pragma unroll
@@ -475,13 +483,17 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 bh[j] = *reinterpret_cast<const bf16x8*>(smem + fb + j * 2048);
-                bl[j] = *reinterpret_cast<const bf16x8*>(smem + ((fb + j * 2048) ^ 32));
+                bl[j] = *reinterpret_cast<const bf16x8*>(smem + fb2 + j * 2048);
             }
         };
         auto ld_a = [&](int i) {
-            const int q = fa + i * fstride;
-            f0[i] = *reinterpret_cast<const u32x4*>(smem + q);
-            f1[i] = *reinterpret_cast<const u32x4*>(smem + (q ^ fxor));
+            if constexpr (DUAL) {
+                f0[i] = *reinterpret_cast<const u32x4*>(smem + fa_1 + i * fstride);
+                f1[i] = *reinterpret_cast<const u32x4*>(smem + fa_2 + i * fstride);
+            } else {
+                f0[i] = *reinterpret_cast<const u32x4*>(smem + fa_1 + i * 2048);
+                f1[i] = *reinterpret_cast<const u32x4*>(smem + fa_2 + i * 2048);
+            }
         };
         auto cvt_a = [&](int i) {
             if constexpr (DUAL) {
@@ -519,6 +531,10 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
         };
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = f32x2v{0.f, 0.f};
+        // The slot's patch pieces go out BETWEEN the segments, two per segment (the weight pieces, one or two, at the top of the slot:
+        // they are what the slot's end waits for): issued in one block at the top of the slot they cost every wave ~1000 cycles in which
+        // nothing else runs (a piece occupies the CU's one address path for >= 16 cycles and the issuing wave until it is accepted).
+        constexpr int P3 = (PP + 2) / 3;
         ld_b();
         seg_pre(0);
         rd_row(0);
@@ -527,15 +543,18 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
         fma_row();
         rd_row(1);
         seg_pre(1);
+        if (DIN && dq.patch) issue_patch(dq.pstage, dq.pcoff, 0, P3);
         __builtin_amdgcn_sched_barrier(0);
         seg_mm(1);
         fma_row();
         rd_row(2);
         seg_pre(2);
+        if (DIN && dq.patch) issue_patch(dq.pstage, dq.pcoff, P3, 2 * P3 < PP ? 2 * P3 : PP);
         __builtin_amdgcn_sched_barrier(0);
         seg_mm(2);
         fma_row();
         seg_pre(3);
+        if (DIN && dq.patch) issue_patch(dq.pstage, dq.pcoff, 2 * P3 < PP ? 2 * P3 : PP, PP);
         __builtin_amdgcn_sched_barrier(0);
         seg_mm(3);
 #pragma unroll
@@ -568,27 +587,32 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
         const int ct2 = ct1 + 1 == nchunks ? 0 : ct1 + 1;
         const bool last0 = k >= 0 && ct1 == 0;        // chunk k is the last of its tile
         const bool rp = RPRE && res_on && last0;
-        // ---- epilogue of the tile whose last MFMAs ran in the slot before (projection waves in the odd slot, the block's in the even one) and
-        // this slot's DMA issue: weights first (what the slot's end waits for), then residual values, then the patch.  The epilogue comes
-        // BEHIND the DMA issue -- its stores are then the youngest entries of the in-order queue and have until the end of the NEXT slot
-        // to drain -- except with a residual: the compiler's wait for the residual values would also cover the pieces just issued.
+        // ---- what this slot requests, the epilogue of the tile whose last MFMAs ran in the slot before (projection waves: odd slot, the
+        // block's: even slot), the slot's arithmetic
         const bool epi_here = last0 && (odd != 0) == out2;
-        const bool epi_first = epi_here && res_on;
-        if (epi_first) epilogue(x_epi);
-        if (odd) {
-            issue_B(0, ct1 * 32, 1, ct1 * 32);        // block: step 2k + 2; projection: step 2k + 3
-            if (rp) res_prefetch(x_epi);
-            if (k >= 0) {
-                advance_issue();
-                issue_patch(k & 1, ic * 32);          // chunk k + 2 into the stage chunk k has left
-            }
+        SlotDma dq;
+        dq.hm = odd ? 0 : 1; dq.cm = ct1 * 32;                  // block: step 2k + 2 (odd slot) / 2k + 3 (even slot)
+        dq.hp = odd ? 1 : 0; dq.cp = (odd ? ct1 : ct2) * 32;    // projection: step 2k + 3 / 2k + 4
+        dq.patch = odd && k >= 0; dq.pstage = k & 1;            // odd slot: chunk k + 2 into the stage chunk k has left
+        dq.rp = rp && odd; dq.x = x_epi;
+        if (dq.patch) advance_issue();
+        dq.pcoff = ic * 32;
+        if (epi_here) {
+            // a slot with an epilogue issues its DMA pieces here, in one block: the epilogue must precede the slot's MFMAs, and its stores
+            // should be the YOUNGEST entries of the in-order queue (they then have until the end of the next slot to drain) -- except with
+            // a residual: the compiler's wait for the residual values would also cover the pieces just issued, so it goes first
+            const bool epi_first = res_on;
+            if (epi_first) epilogue(x_epi);
+            issue_B(dq.hm, dq.cm, dq.hp, dq.cp);
+            if (dq.patch) issue_patch(dq.pstage, dq.pcoff);
+            if (!epi_first) epilogue(x_epi);
         } else {
-            issue_B(1, ct1 * 32, 0, ct2 * 32);        // block: step 2k + 3; projection: step 2k + 4
+            issue_B(dq.hm, dq.cm, dq.hp, dq.cp);   // (the weights at the top: they have the whole slot to land; the patch pieces between the segments)
+            if (dq.rp) res_prefetch(dq.x);
         }
-        const bool epi_last = epi_here && !epi_first; // its stores are younger than every DMA piece of this slot
-        if (epi_last) epilogue(x_epi);
+        const bool epi_last = epi_here && !res_on;            // its stores are younger than every DMA piece of this slot
         PIPE_STAMP(0)
-        slot_body(odd, stg);
+        slot_body(odd, stg, !epi_here, dq);
         if (s == -1 && !out2) zero_acc();
         PIPE_STAMP(1)
         wait_lgkm0();

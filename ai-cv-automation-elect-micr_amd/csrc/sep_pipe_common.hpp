@@ -20,13 +20,17 @@ __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0
 // (the outputs are not re-read by this launch: L2 is kept for the patch halos).  Inline asm: the address form costs one VGPR per lane
 // instead of a 64-bit pointer per access, and the loads are waited for by hand (wait_vm) -- the compiler does not see them.
 // 16 bytes per lane, not 4: tools/dmabench.hip measures dword stores of this shape at 2.9 TB/s against 6.0 for dwordx4.
-// The s_nop covers the store-data hazard the compiler cannot see inside the asm (a store of more than 64 bits reads its data late:
-// the next instruction must not overwrite those registers).
+// The s_nop covers the store-data hazard the compiler cannot see inside the asm: a store of more than 64 bits reads its data late, and a
+// VALU write to those registers must stay >= 2 wait states behind it on this ISA (LLVM's hazard recognizer: 2 for gfx940+).  Rounds 1-3
+// had "s_nop 0" (ONE wait state), which held while the compiler happened to put other work first; round 4's epilogue with plain residual
+// loads got a v_lshl_add_u64 (the next load's address, allocated INTO the dead store-data registers) two instructions behind the
+// store, and the last four lanes of every 16 stored the address words instead of two channels -- intermittently, 64 values per tile
+// (tools/sep2_debug.py).  s_nop 3 = four wait states, in every copy of this helper (conv3_pipe.hip, deconv_pipe.hip, mfma_common.hpp).
 __device__ __forceinline__ void store_nt_s(const void* sbase, unsigned voff, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 3" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void store_nt_s(const void* sbase, unsigned voff, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 3" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ f32x4 load_s(const void* sbase, unsigned voff) {
     f32x4 v;

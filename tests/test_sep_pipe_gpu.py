@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=[(0, 2), (4, 2), (0, 0)], ids=["epi_rule", "epi_16B", "lockstep"])
 def _restore_knobs(request):
     """Every test runs (a) on the software-pipelined kernel (csrc/sep_pipe2.hip, round 4) wherever it has an instance -- dev knob sep_pipe2
-    = 2; the product rule, 1, leaves some residual shapes to sep_pipe.hip -- with the epilogue its rule picks (per-channel dword
+    = 2; it is off by default (0: measured no faster, profiles/r04_experiments.txt) -- with the epilogue its rule picks (per-channel dword
     stores, mostly), (b) the same with the transposed 16-byte epilogue forced (dev knob epi_width = 4): same values, other lanes, and
     (c) with sep_pipe2 = 0: the lockstep kernel (csrc/sep_pipe.hip) alone, as in round 3.  sep_nw = 4 always means sep_pipe.hip's
     4-wave form."""
@@ -31,7 +31,7 @@ def _restore_knobs(request):
     _lib.knob("epi_width", request.param[0])
     _lib.knob("sep_pipe2", request.param[1])
     yield
-    for k, v in (("sep_pipe", 1), ("sep_pipe2", 1), ("sep_mode", -1), ("sep_tpw", 0), ("sep_nw", 0), ("epi_width", 0)):
+    for k, v in (("sep_pipe", 1), ("sep_pipe2", 0), ("sep_mode", -1), ("sep_tpw", 0), ("sep_nw", 0), ("epi_width", 0)):
         _lib.knob(k, v)
 
 

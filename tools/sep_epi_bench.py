@@ -21,7 +21,7 @@ B = int(os.environ.get("SB_B", "32"))
 REP, ROUNDS = 5, 3
 KNOB = os.environ.get("SEB_KNOB", "epi_width")
 VALS = tuple(int(v) for v in os.environ["SEB_VALS"].split(",")) if "SEB_VALS" in os.environ else ((1, 4) if KNOB == "epi_width" else (0, 2) if KNOB == "sep_pipe2" else (8, 4))
-RESET = 1 if KNOB == "sep_pipe2" else 0
+RESET = 0
 ONLY = os.environ.get("SEB_ONLY", "")
 _lib.load()
 
@@ -78,5 +78,19 @@ for nm, (S, ci, co, res, co2, osplit, stride) in SHAPES.items():
     for k in T:
         tot[k] += float(np.median(T[k]))
     gb = 4.0 * B * (S * S * ci + So * So * (co + co2 + (co if res else 0))) / 1e9      # algorithmic bytes: input + outputs (+ residual)
-    print(f"{nm:13s} same bits {same}: " + "  ".join(f"{KNOB}={k} {np.median(T[k]):8.1f} us ({gb / np.median(T[k]) * 1e3:5.2f} TB/s)" for k in T), flush=True)
+    stamp_txt = ""
+    if os.environ.get("SEB_STAMPS"):     # in-kernel phase stamps of workgroup wave 0 (sep_pipe2: top of slot = DMA issue + epilogue | slot body | wait + barrier)
+        import ctypes
+        lib = _lib.load()
+        for k, f in fns.items():
+            st = torch.zeros(B * (S // 8) * (S // 16) * 8, dtype=torch.int64, device=dev)
+            lib.emd_debug_sep_stamps(ctypes.c_void_p(st.data_ptr()))
+            f()
+            torch.cuda.synchronize()
+            lib.emd_debug_sep_stamps(ctypes.c_void_p(0))
+            v = st.view(-1, 8).double()
+            v = v[v.sum(1) > 0]
+            m = v.mean(0)
+            stamp_txt += f"\n      stamps {KNOB}={k}: {len(v)} workgroups, {m.sum().item():.0f} ticks each: " + " ".join(f"[{i}] {100 * a / m.sum().item():.0f}%" for i, a in enumerate(m.tolist()) if a > 0)
+    print(f"{nm:13s} same bits {same}: " + "  ".join(f"{KNOB}={k} {np.median(T[k]):8.1f} us ({gb / np.median(T[k]) * 1e3:5.2f} TB/s)" for k in T) + stamp_txt, flush=True)
 print("sum: " + "  ".join(f"{KNOB}={k} {v:8.1f} us" for k, v in tot.items()))
