@@ -123,6 +123,12 @@ SIGNATURES = {
     # x ldx B npix_img C mean var workspace stream
     "emd_bn_stats_images_f32": (C.c_int, [_c_float_p, C.c_int, C.c_int, C.c_long, C.c_int, _c_float_p, _c_float_p, C.c_void_p,
                                           C.c_void_p]),
+    "emd_conv_stats_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int]),
+    # x ldx whi wlo ones zeros y ldy B H W Cin Cout stride|rate precision images mean var workspace stream
+    "emd_conv1x1_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] +
+                              [C.c_int] * 8 + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
+    "emd_conv3x3_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] +
+                              [C.c_int] * 8 + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
     # x ldx scale shift res ldres y ldy B npix_img C act stream
     "emd_affine_act_images_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p,
                                             C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]),

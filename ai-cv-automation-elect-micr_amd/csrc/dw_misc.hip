@@ -777,12 +777,13 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
 // second stage of the batch statistics (sum over `nslab` partials per channel, fixed order), for producers of partials
 // outside this file (the statistics epilogue of gemm_split.hip)
 int emd::launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st,
-                               const float* gamma, const float* beta, float eps, float* scale, float* shift) {
+                               const float* gamma, const float* beta, float eps, float* scale, float* shift, int images) {
+    // images > 1: per-image statistics -- `nslab` partials and `npix` pixels PER IMAGE, part [image][nslab][2][C], mean / var [image][C]
     if (scale)
         hipLaunchKernelGGL(bn_stats_final<true>, dim3((C + 15) / 16), dim3(256), 0, st, part, nslab, C, npix, mean, var, gamma, beta,
                            eps, scale, shift);
     else
-        hipLaunchKernelGGL(bn_stats_final<false>, dim3((C + 15) / 16), dim3(256), 0, st, part, nslab, C, npix, mean, var);
+        hipLaunchKernelGGL(bn_stats_final<false>, dim3((C + 15) / 16, images > 1 ? images : 1), dim3(256), 0, st, part, nslab, C, npix, mean, var);
     return emd::check_launch("bn_stats_final");
 }
 

@@ -39,7 +39,7 @@ int launch_conv3x3_cout1_reflect_roll(const float* x, int ldx, const float* w, f
 
 int launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st,
                           const float* gamma = nullptr, const float* beta = nullptr, float eps = 0.f, float* scale = nullptr,
-                          float* shift = nullptr);   // scale != NULL: the norm is folded in the same launch
+                          float* shift = nullptr, int images = 1);   // scale != NULL: the norm is folded in the same launch; images > 1 (no fold): per-image statistics
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -67,6 +67,8 @@ struct Knobs {
     int split_wide = 0;      // pointwise split32 GEMM: 256 x 192 tiles (gemm_split16_wide_kernel) where they fill the chip: 0 never (default: slower in graph D), 1 = 8 waves of 64 x 96, 2 = 4 waves of 128 x 96
     int conv3_pipe = 1;      // dense 3x3 conv (stride 1, rate 1, H % 8 == 0, W % 32 == 0) on the patch-resident kernel (conv3_pipe.hip): 1 = up to 192 output channels, 2 = any width, 0 = never
     int split_variant = -1;  // pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
+    int wgrad_msplit = 0;    // weight-gradient GEMM: slices of the pixel dimension (each adds its partial sums atomically): 0 = rule, n = at most n
+    int wgrad_tile = 0;      // weight-gradient GEMM: 0 = rule (128 where a dimension exceeds 64), 64 = 64 x 64 tiles everywhere
     long long* sep_stamps = nullptr;   // device buffer for the in-kernel phase stamps of the fused separable convs
 };
 extern Knobs g_knobs;

@@ -58,6 +58,8 @@ struct GemmParams {
     int Hg, Wg, Ha, Wa, Hc, Wc, sa, sc, py, px;
     unsigned long long dyp, dxp;  // per-tap source offsets, 7 bits each, biased by 64 (no dynamic kernarg indexing)
     int n_mtiles, n_ntiles;
+    double* stats_part;   // optional [n_mtiles][2][N]: per-channel sum / sum of squares of the values each M tile STORES (training: the
+                          // batch norm behind the conv takes batch statistics -- no second pass over y)
 };
 
 // Block tile 128 x BN (BN = 128: 2x2 waves of 64x64; BN = 64: 4x1 waves of 32x64), K step 64.
@@ -274,6 +276,8 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
     constexpr int NROWS = BM / ROWS_PER_PASS;
     const int ec = (tid % C4) * 4, er = tid / C4;
     const int n = n0 + ec;
+    double ssum[4] = {0.0, 0.0, 0.0, 0.0}, ssq[4] = {0.0, 0.0, 0.0, 0.0};
+    static_assert(ROWS_PER_PASS * BN * 2 * 8 <= TILE_BYTES && 2 * BN <= 256, "the statistics reduction reuses the tile memory");
     if (n < p.N) {                        // N % 4 == 0: a chunk is all inside or all outside
         const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n);
         const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n);
@@ -313,12 +317,47 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
                 const long long pix = rowP[r];
                 if (pix >= 0) *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec])) + rv[k];
             }
+        } else if (p.stats_part) {
+            // batch statistics of the output gathered while the tile is in hand (as gemm_split.hip's: per-thread double sums over its
+            // rows here, row groups -> 1 below, one partial per (M tile, channel) for the fixed-order final reduction bn_stats_final)
+#pragma unroll 4
+            for (int r = er; r < BM; r += ROWS_PER_PASS) {
+                const long long pix = rowP[r];
+                if (pix < 0) continue;
+                const f32x4 v = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec]));
+                *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double d = (double)v[c];
+                    ssum[c] += d;
+                    ssq[c] += d * d;
+                }
+            }
         } else {
 #pragma unroll 4
             for (int r = er; r < BM; r += ROWS_PER_PASS) {
                 const long long pix = rowP[r];
                 if (pix < 0) continue;
                 *reinterpret_cast<f32x4*>(outp + pix * p.ldc + n) = finish(*reinterpret_cast<const f32x4*>(&stage[r][ec]));
+            }
+        }
+    }
+    if (p.stats_part) {   // block-uniform
+        __syncthreads();  // the staging tile has been read out
+        double(*red)[BN][2] = reinterpret_cast<double(*)[BN][2]>(smem);   // [row groups][BN channels][sum, sum of squares]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[er][ec + c][0] = ssum[c];
+            red[er][ec + c][1] = ssq[c];
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, col = tid % BN;
+            if (n0 + col < p.N) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < ROWS_PER_PASS; ++k) t += red[k][col][which];
+                p.stats_part[((long)mt * 2 + which) * p.N + n0 + col] = t;
             }
         }
     }
@@ -448,6 +487,81 @@ extern "C" int emd_conv1x1_f32(const float* x, int ldx, const uint16_t* whi, con
     p.Hg = Ho; p.Wg = Wo; p.Ha = H; p.Wa = W; p.Hc = Ho; p.Wc = Wo; p.sa = stride; p.sc = 1; p.py = p.px = 0;
     set_taps(p, 1, nullptr, nullptr);
     return dispatch(p, precision, static_cast<hipStream_t>(stream));
+}
+
+// The convolutions of a TRAINING forward pass (misc_py/denoiser-multi-gpu.py:200-540 with phase = True: every conv is followed by a batch
+// norm on batch statistics): y = conv(x) with no affine and no activation, plus the per-channel mean and biased variance of y gathered in
+// the GEMM's epilogue (one partial per 128-row tile, reduced in a fixed order by bn_stats_final): what emd_bn_stats_f32 /
+// emd_bn_stats_images_f32 would return for y, without their pass over it.  images = 0: statistics over all B * Ho * Wo pixels (mean / var
+// [Cout]); images = 1: per image ([B][Cout]; needs Ho * Wo % 128 == 0 so that no tile straddles two images: EMD_E_UNSUPPORTED
+// otherwise -- call the conv and the statistics separately).  workspace: emd_conv_stats_workspace_bytes(B * Ho * Wo, Cout) bytes.
+extern "C" size_t emd_conv_stats_workspace_bytes(long M, int Cout) {
+    if (M <= 0 || Cout <= 0) return 0;
+    return (size_t)((M + 127) / 128) * 2 * Cout * sizeof(double);
+}
+
+static int conv_stats_run(GemmParams& p, int B, long npix_img, int images, float* mean, float* var, void* workspace, int precision,
+                          emd_stream_t stream) {
+    EMD_REQUIRE(mean && var && workspace && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EMD_E_INVALID,
+                "emd_conv*_stats_f32: mean, var and an 8-byte aligned workspace are required");
+    EMD_REQUIRE(!images || npix_img % 128 == 0, EMD_E_UNSUPPORTED,
+                "emd_conv*_stats_f32: per-image statistics need Ho * Wo % 128 == 0 (a 128-row tile must not straddle two images)");
+    p.stats_part = static_cast<double*>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // (always 128-row tiles: the number of partials per image must not depend on the column tile dispatch picks)
+    int rc = dispatch(p, precision, st);
+    if (rc != EMD_OK) return rc;
+    if (images)
+        return emd::launch_bn_stats_final(p.stats_part, (int)(npix_img / 128), p.N, npix_img, mean, var, st, nullptr, nullptr, 0.f, nullptr,
+                                          nullptr, B);
+    return emd::launch_bn_stats_final(p.stats_part, (int)((p.M + 127) / 128), p.N, p.M, mean, var, st);
+}
+
+extern "C" int emd_conv1x1_stats_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones,
+                                     const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int stride,
+                                     int precision, int images, float* mean, float* var, void* workspace, emd_stream_t stream) {
+    int rc = common_checks("emd_conv1x1_stats_f32", x, whi, wlo, ones, zeros, nullptr, nullptr, nullptr, y, Cin, Cout, ldx, ldy, 0,
+                           precision);
+    if (rc != EMD_OK) return rc;
+    EMD_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_conv1x1_stats_f32: bad shape");
+    EMD_REQUIRE(stride == 1 || stride == 2, EMD_E_UNSUPPORTED, "emd_conv1x1_stats_f32: stride must be 1 or 2");
+    GemmParams p{};
+    p.A = x; p.Whi = whi; p.Wlo = wlo; p.C = y; p.res = nullptr;
+    p.scale1 = ones; p.shift1 = zeros; p.scale2 = p.shift2 = nullptr;
+    p.N = Cout; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK; p.ntaps = 1;
+    p.lda = ldx; p.ldc = ldy; p.ldres = 0; p.act = 0;
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    p.M = (long)B * Ho * Wo;
+    p.flat = stride == 1;
+    p.Hg = Ho; p.Wg = Wo; p.Ha = H; p.Wa = W; p.Hc = Ho; p.Wc = Wo; p.sa = stride; p.sc = 1; p.py = p.px = 0;
+    set_taps(p, 1, nullptr, nullptr);
+    return conv_stats_run(p, B, (long)Ho * Wo, images, mean, var, workspace, precision, stream);
+}
+
+extern "C" int emd_conv3x3_stats_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones,
+                                     const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int rate,
+                                     int precision, int images, float* mean, float* var, void* workspace, emd_stream_t stream) {
+    int rc = common_checks("emd_conv3x3_stats_f32", x, whi, wlo, ones, zeros, nullptr, nullptr, nullptr, y, Cin, Cout, ldx, ldy, 0,
+                           precision);
+    if (rc != EMD_OK) return rc;
+    EMD_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_conv3x3_stats_f32: bad shape");
+    EMD_REQUIRE(rate >= 1 && rate <= 31, EMD_E_UNSUPPORTED, "emd_conv3x3_stats_f32: rate must be 1..31 (stride 1)");
+    GemmParams p{};
+    p.A = x; p.Whi = whi; p.Wlo = wlo; p.C = y; p.res = nullptr;
+    p.scale1 = ones; p.shift1 = zeros; p.scale2 = p.shift2 = nullptr;
+    p.N = Cout; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK;
+    p.lda = ldx; p.ldc = ldy; p.ldres = 0; p.act = 0;
+    p.M = (long)B * H * W;
+    p.flat = 0;
+    p.Hg = H; p.Wg = W; p.Ha = H; p.Wa = W; p.Hc = H; p.Wc = W; p.sa = 1; p.sc = 1; p.py = p.px = 0;
+    int dy[9], dx[9];
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {   // TF SAME at stride 1: (rate, rate) on both sides
+            dy[ky * 3 + kx] = (ky - 1) * rate;
+            dx[ky * 3 + kx] = (kx - 1) * rate;
+        }
+    set_taps(p, 9, dy, dx);
+    return conv_stats_run(p, B, (long)H * W, images, mean, var, workspace, precision, stream);
 }
 
 // Data gradient of the stride-2 1x1 convolution: dx[b, 2i, 2j, :] (+)= dy[b, i, j, :] * W^T, the other pixels of dx

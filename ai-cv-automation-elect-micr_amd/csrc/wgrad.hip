@@ -325,7 +325,9 @@ extern "C" int emd_conv_wgrad_f32(const float* a, int lda, const float* dy, int 
     }
     const bool mfma = K >= 32 && N >= 32;
     EMD_REQUIRE(p.M < (1L << 31), EMD_E_UNSUPPORTED, "emd_conv_wgrad_f32: more than 2^31 pixels");
-    const int tk = mfma ? (K > 64 ? 128 : 64) : 64, tn = mfma ? (N > 64 ? 128 : 64) : 64;
+    const bool small_m = p.M <= 8192;   // (the dev knobs below act on the 1/16-resolution layers of a tower only)
+    const bool t64 = emd::g_knobs.wgrad_tile == 64 && small_m;
+    const int tk = mfma ? (K > 64 && !t64 ? 128 : 64) : 64, tn = mfma ? (N > 64 && !t64 ? 128 : 64) : 64;
     const int kt = (K + tk - 1) / tk, nt = (N + tn - 1) / tn;
     const long tiles = (long)kt * nt * ntaps;
     const long maxsplit = (p.M + (mfma ? 511 : 2047)) / (mfma ? 512 : 2048);
@@ -341,6 +343,7 @@ extern "C" int emd_conv_wgrad_f32(const float* a, int lda, const float* dy, int 
         want = 2048 / tiles;  // enough workgroups to fill the chip a few times
     }
     if (want < 1) want = 1;
+    if (emd::g_knobs.wgrad_msplit > 0 && small_m && want > emd::g_knobs.wgrad_msplit) want = emd::g_knobs.wgrad_msplit;
     p.msplit = (int)(want < maxsplit ? want : maxsplit);
     if (p.msplit < 1) p.msplit = 1;
     if (mfma) {   // slices are whole 64-pixel chunks: drop the ones that rounding left empty

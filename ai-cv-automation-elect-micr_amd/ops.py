@@ -118,6 +118,37 @@ def conv3x3(x: Act, w: PackedWeights, scale1, shift1, out: Act, stride=1, rate=1
     return out
 
 
+def conv_stats_supported(x: Act, stride=1, images=False):
+    """Can conv1x1_stats / conv3x3_stats deliver the statistics of this convolution's output?  Per-image statistics need whole
+    128-row tiles per image."""
+    Ho, Wo = -(-x.H // stride), -(-x.W // stride)
+    return (not images) or (Ho * Wo) % 128 == 0
+
+
+def conv_stats(x: Act, w: PackedWeights, ones, zeros, out: Act, stride=1, rate=1, images=False, precision=PREC_BF16X3, stream=None):
+    """out = conv(x) (1x1, stride 1 / 2; or dense 3x3 with dilation `rate`: by w.taps), no affine, no activation, and the batch
+    statistics of out from the GEMM's epilogue -> (mean, var): [Cout], or [B][Cout] flattened with images=True."""
+    import torch
+
+    lib = _lib.load()
+    Ho, Wo = -(-x.H // stride), -(-x.W // stride)
+    assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, w.cout) and w.cin == x.C and w.taps in (1, 9)
+    n = x.B * w.cout if images else w.cout
+    mean = torch.empty(n, dtype=torch.float32, device=x.buf.device)
+    var = torch.empty_like(mean)
+    ws = torch.empty(max(lib.emd_conv_stats_workspace_bytes(x.B * Ho * Wo, w.cout) // 8, 1), dtype=torch.float64, device=x.buf.device)
+    if w.taps == 1:
+        rc = lib.emd_conv1x1_stats_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(ones), _p(zeros), out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout,
+                                       stride, precision, 1 if images else 0, _p(mean), _p(var), _p(ws), _lib.stream_ptr(stream))
+        _lib.check(rc, "emd_conv1x1_stats_f32")
+    else:
+        assert stride == 1
+        rc = lib.emd_conv3x3_stats_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(ones), _p(zeros), out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout,
+                                       rate, precision, 1 if images else 0, _p(mean), _p(var), _p(ws), _lib.stream_ptr(stream))
+        _lib.check(rc, "emd_conv3x3_stats_f32")
+    return mean, var
+
+
 def avgpool2x2(x: Act, out: Act, stream=None):
     lib = _lib.load()
     assert (out.B, out.H, out.W, out.C) == (x.B, -(-x.H // 2), -(-x.W // 2), x.C)

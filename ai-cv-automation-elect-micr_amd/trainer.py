@@ -118,6 +118,7 @@ class DenoiserTrainer:
         self._pack_batch = None
         self._flip_idx = self._flip_flat = None
         self._per_image = False
+        self.fuse_stats = os.environ.get("EMD_T_FUSE_STATS", "1") == "1"   # batch statistics from the producing GEMM's epilogue (ops.conv_stats)
         self.teacher = None   # test hook: scope -> {"d": ..., "r": ...} reference tensors that REPLACE the forward's conv outputs (see _force)
         self.repack()
         self.last = None
@@ -244,11 +245,15 @@ class DenoiserTrainer:
     def _E(self, B, H, W, Cc):
         return ops.Act.empty(B, H, W, Cc, self.device)
 
-    def _bn(self, key, r, bias_name=None):
-        """Batch statistics of r -> fold dict of the layer's BN chain (+ moving-average updates on the first tower)."""
+    def _bn(self, key, r, bias_name=None, stats=None):
+        """Batch statistics of r -> fold dict of the layer's BN chain (+ moving-average updates on the first tower).  stats: (mean,
+        var) when the producing convolution has delivered them already (ops.conv_stats: the GEMM's epilogue)."""
         L = self.layers[key]
         img = r.B if self._per_image else 0    # per-image statistics: B one-image towers as one batched pass
-        if img:
+        if stats is not None:
+            mean, var = stats
+            npix = r.H * r.W if img else r.B * r.H * r.W
+        elif img:
             mean, var = ops.bn_batch_stats_images(r)
             npix = r.H * r.W
         else:
@@ -284,15 +289,25 @@ class DenoiserTrainer:
         v = torch.from_numpy(np.ascontiguousarray(self.teacher[scope][which], dtype=np.float32)).to(self.device)
         act.torch()[..., : v.shape[-1]].copy_(v)
 
+    def _fuse_stats(self, x, stride=1):
+        """Statistics in the producing GEMM's epilogue (ops.conv_stats) -- not under teacher forcing (the statistics must then be those of
+        the FORCED tensor) and only where per-image statistics see whole tiles."""
+        return self.fuse_stats and self.teacher is None and ops.conv_stats_supported(x, stride, images=self._per_image)
+
     def _sep_fwd(self, key, x, out=None, res=None):
         L = self.layers[key]
         Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
         d = ops.dw3x3(x, self._dw(key), self._E(x.B, Ho, Wo, x.C), stride=L.stride, rate=L.rate)
         self._force(d, L.scope, "d")
-        r = ops.conv1x1(d, self.pk_f[key], self.ones, self.zeros, self._E(x.B, Ho, Wo, L.cout), act=False,
-                        precision=self.precision)
+        stats = None
+        if self._fuse_stats(d):     # the batch statistics of r from the pointwise GEMM's epilogue: no second pass over r
+            r = self._E(x.B, Ho, Wo, L.cout)
+            stats = ops.conv_stats(d, self.pk_f[key], self.ones, self.zeros, r, images=self._per_image, precision=self.precision)
+        else:
+            r = ops.conv1x1(d, self.pk_f[key], self.ones, self.zeros, self._E(x.B, Ho, Wo, L.cout), act=False,
+                            precision=self.precision)
         self._force(r, L.scope, "r")
-        fold = self._bn(key, r)
+        fold = self._bn(key, r, stats=stats)
         if out is None:
             out = self._E(x.B, Ho, Wo, L.cout)
         self._affine(r, fold, out, ops.ACT_RELU6, res)
@@ -306,7 +321,11 @@ class DenoiserTrainer:
         has_bn = bool(L.bn)
         tgt = self._E(x.B, Ho, Wo, L.cout) if (has_bn or out is None) else out
         shift = self.zeros if has_bn else bias
-        if L.k == 1:
+        stats = None
+        if has_bn and (L.k == 1 or L.stride == 1) and self._fuse_stats(x, L.stride):
+            stats = ops.conv_stats(x, self.pk_f[key], self.ones, self.zeros, tgt, stride=L.stride, rate=L.rate, images=self._per_image,
+                                   precision=self.precision)
+        elif L.k == 1:
             ops.conv1x1(x, self.pk_f[key], self.ones, shift, tgt, stride=L.stride, act=False, precision=self.precision)
         else:
             ops.conv3x3(x, self.pk_f[key], self.ones, shift, tgt, stride=L.stride, rate=L.rate, act=False,
@@ -314,7 +333,7 @@ class DenoiserTrainer:
         self._force(tgt, L.scope, "r")
         if not has_bn:
             return tgt, {"x": x}
-        fold = self._bn(key, tgt, L.scope + "/" + L.bname)
+        fold = self._bn(key, tgt, L.scope + "/" + L.bname, stats=stats)
         if out is None:
             out = self._E(x.B, Ho, Wo, L.cout)
         self._affine(tgt, fold, out, ops.ACT_RELU6 if act else ops.ACT_NONE)

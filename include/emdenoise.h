@@ -307,6 +307,24 @@ int emd_affine_act_f32(const float* x, int ldx, const float* scale, const float*
  * B x emd_bn_stats_workspace_bytes(npix_img, C) bytes.  Image b gets exactly the bits emd_bn_stats_f32 gives it alone. */
 int emd_bn_stats_images_f32(const float* x, int ldx, int B, long npix_img, int C, float* mean, float* var, void* workspace,
                             emd_stream_t stream);
+
+/* The convolutions of a TRAINING forward pass (misc_py/denoiser-multi-gpu.py:200-540 with phase = True, :752-782: every convolution is
+ * followed by a batch norm on BATCH statistics): y = conv(x), no affine, no activation (ones / zeros: device vectors of Cout ones and
+ * zeros, 16-byte aligned), plus the per-channel mean and biased variance of y, gathered in the GEMM's epilogue -- what
+ * emd_bn_stats_f32 (images = 0: over all B * Ho * Wo pixels, mean / var [Cout]) or emd_bn_stats_images_f32 (images = 1: per image,
+ * [B][Cout]) would return for y, without their pass over it (one partial per 128-row tile, reduced in a fixed order: deterministic;
+ * the last bits differ from the two-launch form's, whose partials are cut differently).  images = 1 needs Ho * Wo % 128 == 0
+ * (EMD_E_UNSUPPORTED otherwise: call the convolution and the statistics separately).
+ * workspace: emd_conv_stats_workspace_bytes(B * Ho * Wo, Cout) bytes, 8-byte aligned.  emd_conv1x1_stats_f32: slim.conv2d 1x1 /
+ * the pointwise half of slim.separable_convolution2d, stride 1 or 2 (TF SAME: samples x[0::2]); emd_conv3x3_stats_f32: dense 3x3,
+ * stride 1, dilation `rate` (the ASPP branches of graph D', :330-353). */
+size_t emd_conv_stats_workspace_bytes(long M, int Cout);
+int emd_conv1x1_stats_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones, const float* zeros,
+                          float* y, int ldy, int B, int H, int W, int Cin, int Cout, int stride, int precision, int images,
+                          float* mean, float* var, void* workspace, emd_stream_t stream);
+int emd_conv3x3_stats_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones, const float* zeros,
+                          float* y, int ldy, int B, int H, int W, int Cin, int Cout, int rate, int precision, int images,
+                          float* mean, float* var, void* workspace, emd_stream_t stream);
 int emd_affine_act_images_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
                               float* y, int ldy, int B, long npix_img, int C, int act, emd_stream_t stream);
 size_t emd_bn_stats_workspace_bytes(long npix, int C);

@@ -428,3 +428,56 @@ def test_nesterov_step_matches_apply_momentum():
     p2 = p - (g * gs * lr + a2 * mom * lr)
     torch.cuda.synchronize()
     assert rel_l2(ad.cpu().numpy(), a2) < 1e-6 and rel_l2(pd.cpu().numpy(), p2) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,k,stride,rate,images", [
+    (2, 32, 32, 728, 728, 1, 1, 1, True),      # the 1/16-resolution flow of two one-image towers (128 x 64 tiles: < 192 tiles of 128)
+    (3, 16, 24, 64, 36, 1, 1, 1, True),        # 384 pixels per image = three tiles; channel tail in a 64-column tile
+    (2, 64, 64, 128, 256, 1, 2, 1, True),      # strided 1x1 (the encoder's residual convs): the row map, 1024 output pixels per image
+    (2, 32, 32, 96, 160, 3, 1, 6, True),       # dense dilated 3x3 (ASPP of graph D'), per-image
+    (2, 20, 12, 64, 64, 1, 1, 1, False),       # batch statistics over a ragged M (480 rows: the last tile is partial)
+    (4, 64, 64, 64, 128, 1, 1, 1, False),
+])
+def test_conv_stats_equals_conv_then_statistics(B, H, W, ci, co, k, stride, rate, images):
+    """emd_conv1x1_stats_f32 / emd_conv3x3_stats_f32 (round 4: the training forward's batch statistics from the GEMM's epilogue,
+    misc_py/denoiser-multi-gpu.py:200-540 phase = True): y bit for bit the plain convolution's, mean / var equal to
+    emd_bn_stats_f32 / emd_bn_stats_images_f32 of y to float32 rounding (both sum in double; the partials are cut differently), and
+    to the float64 oracle; image b of the batch gets the statistics it gets alone."""
+    from emdenoise import ops
+
+    x = rnd((B, H, W, ci), 700, positive=True)
+    w = rnd((k * k, ci, co), 701, scale=(2.0 / (k * k * ci + co)) ** 0.5)
+    pk = ops.PackedWeights(w, False, dev())
+    ones, zeros = torch.ones(co, device=dev()), torch.zeros(co, device=dev())
+    xa = to_act(x, ld=ci + 8, c0=4)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    y1, y2 = out_act(B, Ho, Wo, co, ld=co + 4, c0=0), out_act(B, Ho, Wo, co, ld=co + 4, c0=0)
+    assert ops.conv_stats_supported(xa, stride, images)
+    mean, var = ops.conv_stats(xa, pk, ones, zeros, y1, stride=stride, rate=rate, images=images)
+    if k == 1:
+        ops.conv1x1(xa, pk, ones, zeros, y2, stride=stride, act=False)
+    else:
+        ops.conv3x3(xa, pk, ones, zeros, y2, rate=rate, act=False)
+    m2, v2 = ops.bn_batch_stats_images(y2) if images else ops.bn_batch_stats(y2)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.torch(), y2.torch())
+    yy = y2.torch().double().cpu().numpy()
+    ax = (1, 2) if images else (0, 1, 2)
+    assert rel_l2(mean.cpu().numpy(), yy.mean(ax).ravel()) < 2e-7 and rel_l2(var.cpu().numpy(), yy.var(ax).ravel()) < 2e-6
+    assert rel_l2(mean.cpu().numpy(), m2.cpu().numpy()) < 2e-7 and rel_l2(var.cpu().numpy(), v2.cpu().numpy()) < 2e-6
+    if images:    # the statistics of image 1 do not depend on the batch it came in
+        xb = to_act(x[1:2], ld=ci + 8, c0=4)
+        mo, vo = ops.conv_stats(xb, pk, ones, zeros, out_act(1, Ho, Wo, co), stride=stride, rate=rate, images=True)
+        torch.cuda.synchronize()
+        assert torch.equal(mo, mean[co:2 * co]) and torch.equal(vo, var[co:2 * co])
+
+
+def test_conv_stats_rejects_images_that_share_a_tile():
+    from emdenoise import _lib, ops
+
+    x = to_act(rnd((2, 10, 10, 64), 710))
+    assert not ops.conv_stats_supported(x, 1, images=True)
+    pk = ops.PackedWeights(rnd((1, 64, 64), 711, 0.1), False, dev())
+    ones, zeros = torch.ones(64, device=dev()), torch.zeros(64, device=dev())
+    with pytest.raises(RuntimeError, match="straddle"):
+        ops.conv_stats(x, pk, ones, zeros, out_act(2, 10, 10, 64), images=True)
