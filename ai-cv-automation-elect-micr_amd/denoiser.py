@@ -393,6 +393,14 @@ class DenoiserEngine:
         # launches side by side lose to one (B = 4 at 512^2: 3.84 ms as halves, 3.71 ms whole; B = 8: 6.65 vs 6.72; profiles/r03_experiments.txt 12)
         if (self.two_streams and not fused and x.B % 2 == 0 and half * x.H * x.W >= 4096 and self.precision == ops.PREC_BF16X3
                 and ops.conv1x1_split32_supported(half * x.H * x.W, x.C, out.C)):
+            # experiment (EMD_D_PARTS = 4 / 8): the batch in that many parts, two at a time on the two streams, each part through ALL 27 layers
+            # before the next pair starts -- a part's 24 / 12 MB tensors stay in the 256 MiB Infinity Cache from layer to layer
+            parts = int(os.environ.get("EMD_D_PARTS", "2"))
+            if parts > 2 and x.B % parts == 0 and ops.conv1x1_split32_supported((x.B // parts) * x.H * x.W, x.C, out.C):
+                per = 2 * (x.B // parts)
+                for a in range(0, x.B, per):
+                    self._halves.run(x.images(a, a + per), out.images(a, a + per), self._middle_chain)
+                return out
             return self._halves.run(x, out, self._middle_chain)
         for _ in self._middle_chain(x, out):
             pass

@@ -170,6 +170,15 @@ def whole_step_traffic_roofline(w, ms, kernel):
                    "traffic-based, not algorithmic"}
 
 
+def step_traffic(w):
+    """HBM bytes of ONE step of workload w from the committed PMC run ("<w>:*step total*"), or (None, why)."""
+    tr, src = pmc_traffic()
+    rec = (tr or {}).get(f"{w}:*step total*")
+    if not rec:
+        return None, src
+    return round(rec["hbm_bytes_per_step_corrected"]), src
+
+
 def synthetic_lq(B, H, W, seed=1234):
     """Synthetic low-quality crops of the reference's shape and statistics: smooth field ->
     Poisson counts (scale = 25 + Exp(75), denoiser-multi-gpu.py:783-799) -> min-max to [0,1]."""
@@ -1019,7 +1028,9 @@ def bench_X(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
            "tflops_algorithmic": round(9.01 * scale / (ms / 1e3), 1),
            "roofline": {"bound": "mfma", "kernel": "decoder family: dense 3x3 convs + transposed convs (gemm_split_conv / gemm_conv), 60 % of X's flops",
                         "achieved": round(dec_fl / (max(dec_ms, 1e-9) * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(dec_fl / (max(dec_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "frac": round(dec_fl / (max(dec_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "traffic": step_traffic("X")[0] if (B, H, W) == (32, 512, 512) else None, "traffic_source": step_traffic("X")[1],
+                        "traffic_note": "HBM bytes of one WHOLE step (PMC), not of the decoder family alone",
                         "issued_frac": round(3.0 * dec_fl / (max(dec_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                         "algorithmic_flops_per_step": dec_fl, "kernel_ms_per_step": round(dec_ms, 3),
                         "how": "HIP events around every launch of the family in one extra step; flops from the launch arguments"},
@@ -1236,7 +1247,11 @@ def bench_T(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
                             "note": "RCCL all-reduce (sum) of the fp32 gradient vector + broadcast of the moving statistics, HIP events over 5 rounds"}
     out["roofline"] = {"bound": "mfma", "kernel": "whole step (forward + data-gradient + weight-gradient GEMMs dominate)", "achieved": out["tflops_algorithmic"],
                        "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(out["tflops_algorithmic"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
+                       "frac": round(out["tflops_algorithmic"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                       "traffic": step_traffic("T")[0] if (B, S, tb, a.tower_mode) == (8, 512, 1, "batched") else None,
+                       "traffic_source": step_traffic("T")[1]}
+    if out["roofline"]["traffic"]:
+        out["roofline"]["hbm_busy_frac"] = round(out["roofline"]["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
     attach_cpu(out, cpu, "T")
     return out
 
