@@ -180,6 +180,13 @@ SIGNATURES = {
     "emd_bn_bwd_prep_images_f32": (C.c_int, [_c_float_p] * 6 + [C.c_float, C.c_long, C.c_int, C.c_int] + [_c_float_p] * 6 + [C.c_void_p]),
     "emd_bn_bwd_apply_images_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int] + [_c_float_p] * 6 +
                                     [C.c_int, _c_float_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p]),
+    "emd_bn_train_small_supported": (C.c_int, [C.c_long, C.c_int]),
+    # r ldr B npix C gamma1 beta1 gamma2 beta2 bias eps scale shift rstd1 rstd2 mean mm1 mv1 mm2 mv2 decay res ldres out ldo act stream
+    "emd_bn_train_fwd_small_f32": (C.c_int, [_c_float_p, C.c_int, C.c_int, C.c_long, C.c_int] + [_c_float_p] * 5 + [C.c_float] +
+                                   [_c_float_p] * 9 + [C.c_double, _c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_void_p]),
+    # dy ldd x ldx B npix C mean rstd1 rstd2 mscale mshift mask gamma1 gamma2 eps dgamma1 dgamma2 dbeta2 dx ldo stream
+    "emd_bn_train_bwd_small_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_long, C.c_int] + [_c_float_p] * 5 +
+                                   [C.c_int, _c_float_p, _c_float_p, C.c_float] + [_c_float_p] * 4 + [C.c_int, C.c_void_p]),
     # x ldx dy ldd dw B H W C stride rate stream
     "emd_dw3x3_wgrad_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p] + [C.c_int] * 6 + [C.c_void_p]),
     # dy ldd w dx ldx B H W C stride rate stream

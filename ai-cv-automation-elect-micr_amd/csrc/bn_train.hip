@@ -286,6 +286,221 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the batch norm of a SMALL map as one launch per direction.  A tower's 1/16- and 1/8-resolution layers (32 x 32 and 64 x 64
+// pixels per image, 36 + 9 of graph D's 60 norms) ran as statistics partial + final + fold + affine forward and reduction partial +
+// final + prep + apply backward: eight launches of 4-20 us on 3-12 MB, none of which fills the chip.  Here one workgroup owns 64
+// channels of ONE image for all of its pixels (16 channel quads x 16 row lanes, 16-byte accesses): pass 1 reduces in double, the
+// per-channel step runs in the workgroup, pass 2 re-reads the slice (L2) and writes.  Same formulas, statement for statement, as
+// bn_stats_final + bn_train_fold_kernel + affine_relu6_kernel and chan_reduce_* + bn_bwd_prep_kernel + bn_bwd_apply_kernel; the sums
+// are cut differently (16 row lanes over the whole image instead of slabs), so results agree to double rounding, not bit for bit.
+// blockIdx.y = image; every per-channel vector is [B][C]; parameters and moving statistics are indexed by the channel, the moving
+// statistics follow image 0 (the first tower, misc_py/denoiser-multi-gpu.py:701-707).
+// Geometry: CB = 16 channels (CQ = 4 quads) x RL = 64 row lanes per workgroup -- a first version with 64 channels x 16 row lanes had 24
+// workgroups for a pair of 32 x 32 x 728 maps, each walking 64 rows twice: 50 us of latency in a chain of 5-20 us kernels, and the
+// step got 5 ms SLOWER (the step is bound by the length of each stream's chain, not by the work).
+constexpr int CB = 16, CQ = CB / 4, RL = 256 / CQ;
+__global__ __launch_bounds__(256) void bn_fwd_small_kernel(const float* r, int ldr, long npix, int C, const float* __restrict__ gamma1,
+                                                           const float* __restrict__ beta1, const float* __restrict__ gamma2,
+                                                           const float* __restrict__ beta2, const float* __restrict__ bias, float eps,
+                                                           float omd, float* mm1, float* mv1, float* mm2, float* mv2,
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ rstd1, float* __restrict__ rstd2,
+                                                           float* __restrict__ mean_out, const float* res, int ldres, float* out,
+                                                           int ldo, int act) {
+    __shared__ double sm[2][RL][CB + 1];
+    __shared__ float fs[2][CB];          // scale, shift of this workgroup's channels
+    const long b = blockIdx.y;
+    r += b * npix * ldr;
+    out += b * npix * ldo;
+    if (res) res += b * npix * ldres;
+    const int cl = (threadIdx.x % CQ) * 4, rl = threadIdx.x / CQ;
+    const int c = blockIdx.x * CB + cl;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c < C) {
+#pragma unroll 4
+        for (long p = rl; p < npix; p += RL) {
+            const float4 v = *reinterpret_cast<const float4*>(r + p * ldr + c);
+            const float xx[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double d = (double)xx[k];
+                s[k] += d;
+                q[k] += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sm[0][rl][cl + k] = s[k];
+        sm[1][rl][cl + k] = q[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < CB) {
+        const int l = threadIdx.x, cc = blockIdx.x * CB + l;
+        if (cc < C) {
+            double ss = 0.0, qq = 0.0;
+            for (int k = 0; k < RL; ++k) {
+                ss += sm[0][k][l];
+                qq += sm[1][k][l];
+            }
+            // bn_stats_final
+            const double m = ss / (double)npix;
+            const double vd = qq / (double)npix - m * m;
+            const float mu = (float)m, v = (float)(vd > 0.0 ? vd : 0.0);
+            // bn_train_fold_kernel
+            const long i = b * C + cc;
+            const float n = (float)npix;
+            const float r1 = rsqrtf(v + eps);
+            const float bessel = n > 1.f ? n / (n - 1.f) : 1.f;
+            const bool mov = b == 0 && mm2 != nullptr;
+            rstd1[i] = r1;
+            mean_out[i] = mu;
+            float sc, sh;
+            if (gamma1) {
+                const float g1 = gamma1[cc];
+                const float var2 = g1 * g1 * v * r1 * r1;
+                const float r2 = rsqrtf(var2 + eps);
+                rstd2[i] = r2;
+                sc = g1 * gamma2[cc] * r1 * r2;
+                sh = beta2[cc] - mu * sc;
+                if (mov) {
+                    mm1[cc] -= (mm1[cc] - mu) * omd;
+                    mv1[cc] -= (mv1[cc] - v * bessel) * omd;
+                    mm2[cc] -= (mm2[cc] - beta1[cc]) * omd;
+                    mv2[cc] -= (mv2[cc] - var2 * bessel) * omd;
+                }
+            } else {
+                sc = gamma2[cc] * r1;
+                sh = beta2[cc] - mu * sc;
+                if (mov) {
+                    mm2[cc] -= (mm2[cc] - (mu + (bias ? bias[cc] : 0.f))) * omd;
+                    mv2[cc] -= (mv2[cc] - v * bessel) * omd;
+                }
+            }
+            scale[i] = sc;
+            shift[i] = sh;
+            fs[0][l] = sc;
+            fs[1][l] = sh;
+        }
+    }
+    __syncthreads();
+    if (c >= C) return;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sc[k] = fs[0][cl + k]; sh[k] = fs[1][cl + k]; }
+    const float hi = act == 2 ? __builtin_inff() : (act == 3 ? 1.f : 6.f);   // affine_relu6_kernel's codes (3: relu6 then clip to [0,1])
+#pragma unroll 4
+    for (long p = rl; p < npix; p += RL) {
+        const float4 v = *reinterpret_cast<const float4*>(r + p * ldr + c);
+        float o[4] = {fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3])};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (act == 4) o[k] = o[k] > 0.f ? o[k] : 0.2f * o[k];
+            else if (act) o[k] = fminf(fmaxf(o[k], 0.f), hi);
+        }
+        if (res) {
+            const float4 rv = *reinterpret_cast<const float4*>(res + p * ldres + c);
+            o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+        }
+        *reinterpret_cast<float4*>(out + p * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* dy, int ldd, const float* x, int ldx, long npix, int C,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd1,
+                                                           const float* __restrict__ rstd2, const float* __restrict__ mscale,
+                                                           const float* __restrict__ mshift, int mask,
+                                                           const float* __restrict__ gamma1, const float* __restrict__ gamma2, float eps,
+                                                           float* dgamma1, float* dgamma2, float* dbeta2, float* dx, int ldo) {
+    __shared__ double sm[2][RL][CB + 1];
+    __shared__ float cf[3][CB];          // K, m1, m2 of this workgroup's channels
+    const long b = blockIdx.y;
+    dy += b * npix * ldd;
+    x += b * npix * ldx;
+    dx += b * npix * ldo;
+    const long vo = b * C;
+    const int cl = (threadIdx.x % CQ) * 4, rl = threadIdx.x / CQ;
+    const int c = blockIdx.x * CB + cl;
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, ms[4] = {0.f, 0.f, 0.f, 0.f}, mh[4] = {0.f, 0.f, 0.f, 0.f};
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c < C) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mu[k] = mean[vo + c + k]; rs[k] = rstd1[vo + c + k];
+            if (mask) { ms[k] = mscale[vo + c + k]; mh[k] = mshift[vo + c + k]; }
+        }
+#pragma unroll 4
+        for (long p = rl; p < npix; p += RL) {
+            const float4 d = *reinterpret_cast<const float4*>(dy + p * ldd + c);
+            const float4 xv = *reinterpret_cast<const float4*>(x + p * ldx + c);
+            const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {   // chan_reduce_partial_v4
+                const float g = grad_mask(dd[k], fmaf(xx[k], ms[k], mh[k]), mask);
+                s[k] += (double)g;
+                q[k] += (double)g * (double)((xx[k] - mu[k]) * rs[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sm[0][rl][cl + k] = s[k];
+        sm[1][rl][cl + k] = q[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < CB) {
+        const int l = threadIdx.x, cc = blockIdx.x * CB + l;
+        if (cc < C) {
+            double ss = 0.0, qq = 0.0;
+            for (int k = 0; k < RL; ++k) {
+                ss += sm[0][k][l];
+                qq += sm[1][k][l];
+            }
+            // chan_reduce_final -> bn_bwd_prep_kernel
+            const float sv = (float)ss, tv = (float)qq;
+            const float inv_n = 1.f / (float)npix;
+            const float r1 = rstd1[vo + cc];
+            float Kc, m2c;
+            atomicAdd(dbeta2 + cc, sv);
+            if (gamma1) {
+                const float g1 = gamma1[cc], g2 = gamma2[cc], r2 = rstd2[vo + cc];
+                const float a = g1 * r2;
+                const float e2 = eps * r2 * r2;
+                Kc = g1 * g2 * r1 * r2;
+                m2c = r1 * tv * inv_n * (a * a + e2);
+                atomicAdd(dgamma2 + cc, a * tv);
+                atomicAdd(dgamma1 + cc, g2 * r2 * e2 * tv);
+            } else {
+                Kc = gamma2[cc] * r1;
+                m2c = r1 * tv * inv_n;
+                atomicAdd(dgamma2 + cc, tv);
+            }
+            cf[0][l] = Kc;
+            cf[1][l] = sv * inv_n;
+            cf[2][l] = m2c;
+        }
+    }
+    __syncthreads();
+    if (c >= C) return;
+    float kk[4], m1[4], m2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { kk[k] = cf[0][cl + k]; m1[k] = cf[1][cl + k]; m2[k] = cf[2][cl + k]; }
+#pragma unroll 4
+    for (long p = rl; p < npix; p += RL) {   // bn_bwd_apply_kernel; dx may alias dy or x (each element is read before it is written, by this thread)
+        const float4 d = *reinterpret_cast<const float4*>(dy + p * ldd + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + p * ldx + c);
+        const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g = grad_mask(dd[k], fmaf(xx[k], ms[k], mh[k]), mask);
+            o[k] = kk[k] * (g - m1[k] - (xx[k] - mu[k]) * m2[k]);
+        }
+        *reinterpret_cast<float4*>(dx + p * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 }  // namespace
 
 extern "C" size_t emd_chan_reduce_workspace_bytes(long npix, int C) {
@@ -420,4 +635,43 @@ extern "C" int emd_bn_bwd_prep_images_f32(const float* s1, const float* t, const
                                           float* m1, float* m2, float* dgamma1, float* dgamma2, float* dbeta2,
                                           emd_stream_t stream) {
     return bwd_prep_impl(s1, t, gamma1, gamma2, rstd1, rstd2, eps, npix, B, C, K, m1, m2, dgamma1, dgamma2, dbeta2, stream);
+}
+
+
+// ---- the small-map one-launch forms (round 4; kernels above).  Per-image statistics only (a tower of one image, or B such towers as
+// one batched pass: B = 1 is the plain batch norm of one image).  npix <= 4096 (EMD_E_UNSUPPORTED above: one workgroup per 64 channels
+// and image would leave the chip idle -- use the slab forms), C, pitches multiples of 4, 16-byte aligned tensors.
+extern "C" int emd_bn_train_small_supported(long npix, int C) { return npix >= 1 && npix <= 4096 && C >= 4 && C % 4 == 0; }
+
+extern "C" int emd_bn_train_fwd_small_f32(const float* r, int ldr, int B, long npix, int C, const float* gamma1, const float* beta1,
+                                          const float* gamma2, const float* beta2, const float* bias, float eps, float* scale,
+                                          float* shift, float* rstd1, float* rstd2, float* mean, float* mm1, float* mv1, float* mm2,
+                                          float* mv2, double decay, const float* res, int ldres, float* out, int ldo, int act,
+                                          emd_stream_t stream) {
+    EMD_REQUIRE(r && gamma2 && beta2 && scale && shift && rstd1 && mean && out, EMD_E_INVALID, "emd_bn_train_fwd_small_f32: null pointer");
+    EMD_REQUIRE((gamma1 == nullptr) == (beta1 == nullptr) && (!gamma1 || rstd2), EMD_E_INVALID, "emd_bn_train_fwd_small_f32: BN1 needs gamma1, beta1, rstd2");
+    EMD_REQUIRE(B >= 1 && B <= 65535 && act >= 0 && act <= 4, EMD_E_INVALID, "emd_bn_train_fwd_small_f32: bad argument");
+    EMD_REQUIRE(emd_bn_train_small_supported(npix, C), EMD_E_UNSUPPORTED, "emd_bn_train_fwd_small_f32: needs npix <= 4096 and C % 4 == 0");
+    EMD_REQUIRE(ldr % 4 == 0 && ldo % 4 == 0 && ldr >= C && ldo >= C && emd::aligned16(r) && emd::aligned16(out) &&
+                    (!res || (ldres % 4 == 0 && ldres >= C && emd::aligned16(res))), EMD_E_ALIGN, "emd_bn_train_fwd_small_f32: alignment");
+    EMD_REQUIRE(!mm2 || (mv2 && (!gamma1 || (mm1 && mv1))), EMD_E_INVALID, "emd_bn_train_fwd_small_f32: moving statistics come in pairs");
+    hipLaunchKernelGGL(bn_fwd_small_kernel, dim3((C + CB - 1) / CB, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), r, ldr, npix, C,
+                       gamma1, beta1, gamma2, beta2, bias, eps, (float)(1.0 - decay), mm1, mv1, mm2, mv2, scale, shift, rstd1, rstd2, mean,
+                       res, ldres, out, ldo, act);
+    return emd::check_launch("bn_fwd_small_kernel");
+}
+
+extern "C" int emd_bn_train_bwd_small_f32(const float* dy, int ldd, const float* x, int ldx, int B, long npix, int C, const float* mean,
+                                          const float* rstd1, const float* rstd2, const float* mscale, const float* mshift, int mask,
+                                          const float* gamma1, const float* gamma2, float eps, float* dgamma1, float* dgamma2,
+                                          float* dbeta2, float* dx, int ldo, emd_stream_t stream) {
+    EMD_REQUIRE(dy && x && mean && rstd1 && gamma2 && dgamma2 && dbeta2 && dx, EMD_E_INVALID, "emd_bn_train_bwd_small_f32: null pointer");
+    EMD_REQUIRE(!gamma1 || (rstd2 && dgamma1), EMD_E_INVALID, "emd_bn_train_bwd_small_f32: BN1 needs rstd2 and dgamma1");
+    EMD_REQUIRE(B >= 1 && B <= 65535 && mask >= 0 && mask <= 3 && (!mask || (mscale && mshift)), EMD_E_INVALID, "emd_bn_train_bwd_small_f32: bad argument");
+    EMD_REQUIRE(emd_bn_train_small_supported(npix, C), EMD_E_UNSUPPORTED, "emd_bn_train_bwd_small_f32: needs npix <= 4096 and C % 4 == 0");
+    EMD_REQUIRE(ldd % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldd >= C && ldx >= C && ldo >= C && emd::aligned16(dy) && emd::aligned16(x) &&
+                    emd::aligned16(dx), EMD_E_ALIGN, "emd_bn_train_bwd_small_f32: alignment");
+    hipLaunchKernelGGL(bn_bwd_small_kernel, dim3((C + CB - 1) / CB, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), dy, ldd, x, ldx,
+                       npix, C, mean, rstd1, rstd2, mscale, mshift, mask, gamma1, gamma2, eps, dgamma1, dgamma2, dbeta2, dx, ldo);
+    return emd::check_launch("bn_bwd_small_kernel");
 }

@@ -150,6 +150,48 @@ def bn_train_fold(mean, var, gamma2, beta2, npix, gamma1=None, beta1=None, bias=
     return {"scale": scale, "shift": shift, "rstd1": rstd1, "rstd2": rstd2, "mean": mean}
 
 
+def bn_small_supported(r: Act):
+    """The one-launch training batch norm (emd_bn_train_fwd_small_f32 / _bwd_small_f32) takes per-image maps of up to 4096 pixels."""
+    return bool(_lib.load().emd_bn_train_small_supported(C.c_long(r.H * r.W), r.C)) and r.ld % 4 == 0
+
+
+def bn_train_fwd_small(r: Act, gamma2, beta2, out: Act, act, gamma1=None, beta1=None, bias=None, moving=None, res: Act | None = None,
+                       eps=BN_EPS, decay=BN_DECAY, stream=None):
+    """Per-image batch statistics of r, the fold of the layer's BN chain, out = act(r * scale + shift) [+ res] and the moving-average
+    update (from image 0) in ONE launch -> the fold dict bn_train_fold returns (per-image form)."""
+    import torch
+
+    n = r.B * r.C
+    dev = r.buf.device
+    scale, shift, rstd1, mean = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
+    rstd2 = torch.empty(n, dtype=torch.float32, device=dev) if gamma1 is not None else None
+    mm1 = mv1 = mm2 = mv2 = None
+    if moving is not None:
+        if gamma1 is not None:
+            mm1, mv1, mm2, mv2 = moving
+        else:
+            mm2, mv2 = moving
+    rc = _lib.load().emd_bn_train_fwd_small_f32(r.ptr, r.ld, r.B, C.c_long(r.H * r.W), r.C, _p(gamma1), _p(beta1), _p(gamma2), _p(beta2),
+                                                _p(bias), C.c_float(eps), _p(scale), _p(shift), _p(rstd1), _p(rstd2), _p(mean), _p(mm1),
+                                                _p(mv1), _p(mm2), _p(mv2), C.c_double(decay), res.ptr if res is not None else C.c_void_p(0),
+                                                res.ld if res is not None else 0, out.ptr, out.ld, act, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_bn_train_fwd_small_f32")
+    return {"scale": scale, "shift": shift, "rstd1": rstd1, "rstd2": rstd2, "mean": mean, "B": r.B, "small": True}
+
+
+def bn_backward_small(dy: Act, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MASK_RELU6, gamma1=None, dgamma1=None, eps=BN_EPS,
+                      stream=None):
+    """bn_backward (per-image form) as one launch."""
+    assert fold.get("B") == dy.B
+    ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
+    rc = _lib.load().emd_bn_train_bwd_small_f32(dy.ptr, dy.ld, r.ptr, r.ld, dy.B, C.c_long(dy.H * dy.W), dy.C, _p(fold["mean"]),
+                                                _p(fold["rstd1"]), _p(fold["rstd2"]), _p(ms), _p(mh), mask, _p(gamma1), _p(gamma2),
+                                                C.c_float(eps), _p(dgamma1), _p(dgamma2), _p(dbeta2), dr.ptr, dr.ld,
+                                                _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_bn_train_bwd_small_f32")
+    return dr
+
+
 def chan_reduce(dy: Act, s1, x: Act | None = None, mean=None, rstd=None, s2=None, mscale=None, mshift=None,
                 mask=MASK_NONE, accumulate_s1=False, stream=None):
     npix = dy.B * dy.H * dy.W

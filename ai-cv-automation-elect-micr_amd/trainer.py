@@ -118,6 +118,9 @@ class DenoiserTrainer:
         self._pack_batch = None
         self._flip_idx = self._flip_flat = None
         self._per_image = False
+        # the norms of small per-image maps as one launch per direction (train_ops.bn_train_fwd_small / bn_backward_small): opt-in -- measured
+        # 47.3-47.7 ms per step against 46.2 with the four-launch forms (profiles/r04_experiments.txt 6)
+        self.fuse_bn_small = os.environ.get("EMD_T_BN_SMALL", "0") == "1"
         self.fuse_stats = os.environ.get("EMD_T_FUSE_STATS", "1") == "1"   # batch statistics from the producing GEMM's epilogue (ops.conv_stats)
         self.teacher = None   # test hook: scope -> {"d": ..., "r": ...} reference tensors that REPLACE the forward's conv outputs (see _force)
         self.repack()
@@ -271,6 +274,38 @@ class DenoiserTrainer:
         return TO.bn_train_fold(mean, var, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], npix,
                                 bias=self.v[bias_name] if bias_name else None, moving=mv, images=img)
 
+    def _bn_small_shape(self, npix_img, cout, B):
+        """The one-launch forms of the norm (train_ops.bn_train_fwd_small / bn_backward_small) for the small per-image maps (32 x 32,
+        64 x 64) of a batched pass of one-image towers -- and of a tower of ONE image, whose batch statistics are per-image statistics:
+        a tower alone and the same image inside a batched pass then run the same arithmetic (tests/test_train_gpu.py holds them to
+        equality).  Not under teacher forcing (its hooks sit between the launches)."""
+        return (self.fuse_bn_small and (self._per_image or B == 1) and self.teacher is None and npix_img <= 4096 and cout % 4 == 0)
+
+    def _bn_small(self, r):
+        return self._bn_small_shape(r.H * r.W, r.C, r.B) and TO.bn_small_supported(r)
+
+    def _bn_apply(self, key, r, out, act, res=None, bias_name=None, stats=None):
+        """Batch norm chain of layer `key` on the conv output r + activation (+ residual) -> (out, fold): one launch for small per-image
+        maps, else statistics (unless the conv delivered them) + fold + affine."""
+        if self._bn_small(r):
+            L = self.layers[key]
+            upd = self._update_moving
+            if len(L.bn) == 2:
+                b1, b2 = L.bn
+                mv = (self.m[b1 + "/moving_mean"], self.m[b1 + "/moving_variance"], self.m[b2 + "/moving_mean"],
+                      self.m[b2 + "/moving_variance"]) if upd else None
+                fold = TO.bn_train_fwd_small(r, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], out, act, gamma1=self.v[b1 + "/gamma"],
+                                             beta1=self.v[b1 + "/beta"], moving=mv, res=res)
+            else:
+                (b2,) = L.bn
+                mv = (self.m[b2 + "/moving_mean"], self.m[b2 + "/moving_variance"]) if upd else None
+                fold = TO.bn_train_fwd_small(r, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], out, act,
+                                             bias=self.v[bias_name] if bias_name else None, moving=mv, res=res)
+            return out, fold
+        fold = self._bn(key, r, bias_name, stats=stats)
+        self._affine(r, fold, out, act, res)
+        return out, fold
+
     @staticmethod
     def _affine(r, fold, out, act, res=None):
         """out = act(r * scale + shift) [+ res] with the fold of _bn: per-channel, or per (image, channel) for per-image statistics."""
@@ -300,17 +335,17 @@ class DenoiserTrainer:
         d = ops.dw3x3(x, self._dw(key), self._E(x.B, Ho, Wo, x.C), stride=L.stride, rate=L.rate)
         self._force(d, L.scope, "d")
         stats = None
-        if self._fuse_stats(d):     # the batch statistics of r from the pointwise GEMM's epilogue: no second pass over r
+        small = self._bn_small_shape(Ho * Wo, L.cout, x.B)   # the one-launch norm takes its own statistics
+        if not small and self._fuse_stats(d):     # the batch statistics of r from the pointwise GEMM's epilogue: no second pass over r
             r = self._E(x.B, Ho, Wo, L.cout)
             stats = ops.conv_stats(d, self.pk_f[key], self.ones, self.zeros, r, images=self._per_image, precision=self.precision)
         else:
             r = ops.conv1x1(d, self.pk_f[key], self.ones, self.zeros, self._E(x.B, Ho, Wo, L.cout), act=False,
                             precision=self.precision)
         self._force(r, L.scope, "r")
-        fold = self._bn(key, r, stats=stats)
         if out is None:
             out = self._E(x.B, Ho, Wo, L.cout)
-        self._affine(r, fold, out, ops.ACT_RELU6, res)
+        out, fold = self._bn_apply(key, r, out, ops.ACT_RELU6, res, stats=stats)
         return out, {"x": x, "d": d, "r": r, "fold": fold}
 
     def _conv_fwd(self, key, x, out=None, act=True):
@@ -322,7 +357,8 @@ class DenoiserTrainer:
         tgt = self._E(x.B, Ho, Wo, L.cout) if (has_bn or out is None) else out
         shift = self.zeros if has_bn else bias
         stats = None
-        if has_bn and (L.k == 1 or L.stride == 1) and self._fuse_stats(x, L.stride):
+        small = has_bn and self._bn_small_shape(Ho * Wo, L.cout, x.B)
+        if has_bn and not small and (L.k == 1 or L.stride == 1) and self._fuse_stats(x, L.stride):
             stats = ops.conv_stats(x, self.pk_f[key], self.ones, self.zeros, tgt, stride=L.stride, rate=L.rate, images=self._per_image,
                                    precision=self.precision)
         elif L.k == 1:
@@ -333,10 +369,9 @@ class DenoiserTrainer:
         self._force(tgt, L.scope, "r")
         if not has_bn:
             return tgt, {"x": x}
-        fold = self._bn(key, tgt, L.scope + "/" + L.bname, stats=stats)
         if out is None:
             out = self._E(x.B, Ho, Wo, L.cout)
-        self._affine(tgt, fold, out, ops.ACT_RELU6 if act else ops.ACT_NONE)
+        out, fold = self._bn_apply(key, tgt, out, ops.ACT_RELU6 if act else ops.ACT_NONE, None, L.scope + "/" + L.bname, stats=stats)
         return out, {"x": x, "r": tgt, "fold": fold}
 
     def _deconv_fwd(self, key, x, out):
@@ -386,12 +421,13 @@ class DenoiserTrainer:
         """dy -> d loss / d r, written over r (no longer needed); BN parameter gradients accumulate."""
         L = self.layers[key]
         r = ctx["r"]
+        bwd = TO.bn_backward_small if (ctx["fold"].get("small") and self._bn_small(r)) else TO.bn_backward
         if len(L.bn) == 2:
             b1, b2 = L.bn
-            return TO.bn_backward(dy, r, ctx["fold"], self.v[b2 + "/gamma"], self.g[b2 + "/gamma"], self.g[b2 + "/beta"], r,
-                                  mask=mask, gamma1=self.v[b1 + "/gamma"], dgamma1=self.g[b1 + "/gamma"])
+            return bwd(dy, r, ctx["fold"], self.v[b2 + "/gamma"], self.g[b2 + "/gamma"], self.g[b2 + "/beta"], r,
+                       mask=mask, gamma1=self.v[b1 + "/gamma"], dgamma1=self.g[b1 + "/gamma"])
         (b2,) = L.bn
-        return TO.bn_backward(dy, r, ctx["fold"], self.v[b2 + "/gamma"], self.g[b2 + "/gamma"], self.g[b2 + "/beta"], r, mask=mask)
+        return bwd(dy, r, ctx["fold"], self.v[b2 + "/gamma"], self.g[b2 + "/gamma"], self.g[b2 + "/beta"], r, mask=mask)
 
     def _sep_bwd(self, key, dy, ctx, gslot, need_dx=True):
         L = self.layers[key]

@@ -49,7 +49,7 @@ CPU_THREADS = min(16, os.cpu_count() or 1)  # a 1-GPU box owns a 16-CPU share; m
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 D_GMAC_MATRIX_B32_512 = 2218.3  # pointwise 1304.5 + dense 1x1 295.3 - final 4.8 + conv-T 618.5 ... per B=32 batch
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
+PMC_FILES = tuple(f"r{n:02d}_pmc_traffic.json" for n in range(9, 0, -1))   # newest first (a round that has not refreshed it yet falls back to the last one, stale if csrc changed)
 
 
 # ================================================================================================

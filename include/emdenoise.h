@@ -427,6 +427,25 @@ int emd_bn_bwd_apply_images_f32(const float* dy, int ldd, const float* x, int ld
                                 const float* mean, const float* m2, const float* mscale, const float* mshift, int mask,
                                 float* dx, int ldo, int B, long npix, int C, emd_stream_t stream);
 
+/* The training-mode batch norm of a SMALL map as ONE launch per direction (round 4): per-image statistics (a tower of one image,
+ * misc_py/denoiser-multi-gpu.py:763, or B of them as one batched pass; vectors [B][C]), npix <= 4096 pixels per image, C % 4 == 0
+ * (emd_bn_train_small_supported; EMD_E_UNSUPPORTED otherwise: use the slab forms above).
+ * emd_bn_train_fwd_small_f32 == emd_bn_stats_images_f32 + emd_bn_train_fold_images_f32 + emd_affine_act_images_f32:
+ *   out = act(r * scale + shift) [+ res], with scale / shift / rstd1 / rstd2 / mean returned for the reverse pass and the moving
+ *   statistics (NULL = leave them) updated from image 0.  gamma1 / beta1 NULL: a single norm (gamma2, beta2) behind conv + bias.
+ * emd_bn_train_bwd_small_f32 == emd_bn_bwd_reduce_images_f32 + emd_bn_bwd_prep_images_f32 + emd_bn_bwd_apply_images_f32:
+ *   dx = d loss / d r (dx may be dy or x), the norms' parameter gradients ADDED (float atomics) into dgamma1 / dgamma2 / dbeta2.
+ * Same formulas as the slab forms; their sums are cut differently, so the two agree to rounding, not bit for bit. */
+int emd_bn_train_small_supported(long npix, int C);
+int emd_bn_train_fwd_small_f32(const float* r, int ldr, int B, long npix, int C, const float* gamma1, const float* beta1,
+                               const float* gamma2, const float* beta2, const float* bias, float eps, float* scale, float* shift,
+                               float* rstd1, float* rstd2, float* mean, float* mm1, float* mv1, float* mm2, float* mv2, double decay,
+                               const float* res, int ldres, float* out, int ldo, int act, emd_stream_t stream);
+int emd_bn_train_bwd_small_f32(const float* dy, int ldd, const float* x, int ldx, int B, long npix, int C, const float* mean,
+                               const float* rstd1, const float* rstd2, const float* mscale, const float* mshift, int mask,
+                               const float* gamma1, const float* gamma2, float eps, float* dgamma1, float* dgamma2, float* dbeta2,
+                               float* dx, int ldo, emd_stream_t stream);
+
 /* Depthwise 3x3 backward (the depthwise half of slim.separable_convolution2d, :253-273); shapes as emd_dw3x3_f32
  * (x, dx [B,H,W,C]; dy [B,ceil(H/s),ceil(W/s),C]); dw [3][3][C] +=. */
 int emd_dw3x3_wgrad_f32(const float* x, int ldx, const float* dy, int ldd, float* dw, int B, int H, int W, int C, int stride,

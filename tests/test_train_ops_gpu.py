@@ -481,3 +481,72 @@ def test_conv_stats_rejects_images_that_share_a_tile():
     ones, zeros = torch.ones(64, device=dev()), torch.zeros(64, device=dev())
     with pytest.raises(RuntimeError, match="straddle"):
         ops.conv_stats(x, pk, ones, zeros, out_act(2, 10, 10, 64), images=True)
+
+
+@pytest.mark.parametrize("B,H,W,Cc,double,mask,res", [
+    (2, 32, 32, 728, True, 1, True),      # the middle flow of a pair of one-image towers: BN1 -> BN2 -> relu6 (+ residual), 12 channel blocks
+    (3, 64, 64, 256, True, 1, False),     # 4096 pixels per image: the largest map the one-launch form takes
+    (2, 16, 16, 36, False, 1, False),     # a single norm behind conv + bias, channel tail in a 64-channel block
+    (1, 32, 32, 64, False, 2, False),     # relu6 then clip to [0, 1]
+    (2, 8, 8, 128, True, 0, False),       # no activation
+])
+def test_bn_small_one_launch_forms_equal_the_slab_forms(B, H, W, Cc, double, mask, res):
+    """emd_bn_train_fwd_small_f32 / emd_bn_train_bwd_small_f32 (round 4) against the launches they replace (emd_bn_stats_images_f32 +
+    emd_bn_train_fold_images_f32 + emd_affine_act_images_f32; emd_bn_bwd_reduce / _prep / _apply_images_f32 -- themselves checked against
+    float64 autograd above and in test_bn_backward_per_image_at_tower_sizes): same formulas, sums cut differently -> agreement to
+    rounding; plus the moving-average update from image 0 and "dx may be written over r"."""
+    from emdenoise import ops, train_ops as TO
+
+    r = rnd((B, H, W, Cc), 800, 1.5) + 0.7
+    g1, b1 = d32(rnd((Cc,), 801, 0.3) + 1.0), d32(rnd((Cc,), 802, 0.3))
+    g2, b2 = d32(rnd((Cc,), 803, 0.3) + 1.2), d32(rnd((Cc,), 804, 0.5) + (0.4 if mask == 2 else 1.0))
+    bias = None if double else d32(rnd((Cc,), 805, 0.2))
+    dy = rnd((B, H, W, Cc), 806)
+    rr = to_act(rnd((B, H, W, Cc), 807, positive=True)) if res else None
+    act = {0: ops.ACT_NONE, 1: ops.ACT_RELU6, 2: ops.ACT_RELU6_CLIP01}[mask]
+    ra = to_act(r, ld=Cc + 8, c0=4)
+    assert TO.bn_small_supported(ra)
+    mk = lambda: [torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev()), torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())]
+    # the slab forms
+    mean, var = ops.bn_batch_stats_images(ra)
+    mm_ref = mk()
+    fold_ref = TO.bn_train_fold(mean, var, g2, b2, H * W, gamma1=g1 if double else None, beta1=b1 if double else None, bias=bias,
+                                moving=mm_ref if double else mm_ref[2:], images=B)
+    y_ref = ops.affine_act_images(ra, fold_ref["scale"], fold_ref["shift"], out_act(B, H, W, Cc), act=act, res=rr)
+    # one launch
+    mm = mk()
+    y = out_act(B, H, W, Cc, ld=Cc + 4, c0=0)
+    fold = TO.bn_train_fwd_small(ra, g2, b2, y, act, gamma1=g1 if double else None, beta1=b1 if double else None, bias=bias,
+                                 moving=mm if double else mm[2:], res=rr)
+    torch.cuda.synchronize()
+    for k in ("scale", "shift", "rstd1", "mean") + (("rstd2",) if double else ()):
+        assert rel_l2(fold[k].cpu().numpy(), fold_ref[k].cpu().numpy()) < 1e-6, k
+    assert rel_l2(y.torch().cpu().numpy(), y_ref.torch().cpu().numpy()) < 1e-6
+    for a, b in zip(mm, mm_ref):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+    assert not np.isnan(y.torch().cpu().numpy()).any() and np.isnan(y.buf.cpu().numpy()[..., Cc:]).all()
+    # backward: dx written over a copy of r (as the trainer does)
+    bm = {0: TO.MASK_NONE, 1: TO.MASK_RELU6, 2: TO.MASK_RELU6_CLIP}[mask]
+    dya = to_act(dy)
+    dgr = [torch.zeros(Cc, device=dev()) for _ in range(3)]
+    dr_ref = TO.bn_backward(dya, ra, fold_ref, g2, dgr[1], dgr[2], out_act(B, H, W, Cc), mask=bm, gamma1=g1 if double else None,
+                            dgamma1=dgr[0] if double else None)
+    dg = [torch.zeros(Cc, device=dev()) for _ in range(3)]
+    r2 = to_act(r, ld=Cc + 8, c0=4)
+    dr = TO.bn_backward_small(dya, r2, fold, g2, dg[1], dg[2], r2, mask=bm, gamma1=g1 if double else None, dgamma1=dg[0] if double else None)
+    torch.cuda.synchronize()
+    assert rel_l2(dr.torch().cpu().numpy(), dr_ref.torch().cpu().numpy()) < 2e-6
+    scale = float(dgr[1].abs().max())
+    for a, b in zip(dg, dgr):
+        assert np.abs(a.cpu().numpy() - b.cpu().numpy()).max() < 2e-6 * scale + 1e-12
+    assert np.isnan(r2.buf.cpu().numpy()[..., :4]).all()        # nothing outside the slice
+
+
+def test_bn_small_refuses_large_maps():
+    from emdenoise import ops, train_ops as TO
+
+    x = to_act(rnd((1, 128, 64, 64), 810))
+    assert not TO.bn_small_supported(x)
+    g = torch.ones(64, device=dev())
+    with pytest.raises(RuntimeError, match="4096"):
+        TO.bn_train_fwd_small(x, g, g, out_act(1, 128, 64, 64), ops.ACT_RELU6)
