@@ -67,6 +67,7 @@ struct Knobs {
     int split_wide = 0;      // pointwise split32 GEMM: 256 x 192 tiles (gemm_split16_wide_kernel) where they fill the chip: 0 never (default: slower in graph D), 1 = 8 waves of 64 x 96, 2 = 4 waves of 128 x 96
     int conv3_pipe = 1;      // dense 3x3 conv (stride 1, rate 1, H % 8 == 0, W % 32 == 0) on the patch-resident kernel (conv3_pipe.hip): 1 = up to 192 output channels, 2 = any width, 0 = never
     int split_variant = -1;  // pointwise split32 GEMM pipeline variant (-1 = dispatch rule)
+    int sep_stamp_wave = 0;  // sep_pipe2 in-kernel stamps: the wave (0-7) that reports
     int wgrad_msplit = 0;    // weight-gradient GEMM: slices of the pixel dimension (each adds its partial sums atomically): 0 = rule, n = at most n
     int wgrad_tile = 0;      // weight-gradient GEMM: 0 = rule (128 where a dimension exceeds 64), 64 = 64 x 64 tiles everywhere
     long long* sep_stamps = nullptr;   // device buffer for the in-kernel phase stamps of the fused separable convs

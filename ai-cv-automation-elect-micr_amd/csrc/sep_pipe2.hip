@@ -607,7 +607,9 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
             if (dq.patch) issue_patch(dq.pstage, dq.pcoff);
             if (!epi_first) epilogue(x_epi);
         } else {
-            issue_B(dq.hm, dq.cm, dq.hp, dq.cp);   // (the weights at the top: they have the whole slot to land; the patch pieces between the segments)
+            // the weights at the top: they have the whole slot to land; the patch pieces between the segments.  (Also tried: the weight pieces
+            // inside the body too, behind segment wave % 3 -- deconv1_a + residual1_d 1991 -> 2175 us, every shape slower: less time to land.)
+            issue_B(dq.hm, dq.cm, dq.hp, dq.cp);
             if (dq.rp) res_prefetch(dq.x);
         }
         const bool epi_last = epi_here && !res_on;            // its stores are younger than every DMA piece of this slot
@@ -616,6 +618,7 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
         if (s == -1 && !out2) zero_acc();
         PIPE_STAMP(1)
         wait_lgkm0();
+        PIPE_STAMP(2)
         if (odd) {
             // need: this slot's weight pieces; younger: residual loads, patch pieces, the projection's stores
             if (k < 0 || (!full && (epi_last || rp))) wait_vm<0>();
@@ -627,8 +630,9 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
             if (epi_last && full) wait_vm<E>();
             else wait_vm<0>();
         }
+        PIPE_STAMP(3)
         __builtin_amdgcn_s_barrier();
-        PIPE_STAMP(2)
+        PIPE_STAMP(4)
         if (!odd) {
             if (last0) x_epi += TW;
             ct1 = ct2;
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void sep_pipe2_kernel(const SepParams p) {
         }
     }
     wait_vm<0>();   // the surplus DMA groups must have landed before this workgroup's LDS goes to the next one
-    if (p.stamps && tid == 0) {
+    if (p.stamps && tid == p.ablate * 64) {   // (dev: the wave whose stamps are reported rides in the otherwise unused ablate field)
         long long* o = p.stamps + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = ph[i];
@@ -673,7 +677,7 @@ int sep_pipe2_launch(const SepParams& p, int B, hipStream_t st) {
     if (g_knobs.sep_tpw > 0 && tiles_w % g_knobs.sep_tpw == 0) tpw = g_knobs.sep_tpw;
     q.tpw = tpw;
     q.stamps = g_knobs.sep_stamps;
-    q.ablate = 0;
+    q.ablate = g_knobs.sep_stamp_wave & 7;
     const dim3 grid(tiles_w / tpw, p.H / 8, B);
     q.xcd = g_knobs.sep_xcd && ((long)grid.x * grid.y * grid.z) % 8 == 0;
     const int epi = g_knobs.epi_width ? g_knobs.epi_width : ((p.res && p.N > 128) ? 4 : 1);

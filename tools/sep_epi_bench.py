@@ -82,12 +82,15 @@ for nm, (S, ci, co, res, co2, osplit, stride) in SHAPES.items():
     if os.environ.get("SEB_STAMPS"):     # in-kernel phase stamps of workgroup wave 0 (sep_pipe2: top of slot = DMA issue + epilogue | slot body | wait + barrier)
         import ctypes
         lib = _lib.load()
-        for k, f in fns.items():
+        for k, f in [(k, f) for k, f in fns.items()] + ([(("wave4", b), fns[b])] if KNOB == "sep_pipe2" else []):
+            if isinstance(k, tuple):
+                _lib.knob("sep_stamp_wave", 4)
             st = torch.zeros(B * (S // 8) * (S // 16) * 8, dtype=torch.int64, device=dev)
             lib.emd_debug_sep_stamps(ctypes.c_void_p(st.data_ptr()))
             f()
             torch.cuda.synchronize()
             lib.emd_debug_sep_stamps(ctypes.c_void_p(0))
+            _lib.knob("sep_stamp_wave", 0)
             v = st.view(-1, 8).double()
             v = v[v.sum(1) > 0]
             m = v.mean(0)
