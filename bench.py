@@ -821,6 +821,9 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
     pw728_ms = sum(e0.elapsed_time(e1) for (e0, e1), sh in zip(fam.ev.get("conv1x1_split32", []), fam.pw_shapes) if 728 in sh[:2])
     pw728_flops = 3.0 * sum(sh[3] for sh in fam.pw_shapes if 728 in sh[:2])
     pw728_n = sum(1 for sh in fam.pw_shapes if 728 in sh[:2])
+    # what the matrix cores execute for those launches: K zero-padded to the MFMA's 16 and N to the 64-column wave tile (728 -> 736 and 768;
+    # every tile variant of gemm_split.hip pads at least this much).  Reported beside pointwise_frac, never in its place.
+    pw728_exec = 3.0 * sum(2.0 * sh[2] * (-(-sh[0] // 16) * 16) * (-(-sh[1] // 64) * 64) for sh in fam.pw_shapes if 728 in sh[:2])
     # north_star's "depthwise path": EVERY launch that contains a depthwise stage -- the standalone depthwise kernels and the fused
     # separable convs (depthwise -> pointwise in one kernel, one or two outputs) -- algorithmic bytes over their summed device time
     DWP = ("dw3x3", "dw3x3_split32", "sep_fused", "sep_fused_gen", "sep_dual")
@@ -882,6 +885,9 @@ def bench_D(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
                       "channels_728": {"launches": pw728_n, "issued_flops_per_step": pw728_flops, "ms_per_step": round(pw728_ms, 3),
                                        "issued_tflops": round(pw728_flops / (max(pw728_ms, 1e-9) * 1e-3) / 1e12, 1),
                                        "frac_of_2500": round(pw728_flops / (max(pw728_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                       "mfma_executed_frac_of_2500": round(pw728_exec / (max(pw728_ms, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                       "mfma_executed_note": "the same launches with the zero padding the tiles carry (K 728 -> 736, N 728 -> 768): what the "
+                                                             "matrix pipe is busy with; pointwise_frac counts the unpadded 3 x 2MKN only",
                                        "note": "the launches with K or N = 728 (the matrix-core bound ones); the other launches of the family are HBM-bound"}},
         "kernel_family_ms": fam.table(),
     }
