@@ -50,6 +50,7 @@ constexpr int kWave = 64;  // CDNA4 wavefront
 struct Knobs {
     int sep_pipe = 1;        // 1: the LDS-DMA pipelined fused separable conv (sep_pipe.hip) where it covers the shape; 0: sep_fused.hip
     int sep_pipe2 = 0;       // the software-pipelined kernel (sep_pipe2.hip, round 4): 0 never (default: measured at parity standalone on its best shape and slower inside graph D, profiles/r04_experiments.txt 3), 1 the two-output launches of more than 64 columns, 2 wherever it has an instance (the parity tests)
+    int sep_gen_pipe = 0;    // generated-input fused separable conv (cnn0_last): 1 = sep_pipe.hip's 4-wave instance (round 4; same bits), 0 (default) = sep_fused.hip's register-staged kernel -- measured 814-841 us (0) against 833-849 (1) at [32,512,512,64 -> 64], profiles/r04_experiments.txt 9
     int sep_mode = -1;       // sep_pipe schedule of the one-output instances: -1 = rule, 0 / 1 = the patch two / one steps ahead
     int sep_nw = 0;          // sep_pipe waves per workgroup: 0 = rule (4 wherever there is an instance), 8 (8 x 32 tiles, one workgroup per CU) or 4 (8 x 16 tiles, two per CU; <= 128 output channels, 64 | 64 for two outputs)
     int sep_ablate = 0;      // sep_pipe phase ablation bits for timing experiments (results are wrong when non-zero)

@@ -47,7 +47,12 @@ __device__ __attribute__((aligned(16))) float g_zero_pipe[4096];
 // before, one pixel after): output tile 4 x 16 pixels (64 GEMM rows) from a 9 x 33 pixel patch, a thread one output pixel x 4 channels
 // in stage 1 (9 patch + 9 weight reads), every wave one 32 x (BN / 4) accumulator block -- the depthwise result of the strided
 // blocks no longer goes through HBM (cnn0_strided: 0.54 GB written and read back per batch).
-template <int BN, bool DUAL, int MODE, bool OSPLIT, int NW = 8, int STRIDE = 1, int EPI = 1>     // EPI: dwords a lane stores at a time (epilogue)
+// GEN (round 4): the layer's input is GENERATED -- act(d[pixel] * gen_a[c] + gen_t[c]), d a one-value-per-pixel tensor (the 1 -> 64
+// channel separable conv in front of it, whose pointwise half is rank 1; sep_fused.hip's generated-input form, same arithmetic) -- so
+// there is no patch to fetch: where the other instances request the DMA pieces of a chunk, every lane computes the 16 bytes its DMA
+// lane would have received and writes them to the same place.  d of the NEXT tile is loaded one tile ahead; the depthwise weights of
+// all chunks (Cin <= 64) sit in their own 2.25 KiB of LDS for the workgroup's life.
+template <int BN, bool DUAL, int MODE, bool OSPLIT, int NW = 8, int STRIDE = 1, int EPI = 1, bool GEN = false>     // EPI: dwords a lane stores at a time (epilogue)
 __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p) {
     constexpr int TW = STRIDE == 2 ? 16 : 4 * NW, TH = STRIDE == 2 ? 4 : 8, BM = TH * TW;
     constexpr int PW = STRIDE * TW + 3 - STRIDE, PH = STRIDE * TH + 3 - STRIDE, PWS = PW | 1;   // patch pixels per row; slot pitch odd (see above): 34 -> 35, 18 -> 19, 33
@@ -66,13 +71,15 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
     constexpr bool LEAD2 = MODE == 0;
     constexpr int WN = STRIDE == 2 ? 4 : BN / 64, WM = NW / WN, TM = BM / WM / 32, TN = BN / WN / 32;   // a wave owns 32 TM rows x 32 TN columns
     constexpr int A_OFF = 2 * STAGE, B_OFF = A_OFF + A_BYTES;
-    constexpr int SMEM = B_OFF + B_ONE * (BDBL ? 2 : 1);
+    constexpr int GW_OFF = B_OFF + B_ONE * (BDBL ? 2 : 1);    // GEN: depthwise weights [chunk][tap][32] fp32, two chunks at most
+    constexpr int SMEM = GW_OFF + (GEN ? 2 * 9 * 128 : 0);
     constexpr bool SWZ = DUAL;                                // patch chunks XORed with (pixel >> 1) & 3: the projection's centre reads
     constexpr int E = 16 / EPI * TM * TN;                     // stores per wave and tile (exact when no lane is masked: full tiles)
     static_assert(!(DUAL && MODE != 1), "the two-output instances read the patch in stage 2");
     static_assert(!(DUAL && OSPLIT), "split32 output: one-output instances only");
     static_assert(PP >= 2 && PB >= 1 && SMEM <= (NW == 8 ? 160 : 80) * 1024, "shape");
     static_assert(NW == 8 || NW == 4, "4 or 8 waves");
+    static_assert(!GEN || (MODE == 1 && !DUAL && !OSPLIT && STRIDE == 1 && !BDBL), "generated input: one fp32 output, stride 1, schedule 1, one weight tile");
     static_assert(STRIDE == 1 || (STRIDE == 2 && NW == 8 && !DUAL && BN >= 128 && TM == 1), "stride 2: 8 waves, one output, 128 or 256 columns");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
@@ -118,10 +125,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
             const int tap = WPAD ? py : slot - NPATCH;
             const int kk = SWZ ? (dk ^ ((px >> 1) & 3)) : dk;
             const float* o = g_zero_pipe + dk * 4;                                  // padding pixels, unused slots
-            const float* o_px = p.x + (img + (long)gy * p.W + gx) * p.ldx + kk * 4;
+            const float* o_px = p.x + (img + (long)gy * p.W + gx) * p.ldx + (GEN ? 0 : kk * 4);   // GEN: the pixel's one value
             const float* o_wk = p.dw + (long)tap * p.Cin + dk * 4;                 // the chunk's depthwise weights, one tap per slot
             o = real ? o_px : o;
-            o = wk ? o_wk : o;
+            o = (wk && !GEN) ? o_wk : o;                                            // (GEN: the weights are not part of the patch)
             psrc[j] = o;
             pmove |= real ? 1u << j : 0u;
         }
@@ -154,6 +161,49 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
 #pragma unroll
         for (int j = 0; j < PB; ++j)
             __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[j] + coff), (lptr_t)(smem + B_OFF + buf * B_ONE + (wv * PB + j) * 1024), 16, 0, 0);
+    };
+
+    // ---- generated input: this lane's a / t of both chunks, d of the tile being generated (dcur, real-pixel mask greal) and of the one
+    // after it (dnx; psrc / pmove describe THAT tile), and the patch chunk written where the DMA would have put it
+    f32x4 gga[2], ggt[2];
+    float dcur[PP], dnx[PP];
+    unsigned greal = 0;
+    float ghi = 0.f, gsl = 0.f, glo = 0.f;
+    if constexpr (GEN) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = (c * 32 < p.Cin ? c * 32 : 0) + dk * 4;
+            gga[c] = *reinterpret_cast<const f32x4*>(p.gen_a + ch);
+            ggt[c] = *reinterpret_cast<const f32x4*>(p.gen_t + ch);
+        }
+        ghi = p.gen_act == 1 ? 6.f : __builtin_inff();
+        gsl = p.gen_act == 4 ? 0.2f : 1.f;
+        glo = (p.gen_act == 1 || p.gen_act == 2) ? 0.f : -__builtin_inff();
+        for (int i = tid; i < (p.Cin / 32) * 72; i += NW * 64) {   // depthwise weights -> LDS [chunk][tap][32] (visible after the first barrier)
+            const int ch = i / 72, rem = i - ch * 72;
+            *reinterpret_cast<f32x4*>(smem + GW_OFF + i * 16) =
+                *reinterpret_cast<const f32x4*>(p.dw + (long)(rem >> 3) * p.Cin + ch * 32 + (rem & 7) * 4);
+        }
+    }
+    auto load_d = [&](float (&dst)[PP]) {
+#pragma unroll
+        for (int j = 0; j < PP; ++j) dst[j] = *psrc[j];
+    };
+    auto gen_patch = [&](int stage, int chunk) {
+        const f32x4 ga = chunk ? gga[1] : gga[0], gt = chunk ? ggt[1] : ggt[0];
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const int q = wv + NW * j;
+            if (q >= NPIECE) continue;          // (wave-uniform: the surplus pieces of the DMA form have nothing to repeat here)
+            const bool real = (greal >> j) & 1;
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float u = fmaf(dcur[j], ga[c], gt[c]);
+                v[c] = real ? fminf(fmaxf(fmaxf(u, glo), gsl * u), ghi) : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(smem + stage * STAGE + q * 1024 + lane * 16) = v;
+        }
     };
 
     // ---- stage 1 role: 4 consecutive output pixels of one tile row, 4 channels.  A wave covers two 2 x 8 pixel blocks; inside a
@@ -223,6 +273,17 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
         if (++ic == nchunks) {
             ic = 0;
             const int xn = ixt + TW;
+            if constexpr (GEN) {   // the tile whose d values were requested a tile ago becomes current; request the one after it
+#pragma unroll
+                for (int j = 0; j < PP; ++j) dcur[j] = dnx[j];
+                greal = pmove;
+                ixt = xn;
+                if (istep + nchunks < total) {
+                    set_tile(xn + TW);
+                    load_d(dnx);
+                }
+                return;
+            }
             if (((STRIDE == 2 && !p.reflect) || ixt >= 1) && STRIDE * (xn + TW) + 1 <= p.W) {   // both tiles clear of the left / right image edges: every real
                 const long step = (long)STRIDE * TW * p.ldx;                     // pixel moves one tile on
 #pragma unroll
@@ -238,8 +299,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
     if (p.stamps) tprev = __builtin_amdgcn_s_memtime();
 #define PIPE_STAMP(i) if (p.stamps) { const long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tprev; tprev = t_; }
 
-    auto stage1 = [&](const unsigned char* stg) {   // depthwise 3x3 from the patch -> bf16 hi / lo A rows
+    auto stage1 = [&](const unsigned char* stg, int chunk) {   // depthwise 3x3 from the patch -> bf16 hi / lo A rows
         if (abl & 1) return;
+        constexpr int WKT = GEN ? 128 : WKS * 128;                 // bytes from one tap's weights to the next
         if constexpr (STRIDE == 2) {
             const unsigned char* wkp = stg + WK0 * 128 + c4 * 16;
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -256,7 +318,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
             *reinterpret_cast<u32x2*>(smem + (a_wr[0] ^ 64)) = u32x2{l0, l1};
             return;
         }
-            const unsigned char* wkp = stg + WK0 * 128 + c4 * 16;
+            const unsigned char* wkp = GEN ? smem + GW_OFF + chunk * (9 * 128) + c4 * 16 : stg + WK0 * 128 + c4 * 16;
             f32x4 o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -264,7 +326,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
             for (int i = 0; i < 3; ++i) {
                 f32x4 wk[3], pr[6];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) wk[d] = *reinterpret_cast<const f32x4*>(wkp + (i * 3 + d) * (WKS * 128));
+                for (int d = 0; d < 3; ++d) wk[d] = *reinterpret_cast<const f32x4*>(wkp + (i * 3 + d) * WKT);
 #pragma unroll
                 for (int d = 0; d < 6; ++d)
                     pr[d] = *reinterpret_cast<const f32x4*>(stg + rd_base + (i * PWS + d) * 128 + rd_k[d >> 1]);
@@ -576,6 +638,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
         if constexpr (BDBL) issue_B(0, 0);
         advance_issue();
         issue_patch(1, ic * 32);
+    } else if constexpr (GEN) {
+        load_d(dcur);
+        greal = pmove;
+        if (nchunks < total) {     // a second tile: its d values one tile ahead
+            set_tile(xbase + TW);
+            load_d(dnx);
+        }
+        gen_patch(0, 0);
     } else {
         if constexpr (BDBL) issue_B(0, 0);
         issue_patch(0, 0);
@@ -596,6 +666,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
         } else {
             if (epi1 && full) wait_vm<E>();
             else wait_vm<0>();
+            if constexpr (GEN) wait_lgkm0();    // this wave's part of the generated patch of step t is written
         }
         __builtin_amdgcn_s_barrier();
         PIPE_STAMP(0)
@@ -606,12 +677,20 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
             } else {
                 issue_B(0, ct * 32);
             }
-            advance_issue();
-            issue_patch(st ^ 1, ic * 32);
+            if constexpr (GEN) {
+                // (a new tile: the d values of the tile after it are requested here, beside this step's weight pieces; barrier B waits
+                // for everything -- vmcnt 0 -- and by then both have had stage 1 to land)
+                const int before = istep;
+                advance_issue();
+                if (istep != before) gen_patch(st ^ 1, ic);
+            } else {
+                advance_issue();
+                issue_patch(st ^ 1, ic * 32);
+            }
         } else if constexpr (!BDBL) {
             issue_B(0, ct * 32);
         }
-        stage1(stg);
+        stage1(stg, ct);
         const bool rp = RPRE && res_on && ct + 1 == nchunks;   // last step of a tile with a residual: request its values now
         if (rp) res_prefetch(x0);
         PIPE_STAMP(1)
@@ -622,6 +701,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sep_pipe_kernel(const SepParams p)
             else if (rp && full) { if (epi1) wait_vm<PP + R + E>(); else wait_vm<PP + R>(); }
             else if (epi1 && full && !rp) wait_vm<PP + E>();
             else wait_vm<PP>();
+        } else if constexpr (GEN) {
+            wait_vm<0>();
         } else if constexpr (!BDBL) {
             if (rp && full) wait_vm<PP + R>();
             else wait_vm<PP>();
@@ -726,7 +807,10 @@ static bool use_nw4(const SepParams& p) {
 }
 
 bool sep_pipe_covers(const SepParams& p, int precision) {
-    if (!g_knobs.sep_pipe || precision != 3 || p.gen_a) return false;
+    if (!g_knobs.sep_pipe || precision != 3) return false;
+    if (p.gen_a)   // generated input (round 4, opt-in: dev knob sep_gen_pipe): the 4-wave 64-column instance only -- cnn0_last of graphs D / X and its likes
+        return g_knobs.sep_gen_pipe && p.stride == 1 && p.H % 8 == 0 && p.W % 16 == 0 && (p.Cin == 32 || p.Cin == 64) && p.N <= 64 && p.N2 == 0 &&
+               !p.out_split && !p.res && g_knobs.sep_nw != 8;
     if (p.stride == 2)   // output tiles of 4 x 16 pixels: H % 8 == 0, W % 32 == 0 (input sizes); one fp32 output of up to 256 channels
         return p.H % 8 == 0 && p.W % 32 == 0 && p.Cin % 32 == 0 && p.Cin >= 32 && p.Cin <= 4064 && p.N2 == 0 && !p.out_split && p.N <= 256;
     if (p.H % 8 != 0 || p.W % (use_nw4(p) ? 16 : 32) != 0 || p.Cin % 32 != 0 || p.Cin < 32 || p.Cin > 4064) return false;
@@ -743,6 +827,7 @@ bool sep_pipe_covers(const SepParams& p, int precision) {
 // issues ~1.9 x the instructions per chunk -- and graph D 22.10 ms with 0, 22.26 with 1, 23.07 with 2 in one process.  A forced 4-wave
 // form (dev knob sep_nw = 4) always means this file's kernel.
 static bool use_pipe2(const SepParams& p) {
+    if (p.gen_a) return false;
     if (!g_knobs.sep_pipe2 || g_knobs.sep_ablate || g_knobs.sep_nw == 4 || !sep_pipe2_covers(p)) return false;
     if (g_knobs.sep_pipe2 == 2) return true;
     return p.N2 > 0 && (p.N > 64 || p.N2 > 64);
@@ -752,7 +837,7 @@ int sep_pipe_launch(const SepParams& p, int B, hipStream_t st) {
     if (use_pipe2(p)) return sep_pipe2_launch(p, B, st);
     SepParams q = p;
     const bool s2 = p.stride == 2;
-    const int nw = (!s2 && use_nw4(p)) ? 4 : 8, tw = s2 ? 16 : 4 * nw, th = s2 ? 4 : 8;
+    const int nw = (p.gen_a || (!s2 && use_nw4(p))) ? 4 : 8, tw = s2 ? 16 : 4 * nw, th = s2 ? 4 : 8;
     const int Ho = p.H / (s2 ? 2 : 1), Wo = p.W / (s2 ? 2 : 1);
     const int tiles_w = Wo / tw;
     const long wgs1 = (long)tiles_w * (Ho / th) * B;
@@ -770,6 +855,11 @@ int sep_pipe_launch(const SepParams& p, int B, hipStream_t st) {
     const int mode = g_knobs.sep_mode >= 0 ? g_knobs.sep_mode : ((nw == 4 || p.res) ? 1 : 0);
     // epilogue (see the kernel): per-channel dword stores, 2.7 % over graph D's twelve shapes (tools/sep_epi_bench.py; the two-output
     // launches 5 %) -- except with a residual on more than 128 columns (cnn2_last: 445 against 430 us for the transposed 16-byte form)
+    if (p.gen_a) {
+        if (g_knobs.epi_width == 4) hipLaunchKernelGGL((sep_pipe_kernel<64, false, 1, false, 4, 1, 4, true>), grid, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((sep_pipe_kernel<64, false, 1, false, 4, 1, 1, true>), grid, dim3(256), 0, st, q);
+        return emd::check_launch("sep_pipe_kernel<generated input>");
+    }
     const int epi = g_knobs.epi_width ? g_knobs.epi_width : ((p.res && p.N > 128) ? 4 : 1);
     return epi == 4 ? launch_epi<4>(p, q, grid, mode, nw, st) : launch_epi<1>(p, q, grid, mode, nw, st);
 }

@@ -1092,6 +1092,9 @@ def bench_G(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
             box[0] = eng.forward(x)
 
     ms = timer.run(step, steps, warmup)
+    if a.profile_clean:   # for rocprofv3 (kernel statistics, PMC step totals): the timed steps and nothing else
+        return {"value": round(total * S * S / 1e6 / (ms / 1e3), 1), "unit": "MPx/s in-filled", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+                "dtype": "bf16x3", "config": {"workload": f"G: [{B},{S},{S},1] fp32 per GPU", "profile_clean": True}, "roofline": None}
     two = getattr(eng, "two_streams", None)
     if two is not None:
         eng.two_streams = False
@@ -1112,7 +1115,9 @@ def bench_G(a, torch, emdenoise, dev, timer, rank, world, cpu, primary):
            "tflops_algorithmic": round(tflop / (ms / 1e3), 1),
            "roofline": {"bound": "mfma", "kernel": "matrix-core family (sep_fused + gemm_split + gemm_conv launches of one step)",
                         "achieved": round(mf / (max(mm, 1e-9) * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(mf / (max(mm, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "frac": round(mf / (max(mm, 1e-9) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "traffic": step_traffic("G")[0] if (B, S) == (32, 512) else None, "traffic_source": step_traffic("G")[1],
+                        "hbm_busy_frac": round(step_traffic("G")[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if (step_traffic("G")[0] and (B, S) == (32, 512)) else None,
                         "algorithmic_flops_per_step": mf, "kernel_ms_per_step": round(mm, 3),
                         "note": "<= 128 channels at 256-512 px: the graph is HBM-bound, the matrix-core fraction is low by construction"},
            "kernel_family_ms": fam.table()}

@@ -341,6 +341,44 @@ def test_sep_fused_generated_input(B, H, W, ci, co, gen_act, reflect, extra):
     assert not torch.isnan(got.torch()).any()
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,gen_act,reflect,extra,tpw", [
+    (2, 32, 48, 64, 64, 1, False, False, 0),      # graph D's cnn0 -> cnn0_last; three tile columns: left edge, interior, right edge
+    (1, 16, 16, 64, 64, 1, False, False, 0),      # one tile column: both image edges in the same patch
+    (2, 24, 64, 64, 64, 1, False, True, 2),       # two tiles per workgroup (d of the second tile requested a tile ahead), second affine
+    (1, 16, 128, 64, 40, 2, False, False, 4),     # four, then a workgroup that starts in the interior; relu; a channel tail
+    (1, 16, 128, 64, 64, 4, True, False, 8),      # one workgroup per tile row, reflect border, leaky relu
+    (2, 8, 32, 32, 24, 0, True, False, 2),        # one chunk per tile: a tile change at every step
+])
+def test_sep_generated_input_on_the_pipelined_kernel(B, H, W, ci, co, gen_act, reflect, extra, tpw):
+    """The generated-input fused separable conv on sep_pipe.hip's 4-wave instance (round 4; dev knob sep_gen_pipe = 1) ==
+    sep_fused.hip's register-staged kernel (sep_gen_pipe = 0, the default: the test above holds it to the written-out route), bit for bit."""
+    from emdenoise import _lib, ops
+
+    img = rnd((B, H, W, 1), 150)
+    w9, a, t = rnd((9,), 151, 0.4), rnd((ci,), 152, 0.8), rnd((ci,), 153, 0.5) + 0.5
+    dw = rnd((3, 3, ci), 154, 0.35)
+    pw = ops.PackedWeights(rnd((1, ci, co), 155, scale=(2.0 / (ci + co)) ** 0.5), False, dev())
+    d = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev())
+    s1, t1, s2, t2 = d(rnd((co,), 156, 0.2) + 1), d(rnd((co,), 157, 0.5)), d(rnd((co,), 158, 0.2) + 1), d(rnd((co,), 159, 0.5))
+    d4 = ops.cin1(d(img), d(w9), d(np.array([1, 0, 0, 0])), d(np.zeros(4)), out_act(B, H, W, 4, ld=4, c0=0), act=False)
+    outs = {}
+    try:
+        for k in (1, 0):
+            _lib.knob("sep_gen_pipe", k)
+            _lib.knob("sep_tpw", tpw if k else 0)
+            o = out_act(B, H, W, co, ld=co + 4, c0=0)
+            o.buf.fill_(float("nan"))
+            outs[k] = ops.sep_fused_gen(d4, d(a), d(t), d(dw), pw, s1, t1, o, gen_act=gen_act, scale2=s2 if extra else None,
+                                        shift2=t2 if extra else None, reflect=reflect)
+    finally:
+        _lib.knob("sep_gen_pipe", 0)
+        _lib.knob("sep_tpw", 0)
+    torch.cuda.synchronize()
+    assert not torch.isnan(outs[1].torch()).any()
+    assert torch.equal(outs[1].torch(), outs[0].torch())
+    assert torch.isnan(outs[1].buf.view(B, H, W, co + 4)[..., co:]).all()      # nothing written past the layer's channels
+
+
 @pytest.mark.parametrize("B,H,W,ci,co,co2", [
     (2, 16, 32, 128, 64, 64),       # deconv0_a + residual0_d: 64 | 64 columns on 8 x 16 tiles
     (1, 8, 16, 384, 128, 128),      # deconv1_a + residual1_d: 128 | 128 columns on 4 x 16 tiles, concat-slice input

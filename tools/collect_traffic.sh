@@ -13,6 +13,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/A_$c -- python3 $GRAFT_REPO_ROOT/bench.py --workload A --no-cpu-baseline --no-graph --steps 3 --warmup 1 > /dev/null 2>&1
   # graphs X and T (round 4): step totals as for S and A -- bench.py --profile-clean runs the 1 + 3 steps and nothing else
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/X_$c -- python3 $GRAFT_REPO_ROOT/bench.py --workload X --no-cpu-baseline --profile-clean --steps 3 --warmup 1 > /dev/null 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $OUT/G_$c -- python3 $GRAFT_REPO_ROOT/bench.py --workload G --no-cpu-baseline --profile-clean --steps 3 --warmup 1 > /dev/null 2>&1
   timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $OUT/T_$c -- python3 $GRAFT_REPO_ROOT/bench.py --workload T --no-cpu-baseline --profile-clean --no-graph --steps 3 --warmup 1 > /dev/null 2>&1
 done
 python3 - <<PY
@@ -20,9 +21,9 @@ import csv, glob, json, collections, sys
 sys.path.insert(0, "$GRAFT_REPO_ROOT")
 import bench
 out = {}
-# graphs S, A, X and T: HBM bytes of one step = everything the 4 executions (1 warm-up + 3 timed, eager) moved / 4
+# graphs S, A, X, T and G: HBM bytes of one step = everything the 4 executions (1 warm-up + 3 timed, eager) moved / 4
 # (T: its hipGraph capture is off under the profiler, and the trainer's one warm-up tower of 32 x 32 px before it is noise)
-for wl in ("S", "A", "X", "T"):
+for wl in ("S", "A", "X", "T", "G"):
     tot = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         tot[c] = sum(float(r["Counter_Value"]) for f in glob.glob("$OUT/%s_%s/*/*counter_collection.csv" % (wl, c)) for r in csv.DictReader(open(f)))
