@@ -677,7 +677,11 @@ def cpu_baseline_D(x_host, weights):
     el = time.perf_counter() - t0
     return {"value": round(n * S * S / 1e6 / el, 4), "unit": "MPx/s", "cores": cores, "kind": "port",
             "sample": f"1 pass over the first {n} images of the batch ([{n},{S},{S},1]), oracle/denoiser_graph.py "
-                      f"(PyTorch-CPU float32, {torch.get_num_threads()} threads), {el:.1f} s"}, y
+                      f"(PyTorch-CPU float32, {torch.get_num_threads()} threads), {el:.1f} s",
+            # the figure is noisy (one pass, a shared host): the one-image pass before it is the second sample of this run, and the
+            # committed lines of rounds 2-4 are the run-to-run range
+            "spread": {"one_image_pass_before": round(S * S / 1e6 / t1, 4), "batch_pass": round(n * S * S / 1e6 / el, 4),
+                       "committed_lines_r02_r04": [0.146, 0.195]}}, y
 
 
 def local_batch(a, rank, world):
