@@ -66,6 +66,9 @@ SIGNATURES = {
     # x ldx pre_scale pre_shift w y ldy B H W C stride rate stream
     "emd_dw3x3_pre_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    # x ldx pre_scale pre_shift pre_images act w y ldy B H W C stride rate stream
+    "emd_dw3x3_pre_act_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, C.c_int, _c_float_p, _c_float_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "emd_dw3x3_pre_split32_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_void_p, C.c_int,
                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "emd_split32_ld": (C.c_int, [C.c_int]),
@@ -189,6 +192,9 @@ SIGNATURES = {
                                    [C.c_int, _c_float_p, _c_float_p, C.c_float] + [_c_float_p] * 4 + [C.c_int, C.c_void_p]),
     # x ldx dy ldd dw B H W C stride rate stream
     "emd_dw3x3_wgrad_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p] + [C.c_int] * 6 + [C.c_void_p]),
+    # r ldx pre_scale pre_shift pre_images act dy ldd dw B H W C stride rate stream
+    "emd_dw3x3_wgrad_pre_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, C.c_int, _c_float_p, C.c_int, _c_float_p]
+                                + [C.c_int] * 6 + [C.c_void_p]),
     # dy ldd w dx ldx B H W C stride rate stream
     "emd_dw3x3_bwd_data_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 6 + [C.c_void_p]),
     # x ldx dy dw B H W Cin stream

@@ -15,6 +15,10 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
+// relu (hi = +inf) / relu6 (hi = 6) in affine_relu6_kernel's order (dw_misc.hip): the PRE forms rebuild its bits
+__device__ __forceinline__ float4 clamp4(float4 a, float hi) {
+    return make_float4(fminf(fmaxf(a.x, 0.f), hi), fminf(fmaxf(a.y, 0.f), hi), fminf(fmaxf(a.z, 0.f), hi), fminf(fmaxf(a.w, 0.f), hi));
+}
 __device__ __forceinline__ float4 fma4s(float4 a, float s, float4 c) {
     return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
 }
@@ -29,10 +33,14 @@ inline int same_pad_before(int n, int s, int r) {  // TF SAME, k = 3
 // dw[t][c] += sum_{b,oy,ox} x[b, oy*s + ky*r - pt, ox*s + kx*r - pl, c] * dy[b,oy,ox,c]      (t = 3*ky + kx)
 // SCALAR: dy has ONE channel (the weight gradient of the 3x3 conv to one output channel, w[t][c]).
 // Block: 16 channel-quads x 16 pixel lanes; grid (ceil(C/64), slabs of output pixels).
-template <bool SCALAR>
+// PRE: x is act(r * pre_s + pre_t) of the tensor given (the forward pass left the previous layer's affine + activation to its consumer's
+// loads, emd_dw3x3_pre_act_f32: the same values are rebuilt here); pre_ld != 0: pre_s / pre_t are [image][pre_ld]; pre_hi 6 / inf.
+template <bool SCALAR, bool PRE = false>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
                                                        int ldd, float* __restrict__ dw, int H, int W, int Ho, int Wo, int C,
-                                                       int s, int r, int pt, int pl, long npix, long pix_per_slab) {
+                                                       int s, int r, int pt, int pl, long npix, long pix_per_slab,
+                                                       const float* __restrict__ pre_s = nullptr, const float* __restrict__ pre_t = nullptr,
+                                                       long pre_ld = 0, float pre_hi = 0.f) {
     const int c = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4;
     const int plane = threadIdx.x >> 4;
     const long p0 = (long)blockIdx.y * pix_per_slab;
@@ -54,6 +62,11 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
                 g = *reinterpret_cast<const float4*>(dy + p * ldd + c);
             }
             const float* xb = x + b * H * (long)W * ldx + c;
+            float4 ps = f4zero(), pq = f4zero();
+            if (PRE) {
+                ps = *reinterpret_cast<const float4*>(pre_s + b * pre_ld + c);
+                pq = *reinterpret_cast<const float4*>(pre_t + b * pre_ld + c);
+            }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = oy * s + ky * r - pt;
@@ -62,7 +75,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
                 for (int kx = 0; kx < 3; ++kx) {
                     const int ix = ox * s + kx * r - pl;
                     if (ix < 0 || ix >= W) continue;
-                    acc[ky * 3 + kx] = fma4(*reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx), g, acc[ky * 3 + kx]);
+                    float4 xv = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx);
+                    if (PRE) xv = clamp4(fma4(xv, ps, pq), pre_hi);
+                    acc[ky * 3 + kx] = fma4(xv, g, acc[ky * 3 + kx]);
                 }
             }
         }
@@ -91,9 +106,11 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 // a strip of TH output rows keeping the three live input rows x[.][ox-1..ox+1] in registers, so every output pixel
 // costs 4 vector loads (3 of x, 1 of dy) instead of 10; neighbouring lanes share the x loads through L1.
 // Block = 16 channel quads x 16 columns; grid (ceil(C/64), ceil(W/16), B * strips).
-template <int TH>
+template <int TH, bool PRE = false>
 __global__ __launch_bounds__(256) void dw_wgrad_roll_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
-                                                            int ldd, float* __restrict__ dw, int H, int W, int C, int nstrip) {
+                                                            int ldd, float* __restrict__ dw, int H, int W, int C, int nstrip,
+                                                            const float* __restrict__ pre_s = nullptr, const float* __restrict__ pre_t = nullptr,
+                                                            long pre_ld = 0, float pre_hi = 0.f) {
     const int cl = (threadIdx.x & 15) * 4;
     const int c = blockIdx.x * 64 + cl;
     const int ox = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -105,13 +122,25 @@ __global__ __launch_bounds__(256) void dw_wgrad_roll_kernel(const float* __restr
         const float* xb = x + ((long)b * H) * W * ldx + c;
         const float* db = dy + ((long)b * H) * W * ldd + c;
         const bool hl = ox > 0, hr = ox + 1 < W;
+        float4 ps = f4zero(), pq = f4zero();
+        if (PRE) {
+            ps = *reinterpret_cast<const float4*>(pre_s + b * pre_ld + c);
+            pq = *reinterpret_cast<const float4*>(pre_t + b * pre_ld + c);
+        }
         auto row = [&](int iy, float4& l, float4& m, float4& r) {
             l = m = r = f4zero();
             if (iy >= 0 && iy < H) {
                 const float* rp = xb + ((long)iy * W + ox) * ldx;
                 m = *reinterpret_cast<const float4*>(rp);
-                if (hl) l = *reinterpret_cast<const float4*>(rp - ldx);
-                if (hr) r = *reinterpret_cast<const float4*>(rp + ldx);
+                if (PRE) m = clamp4(fma4(m, ps, pq), pre_hi);
+                if (hl) {
+                    l = *reinterpret_cast<const float4*>(rp - ldx);
+                    if (PRE) l = clamp4(fma4(l, ps, pq), pre_hi);
+                }
+                if (hr) {
+                    r = *reinterpret_cast<const float4*>(rp + ldx);
+                    if (PRE) r = clamp4(fma4(r, ps, pq), pre_hi);
+                }
             }
         };
         float4 a0, a1, a2, b0, b1, b2, c0, c1, c2;   // rows oy-1, oy, oy+1
@@ -314,26 +343,26 @@ int blocks_for(long nthreads, unsigned* nb) {
     return EMD_OK;
 }
 
-template <bool SCALAR>
+template <bool SCALAR, bool PRE = false>
 int launch_wgrad(const float* x, int ldx, const float* dy, int ldd, float* dw, int B, int H, int W, int C, int stride,
-                 int rate, hipStream_t st) {
+                 int rate, hipStream_t st, const float* pre_s = nullptr, const float* pre_t = nullptr, long pre_ld = 0, float pre_hi = 0.f) {
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const long npix = (long)B * Ho * Wo;
     if (!SCALAR && stride == 1 && rate == 1 && H >= 64 && W >= 64) {  // the large maps: rolling-window form
         constexpr int TH = 32;
         const int nstrip = (H + TH - 1) / TH;
         if ((long)B * nstrip <= 65535 && (W + 15) / 16 <= 65535) {
-            hipLaunchKernelGGL(dw_wgrad_roll_kernel<TH>, dim3((C + 63) / 64, (W + 15) / 16, B * nstrip), dim3(256), 0, st, x, ldx,
-                               dy, ldd, dw, H, W, C, nstrip);
+            hipLaunchKernelGGL((dw_wgrad_roll_kernel<TH, PRE>), dim3((C + 63) / 64, (W + 15) / 16, B * nstrip), dim3(256), 0, st, x, ldx,
+                               dy, ldd, dw, H, W, C, nstrip, pre_s, pre_t, pre_ld, pre_hi);
             return emd::check_launch("dw_wgrad_roll_kernel");
         }
     }
     long nslab = (npix + 63) / 64;  // >= 4 pixels per pixel lane; few enough slabs to keep the atomics cheap
     if (nslab > 512) nslab = 512;
     const long pps = (npix + nslab - 1) / nslab;
-    hipLaunchKernelGGL(dw_wgrad_kernel<SCALAR>, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, dy, ldd, dw,
+    hipLaunchKernelGGL((dw_wgrad_kernel<SCALAR, PRE>), dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, dy, ldd, dw,
                        H, W, Ho, Wo, C, stride, rate, same_pad_before(H, stride, rate), same_pad_before(W, stride, rate), npix,
-                       pps);
+                       pps, pre_s, pre_t, pre_ld, pre_hi);
     return emd::check_launch("dw_wgrad_kernel");
 }
 
@@ -353,6 +382,23 @@ int launch_bwd_data(const float* dy, int ldd, const float* w, float* dx, int ldx
 bool dw_args_ok(const float* a, int lda, int C) { return C >= 4 && C % 4 == 0 && lda % 4 == 0 && lda >= C && emd::aligned16(a); }
 
 }  // namespace
+
+// The depthwise weight gradient with the layer's input given as the PRE-activation tensor r of the layer before it: x = act(r * pre_scale +
+// pre_shift) is rebuilt in the loads (the forward pass did the same, emd_dw3x3_pre_act_f32, and never wrote x).  pre_images != 0:
+// [B][C] scale / shift (per-image statistics); act EMD_ACT_RELU6 or EMD_ACT_RELU.  Bits of emd_affine_act[_images]_f32 + emd_dw3x3_wgrad_f32.
+extern "C" int emd_dw3x3_wgrad_pre_f32(const float* r, int ldx, const float* pre_scale, const float* pre_shift, int pre_images, int act,
+                                       const float* dy, int ldd, float* dw, int B, int H, int W, int C, int stride, int rate,
+                                       emd_stream_t stream) {
+    EMD_REQUIRE(r && dy && dw && pre_scale && pre_shift, EMD_E_INVALID, "emd_dw3x3_wgrad_pre_f32: null pointer");
+    EMD_REQUIRE(emd::aligned16(pre_scale) && emd::aligned16(pre_shift), EMD_E_ALIGN, "emd_dw3x3_wgrad_pre_f32: pre_scale / pre_shift 16-byte aligned");
+    EMD_REQUIRE(act == 1 || act == 2, EMD_E_INVALID, "emd_dw3x3_wgrad_pre_f32: act must be EMD_ACT_RELU6 or EMD_ACT_RELU");
+    EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (stride == 1 || stride == 2) && rate >= 1 && (rate == 1 || stride == 1),
+                EMD_E_INVALID, "emd_dw3x3_wgrad_pre_f32: bad shape");
+    EMD_REQUIRE(dw_args_ok(r, ldx, C) && dw_args_ok(dy, ldd, C), EMD_E_ALIGN, "emd_dw3x3_wgrad_pre_f32: C, ldx, ldd multiples of 4, 16-byte aligned");
+    if (B == 0) return EMD_OK;
+    return launch_wgrad<false, true>(r, ldx, dy, ldd, dw, B, H, W, C, stride, rate, static_cast<hipStream_t>(stream), pre_scale, pre_shift,
+                                     pre_images ? (long)C : 0L, act == 1 ? 6.f : __builtin_inff());
+}
 
 extern "C" int emd_dw3x3_wgrad_f32(const float* x, int ldx, const float* dy, int ldd, float* dw, int B, int H, int W, int C,
                                    int stride, int rate, emd_stream_t stream) {

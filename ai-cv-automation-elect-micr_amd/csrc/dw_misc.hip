@@ -36,6 +36,10 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 __device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
+// relu (hi = +inf) or relu6 (hi = 6), in the order affine_relu6_kernel applies them: the PRE forms produce its bits
+__device__ __forceinline__ float4 clamp4(float4 a, float hi) {
+    return make_float4(fminf(fmaxf(a.x, 0.f), hi), fminf(fmaxf(a.y, 0.f), hi), fminf(fmaxf(a.z, 0.f), hi), fminf(fmaxf(a.w, 0.f), hi));
+}
 // act code of the Cout=1 kernels: 0 none, 1 relu6, 2 relu6 followed by tf.clip_by_value(0,1) = clamp to [0,1]
 __device__ __forceinline__ float act_out(float v, int act) { return act == 0 ? v : fminf(fmaxf(v, 0.f), act == 2 ? 1.f : 6.f); }
 // the Cout=1 kernels' output stage: optional "+pre_bias, relu" first (tf.layers.conv2d(activation=relu) before the
@@ -55,9 +59,11 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
                                                      const float* __restrict__ w, float* __restrict__ y,
                                                      int ldy, int H, int W, int C4, long nthreads, int nstrip, int C4t,
                                                      const float* __restrict__ pre_s = nullptr,
-                                                     const float* __restrict__ pre_t = nullptr, int xcd = 0) {
+                                                     const float* __restrict__ pre_t = nullptr, int xcd = 0, long pre_ld = 0,
+                                                     float pre_hi = __builtin_inff()) {
     // PRE: the input is relu(x * pre_s + pre_t) per channel -- the batch-statistics norm + relu of the previous separable
-    // block (misc_py/modified_Xception.py:302-323) applied on the fly instead of in a pass of its own
+    // block (misc_py/modified_Xception.py:302-323) applied on the fly instead of in a pass of its own.  pre_ld != 0: pre_s / pre_t are
+    // [image][pre_ld] (per-image statistics: a batched pass of one-image towers); pre_hi = 6: relu6 (graph D', round 4)
     // C4t = channel quads per pixel that have a thread: C4, or ceil32(C)/4 when the split32 padding is written too.
     // A workgroup = 16 adjacent pixel columns x 16 channel quads (64 channels, 256 contiguous bytes per pixel): the left /
     // right neighbours of a pixel are loaded by the SAME workgroup (L1 hits).  With one thread per (pixel, quad) in
@@ -85,8 +91,8 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
     for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(w + k * C + c4 * 4);
     float4 ps4 = f4zero(), pt4 = f4zero();
     if (PRE) {
-        ps4 = *reinterpret_cast<const float4*>(pre_s + c4 * 4);
-        pt4 = *reinterpret_cast<const float4*>(pre_t + c4 * 4);
+        ps4 = *reinterpret_cast<const float4*>(pre_s + b * pre_ld + c4 * 4);
+        pt4 = *reinterpret_cast<const float4*>(pre_t + b * pre_ld + c4 * 4);
     }
 
     const float* xb = x + (b * H) * (long)W * ldx + c4 * 4;
@@ -121,9 +127,9 @@ __global__ __launch_bounds__(256) void dw3x3_s1_roll(const float* __restrict__ x
         const bool ok = REFLECT || (iy >= 0 && iy < H);
         float4 c = rc[tt % PF], l = rl[tt % PF], r = rr[tt % PF];
         if (PRE) {
-            c = relu4(fma4(c, ps4, pt4));
-            l = relu4(fma4(l, ps4, pt4));
-            r = relu4(fma4(r, ps4, pt4));
+            c = clamp4(fma4(c, ps4, pt4), pre_hi);
+            l = clamp4(fma4(l, ps4, pt4), pre_hi);
+            r = clamp4(fma4(r, ps4, pt4), pre_hi);
         }
         c = ok ? c : f4zero();
         l = ok && (REFLECT || hasl) ? l : f4zero();
@@ -153,7 +159,8 @@ __global__ __launch_bounds__(256) void dw3x3_generic(const float* __restrict__ x
                                                      int ldy, int H, int W, int C4, int Ho, int Wo,
                                                      int stride, int rate, int pt, int pl, long nthreads, int C4t,
                                                      const float* __restrict__ pre_s = nullptr,
-                                                     const float* __restrict__ pre_t = nullptr, int xcd = 0) {
+                                                     const float* __restrict__ pre_t = nullptr, int xcd = 0, long pre_ld = 0,
+                                                     float pre_hi = __builtin_inff()) {
     // a workgroup = 4 x 4 output pixels x 16 channel quads: the overlapping windows of neighbouring outputs are served by
     // the workgroup's L1 instead of by neighbouring workgroups on other XCDs (see dw3x3_s1_roll)
     (void)nthreads;
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void dw3x3_generic(const float* __restrict__ x
             const int ix = ox * stride - pl + j * rate;
             if (ix < 0 || ix >= W) continue;
             float4 v = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx);
-            if (PRE) v = relu4(fma4(v, *reinterpret_cast<const float4*>(pre_s + c4 * 4), *reinterpret_cast<const float4*>(pre_t + c4 * 4)));
+            if (PRE) v = clamp4(fma4(v, *reinterpret_cast<const float4*>(pre_s + b * pre_ld + c4 * 4), *reinterpret_cast<const float4*>(pre_t + b * pre_ld + c4 * 4)), pre_hi);
             const float4 wk = *reinterpret_cast<const float4*>(w + (i * 3 + j) * C + c4 * 4);
             acc = fma4(wk, v, acc);
         }
@@ -710,7 +717,8 @@ inline int grid_for(long nthreads, unsigned* blocks) {
 
 template <bool SPLIT, bool PRE = false>
 int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
-                 int stride, int rate, emd_stream_t stream, const float* pre_s = nullptr, const float* pre_t = nullptr) {
+                 int stride, int rate, emd_stream_t stream, const float* pre_s = nullptr, const float* pre_t = nullptr, long pre_ld = 0,
+                 float pre_hi = __builtin_inff()) {
     (void)who;
     if (PRE) EMD_REQUIRE(pre_s && pre_t && emd::aligned16(pre_s) && emd::aligned16(pre_t), EMD_E_INVALID,
                          "emd_dw3x3_pre: pre_scale / pre_shift must be non-null and 16-byte aligned");
@@ -755,20 +763,20 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
         int rc = grid_for(nthreads, &nb);
         if (rc != EMD_OK) return rc;
         if (TH == 32)
-            hipLaunchKernelGGL((dw3x3_s1_roll<32, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
+            hipLaunchKernelGGL((dw3x3_s1_roll<32, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W), pre_ld, pre_hi);
         else if (TH == 16)
-            hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
+            hipLaunchKernelGGL((dw3x3_s1_roll<16, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W), pre_ld, pre_hi);
         else if (TH == 4)
-            hipLaunchKernelGGL((dw3x3_s1_roll<4, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
+            hipLaunchKernelGGL((dw3x3_s1_roll<4, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W), pre_ld, pre_hi);
         else
-            hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W));
+            hipLaunchKernelGGL((dw3x3_s1_roll<8, SPLIT, false, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, nthreads, nstrip, C4t, pre_s, pre_t, dw_xcd(H, W), pre_ld, pre_hi);
         return emd::check_launch("dw3x3_s1_roll");
     }
     const long nthreads = (long)B * ((Ho + 3) / 4) * ((Wo + 3) / 4) * ((C4t + 15) / 16) * 256;
     int rc = grid_for(nthreads, &nb);
     if (rc != EMD_OK) return rc;
     hipLaunchKernelGGL((dw3x3_generic<SPLIT, PRE>), dim3(nb), dim3(256), 0, st, x, ldx, w, y, ldy, H, W, C4, Ho, Wo, stride, rate, pt,
-                       pl, nthreads, C4t, pre_s, pre_t, dw_xcd(H, W));
+                       pl, nthreads, C4t, pre_s, pre_t, dw_xcd(H, W), pre_ld, pre_hi);
     return emd::check_launch("dw3x3_generic");
 }
 
@@ -836,6 +844,17 @@ extern "C" int emd_dw3x3_split32_f32(const float* x, int ldx, const float* w, vo
 extern "C" int emd_dw3x3_pre_f32(const float* x, int ldx, const float* pre_scale, const float* pre_shift, const float* w, float* y,
                                  int ldy, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream) {
     return dw3x3_launch<false, true>("emd_dw3x3_pre_f32", x, ldx, w, y, ldy, B, H, W, C, stride, rate, stream, pre_scale, pre_shift);
+}
+
+// The same with the activation and the statistics' granularity chosen (round 4: graph D' -- the training step's affine + relu6 of a
+// separable conv whose only consumer is the next one's depthwise stage is applied in that stage's loads; slim.separable_convolution2d +
+// _batch_norm_fn + relu6, machine_learning/denoiser.py:110-136 with phase = True): pre_images != 0: pre_scale / pre_shift are [B][C]
+// (per-image statistics); act: EMD_ACT_RELU6 (1) or EMD_ACT_RELU (2).  Bits of emd_affine_act[_images]_f32 followed by emd_dw3x3_f32.
+extern "C" int emd_dw3x3_pre_act_f32(const float* x, int ldx, const float* pre_scale, const float* pre_shift, int pre_images, int act,
+                                     const float* w, float* y, int ldy, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream) {
+    EMD_REQUIRE(act == 1 || act == 2, EMD_E_INVALID, "emd_dw3x3_pre_act_f32: act must be EMD_ACT_RELU6 or EMD_ACT_RELU");
+    return dw3x3_launch<false, true>("emd_dw3x3_pre_act_f32", x, ldx, w, y, ldy, B, H, W, C, stride, rate, stream, pre_scale, pre_shift,
+                                     pre_images ? (long)C : 0L, act == 1 ? 6.f : __builtin_inff());
 }
 
 extern "C" int emd_dw3x3_pre_split32_f32(const float* x, int ldx, const float* pre_scale, const float* pre_shift, const float* w,

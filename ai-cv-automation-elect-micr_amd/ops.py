@@ -295,6 +295,31 @@ def dw3x3(x: Act, w_dev, out: Act, stride=1, rate=1, stream=None, pre=None):
     return out
 
 
+class PreAct:
+    """An activation that was never written: act(r * scale + shift) of the tensor ``r`` (an Act), applied by its consumers while they
+    load r (emd_dw3x3_pre_act_f32, emd_dw3x3_wgrad_pre_f32).  scale / shift: device float[C], or [B][C] with images=True (per-image
+    statistics).  Shape attributes and ``buf`` / ``c0`` are r's, so that it keys gradient tables like the Act it stands for."""
+
+    __slots__ = ("r", "scale", "shift", "images", "act", "buf", "B", "H", "W", "C", "c0", "ld")
+
+    def __init__(self, r, scale, shift, images=False, act=ACT_RELU6):
+        assert act in (ACT_RELU6, ACT_RELU)
+        assert scale.numel() == (r.B * r.C if images else r.C) and shift.numel() == scale.numel()
+        self.r, self.scale, self.shift, self.images, self.act = r, scale, shift, bool(images), act
+        self.buf, self.B, self.H, self.W, self.C, self.c0, self.ld = r.buf, r.B, r.H, r.W, r.C, r.c0, r.ld
+
+
+def dw3x3_pre_act(x: PreAct, w_dev, out: Act, stride=1, rate=1, stream=None):
+    """Depthwise 3x3 of the never-written activation x (emd_dw3x3_pre_act_f32): the bits of affine_act[_images] followed by dw3x3."""
+    lib = _lib.load()
+    r = x.r
+    assert out.C == r.C and out.B == r.B and (out.H, out.W) == (-(-r.H // stride), -(-r.W // stride))
+    rc = lib.emd_dw3x3_pre_act_f32(r.ptr, r.ld, _p(x.scale), _p(x.shift), 1 if x.images else 0, _act(x.act), _p(w_dev), out.ptr, out.ld,
+                                   r.B, r.H, r.W, r.C, stride, rate, _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_dw3x3_pre_act_f32")
+    return out
+
+
 class SplitAct:
     """A split32 activation tensor [B,H,W,C] (include/emdenoise.h: every value as bf16 hi + bf16 lo, 32-channel groups of
     128 bytes); ``buf`` is a float32 torch tensor [B,H,W,ld] of the same bytes, ld = C rounded up to 32."""

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 
 from . import _lib
-from .ops import PREC_BF16X3, Act, _p
+from .ops import PREC_BF16X3, Act, _act, _p
 
 MASK_NONE, MASK_RELU6, MASK_RELU6_CLIP, MASK_LEAKY = 0, 1, 2, 3
 BN_EPS = 1e-3
@@ -249,6 +249,16 @@ def dw3x3_wgrad(x: Act, dy: Act, dw_dev, stride=1, rate=1, stream=None):
     assert (dy.B, dy.H, dy.W) == (x.B, -(-x.H // stride), -(-x.W // stride))
     _lib.check(_lib.load().emd_dw3x3_wgrad_f32(x.ptr, x.ld, dy.ptr, dy.ld, _p(dw_dev), x.B, x.H, x.W, x.C, stride, rate,
                                                _lib.stream_ptr(stream)), "emd_dw3x3_wgrad_f32")
+
+
+def dw3x3_wgrad_pre(x, dy: Act, dw_dev, stride=1, rate=1, stream=None):
+    """dw3x3_wgrad with the layer's input given as an ops.PreAct (never written; rebuilt from its r in the loads)."""
+    r = x.r
+    assert dw_dev.is_contiguous() and dw_dev.numel() == 9 * r.C and dy.C == r.C
+    assert (dy.B, dy.H, dy.W) == (r.B, -(-r.H // stride), -(-r.W // stride))
+    _lib.check(_lib.load().emd_dw3x3_wgrad_pre_f32(r.ptr, r.ld, _p(x.scale), _p(x.shift), 1 if x.images else 0, _act(x.act), dy.ptr,
+                                                   dy.ld, _p(dw_dev), r.B, r.H, r.W, r.C, stride, rate, _lib.stream_ptr(stream)),
+               "emd_dw3x3_wgrad_pre_f32")
 
 
 def dw3x3_bwd_data(dy: Act, w_dev, dx: Act, stride=1, rate=1, stream=None):

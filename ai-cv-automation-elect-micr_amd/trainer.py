@@ -121,6 +121,8 @@ class DenoiserTrainer:
         # the norms of small per-image maps as one launch per direction (train_ops.bn_train_fwd_small / bn_backward_small): opt-in -- measured
         # 47.3-47.7 ms per step against 46.2 with the four-launch forms (profiles/r04_experiments.txt 6)
         self.fuse_bn_small = os.environ.get("EMD_T_BN_SMALL", "0") == "1"
+        # affine + relu6 of a separable conv that feeds only the next one applied in that one's loads (ops.PreAct; round 4)
+        self.lazy_affine = os.environ.get("EMD_T_LAZY_AFFINE", "1") == "1"
         self.fuse_stats = os.environ.get("EMD_T_FUSE_STATS", "1") == "1"   # batch statistics from the producing GEMM's epilogue (ops.conv_stats)
         self.teacher = None   # test hook: scope -> {"d": ..., "r": ...} reference tensors that REPLACE the forward's conv outputs (see _force)
         self.repack()
@@ -329,10 +331,16 @@ class DenoiserTrainer:
         the FORCED tensor) and only where per-image statistics see whole tiles."""
         return self.fuse_stats and self.teacher is None and ops.conv_stats_supported(x, stride, images=self._per_image)
 
-    def _sep_fwd(self, key, x, out=None, res=None):
+    def _sep_fwd(self, key, x, out=None, res=None, lazy=False):
+        """lazy=True (the caller's promise: the output feeds ONE separable conv and nothing else): the affine + relu6 is left to that
+        consumer's loads -- the result is an ops.PreAct (r, scale, shift), never written (round 4: two passes over the tensor and
+        one launch less; same bits).  x may be such a PreAct."""
         L = self.layers[key]
         Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
-        d = ops.dw3x3(x, self._dw(key), self._E(x.B, Ho, Wo, x.C), stride=L.stride, rate=L.rate)
+        if isinstance(x, ops.PreAct):
+            d = ops.dw3x3_pre_act(x, self._dw(key), self._E(x.B, Ho, Wo, x.C), stride=L.stride, rate=L.rate)
+        else:
+            d = ops.dw3x3(x, self._dw(key), self._E(x.B, Ho, Wo, x.C), stride=L.stride, rate=L.rate)
         self._force(d, L.scope, "d")
         stats = None
         small = self._bn_small_shape(Ho * Wo, L.cout, x.B)   # the one-launch norm takes its own statistics
@@ -343,6 +351,11 @@ class DenoiserTrainer:
             r = ops.conv1x1(d, self.pk_f[key], self.ones, self.zeros, self._E(x.B, Ho, Wo, L.cout), act=False,
                             precision=self.precision)
         self._force(r, L.scope, "r")
+        # (not with the weight gradients on a side stream: the consumer's depthwise weight gradient re-reads r, which this layer's own
+        # BN backward overwrites on the main stream; not under teacher forcing, whose hooks replace whole tensors)
+        if lazy and self.lazy_affine and not small and out is None and res is None and self._wg_side is None and self.teacher is None:
+            fold = self._bn(key, r, stats=stats)
+            return ops.PreAct(r, fold["scale"], fold["shift"], images=bool(fold.get("B")), act=ops.ACT_RELU6), {"x": x, "d": d, "r": r, "fold": fold}
         if out is None:
             out = self._E(x.B, Ho, Wo, L.cout)
         out, fold = self._bn_apply(key, r, out, ops.ACT_RELU6, res, stats=stats)
@@ -437,7 +450,10 @@ class DenoiserTrainer:
         # the data gradient lands on d -- unless the weight gradient above may still be reading d on its side stream
         dd_buf = d if self._wg_side is None else self._E(d.B, d.H, d.W, d.C)
         dd = ops.conv1x1(dr, self.pk_b[key], self.ones, self.zeros, dd_buf, act=False, precision=self.precision)
-        self._wg(lambda: TO.dw3x3_wgrad(x, dd, self._gdw(key), stride=L.stride, rate=L.rate), dd)
+        if isinstance(x, ops.PreAct):    # the input was never written: rebuilt from the previous layer's r in the loads
+            self._wg(lambda: TO.dw3x3_wgrad_pre(x, dd, self._gdw(key), stride=L.stride, rate=L.rate), dd)
+        else:
+            self._wg(lambda: TO.dw3x3_wgrad(x, dd, self._gdw(key), stride=L.stride, rate=L.rate), dd)
         if not need_dx:
             return
         if L.stride == 1:
@@ -553,22 +569,22 @@ class DenoiserTrainer:
         x4 = torch.zeros((B, S, S, 4), dtype=torch.float32, device=self.device)
         x4[..., 0:1].copy_(lq)
         x = ops.Act(x4)
-        cnn0, C["cnn0"] = self._sep_fwd("cnn0", x)
-        cnn0_last, C["cnn0_last"] = self._sep_fwd("cnn0_last", cnn0)
+        cnn0, C["cnn0"] = self._sep_fwd("cnn0", x, lazy=True)
+        cnn0_last, C["cnn0_last"] = self._sep_fwd("cnn0_last", cnn0, lazy=True)
         residual0, C["residual0"] = self._conv_fwd("residual0", x)
         st.concat1 = E(S2, f2 + f1)
         st.cnn0_strided, C["cnn0_strided"] = self._sep_fwd("cnn0_strided", cnn0_last, out=st.concat1.slice(f2, f1), res=residual0)
-        cnn1, C["cnn1"] = self._sep_fwd("cnn1", st.cnn0_strided)
-        cnn1_last, C["cnn1_last"] = self._sep_fwd("cnn1_last", cnn1)
+        cnn1, C["cnn1"] = self._sep_fwd("cnn1", st.cnn0_strided, lazy=True)
+        cnn1_last, C["cnn1_last"] = self._sep_fwd("cnn1_last", cnn1, lazy=True)
         residual1, C["residual1"] = self._conv_fwd("residual1", st.cnn0_strided)
         st.concat2 = E(S4, aspp_output + f1)
         st.cnn1_strided, C["cnn1_strided"] = self._sep_fwd("cnn1_strided", cnn1_last, out=st.concat2.slice(aspp_output, f1), res=residual1)
-        cnn2, C["cnn2"] = self._sep_fwd("cnn2", st.cnn1_strided)
-        cnn2_last, C["cnn2_last"] = self._sep_fwd("cnn2_last", cnn2)
+        cnn2, C["cnn2"] = self._sep_fwd("cnn2", st.cnn1_strided, lazy=True)
+        cnn2_last, C["cnn2_last"] = self._sep_fwd("cnn2_last", cnn2, lazy=True)
         residual2, C["residual2"] = self._conv_fwd("residual2", st.cnn1_strided)
         st.cnn2_strided, C["cnn2_strided"] = self._sep_fwd("cnn2_strided", cnn2_last, res=residual2)
-        cnn3, C["cnn3"] = self._sep_fwd("cnn3", st.cnn2_strided)
-        cnn3_last, C["cnn3_last"] = self._sep_fwd("cnn3_last", cnn3)
+        cnn3, C["cnn3"] = self._sep_fwd("cnn3", st.cnn2_strided, lazy=True)
+        cnn3_last, C["cnn3_last"] = self._sep_fwd("cnn3_last", cnn3, lazy=True)
         residual3, C["residual3"] = self._conv_fwd("residual3", st.cnn2_strided)
         st.cnn3_strided, C["cnn3_strided"] = self._sep_fwd("cnn3_strided", cnn3_last, out=mid_out, res=residual3)
         return st
@@ -580,12 +596,12 @@ class DenoiserTrainer:
         E = lambda H, Cc: self._E(B, H, H, Cc)
         af = aspp_filters
         C = ms.C
-        t, C["cnn4_a"] = self._sep_fwd("cnn4_a", x)
-        t, C["cnn4_b"] = self._sep_fwd("cnn4_b", t)
+        t, C["cnn4_a"] = self._sep_fwd("cnn4_a", x, lazy=True)
+        t, C["cnn4_b"] = self._sep_fwd("cnn4_b", t, lazy=True)
         cur, C["cnn4_last"] = self._sep_fwd("cnn4_last", t, res=x)
         for i in range(num_extra_blocks):
-            t, C[f"middle{i}_0"] = self._sep_fwd(f"middle{i}_0", cur)
-            t, C[f"middle{i}_1"] = self._sep_fwd(f"middle{i}_1", t)
+            t, C[f"middle{i}_0"] = self._sep_fwd(f"middle{i}_0", cur, lazy=True)
+            t, C[f"middle{i}_1"] = self._sep_fwd(f"middle{i}_1", t, lazy=True)
             cur, C[f"middle{i}_2"] = self._sep_fwd(f"middle{i}_2", t, res=cur)
         ms.cur = cur
         ms.cat = cat = E(S16, 5 * af)
@@ -611,15 +627,15 @@ class DenoiserTrainer:
         E = lambda H, Cc: self._E(B, H, H, Cc)
         f0, f1, f2 = features0, features1, features2
         ops.resize_bilinear(aspp, st.concat2.slice(0, aspp_output))
-        t, C["deconv2_a"] = self._sep_fwd("deconv2_a", st.concat2)
+        t, C["deconv2_a"] = self._sep_fwd("deconv2_a", st.concat2, lazy=True)
         residual2_d, C["residual2_d"] = self._conv_fwd("residual2_d", st.concat2)
         st.deconv2, C["deconv2_b"] = self._sep_fwd("deconv2_b", t, res=residual2_d)
         _, C["deconv2to1"] = self._deconv_fwd("deconv2to1", st.deconv2, st.concat1.slice(0, f2))
-        t, C["deconv1_a"] = self._sep_fwd("deconv1_a", st.concat1)
+        t, C["deconv1_a"] = self._sep_fwd("deconv1_a", st.concat1, lazy=True)
         residual1_d, C["residual1_d"] = self._conv_fwd("residual1_d", st.concat1)
         st.deconv1, C["deconv1_b"] = self._sep_fwd("deconv1_b", t, res=residual1_d)
         st.deconv1to0, C["deconv1to0"] = self._deconv_fwd("deconv1to0", st.deconv1, E(S, f1))
-        t, C["deconv0_a"] = self._sep_fwd("deconv0_a", st.deconv1to0)
+        t, C["deconv0_a"] = self._sep_fwd("deconv0_a", st.deconv1to0, lazy=True)
         residual0_d, C["residual0_d"] = self._conv_fwd("residual0_d", st.deconv1to0)
         st.deconv0, C["deconv0_b"] = self._sep_fwd("deconv0_b", t, res=residual0_d)
         # final 3x3 conv to one channel (+ bias) -> BN -> relu6 -> clip [0,1]  (:528-538)

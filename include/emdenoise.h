@@ -256,6 +256,13 @@ int emd_dw3x3_pre_f32(const float* x, int ldx, const float* pre_scale, const flo
                       int ldy, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream);
 int emd_dw3x3_pre_split32_f32(const float* x, int ldx, const float* pre_scale, const float* pre_shift, const float* w,
                               void* y, int ldy, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream);
+/* The same for the training step (round 4; graph D', slim.separable_convolution2d + _batch_norm_fn(is_training) + relu6,
+ * machine_learning/denoiser.py:110-136 with phase = True; misc_py/denoiser-multi-gpu.py:752-782): the affine + activation of a
+ * separable conv whose only consumer is the next one's depthwise stage is applied in that stage's loads.  act: EMD_ACT_RELU6 or
+ * EMD_ACT_RELU; pre_images != 0: pre_scale / pre_shift are [B][C] (per-image statistics: a batched pass of one-image towers), else
+ * [C].  Bits of emd_affine_act_f32 / emd_affine_act_images_f32 followed by emd_dw3x3_f32. */
+int emd_dw3x3_pre_act_f32(const float* x, int ldx, const float* pre_scale, const float* pre_shift, int pre_images, int act,
+                          const float* w, float* y, int ldy, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream);
 
 /* Dense 3x3 conv of a ONE-channel image + per-channel affine + activation (graph X's entry conv: tf.layers.conv2d(1 -> 32, k 3,
  * stride 2) + bias -> batch norm -> relu, misc_py/modified_Xception.py:356-364; the caller folds bias and norm into scale / shift):
@@ -452,6 +459,10 @@ int emd_dw3x3_wgrad_f32(const float* x, int ldx, const float* dy, int ldd, float
                         int rate, emd_stream_t stream);
 int emd_dw3x3_bwd_data_f32(const float* dy, int ldd, const float* w, float* dx, int ldx, int B, int H, int W, int C,
                            int stride, int rate, emd_stream_t stream);
+/* emd_dw3x3_wgrad_f32 with the layer's input given as the pre-activation tensor r of the layer before it (the forward pass ran
+ * emd_dw3x3_pre_act_f32 on it and never wrote x = act(r * pre_scale + pre_shift)): x is rebuilt in the loads.  Arguments as there. */
+int emd_dw3x3_wgrad_pre_f32(const float* r, int ldx, const float* pre_scale, const float* pre_shift, int pre_images, int act,
+                            const float* dy, int ldd, float* dw, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream);
 
 /* Backward of the final 3x3 conv to one channel (:528-532): dy [B,H,W]; dw [3][3][Cin] +=; dx [B,H,W,Cin]. */
 int emd_conv3x3_cout1_wgrad_f32(const float* x, int ldx, const float* dy, float* dw, int B, int H, int W, int Cin,

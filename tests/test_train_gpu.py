@@ -308,6 +308,35 @@ def test_batched_per_image_towers_equal_towers_of_one():
     assert rel_l2(pb.params.cpu().numpy(), pa.params.cpu().numpy()) < 1e-7
 
 
+def test_affine_in_the_consumers_loads_changes_nothing():
+    """Round 4: the affine + relu6 of a separable conv that feeds only the next one is applied in that one's loads (ops.PreAct,
+    emd_dw3x3_pre_act_f32 / emd_dw3x3_wgrad_pre_f32; DenoiserTrainer.lazy_affine, the default) -- against the written-out form
+    (lazy_affine = False): outputs, losses and moving statistics bit for bit (the loads rebuild affine_relu6_kernel's bits), the
+    accumulated gradient to the run-to-run spread of its float atomics.  A tower of several images (batch statistics) and a batched
+    pass of one-image towers (per-image statistics)."""
+    from emdenoise import trainer as TR
+
+    S, B = 64, 3
+    w = weights()
+    lq, hq = synthetic_pair(B, S, S, seed=23)
+    x, t = torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev())
+    for per_image in (False, True):
+        res = {}
+        for lazy in (True, False):
+            tr = TR.DenoiserTrainer(w, dev())
+            assert tr.lazy_affine
+            tr.lazy_affine = lazy
+            tr.zero_grad()
+            o, r = tr.tower(x, t, update_moving=True, per_image=per_image)
+            torch.cuda.synchronize()
+            res[lazy] = (o.clone(), r.clone(), tr.moving.clone(), tr.grads.detach().cpu().numpy().astype(np.float64))
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+        assert torch.equal(res[True][2], res[False][2])
+        spread = rel_l2(res[True][3], res[False][3])
+        print(f"affine in the consumer's loads vs written out, per_image={per_image}: outputs / losses / moving statistics identical; gradient rel L2 {spread:.2e}")
+        assert spread < 2e-6
+
+
 def test_train_steps_follow_the_oracle():
     """Free-running: three optimizer steps (2 towers of 1 image, averaged; Nesterov momentum 0.9, lr 1e-3; moving
     statistics from tower 0) against the oracle's float64 loop, in the regime where no unit sits on a kink."""

@@ -550,3 +550,75 @@ def test_bn_small_refuses_large_maps():
     g = torch.ones(64, device=dev())
     with pytest.raises(RuntimeError, match="4096"):
         TO.bn_train_fwd_small(x, g, g, out_act(1, 128, 64, 64), ops.ACT_RELU6)
+
+
+@pytest.mark.parametrize("B,H,W,Cc,stride,rate,images,act", [
+    (2, 32, 32, 728, 1, 1, True, 1),      # the 1/16-resolution flow of a batched pass of one-image towers
+    (3, 20, 24, 64, 2, 1, True, 1),       # a strided consumer (cnn*_strided), ragged tiles
+    (2, 16, 16, 128, 1, 2, False, 1),     # dilated, batch statistics
+    (1, 72, 80, 64, 1, 1, False, 2),      # 16-row strips, relu
+])
+def test_dw3x3_pre_act_equals_affine_then_depthwise(B, H, W, Cc, stride, rate, images, act):
+    """emd_dw3x3_pre_act_f32 (round 4: the training step's affine + relu6 in the consumer's loads) == emd_affine_act[_images]_f32 written
+    out, then emd_dw3x3_f32 -- bit for bit (padding is applied to the ACTIVATED tensor: a padded tap contributes 0, not act(shift))."""
+    from emdenoise import ops
+
+    g = torch.Generator(device=dev()).manual_seed(5)
+    r = ops.Act(torch.randn(B, H, W, Cc, device=dev(), generator=g) * 3)
+    n = B * Cc if images else Cc
+    sc, sh = torch.rand(n, device=dev(), generator=g) + 0.5, torch.randn(n, device=dev(), generator=g)
+    wd = torch.randn(9, Cc, device=dev(), generator=g) * 0.3
+    y = ops.Act.empty(B, H, W, Cc, dev())
+    (ops.affine_act_images if images else ops.affine_act)(r, sc, sh, y, act=act)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    want = ops.dw3x3(y, wd, ops.Act.empty(B, Ho, Wo, Cc, dev()), stride=stride, rate=rate)
+    out = ops.Act.empty(B, Ho, Wo, Cc, dev())
+    out.buf.fill_(float("nan"))
+    got = ops.dw3x3_pre_act(ops.PreAct(r, sc, sh, images=images, act=act), wd, out, stride=stride, rate=rate)
+    torch.cuda.synchronize()
+    assert torch.equal(got.buf, want.buf)
+
+
+@pytest.mark.parametrize("B,H,W,Cc,stride,rate,images,act", [
+    (2, 32, 32, 728, 1, 1, True, 1),
+    (2, 64, 80, 64, 1, 1, True, 1),       # the rolling-window form (H, W >= 64)
+    (3, 20, 24, 64, 2, 1, False, 1),
+    (2, 16, 16, 128, 1, 2, False, 2),
+])
+def test_dw3x3_wgrad_pre_equals_affine_then_weight_gradient(B, H, W, Cc, stride, rate, images, act):
+    """emd_dw3x3_wgrad_pre_f32 == emd_affine_act[_images]_f32 written out, then emd_dw3x3_wgrad_f32 (to the spread of the float atomics
+    both end in), and both against a float64 sum of the same products on the host."""
+    from emdenoise import ops, train_ops as TO
+
+    g = torch.Generator(device=dev()).manual_seed(6)
+    r = ops.Act(torch.randn(B, H, W, Cc, device=dev(), generator=g) * 3)
+    n = B * Cc if images else Cc
+    sc, sh = torch.rand(n, device=dev(), generator=g) + 0.5, torch.randn(n, device=dev(), generator=g)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    dy = ops.Act(torch.randn(B, Ho, Wo, Cc, device=dev(), generator=g))
+    y = ops.Act.empty(B, H, W, Cc, dev())
+    (ops.affine_act_images if images else ops.affine_act)(r, sc, sh, y, act=act)
+    want = torch.zeros(9, Cc, device=dev())
+    TO.dw3x3_wgrad(y, dy, want, stride=stride, rate=rate)
+    got = torch.zeros(9, Cc, device=dev())
+    TO.dw3x3_wgrad_pre(ops.PreAct(r, sc, sh, images=images, act=act), dy, got, stride=stride, rate=rate)
+    torch.cuda.synchronize()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() < 2e-5 * scale
+    # float64 on the host: dw[t][c] = sum x[b, oy*s + ky*r - pt, ox*s + kx*r - pl, c] * dy[b, oy, ox, c]  (TF SAME)
+    xa, da = y.buf.double().cpu(), dy.buf.double().cpu()
+    def pad_before(nn):
+        o = -(-nn // stride)
+        return max((o - 1) * stride + 2 * rate + 1 - nn, 0) // 2
+    pt, pl = pad_before(H), pad_before(W)
+    xp = torch.zeros(B, H + 4 * rate + 2, W + 4 * rate + 2, Cc, dtype=torch.float64)
+    off = 2 * rate
+    xp[:, off:off + H, off:off + W] = xa
+    ref = torch.zeros(9, Cc, dtype=torch.float64)
+    for ky in range(3):
+        for kx in range(3):
+            ys = off - pt + ky * rate
+            xs = off - pl + kx * rate
+            win = xp[:, ys:ys + (Ho - 1) * stride + 1:stride, xs:xs + (Wo - 1) * stride + 1:stride]
+            ref[ky * 3 + kx] = (win * da).sum(dim=(0, 1, 2))
+    assert (got.double().cpu() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
