@@ -545,6 +545,13 @@ extern "C" int emd_bn_bwd_reduce_images_f32(const float* dy, int ldd, const floa
     return bwd_reduce_impl(dy, ldd, x, ldx, mean, rstd, mscale, mshift, mask, B, npix, C, s1, s2, 0, workspace, stream);
 }
 
+// chan_reduce_final on partials another kernel produced in chan_reduce_partial_v4's layout ([image][slab][2][C] doubles): dw_bn_bwd.hip
+int emd::launch_chan_reduce_final(const double* part, int nslab, int C, int B, float* s1, float* s2, hipStream_t st) {
+    EMD_REQUIRE(part && s1 && nslab >= 1 && C >= 1 && B >= 1 && B <= 65535, EMD_E_INVALID, "chan_reduce_final: bad argument");
+    hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16, (unsigned)B), dim3(256), 0, st, part, nslab, C, s1, s2, 0);
+    return emd::check_launch("chan_reduce_final");
+}
+
 static int bwd_apply_impl(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,
                           const float* mean, const float* m2, const float* mscale, const float* mshift,
                           int mask, float* dx, int ldo, int B, long npix, int C, emd_stream_t stream) {

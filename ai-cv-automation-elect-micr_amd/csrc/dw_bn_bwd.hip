@@ -1,0 +1,228 @@
+// Training step (graph D', misc_py/denoiser-multi-gpu.py:752-782): the data gradient of a stride-1 depthwise 3x3 fused with the batch-norm
+// backward of the layer BEFORE it -- round 4, for the separable convs whose output feeds exactly one separable conv (ops.PreAct): the
+// gradient dy of that output exists only as the depthwise data gradient of the consumer, so it is never written:
+//   pass 1 (EPI = 1)  dy = dw3x3(dd, flipped taps) on the fly;  g = dy * mask(r*ms + mh);  per-workgroup double sums of g and
+//                     g * (r - mean) * rstd  -> partials in chan_reduce_partial_v4's layout (bn_train.hip), finished by chan_reduce_final
+//   [bn_bwd_prep_kernel: K, m1, m2 and the parameter gradients, as for any layer]
+//   pass 2 (EPI = 2)  dy again;  dr = K * (g - m1 - (r - mean) * m2)   written over r.
+// Against  depthwise data gradient (read dd, write dy) + reduction (read dy, r) + apply (read dy, r, write dr): 5 passes instead of 7 over
+// the tensor, two launches instead of three.  dy has the bits of emd_dw3x3_f32 (same window sums in the same order as dw3x3_s1_roll,
+// dw_misc.hip); the reduction is cut into other slabs than chan_reduce_partial_v4's, so s1 / s2 agree with the unfused route to double
+// rounding, not bit for bit.
+// replaces: the gradient of slim.separable_convolution2d's depthwise stage w.r.t. its input followed by the gradient of
+//           _batch_norm_fn(is_training) + relu6 of the previous block (machine_learning/denoiser.py:110-136 under tf.gradients).
+#include "emd_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float grad_mask(float dy, float z, int mask) {   // bn_train.hip
+    if (mask == 1) return (z > 0.f && z < 6.f) ? dy : 0.f;
+    if (mask == 2) return (z > 0.f && z <= 1.f) ? dy : 0.f;
+    if (mask == 3) return z > 0.f ? dy : 0.2f * dy;
+    return dy;
+}
+
+struct DwBnArgs {
+    const float* dd;      // [B,H,W,C] gradient w.r.t. the consumer's depthwise output, pitch ldd
+    const float* w;       // [9][C] the consumer's depthwise taps, FLIPPED (tap t = original tap 8 - t)
+    const float* r;       // [B,H,W,C] this layer's conv output (the batch norm's input), pitch ldr
+    float* dr;            // EPI 2: [B,H,W,C], pitch ldo (may be r)
+    const float *mean, *rstd, *ms, *mh;   // EPI 1: statistics and the mask's affine; [C], or [B][C] when vld = C
+    const float *K, *m1, *m2;             // EPI 2 (with mean, ms, mh)
+    double* part;         // EPI 1: [B][nslab][2][C]
+    int ldd, ldr, ldo, H, W, C4, nstrip, mask;
+    long vld;             // floats between two images' per-channel vectors (0: shared)
+};
+
+// The window arithmetic is dw3x3_s1_roll's (dw_misc.hip): a thread owns (image, column ox, channel quad) and rolls down TH output rows.
+template <int TH, int EPI>
+__global__ __launch_bounds__(256) void dw_bn_bwd_kernel(const DwBnArgs a) {
+    const int ncb = (a.C4 + 15) >> 4, npb = (a.W + 15) >> 4;
+    int bidx = blockIdx.x;
+    const int cblk = bidx % ncb;
+    bidx /= ncb;
+    const int pblk = bidx % npb;
+    bidx /= npb;
+    const int strip = bidx % a.nstrip;
+    const long b = bidx / a.nstrip;
+    const int H = a.H, W = a.W, C = a.C4 * 4;
+    const int c4o = cblk * 16 + (threadIdx.x & 15);
+    const int ox = pblk * 16 + (threadIdx.x >> 4);
+    const bool live = c4o < a.C4 && ox < W;
+    if (EPI == 2 && !live) return;
+    const int c4 = c4o < a.C4 ? c4o : a.C4 - 1, oxc = ox < W ? ox : W - 1;   // (EPI 1: idle threads stay for the reduction, on clamped addresses)
+
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(a.w + k * C + c4 * 4);
+    const long vo = b * a.vld + c4 * 4;
+    const float4 mu = *reinterpret_cast<const float4*>(a.mean + vo);
+    float4 ms = f4zero(), mh = f4zero();
+    if (a.mask) {
+        ms = *reinterpret_cast<const float4*>(a.ms + vo);
+        mh = *reinterpret_cast<const float4*>(a.mh + vo);
+    }
+    float4 e0 = f4zero(), e1 = f4zero(), e2 = f4zero();   // EPI 1: rstd; EPI 2: K, m1, m2
+    if (EPI == 1) {
+        e0 = *reinterpret_cast<const float4*>(a.rstd + vo);
+    } else {
+        e0 = *reinterpret_cast<const float4*>(a.K + vo);
+        e1 = *reinterpret_cast<const float4*>(a.m1 + vo);
+        e2 = *reinterpret_cast<const float4*>(a.m2 + vo);
+    }
+
+    const float* xb = a.dd + (b * H) * (long)W * a.ldd + c4 * 4;
+    const float* rb = a.r + (b * H) * (long)W * a.ldr + c4 * 4;
+    const int oy0 = strip * TH;
+    const bool hasl = oxc > 0, hasr = oxc + 1 < W;
+    constexpr int PF = 3, NR = TH + 2;
+    const long xl = hasl ? -(long)a.ldd : 0, xr = hasr ? (long)a.ldd : 0;
+    auto row_ptr = [&](int tt) {
+        int iy = oy0 - 1 + tt;
+        iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+        return xb + ((long)iy * W + oxc) * a.ldd;
+    };
+    float4 rc[PF], rl[PF], rr[PF];
+#pragma unroll
+    for (int t0 = 0; t0 < PF && t0 < NR; ++t0) {
+        const float* row = row_ptr(t0);
+        rc[t0] = *reinterpret_cast<const float4*>(row);
+        rl[t0] = *reinterpret_cast<const float4*>(row + xl);
+        rr[t0] = *reinterpret_cast<const float4*>(row + xr);
+    }
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    float4 s0 = f4zero(), s1 = f4zero();
+#pragma unroll
+    for (int tt = 0; tt < NR; ++tt) {
+        const int iy = oy0 - 1 + tt;
+        const bool ok = iy >= 0 && iy < H;
+        float4 c = rc[tt % PF], l = rl[tt % PF], r = rr[tt % PF];
+        c = ok ? c : f4zero();
+        l = ok && hasl ? l : f4zero();
+        r = ok && hasr ? r : f4zero();
+        if (tt + PF < NR) {
+            const float* row = row_ptr(tt + PF);
+            rc[tt % PF] = *reinterpret_cast<const float4*>(row);
+            rl[tt % PF] = *reinterpret_cast<const float4*>(row + xl);
+            rr[tt % PF] = *reinterpret_cast<const float4*>(row + xr);
+        }
+        const float4 h0 = fma4(wk[0], l, fma4(wk[1], c, fma4(wk[2], r, f4zero())));
+        const float4 h1 = fma4(wk[3], l, fma4(wk[4], c, fma4(wk[5], r, f4zero())));
+        const float4 h2 = fma4(wk[6], l, fma4(wk[7], c, fma4(wk[8], r, f4zero())));
+        if (tt >= 2) {
+            const int oy = oy0 + tt - 2;
+            if (oy < H && live) {
+                const float4 dyv = add4(s0, h2);
+                const long pix = (b * H + oy) * (long)W + ox;
+                const float4 rv = *reinterpret_cast<const float4*>(rb + ((long)oy * W + ox) * a.ldr);
+                const float dyk[4] = {dyv.x, dyv.y, dyv.z, dyv.w}, rk[4] = {rv.x, rv.y, rv.z, rv.w};
+                const float msk[4] = {ms.x, ms.y, ms.z, ms.w}, mhk[4] = {mh.x, mh.y, mh.z, mh.w}, muk[4] = {mu.x, mu.y, mu.z, mu.w};
+                const float e0k[4] = {e0.x, e0.y, e0.z, e0.w}, e1k[4] = {e1.x, e1.y, e1.z, e1.w}, e2k[4] = {e2.x, e2.y, e2.z, e2.w};
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float g = grad_mask(dyk[k], fmaf(rk[k], msk[k], mhk[k]), a.mask);
+                    if (EPI == 1) {     // chan_reduce_partial_v4's terms
+                        s[k] += (double)g;
+                        q[k] += (double)g * (double)((rk[k] - muk[k]) * e0k[k]);
+                    } else {            // bn_bwd_apply_kernel's statement
+                        o[k] = e0k[k] * (g - e1k[k] - (rk[k] - muk[k]) * e2k[k]);
+                    }
+                }
+                if (EPI == 2) *reinterpret_cast<float4*>(a.dr + pix * a.ldo + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        s0 = add4(s1, h1);
+        s1 = h0;
+    }
+    if (EPI == 1) {   // 16 columns -> one sum per channel and workgroup = one slab of chan_reduce_final's input
+        __shared__ double sm[2][16][64 + 1];
+        const int cl = (threadIdx.x & 15) * 4, col = threadIdx.x >> 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sm[0][col][cl + k] = s[k];
+            sm[1][col][cl + k] = q[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, lc = threadIdx.x & 63;
+            const int cc = cblk * 64 + lc;
+            if (cc < C) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t += sm[which][k][lc];
+                const long nslab = (long)a.nstrip * npb, slab = (long)strip * npb + pblk;
+                a.part[((b * nslab + slab) * 2 + which) * C + cc] = t;
+            }
+        }
+    }
+}
+
+int strip_height(int H) { return H >= 64 ? 16 : 8; }
+
+bool args_ok(const float* p, int ld, int C) { return p && C >= 4 && C % 4 == 0 && ld % 4 == 0 && ld >= C && emd::aligned16(p); }
+
+template <int EPI>
+int launch(const DwBnArgs& a0, int B, hipStream_t st) {
+    DwBnArgs a = a0;
+    const int TH = strip_height(a.H);
+    a.nstrip = (a.H + TH - 1) / TH;
+    const long nb = (long)B * a.nstrip * ((a.W + 15) / 16) * ((a.C4 + 15) / 16);
+    EMD_REQUIRE(nb >= 1 && nb <= 0x7fffffffL, EMD_E_UNSUPPORTED, "emd_dw3x3_bn_bwd: grid too large");
+    if (TH == 16) hipLaunchKernelGGL((dw_bn_bwd_kernel<16, EPI>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dw_bn_bwd_kernel<8, EPI>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    return emd::check_launch("dw_bn_bwd_kernel");
+}
+
+}  // namespace
+
+extern "C" size_t emd_dw3x3_bn_bwd_workspace_bytes(int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    const int TH = strip_height(H);
+    return (size_t)B * ((H + TH - 1) / TH) * ((W + 15) / 16) * 2 * C * sizeof(double);
+}
+
+// s1[c] = sum g, s2[c] = sum g * (r - mean) * rstd with g = dw3x3(dd, w_flipped) * mask(r * mscale + mshift): emd_dw3x3_f32(stride 1) followed
+// by emd_bn_bwd_reduce[_images]_f32, without the tensor between them.  images != 0: statistics vectors, s1, s2 are [B][C].
+extern "C" int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* mean,
+                                           const float* rstd, const float* mscale, const float* mshift, int mask, int images, int B, int H,
+                                           int W, int C, float* s1, float* s2, void* workspace, emd_stream_t stream) {
+    EMD_REQUIRE(w_flipped && mean && rstd && s1 && s2 && workspace, EMD_E_INVALID, "emd_dw3x3_bn_bwd_reduce_f32: null pointer");
+    EMD_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && mask >= 0 && mask <= 3 && (!mask || (mscale && mshift)), EMD_E_INVALID,
+                "emd_dw3x3_bn_bwd_reduce_f32: bad argument");
+    EMD_REQUIRE(args_ok(dd, ldd, C) && args_ok(r, ldr, C) && emd::aligned16(w_flipped) && emd::aligned16(mean) && emd::aligned16(rstd) &&
+                    (!mask || (emd::aligned16(mscale) && emd::aligned16(mshift))) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+                EMD_E_ALIGN, "emd_dw3x3_bn_bwd_reduce_f32: C, pitches multiples of 4; 16-byte aligned tensors and vectors");
+    DwBnArgs a{};
+    a.dd = dd; a.w = w_flipped; a.r = r; a.mean = mean; a.rstd = rstd; a.ms = mscale; a.mh = mshift; a.part = static_cast<double*>(workspace);
+    a.ldd = ldd; a.ldr = ldr; a.H = H; a.W = W; a.C4 = C / 4; a.mask = mask; a.vld = images ? C : 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = launch<1>(a, B, st);
+    if (rc != EMD_OK) return rc;
+    const int TH = strip_height(H);
+    const int nslab = ((H + TH - 1) / TH) * ((W + 15) / 16);
+    if (images) return emd::launch_chan_reduce_final(a.part, nslab, C, B, s1, s2, st);
+    // batch statistics: the B images' slabs are one list
+    return emd::launch_chan_reduce_final(a.part, nslab * B, C, 1, s1, s2, st);
+}
+
+// dr = K * (g - m1 - (r - mean) * m2), g as above: emd_dw3x3_f32(stride 1) followed by emd_bn_bwd_apply[_images]_f32; dr may be r.
+extern "C" int emd_dw3x3_bn_bwd_apply_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* K,
+                                          const float* m1, const float* mean, const float* m2, const float* mscale, const float* mshift,
+                                          int mask, int images, float* dr, int ldo, int B, int H, int W, int C, emd_stream_t stream) {
+    EMD_REQUIRE(w_flipped && K && m1 && mean && m2 && dr, EMD_E_INVALID, "emd_dw3x3_bn_bwd_apply_f32: null pointer");
+    EMD_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && mask >= 0 && mask <= 3 && (!mask || (mscale && mshift)), EMD_E_INVALID,
+                "emd_dw3x3_bn_bwd_apply_f32: bad argument");
+    EMD_REQUIRE(args_ok(dd, ldd, C) && args_ok(r, ldr, C) && args_ok(dr, ldo, C) && emd::aligned16(w_flipped) && emd::aligned16(K) &&
+                    emd::aligned16(m1) && emd::aligned16(mean) && emd::aligned16(m2) && (!mask || (emd::aligned16(mscale) && emd::aligned16(mshift))),
+                EMD_E_ALIGN, "emd_dw3x3_bn_bwd_apply_f32: C, pitches multiples of 4; 16-byte aligned tensors and vectors");
+    DwBnArgs a{};
+    a.dd = dd; a.w = w_flipped; a.r = r; a.dr = dr; a.mean = mean; a.ms = mscale; a.mh = mshift; a.K = K; a.m1 = m1; a.m2 = m2;
+    a.ldd = ldd; a.ldr = ldr; a.ldo = ldo; a.H = H; a.W = W; a.C4 = C / 4; a.mask = mask; a.vld = images ? C : 0;
+    return launch<2>(a, B, static_cast<hipStream_t>(stream));
+}

@@ -37,6 +37,7 @@ int launch_dw3x3_reflect_roll(const float* x, int ldx, const float* w, float* y,
 int launch_conv3x3_cout1_reflect_roll(const float* x, int ldx, const float* w, float bias, float* y, int B, int H, int W, int Cin,
                                       hipStream_t st);
 
+int launch_chan_reduce_final(const double* part, int nslab, int C, int B, float* s1, float* s2, hipStream_t st);   // bn_train.hip
 int launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st,
                           const float* gamma = nullptr, const float* beta = nullptr, float eps = 0.f, float* scale = nullptr,
                           float* shift = nullptr, int images = 1);   // scale != NULL: the norm is folded in the same launch; images > 1 (no fold): per-image statistics

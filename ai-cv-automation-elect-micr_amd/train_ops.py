@@ -244,6 +244,53 @@ def bn_backward(dy: Act, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MA
     return dr
 
 
+class DwGrad:
+    """A gradient that was never written: dy = dw3x3(dd, w_flipped) (stride 1, rate 1) -- the data gradient of a separable conv's
+    depthwise stage, the ONLY contribution to the gradient of its input.  bn_backward forms it on the fly (emd_dw3x3_bn_bwd_*_f32)."""
+
+    __slots__ = ("dd", "w", "B", "H", "W", "C")
+
+    def __init__(self, dd: Act, w_flipped):
+        assert w_flipped.is_contiguous() and w_flipped.numel() == 9 * dd.C
+        self.dd, self.w = dd, w_flipped
+        self.B, self.H, self.W, self.C = dd.B, dd.H, dd.W, dd.C
+
+
+def bn_backward_dw(dy: DwGrad, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MASK_RELU6, gamma1=None, dgamma1=None, eps=BN_EPS,
+                   stream=None):
+    """bn_backward for a gradient given as a DwGrad: reduction and apply each recompute dy from dd (5 passes over the tensor instead of
+    7, two launches instead of three); the per-channel step between them is bn_backward's."""
+    import torch
+
+    lib = _lib.load()
+    dd, Cc = dy.dd, dy.C
+    assert (r.B, r.H, r.W, r.C) == (dy.B, dy.H, dy.W, Cc) and (dr.B, dr.H, dr.W, dr.C) == (dy.B, dy.H, dy.W, Cc)
+    dev = r.buf.device
+    images = int(fold.get("B") or 0)
+    assert images in (0, dy.B)
+    n = (images or 1) * Cc
+    npix = dy.H * dy.W if images else dy.B * dy.H * dy.W
+    s1, t = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+    ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
+    ws = torch.empty(max(lib.emd_dw3x3_bn_bwd_workspace_bytes(dy.B, dy.H, dy.W, Cc) // 8, 1), dtype=torch.float64, device=dev)
+    _lib.check(lib.emd_dw3x3_bn_bwd_reduce_f32(dd.ptr, dd.ld, _p(dy.w), r.ptr, r.ld, _p(fold["mean"]), _p(fold["rstd1"]), _p(ms), _p(mh), mask,
+                                               1 if images else 0, dy.B, dy.H, dy.W, Cc, _p(s1), _p(t), _p(ws), _lib.stream_ptr(stream)),
+               "emd_dw3x3_bn_bwd_reduce_f32")
+    K, m1, m2 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
+    if images:
+        _lib.check(lib.emd_bn_bwd_prep_images_f32(_p(s1), _p(t), _p(gamma1), _p(gamma2), _p(fold["rstd1"]), _p(fold["rstd2"]),
+                                                  C.c_float(eps), C.c_long(npix), images, Cc, _p(K), _p(m1), _p(m2), _p(dgamma1), _p(dgamma2),
+                                                  _p(dbeta2), _lib.stream_ptr(stream)), "emd_bn_bwd_prep_images_f32")
+    else:
+        _lib.check(lib.emd_bn_bwd_prep_f32(_p(s1), _p(t), _p(gamma1), _p(gamma2), _p(fold["rstd1"]), _p(fold["rstd2"]),
+                                           C.c_float(eps), C.c_long(npix), Cc, _p(K), _p(m1), _p(m2), _p(dgamma1), _p(dgamma2),
+                                           _p(dbeta2), _lib.stream_ptr(stream)), "emd_bn_bwd_prep_f32")
+    _lib.check(lib.emd_dw3x3_bn_bwd_apply_f32(dd.ptr, dd.ld, _p(dy.w), r.ptr, r.ld, _p(K), _p(m1), _p(fold["mean"]), _p(m2), _p(ms), _p(mh),
+                                              mask, 1 if images else 0, dr.ptr, dr.ld, dy.B, dy.H, dy.W, Cc, _lib.stream_ptr(stream)),
+               "emd_dw3x3_bn_bwd_apply_f32")
+    return dr
+
+
 def dw3x3_wgrad(x: Act, dy: Act, dw_dev, stride=1, rate=1, stream=None):
     assert dw_dev.is_contiguous() and dw_dev.numel() == 9 * x.C and dy.C == x.C
     assert (dy.B, dy.H, dy.W) == (x.B, -(-x.H // stride), -(-x.W // stride))

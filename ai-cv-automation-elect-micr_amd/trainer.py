@@ -123,6 +123,9 @@ class DenoiserTrainer:
         self.fuse_bn_small = os.environ.get("EMD_T_BN_SMALL", "0") == "1"
         # affine + relu6 of a separable conv that feeds only the next one applied in that one's loads (ops.PreAct; round 4)
         self.lazy_affine = os.environ.get("EMD_T_LAZY_AFFINE", "1") == "1"
+        # ... and the gradient of such a never-written activation is never written either: the producer's BN backward forms it from the
+        # consumer's depthwise data gradient on the fly (TO.DwGrad / bn_backward_dw; round 4)
+        self.fuse_dw_bn_bwd = os.environ.get("EMD_T_DW_BN_BWD", "1") == "1"
         self.fuse_stats = os.environ.get("EMD_T_FUSE_STATS", "1") == "1"   # batch statistics from the producing GEMM's epilogue (ops.conv_stats)
         self.teacher = None   # test hook: scope -> {"d": ..., "r": ...} reference tensors that REPLACE the forward's conv outputs (see _force)
         self.repack()
@@ -434,7 +437,10 @@ class DenoiserTrainer:
         """dy -> d loss / d r, written over r (no longer needed); BN parameter gradients accumulate."""
         L = self.layers[key]
         r = ctx["r"]
-        bwd = TO.bn_backward_small if (ctx["fold"].get("small") and self._bn_small(r)) else TO.bn_backward
+        if isinstance(dy, TO.DwGrad):     # the gradient exists only as the consumer's depthwise data gradient (see _sep_bwd): formed on the fly
+            bwd = TO.bn_backward_dw
+        else:
+            bwd = TO.bn_backward_small if (ctx["fold"].get("small") and self._bn_small(r)) else TO.bn_backward
         if len(L.bn) == 2:
             b1, b2 = L.bn
             return bwd(dy, r, ctx["fold"], self.v[b2 + "/gamma"], self.g[b2 + "/gamma"], self.g[b2 + "/beta"], r,
@@ -456,7 +462,12 @@ class DenoiserTrainer:
             self._wg(lambda: TO.dw3x3_wgrad(x, dd, self._gdw(key), stride=L.stride, rate=L.rate), dd)
         if not need_dx:
             return
-        if L.stride == 1:
+        if (isinstance(x, ops.PreAct) and self.fuse_dw_bn_bwd and L.stride == 1 and L.rate == 1 and self._wg_side is None
+                and self._gkey(x) not in gslot and id(x.buf) not in self._gparent and x.C % 4 == 0):
+            # x was never written and this layer is its only consumer: its gradient is this depthwise data gradient and nothing else,
+            # so it is not written either -- the producer's BN backward recomputes it from dd in both of its passes (TO.bn_backward_dw)
+            gslot[self._gkey(x)] = TO.DwGrad(dd, self.dw_flip[key])
+        elif L.stride == 1:
             # SAME padding of a stride-1 dilated 3x3 is symmetric (rate, rate): the data gradient is the forward kernel
             # with the taps reversed at the same dilation
             self._put(gslot, x, lambda dst: ops.dw3x3(dd, self.dw_flip[key], dst, rate=L.rate))

@@ -459,6 +459,21 @@ int emd_dw3x3_wgrad_f32(const float* x, int ldx, const float* dy, int ldd, float
                         int rate, emd_stream_t stream);
 int emd_dw3x3_bwd_data_f32(const float* dy, int ldd, const float* w, float* dx, int ldx, int B, int H, int W, int C,
                            int stride, int rate, emd_stream_t stream);
+/* Round 4: the data gradient of a stride-1 depthwise 3x3 fused with the batch-norm backward of the layer BEFORE it, for a gradient that
+ * has no other contribution (the output of a separable conv consumed by exactly one separable conv): dy = emd_dw3x3_f32(dd, w_flipped)
+ * is formed on the fly in both passes and never written.
+ *   emd_dw3x3_bn_bwd_reduce_f32 = emd_dw3x3_f32 + emd_bn_bwd_reduce[_images]_f32 (s1 = sum g, s2 = sum g * (r - mean) * rstd,
+ *                                 g = dy * mask(r * mscale + mshift)); workspace: emd_dw3x3_bn_bwd_workspace_bytes(B, H, W, C)
+ *   emd_dw3x3_bn_bwd_apply_f32  = emd_dw3x3_f32 + emd_bn_bwd_apply[_images]_f32 (dr = K * (g - m1 - (r - mean) * m2); dr may be r)
+ * dd, r, dr [B,H,W,C]; w_flipped [9][C] = the consumer's depthwise taps reversed (tap t = original tap 8 - t); images != 0: every
+ * per-channel vector is [B][C] (per-image statistics).  (tf.gradients of machine_learning/denoiser.py:110-136 with phase = True.) */
+size_t emd_dw3x3_bn_bwd_workspace_bytes(int B, int H, int W, int C);
+int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* mean,
+                                const float* rstd, const float* mscale, const float* mshift, int mask, int images, int B, int H, int W,
+                                int C, float* s1, float* s2, void* workspace, emd_stream_t stream);
+int emd_dw3x3_bn_bwd_apply_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* K, const float* m1,
+                               const float* mean, const float* m2, const float* mscale, const float* mshift, int mask, int images,
+                               float* dr, int ldo, int B, int H, int W, int C, emd_stream_t stream);
 /* emd_dw3x3_wgrad_f32 with the layer's input given as the pre-activation tensor r of the layer before it (the forward pass ran
  * emd_dw3x3_pre_act_f32 on it and never wrote x = act(r * pre_scale + pre_shift)): x is rebuilt in the loads.  Arguments as there. */
 int emd_dw3x3_wgrad_pre_f32(const float* r, int ldx, const float* pre_scale, const float* pre_shift, int pre_images, int act,

@@ -622,3 +622,45 @@ def test_dw3x3_wgrad_pre_equals_affine_then_weight_gradient(B, H, W, Cc, stride,
             win = xp[:, ys:ys + (Ho - 1) * stride + 1:stride, xs:xs + (Wo - 1) * stride + 1:stride]
             ref[ky * 3 + kx] = (win * da).sum(dim=(0, 1, 2))
     assert (got.double().cpu() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,W,Cc,images,double_bn,mask", [
+    (2, 32, 32, 728, True, True, 1),      # the 1/16-resolution flow, a pair of one-image towers
+    (2, 72, 80, 64, True, False, 1),      # 16-row strips, a ragged last strip
+    (3, 20, 24, 24, False, True, 1),      # batch statistics; W, C not multiples of the workgroup's 16 columns / 64 channels
+    (1, 16, 16, 128, False, False, 0),    # no activation mask
+])
+def test_bn_backward_of_a_never_written_gradient(B, H, W, Cc, images, double_bn, mask):
+    """TO.bn_backward_dw (emd_dw3x3_bn_bwd_reduce_f32 / _apply_f32: dy = dw3x3(dd, flipped taps) formed on the fly in both passes) ==
+    ops.dw3x3 written out, then TO.bn_backward: dr and the parameter gradients to the rounding of the re-cut double sums."""
+    from emdenoise import ops, train_ops as TO
+
+    g = torch.Generator(device=dev()).manual_seed(7)
+    rn = lambda *sh: torch.randn(*sh, device=dev(), generator=g)
+    r0 = rn(B, H, W, Cc) * 2
+    dd = ops.Act(rn(B, H, W, Cc))
+    wf = rn(9, Cc) * 0.3
+    gamma2, beta2 = torch.rand(Cc, device=dev(), generator=g) + 0.5, rn(Cc)
+    gamma1, beta1 = (torch.rand(Cc, device=dev(), generator=g) + 0.5, rn(Cc)) if double_bn else (None, None)
+    rA = ops.Act(r0.clone())
+    mean, var = (ops.bn_batch_stats_images if images else ops.bn_batch_stats)(rA)
+    npix = H * W if images else B * H * W
+    fold = TO.bn_train_fold(mean, var, gamma2, beta2, npix, gamma1=gamma1, beta1=beta1, images=B if images else 0)
+    outs = {}
+    for fused in (False, True):
+        r = ops.Act(r0.clone())
+        dg2, db2 = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
+        dg1 = torch.zeros(Cc, device=dev()) if double_bn else None
+        if fused:
+            TO.bn_backward_dw(TO.DwGrad(dd, wf), r, fold, gamma2, dg2, db2, r, mask=mask, gamma1=gamma1, dgamma1=dg1)
+        else:
+            dy = ops.dw3x3(dd, wf, ops.Act.empty(B, H, W, Cc, dev()))
+            TO.bn_backward(dy, r, fold, gamma2, dg2, db2, r, mask=mask, gamma1=gamma1, dgamma1=dg1)
+        torch.cuda.synchronize()
+        outs[fused] = (r.buf.clone(), dg2, db2, dg1)
+    a, b = outs[True], outs[False]
+    assert not torch.isnan(a[0]).any()
+    assert (a[0] - b[0]).abs().max().item() < 2e-5 * b[0].abs().max().item()
+    for u, v in zip(a[1:], b[1:]):
+        if u is not None:
+            assert (u - v).abs().max().item() < 2e-5 * max(v.abs().max().item(), 1e-3)
