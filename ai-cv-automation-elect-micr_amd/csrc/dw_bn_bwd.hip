@@ -35,13 +35,19 @@ struct DwBnArgs {
     const float *mean, *rstd, *ms, *mh;   // EPI 1: statistics and the mask's affine; [C], or [B][C] when vld = C
     const float *K, *m1, *m2;             // EPI 2 (with mean, ms, mh)
     double* part;         // EPI 1: [B][nslab][2][C]
+    float* dwg;           // EPI 1, WG: [9][C] += the CONSUMER's depthwise weight gradient, sum_p x[p + tap] * dd[p] with x = act(r*ms + mh)
     int ldd, ldr, ldo, H, W, C4, nstrip, mask;
     long vld;             // floats between two images' per-channel vectors (0: shared)
 };
 
 // The window arithmetic is dw3x3_s1_roll's (dw_misc.hip): a thread owns (image, column ox, channel quad) and rolls down TH output rows.
-template <int TH, int EPI>
+// WG (EPI 1 only): the pass streams exactly the two operands of the consumer's depthwise WEIGHT gradient -- dd with its halo, and r, from
+// which x = relu6(r*ms + mh) is the mask's own argument clamped -- so that gradient is accumulated here too (the raw 3 x 3 window of dd
+// around the pixel is kept beside the window sums): dW[3ky + kx] += x[q] * dd[q - (ky-1, kx-1)], 16 columns summed through LDS, one
+// float atomic per (tap, channel) and workgroup as in dw_wgrad_roll_kernel (bwd_misc.hip).  emd_dw3x3_wgrad_pre_f32's launch is gone.
+template <int TH, int EPI, bool WG = false>
 __global__ __launch_bounds__(256) void dw_bn_bwd_kernel(const DwBnArgs a) {
+    static_assert(!WG || EPI == 1, "the weight gradient rides in the reduction pass");
     const int ncb = (a.C4 + 15) >> 4, npb = (a.W + 15) >> 4;
     int bidx = blockIdx.x;
     const int cblk = bidx % ncb;
@@ -97,6 +103,11 @@ __global__ __launch_bounds__(256) void dw_bn_bwd_kernel(const DwBnArgs a) {
     }
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
     float4 s0 = f4zero(), s1 = f4zero();
+    float4 wa[WG ? 9 : 1];                                  // the consumer's weight gradient, this thread's share
+    float4 pl0 = f4zero(), pc0 = f4zero(), pr0 = f4zero();  // raw dd of window row 0 (input row tt - 2) ...
+    float4 pl1 = f4zero(), pc1 = f4zero(), pr1 = f4zero();  // ... and row 1 (tt - 1)
+#pragma unroll
+    for (int k = 0; k < (WG ? 9 : 1); ++k) wa[k] = f4zero();
 #pragma unroll
     for (int tt = 0; tt < NR; ++tt) {
         const int iy = oy0 - 1 + tt;
@@ -135,10 +146,40 @@ __global__ __launch_bounds__(256) void dw_bn_bwd_kernel(const DwBnArgs a) {
                     }
                 }
                 if (EPI == 2) *reinterpret_cast<float4*>(a.dr + pix * a.ldo + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                if constexpr (WG) {   // x = relu6(r*ms + mh): affine_relu6_kernel's bits (what the forward's loads rebuilt); window rows 0, 1, 2 = tt - 2, tt - 1, tt
+                    const float4 x = make_float4(fminf(fmaxf(fmaf(rk[0], msk[0], mhk[0]), 0.f), 6.f), fminf(fmaxf(fmaf(rk[1], msk[1], mhk[1]), 0.f), 6.f),
+                                                 fminf(fmaxf(fmaf(rk[2], msk[2], mhk[2]), 0.f), 6.f), fminf(fmaxf(fmaf(rk[3], msk[3], mhk[3]), 0.f), 6.f));
+                    wa[0] = fma4(x, r, wa[0]);   wa[1] = fma4(x, c, wa[1]);   wa[2] = fma4(x, l, wa[2]);      // ky = 0: window row 2
+                    wa[3] = fma4(x, pr1, wa[3]); wa[4] = fma4(x, pc1, wa[4]); wa[5] = fma4(x, pl1, wa[5]);    // ky = 1: row 1
+                    wa[6] = fma4(x, pr0, wa[6]); wa[7] = fma4(x, pc0, wa[7]); wa[8] = fma4(x, pl0, wa[8]);    // ky = 2: row 0
+                }
             }
         }
         s0 = add4(s1, h1);
         s1 = h0;
+        if constexpr (WG) {
+            pl0 = pl1; pc0 = pc1; pr0 = pr1;
+            pl1 = l; pc1 = c; pr1 = r;
+        }
+    }
+    if constexpr (WG) {   // 16 columns -> one sum per (tap, channel) through LDS, then one atomic each (dw_wgrad_roll_kernel's tail)
+        __shared__ float red[16][9][64 + 1];
+        const int cl = (threadIdx.x & 15) * 4, col = threadIdx.x >> 4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            red[col][t][cl + 0] = wa[t].x; red[col][t][cl + 1] = wa[t].y;
+            red[col][t][cl + 2] = wa[t].z; red[col][t][cl + 3] = wa[t].w;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+            const int t = i / 64, lc = i % 64;
+            const int cc = cblk * 64 + lc;
+            if (cc >= C) continue;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += red[k][t][lc];
+            atomicAdd(a.dwg + (long)t * C + cc, sum);
+        }
     }
     if (EPI == 1) {   // 16 columns -> one sum per channel and workgroup = one slab of chan_reduce_final's input
         __shared__ double sm[2][16][64 + 1];
@@ -174,6 +215,13 @@ int launch(const DwBnArgs& a0, int B, hipStream_t st) {
     a.nstrip = (a.H + TH - 1) / TH;
     const long nb = (long)B * a.nstrip * ((a.W + 15) / 16) * ((a.C4 + 15) / 16);
     EMD_REQUIRE(nb >= 1 && nb <= 0x7fffffffL, EMD_E_UNSUPPORTED, "emd_dw3x3_bn_bwd: grid too large");
+    if constexpr (EPI == 1) {
+        if (a.dwg) {
+            if (TH == 16) hipLaunchKernelGGL((dw_bn_bwd_kernel<16, 1, true>), dim3((unsigned)nb), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((dw_bn_bwd_kernel<8, 1, true>), dim3((unsigned)nb), dim3(256), 0, st, a);
+            return emd::check_launch("dw_bn_bwd_kernel<weight gradient>");
+        }
+    }
     if (TH == 16) hipLaunchKernelGGL((dw_bn_bwd_kernel<16, EPI>), dim3((unsigned)nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dw_bn_bwd_kernel<8, EPI>), dim3((unsigned)nb), dim3(256), 0, st, a);
     return emd::check_launch("dw_bn_bwd_kernel");
@@ -189,9 +237,12 @@ extern "C" size_t emd_dw3x3_bn_bwd_workspace_bytes(int B, int H, int W, int C) {
 
 // s1[c] = sum g, s2[c] = sum g * (r - mean) * rstd with g = dw3x3(dd, w_flipped) * mask(r * mscale + mshift): emd_dw3x3_f32(stride 1) followed
 // by emd_bn_bwd_reduce[_images]_f32, without the tensor between them.  images != 0: statistics vectors, s1, s2 are [B][C].
+// dw_consumer != NULL (needs mask = relu6): [9][C] += the consumer's depthwise weight gradient, emd_dw3x3_wgrad_pre_f32(r, mscale, mshift,
+// relu6, dd) -- the pass reads exactly its operands.
 extern "C" int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* mean,
                                            const float* rstd, const float* mscale, const float* mshift, int mask, int images, int B, int H,
-                                           int W, int C, float* s1, float* s2, void* workspace, emd_stream_t stream) {
+                                           int W, int C, float* s1, float* s2, float* dw_consumer, void* workspace, emd_stream_t stream) {
+    EMD_REQUIRE(!dw_consumer || mask == 1, EMD_E_INVALID, "emd_dw3x3_bn_bwd_reduce_f32: the consumer's weight gradient needs the relu6 mask (x = relu6(r*mscale + mshift))");
     EMD_REQUIRE(w_flipped && mean && rstd && s1 && s2 && workspace, EMD_E_INVALID, "emd_dw3x3_bn_bwd_reduce_f32: null pointer");
     EMD_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && mask >= 0 && mask <= 3 && (!mask || (mscale && mshift)), EMD_E_INVALID,
                 "emd_dw3x3_bn_bwd_reduce_f32: bad argument");
@@ -200,6 +251,7 @@ extern "C" int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float
                 EMD_E_ALIGN, "emd_dw3x3_bn_bwd_reduce_f32: C, pitches multiples of 4; 16-byte aligned tensors and vectors");
     DwBnArgs a{};
     a.dd = dd; a.w = w_flipped; a.r = r; a.mean = mean; a.rstd = rstd; a.ms = mscale; a.mh = mshift; a.part = static_cast<double*>(workspace);
+    a.dwg = dw_consumer;
     a.ldd = ldd; a.ldr = ldr; a.H = H; a.W = W; a.C4 = C / 4; a.mask = mask; a.vld = images ? C : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = launch<1>(a, B, st);

@@ -248,11 +248,14 @@ class DwGrad:
     """A gradient that was never written: dy = dw3x3(dd, w_flipped) (stride 1, rate 1) -- the data gradient of a separable conv's
     depthwise stage, the ONLY contribution to the gradient of its input.  bn_backward forms it on the fly (emd_dw3x3_bn_bwd_*_f32)."""
 
-    __slots__ = ("dd", "w", "B", "H", "W", "C")
+    __slots__ = ("dd", "w", "gdw", "B", "H", "W", "C")
 
-    def __init__(self, dd: Act, w_flipped):
+    def __init__(self, dd: Act, w_flipped, gdw=None):
+        """gdw: the consumer's depthwise weight-gradient slice [9][C] when bn_backward_dw is to add that gradient too (its reduction pass
+        reads exactly the operands: dd and the r behind the consumer's never-written input) -- the consumer then skips its own launch."""
         assert w_flipped.is_contiguous() and w_flipped.numel() == 9 * dd.C
-        self.dd, self.w = dd, w_flipped
+        assert gdw is None or (gdw.is_contiguous() and gdw.numel() == 9 * dd.C)
+        self.dd, self.w, self.gdw = dd, w_flipped, gdw
         self.B, self.H, self.W, self.C = dd.B, dd.H, dd.W, dd.C
 
 
@@ -267,14 +270,15 @@ def bn_backward_dw(dy: DwGrad, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, m
     assert (r.B, r.H, r.W, r.C) == (dy.B, dy.H, dy.W, Cc) and (dr.B, dr.H, dr.W, dr.C) == (dy.B, dy.H, dy.W, Cc)
     dev = r.buf.device
     images = int(fold.get("B") or 0)
-    assert images in (0, dy.B)
+    assert images in (0, dy.B) and (dy.gdw is None or mask == MASK_RELU6)
     n = (images or 1) * Cc
     npix = dy.H * dy.W if images else dy.B * dy.H * dy.W
     s1, t = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
     ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
     ws = torch.empty(max(lib.emd_dw3x3_bn_bwd_workspace_bytes(dy.B, dy.H, dy.W, Cc) // 8, 1), dtype=torch.float64, device=dev)
     _lib.check(lib.emd_dw3x3_bn_bwd_reduce_f32(dd.ptr, dd.ld, _p(dy.w), r.ptr, r.ld, _p(fold["mean"]), _p(fold["rstd1"]), _p(ms), _p(mh), mask,
-                                               1 if images else 0, dy.B, dy.H, dy.W, Cc, _p(s1), _p(t), _p(ws), _lib.stream_ptr(stream)),
+                                               1 if images else 0, dy.B, dy.H, dy.W, Cc, _p(s1), _p(t), _p(dy.gdw), _p(ws),
+                                               _lib.stream_ptr(stream)),
                "emd_dw3x3_bn_bwd_reduce_f32")
     K, m1, m2 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
     if images:

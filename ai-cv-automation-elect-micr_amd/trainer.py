@@ -126,6 +126,7 @@ class DenoiserTrainer:
         # ... and the gradient of such a never-written activation is never written either: the producer's BN backward forms it from the
         # consumer's depthwise data gradient on the fly (TO.DwGrad / bn_backward_dw; round 4)
         self.fuse_dw_bn_bwd = os.environ.get("EMD_T_DW_BN_BWD", "1") == "1"
+        self.fuse_dw_wgrad = os.environ.get("EMD_T_DW_WGRAD", "1") == "1"   # ... whose reduction pass also adds the consumer's depthwise weight gradient
         self.fuse_stats = os.environ.get("EMD_T_FUSE_STATS", "1") == "1"   # batch statistics from the producing GEMM's epilogue (ops.conv_stats)
         self.teacher = None   # test hook: scope -> {"d": ..., "r": ...} reference tensors that REPLACE the forward's conv outputs (see _force)
         self.repack()
@@ -456,18 +457,24 @@ class DenoiserTrainer:
         # the data gradient lands on d -- unless the weight gradient above may still be reading d on its side stream
         dd_buf = d if self._wg_side is None else self._E(d.B, d.H, d.W, d.C)
         dd = ops.conv1x1(dr, self.pk_b[key], self.ones, self.zeros, dd_buf, act=False, precision=self.precision)
+        deferred = (isinstance(x, ops.PreAct) and need_dx and self.fuse_dw_bn_bwd and L.stride == 1 and L.rate == 1 and self._wg_side is None
+                    and self._gkey(x) not in gslot and id(x.buf) not in self._gparent and x.C % 4 == 0)
+        if deferred:
+            # x was never written and this layer is its only consumer: its gradient is this depthwise data gradient and nothing else,
+            # so it is not written either -- the producer's BN backward recomputes it from dd in both of its passes (TO.bn_backward_dw),
+            # and its reduction pass, which streams dd and the r behind x, adds THIS layer's depthwise weight gradient on the way
+            g = TO.DwGrad(dd, self.dw_flip[key], self._gdw(key) if (self.fuse_dw_wgrad and x.act == ops.ACT_RELU6) else None)
+            gslot[self._gkey(x)] = g
+            if g.gdw is None:
+                TO.dw3x3_wgrad_pre(x, dd, self._gdw(key), stride=L.stride, rate=L.rate)
+            return
         if isinstance(x, ops.PreAct):    # the input was never written: rebuilt from the previous layer's r in the loads
             self._wg(lambda: TO.dw3x3_wgrad_pre(x, dd, self._gdw(key), stride=L.stride, rate=L.rate), dd)
         else:
             self._wg(lambda: TO.dw3x3_wgrad(x, dd, self._gdw(key), stride=L.stride, rate=L.rate), dd)
         if not need_dx:
             return
-        if (isinstance(x, ops.PreAct) and self.fuse_dw_bn_bwd and L.stride == 1 and L.rate == 1 and self._wg_side is None
-                and self._gkey(x) not in gslot and id(x.buf) not in self._gparent and x.C % 4 == 0):
-            # x was never written and this layer is its only consumer: its gradient is this depthwise data gradient and nothing else,
-            # so it is not written either -- the producer's BN backward recomputes it from dd in both of its passes (TO.bn_backward_dw)
-            gslot[self._gkey(x)] = TO.DwGrad(dd, self.dw_flip[key])
-        elif L.stride == 1:
+        if L.stride == 1:
             # SAME padding of a stride-1 dilated 3x3 is symmetric (rate, rate): the data gradient is the forward kernel
             # with the taps reversed at the same dilation
             self._put(gslot, x, lambda dst: ops.dw3x3(dd, self.dw_flip[key], dst, rate=L.rate))

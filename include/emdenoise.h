@@ -465,12 +465,14 @@ int emd_dw3x3_bwd_data_f32(const float* dy, int ldd, const float* w, float* dx, 
  *   emd_dw3x3_bn_bwd_reduce_f32 = emd_dw3x3_f32 + emd_bn_bwd_reduce[_images]_f32 (s1 = sum g, s2 = sum g * (r - mean) * rstd,
  *                                 g = dy * mask(r * mscale + mshift)); workspace: emd_dw3x3_bn_bwd_workspace_bytes(B, H, W, C)
  *   emd_dw3x3_bn_bwd_apply_f32  = emd_dw3x3_f32 + emd_bn_bwd_apply[_images]_f32 (dr = K * (g - m1 - (r - mean) * m2); dr may be r)
+ * dw_consumer (or NULL; needs mask = relu6): [9][C] += the CONSUMER's depthwise weight gradient = emd_dw3x3_wgrad_pre_f32(r, mscale,
+ * mshift, relu6, dd): the reduction pass streams exactly its operands.
  * dd, r, dr [B,H,W,C]; w_flipped [9][C] = the consumer's depthwise taps reversed (tap t = original tap 8 - t); images != 0: every
  * per-channel vector is [B][C] (per-image statistics).  (tf.gradients of machine_learning/denoiser.py:110-136 with phase = True.) */
 size_t emd_dw3x3_bn_bwd_workspace_bytes(int B, int H, int W, int C);
 int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* mean,
                                 const float* rstd, const float* mscale, const float* mshift, int mask, int images, int B, int H, int W,
-                                int C, float* s1, float* s2, void* workspace, emd_stream_t stream);
+                                int C, float* s1, float* s2, float* dw_consumer, void* workspace, emd_stream_t stream);
 int emd_dw3x3_bn_bwd_apply_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* K, const float* m1,
                                const float* mean, const float* m2, const float* mscale, const float* mshift, int mask, int images,
                                float* dr, int ldo, int B, int H, int W, int C, emd_stream_t stream);

@@ -322,20 +322,21 @@ def test_affine_in_the_consumers_loads_changes_nothing():
     x, t = torch.from_numpy(lq).to(dev()), torch.from_numpy(hq).to(dev())
     for per_image in (False, True):
         res = {}
-        # (affine in the loads, the never-written gradient: TO.DwGrad / emd_dw3x3_bn_bwd_*_f32): the default, each step back, all written out
-        for mode in ((True, True), (True, False), (False, False)):
+        # (affine in the loads, the never-written gradient: TO.DwGrad / emd_dw3x3_bn_bwd_*_f32, the consumer's depthwise weight gradient inside
+        # its reduction pass): the default, each step back, all written out
+        for mode in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)):
             tr = TR.DenoiserTrainer(w, dev())
-            assert tr.lazy_affine and tr.fuse_dw_bn_bwd
-            tr.lazy_affine, tr.fuse_dw_bn_bwd = mode
+            assert tr.lazy_affine and tr.fuse_dw_bn_bwd and tr.fuse_dw_wgrad
+            tr.lazy_affine, tr.fuse_dw_bn_bwd, tr.fuse_dw_wgrad = mode
             tr.zero_grad()
             o, r = tr.tower(x, t, update_moving=True, per_image=per_image)
             torch.cuda.synchronize()
             res[mode] = (o.clone(), r.clone(), tr.moving.clone(), tr.grads.detach().cpu().numpy().astype(np.float64))
-        ref = res[(False, False)]
-        for mode in ((True, True), (True, False)):
+        ref = res[(False, False, False)]
+        for mode in ((True, True, True), (True, True, False), (True, False, False)):
             assert torch.equal(res[mode][0], ref[0]) and torch.equal(res[mode][1], ref[1]) and torch.equal(res[mode][2], ref[2])
             spread = rel_l2(res[mode][3], ref[3])
-            print(f"affine in the consumer's loads {mode[0]}, gradient never written {mode[1]} vs all written out, per_image={per_image}: "
+            print(f"affine in the consumer's loads {mode[0]}, gradient never written {mode[1]}, consumer's depthwise weight gradient in the reduction {mode[2]} vs all written out, per_image={per_image}: "
                   f"outputs / losses / moving statistics identical; gradient rel L2 {spread:.2e}")
             assert spread < 2e-6
 

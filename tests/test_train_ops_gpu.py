@@ -647,20 +647,26 @@ def test_bn_backward_of_a_never_written_gradient(B, H, W, Cc, images, double_bn,
     npix = H * W if images else B * H * W
     fold = TO.bn_train_fold(mean, var, gamma2, beta2, npix, gamma1=gamma1, beta1=beta1, images=B if images else 0)
     outs = {}
+    wg = mask == 1     # the reduction pass also adds the CONSUMER's depthwise weight gradient (x = relu6(r * scale + shift) behind the mask)
     for fused in (False, True):
         r = ops.Act(r0.clone())
         dg2, db2 = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
         dg1 = torch.zeros(Cc, device=dev()) if double_bn else None
+        gdw = torch.zeros(9, Cc, device=dev())
         if fused:
-            TO.bn_backward_dw(TO.DwGrad(dd, wf), r, fold, gamma2, dg2, db2, r, mask=mask, gamma1=gamma1, dgamma1=dg1)
+            TO.bn_backward_dw(TO.DwGrad(dd, wf, gdw if wg else None), r, fold, gamma2, dg2, db2, r, mask=mask, gamma1=gamma1, dgamma1=dg1)
         else:
+            if wg:
+                TO.dw3x3_wgrad_pre(ops.PreAct(r, fold["scale"], fold["shift"], images=images, act=ops.ACT_RELU6), dd, gdw)
             dy = ops.dw3x3(dd, wf, ops.Act.empty(B, H, W, Cc, dev()))
             TO.bn_backward(dy, r, fold, gamma2, dg2, db2, r, mask=mask, gamma1=gamma1, dgamma1=dg1)
         torch.cuda.synchronize()
-        outs[fused] = (r.buf.clone(), dg2, db2, dg1)
+        outs[fused] = (r.buf.clone(), dg2, db2, dg1, gdw)
     a, b = outs[True], outs[False]
     assert not torch.isnan(a[0]).any()
     assert (a[0] - b[0]).abs().max().item() < 2e-5 * b[0].abs().max().item()
     for u, v in zip(a[1:], b[1:]):
         if u is not None:
             assert (u - v).abs().max().item() < 2e-5 * max(v.abs().max().item(), 1e-3)
+    if wg:
+        assert b[4].abs().max().item() > 0
