@@ -133,6 +133,9 @@ SIGNATURES = {
     "emd_conv3x3_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] +
                               [C.c_int] * 8 + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
     # x ldx scale shift res ldres y ldy B npix_img C act stream
+    # x ldx scale shift res ldres res_scale res_shift res_act y ldy images npix C act stream
+    "emd_affine_act_res_affine_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int,
+                                                _c_float_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "emd_affine_act_images_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p,
                                             C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "emd_bn_stats_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int]),

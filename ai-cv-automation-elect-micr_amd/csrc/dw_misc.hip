@@ -494,7 +494,10 @@ __global__ __launch_bounds__(256) void resize_up2_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void affine_relu6_kernel(const float* x, int ldx, const float* __restrict__ sc,
                                                            const float* __restrict__ sh, const float* res, int ldres,
                                                            float* y, int ldy, int C4, long nthreads, int act,
-                                                           long npix_img) {
+                                                           long npix_img, const float* __restrict__ rsc = nullptr,
+                                                           const float* __restrict__ rsh = nullptr, float rhi = 0.f) {
+    // rsc != NULL: the residual operand is itself given before ITS affine + activation, res = min(max(res*rsc + rsh, 0), rhi) (round 4: the
+    // 1x1 residual projection's norm + relu6 applied here instead of in a pass of its own; vectors indexed like sc / sh)
     // npix_img != 0: scale / shift are [image][C] (per-image statistics: instance norms, graph S), image = pix / npix_img
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nthreads) return;
@@ -513,7 +516,11 @@ __global__ __launch_bounds__(256) void affine_relu6_kernel(const float* x, int l
         o = make_float4(fminf(fmaxf(o.x, 0.f), hi), fminf(fmaxf(o.y, 0.f), hi), fminf(fmaxf(o.z, 0.f), hi),
                         fminf(fmaxf(o.w, 0.f), hi));
     }
-    if (res) o = add4(o, *reinterpret_cast<const float4*>(res + pix * ldres + c4 * 4));
+    if (res) {
+        float4 rv = *reinterpret_cast<const float4*>(res + pix * ldres + c4 * 4);
+        if (rsc) rv = clamp4(fma4(rv, *reinterpret_cast<const float4*>(rsc + so + c4 * 4), *reinterpret_cast<const float4*>(rsh + so + c4 * 4)), rhi);
+        o = add4(o, rv);
+    }
     *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = o;
 }
 
@@ -972,6 +979,29 @@ extern "C" int emd_resize_bilinear_f32(const float* x, int ldx, float* y, int ld
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, y, ldy,
                        Hi, Wi, Ho, Wo, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo, nthreads);
     return emd::check_launch("resize_bilinear_kernel");
+}
+
+// y = act(x*scale + shift) + res_act(res*res_scale + res_shift): emd_affine_act[_images]_f32 whose residual operand is given BEFORE its
+// own affine + activation (round 4, graph D': the 1x1 residual projection's batch norm + relu6 -- conv_block_not_sep, machine_learning/
+// denoiser.py:356-383 with phase = True -- applied where the block adds it, instead of in a pass of its own; bits of the two-pass route).
+// images = 0: all vectors [C], npix = all pixels; images = B > 0: all vectors [B][C], npix = pixels per image.  res_act: RELU6 or RELU.
+extern "C" int emd_affine_act_res_affine_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
+                                             const float* res_scale, const float* res_shift, int res_act, float* y, int ldy, int images,
+                                             long npix, int C, int act, emd_stream_t stream) {
+    EMD_REQUIRE(x && y && scale && shift && res && res_scale && res_shift, EMD_E_INVALID, "emd_affine_act_res_affine_f32: null pointer");
+    EMD_REQUIRE(images >= 0 && npix >= 0 && C >= 4 && act >= 0 && act <= 4 && (res_act == 1 || res_act == 2), EMD_E_INVALID,
+                "emd_affine_act_res_affine_f32: bad argument");
+    EMD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldres % 4 == 0 && ldx >= C && ldy >= C && ldres >= C && emd::aligned16(x) &&
+                    emd::aligned16(y) && emd::aligned16(res) && emd::aligned16(scale) && emd::aligned16(shift) && emd::aligned16(res_scale) &&
+                    emd::aligned16(res_shift), EMD_E_ALIGN, "emd_affine_act_res_affine_f32: alignment");
+    if (npix == 0) return EMD_OK;
+    const long nthreads = (images ? (long)images : 1L) * npix * (C / 4);
+    unsigned nb;
+    int rc = grid_for(nthreads, &nb);
+    if (rc != EMD_OK) return rc;
+    hipLaunchKernelGGL(affine_relu6_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, scale, shift, res, ldres, y, ldy,
+                       C / 4, nthreads, act, images ? npix : 0L, res_scale, res_shift, res_act == 1 ? 6.f : __builtin_inff());
+    return emd::check_launch("affine_relu6_kernel (residual affine)");
 }
 
 extern "C" int emd_affine_act_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res,

@@ -582,6 +582,20 @@ def affine_act_images(x: Act, scale_dev, shift_dev, out: Act, act=ACT_RELU, res:
     return out
 
 
+def affine_act_res_pre(x: Act, scale_dev, shift_dev, out: Act, res: "PreAct", act=ACT_RELU6, stream=None):
+    """out = act(x*scale + shift) + res_act(res.r*res.scale + res.shift): the residual operand a never-written PreAct
+    (emd_affine_act_res_affine_f32); scale / shift per image exactly when res's are."""
+    lib = _lib.load()
+    r = res.r
+    assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, x.C) == (r.B, r.H, r.W, r.C)
+    assert scale_dev.numel() == (x.B * x.C if res.images else x.C)
+    rc = lib.emd_affine_act_res_affine_f32(x.ptr, x.ld, _p(scale_dev), _p(shift_dev), r.ptr, r.ld, _p(res.scale), _p(res.shift), _act(res.act),
+                                           out.ptr, out.ld, x.B if res.images else 0, C.c_long(x.H * x.W if res.images else x.B * x.H * x.W),
+                                           x.C, _act(act), _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_affine_act_res_affine_f32")
+    return out
+
+
 def bn_fold(mean, var, gamma, beta, eps=1e-3, stream=None):
     """(mean, var, gamma|None, beta|None) -> (scale, shift) device vectors of the equivalent affine."""
     import torch

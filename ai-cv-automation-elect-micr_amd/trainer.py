@@ -123,6 +123,7 @@ class DenoiserTrainer:
         self.fuse_bn_small = os.environ.get("EMD_T_BN_SMALL", "0") == "1"
         # affine + relu6 of a separable conv that feeds only the next one applied in that one's loads (ops.PreAct; round 4)
         self.lazy_affine = os.environ.get("EMD_T_LAZY_AFFINE", "1") == "1"
+        self.lazy_res = os.environ.get("EMD_T_LAZY_RES", "1") == "1"   # ... and of a 1x1 residual projection in the pass that adds it (with lazy_affine)
         # ... and the gradient of such a never-written activation is never written either: the producer's BN backward forms it from the
         # consumer's depthwise data gradient on the fly (TO.DwGrad / bn_backward_dw; round 4)
         self.fuse_dw_bn_bwd = os.environ.get("EMD_T_DW_BN_BWD", "1") == "1"
@@ -315,6 +316,9 @@ class DenoiserTrainer:
     @staticmethod
     def _affine(r, fold, out, act, res=None):
         """out = act(r * scale + shift) [+ res] with the fold of _bn: per-channel, or per (image, channel) for per-image statistics."""
+        if isinstance(res, ops.PreAct):   # the residual projection's own norm + relu6 applied here (its output was never written)
+            assert bool(fold.get("B")) == res.images
+            return ops.affine_act_res_pre(r, fold["scale"], fold["shift"], out, res, act=act)
         if fold.get("B"):
             return ops.affine_act_images(r, fold["scale"], fold["shift"], out, act=act, res=res)
         return ops.affine_act(r, fold["scale"], fold["shift"], out, act=act, res=res)
@@ -365,8 +369,10 @@ class DenoiserTrainer:
         out, fold = self._bn_apply(key, r, out, ops.ACT_RELU6, res, stats=stats)
         return out, {"x": x, "d": d, "r": r, "fold": fold}
 
-    def _conv_fwd(self, key, x, out=None, act=True):
-        """conv + bias -> BN -> relu6 (bias folds into the batch mean), or conv + bias alone (the image-level conv)."""
+    def _conv_fwd(self, key, x, out=None, act=True, lazy=False):
+        """conv + bias -> BN -> relu6 (bias folds into the batch mean), or conv + bias alone (the image-level conv).
+        lazy=True (the caller's promise: the output is ONLY the residual operand of one separable conv's affine): the norm + relu6 is
+        left to that affine pass (ops.PreAct as ``res``, emd_affine_act_res_affine_f32): one read and one write of the tensor less."""
         L = self.layers[key]
         Ho, Wo = -(-x.H // L.stride), -(-x.W // L.stride)
         bias = self.v[L.scope + "/" + L.bname]
@@ -386,6 +392,9 @@ class DenoiserTrainer:
         self._force(tgt, L.scope, "r")
         if not has_bn:
             return tgt, {"x": x}
+        if lazy and self.lazy_affine and self.lazy_res and act and not small and not self.fuse_bn_small and out is None and self.teacher is None:
+            fold = self._bn(key, tgt, L.scope + "/" + L.bname, stats=stats)
+            return (ops.PreAct(tgt, fold["scale"], fold["shift"], images=bool(fold.get("B")), act=ops.ACT_RELU6), {"x": x, "r": tgt, "fold": fold})
         if out is None:
             out = self._E(x.B, Ho, Wo, L.cout)
         out, fold = self._bn_apply(key, tgt, out, ops.ACT_RELU6 if act else ops.ACT_NONE, None, L.scope + "/" + L.bname, stats=stats)
@@ -589,21 +598,21 @@ class DenoiserTrainer:
         x = ops.Act(x4)
         cnn0, C["cnn0"] = self._sep_fwd("cnn0", x, lazy=True)
         cnn0_last, C["cnn0_last"] = self._sep_fwd("cnn0_last", cnn0, lazy=True)
-        residual0, C["residual0"] = self._conv_fwd("residual0", x)
+        residual0, C["residual0"] = self._conv_fwd("residual0", x, lazy=True)
         st.concat1 = E(S2, f2 + f1)
         st.cnn0_strided, C["cnn0_strided"] = self._sep_fwd("cnn0_strided", cnn0_last, out=st.concat1.slice(f2, f1), res=residual0)
         cnn1, C["cnn1"] = self._sep_fwd("cnn1", st.cnn0_strided, lazy=True)
         cnn1_last, C["cnn1_last"] = self._sep_fwd("cnn1_last", cnn1, lazy=True)
-        residual1, C["residual1"] = self._conv_fwd("residual1", st.cnn0_strided)
+        residual1, C["residual1"] = self._conv_fwd("residual1", st.cnn0_strided, lazy=True)
         st.concat2 = E(S4, aspp_output + f1)
         st.cnn1_strided, C["cnn1_strided"] = self._sep_fwd("cnn1_strided", cnn1_last, out=st.concat2.slice(aspp_output, f1), res=residual1)
         cnn2, C["cnn2"] = self._sep_fwd("cnn2", st.cnn1_strided, lazy=True)
         cnn2_last, C["cnn2_last"] = self._sep_fwd("cnn2_last", cnn2, lazy=True)
-        residual2, C["residual2"] = self._conv_fwd("residual2", st.cnn1_strided)
+        residual2, C["residual2"] = self._conv_fwd("residual2", st.cnn1_strided, lazy=True)
         st.cnn2_strided, C["cnn2_strided"] = self._sep_fwd("cnn2_strided", cnn2_last, res=residual2)
         cnn3, C["cnn3"] = self._sep_fwd("cnn3", st.cnn2_strided, lazy=True)
         cnn3_last, C["cnn3_last"] = self._sep_fwd("cnn3_last", cnn3, lazy=True)
-        residual3, C["residual3"] = self._conv_fwd("residual3", st.cnn2_strided)
+        residual3, C["residual3"] = self._conv_fwd("residual3", st.cnn2_strided, lazy=True)
         st.cnn3_strided, C["cnn3_strided"] = self._sep_fwd("cnn3_strided", cnn3_last, out=mid_out, res=residual3)
         return st
 
@@ -646,15 +655,15 @@ class DenoiserTrainer:
         f0, f1, f2 = features0, features1, features2
         ops.resize_bilinear(aspp, st.concat2.slice(0, aspp_output))
         t, C["deconv2_a"] = self._sep_fwd("deconv2_a", st.concat2, lazy=True)
-        residual2_d, C["residual2_d"] = self._conv_fwd("residual2_d", st.concat2)
+        residual2_d, C["residual2_d"] = self._conv_fwd("residual2_d", st.concat2, lazy=True)
         st.deconv2, C["deconv2_b"] = self._sep_fwd("deconv2_b", t, res=residual2_d)
         _, C["deconv2to1"] = self._deconv_fwd("deconv2to1", st.deconv2, st.concat1.slice(0, f2))
         t, C["deconv1_a"] = self._sep_fwd("deconv1_a", st.concat1, lazy=True)
-        residual1_d, C["residual1_d"] = self._conv_fwd("residual1_d", st.concat1)
+        residual1_d, C["residual1_d"] = self._conv_fwd("residual1_d", st.concat1, lazy=True)
         st.deconv1, C["deconv1_b"] = self._sep_fwd("deconv1_b", t, res=residual1_d)
         st.deconv1to0, C["deconv1to0"] = self._deconv_fwd("deconv1to0", st.deconv1, E(S, f1))
         t, C["deconv0_a"] = self._sep_fwd("deconv0_a", st.deconv1to0, lazy=True)
-        residual0_d, C["residual0_d"] = self._conv_fwd("residual0_d", st.deconv1to0)
+        residual0_d, C["residual0_d"] = self._conv_fwd("residual0_d", st.deconv1to0, lazy=True)
         st.deconv0, C["deconv0_b"] = self._sep_fwd("deconv0_b", t, res=residual0_d)
         # final 3x3 conv to one channel (+ bias) -> BN -> relu6 -> clip [0,1]  (:528-538)
         Lf = self.layers["deconv_final"]

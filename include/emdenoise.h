@@ -334,6 +334,13 @@ int emd_conv3x3_stats_f32(const float* x, int ldx, const uint16_t* whi, const ui
                           float* mean, float* var, void* workspace, emd_stream_t stream);
 int emd_affine_act_images_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
                               float* y, int ldy, int B, long npix_img, int C, int act, emd_stream_t stream);
+/* y = act(x*scale + shift) + res_act(res*res_scale + res_shift): the residual operand given BEFORE its own affine + activation (round 4,
+ * graph D': the 1x1 residual projection's batch norm + relu6 -- conv_block_not_sep, machine_learning/denoiser.py:356-383 with phase =
+ * True -- applied where the block adds it instead of in a pass of its own; bits of the two-pass route).  images = 0: vectors [C], npix =
+ * all pixels; images = B > 0: vectors [B][C], npix = pixels per image.  res_act: EMD_ACT_RELU6 or EMD_ACT_RELU. */
+int emd_affine_act_res_affine_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
+                                  const float* res_scale, const float* res_shift, int res_act, float* y, int ldy, int images, long npix,
+                                  int C, int act, emd_stream_t stream);
 size_t emd_bn_stats_workspace_bytes(long npix, int C);
 int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float* mean, float* var, void* workspace,
                      emd_stream_t stream);

@@ -670,3 +670,24 @@ def test_bn_backward_of_a_never_written_gradient(B, H, W, Cc, images, double_bn,
             assert (u - v).abs().max().item() < 2e-5 * max(v.abs().max().item(), 1e-3)
     if wg:
         assert b[4].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("B,H,W,Cc,images", [(2, 16, 24, 128, True), (3, 8, 8, 64, False)])
+def test_affine_with_the_residual_before_its_own_affine(B, H, W, Cc, images):
+    """emd_affine_act_res_affine_f32 (round 4: the residual projection's norm + relu6 applied where the block adds it) == the residual's
+    affine pass written out, then emd_affine_act[_images]_f32 with it as ``res`` -- bit for bit."""
+    from emdenoise import ops
+
+    g = torch.Generator(device=dev()).manual_seed(9)
+    rn = lambda *sh: torch.randn(*sh, device=dev(), generator=g)
+    r, r2 = ops.Act(rn(B, H, W, Cc) * 3), ops.Act(rn(B, H, W, Cc) * 3)
+    n = B * Cc if images else Cc
+    sc, sh, sc2, sh2 = torch.rand(n, device=dev(), generator=g) + 0.5, rn(n), torch.rand(n, device=dev(), generator=g) + 0.5, rn(n)
+    aff = ops.affine_act_images if images else ops.affine_act
+    res = aff(r2, sc2, sh2, ops.Act.empty(B, H, W, Cc, dev()), act=ops.ACT_RELU6)
+    want = aff(r, sc, sh, ops.Act.empty(B, H, W, Cc, dev()), act=ops.ACT_RELU6, res=res)
+    out = ops.Act.empty(B, H, W, Cc, dev())
+    out.buf.fill_(float("nan"))
+    got = ops.affine_act_res_pre(r, sc, sh, out, ops.PreAct(r2, sc2, sh2, images=images, act=ops.ACT_RELU6), act=ops.ACT_RELU6)
+    torch.cuda.synchronize()
+    assert torch.equal(got.buf, want.buf)
