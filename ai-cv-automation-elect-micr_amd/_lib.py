@@ -130,6 +130,9 @@ SIGNATURES = {
     # x ldx whi wlo ones zeros y ldy B H W Cin Cout stride|rate precision images mean var workspace stream
     "emd_conv1x1_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] +
                               [C.c_int] * 8 + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
+    # x ldx whi[4] wlo[4] ones zeros y ldy B H W Cin Cout precision images mean var workspace stream
+    "emd_deconv3x3s2_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 7
+                                  + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
     "emd_conv3x3_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] +
                               [C.c_int] * 8 + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
     # x ldx scale shift res ldres y ldy B npix_img C act stream

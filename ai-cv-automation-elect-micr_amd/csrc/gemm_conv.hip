@@ -60,6 +60,8 @@ struct GemmParams {
     int n_mtiles, n_ntiles;
     double* stats_part;   // optional [n_mtiles][2][N]: per-channel sum / sum of squares of the values each M tile STORES (training: the
                           // batch norm behind the conv takes batch statistics -- no second pass over y)
+    int stats_tpi, stats_nph, stats_ph;   // the transposed conv's four phase launches share one table: M tile mt of phase ph is slab
+                                          // ((mt / tpi) * nph + ph) * tpi + mt % tpi  (tpi = tiles per image, or all tiles; nph = 0: slab = mt)
 };
 
 // Block tile 128 x BN (BN = 128: 2x2 waves of 64x64; BN = 64: 4x1 waves of 32x64), K step 64.
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
                 double t = 0.0;
 #pragma unroll
                 for (int k = 0; k < ROWS_PER_PASS; ++k) t += red[k][col][which];
-                p.stats_part[((long)mt * 2 + which) * p.N + n0 + col] = t;
+                const long slab = p.stats_nph ? ((long)(mt / p.stats_tpi) * p.stats_nph + p.stats_ph) * p.stats_tpi + mt % p.stats_tpi : mt;
+                p.stats_part[(slab * 2 + which) * p.N + n0 + col] = t;
             }
         }
     }
@@ -562,6 +565,55 @@ extern "C" int emd_conv3x3_stats_f32(const float* x, int ldx, const uint16_t* wh
         }
     set_taps(p, 9, dy, dx);
     return conv_stats_run(p, B, (long)H * W, images, mean, var, workspace, precision, stream);
+}
+
+// The transposed 3x3 stride-2 conv of a training forward pass (emd_deconv3x3s2_f32 with no affine, no activation) + the batch statistics of
+// its output from the four phase GEMMs' epilogues: mean / var [Cout] over all B * 2H * 2W output pixels, or images != 0: [B][Cout] per
+// image (needs H * W % 128 == 0).  workspace: emd_conv_stats_workspace_bytes(4 * B * H * W, Cout) bytes.
+extern "C" int emd_deconv3x3s2_stats_f32(const float* x, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4], const float* ones,
+                                         const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int precision,
+                                         int images, float* mean, float* var, void* workspace, emd_stream_t stream) {
+    EMD_REQUIRE(whi, EMD_E_INVALID, "emd_deconv3x3s2_stats_f32: null weight table");
+    for (int ph = 0; ph < 4; ++ph) {
+        int rc = common_checks("emd_deconv3x3s2_stats_f32", x, whi[ph], wlo ? wlo[ph] : nullptr, ones, zeros, nullptr, nullptr, nullptr, y,
+                               Cin, Cout, ldx, ldy, 0, precision);
+        if (rc != EMD_OK) return rc;
+    }
+    EMD_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_deconv3x3s2_stats_f32: bad shape");
+    EMD_REQUIRE(mean && var && workspace && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EMD_E_INVALID,
+                "emd_deconv3x3s2_stats_f32: mean, var and an 8-byte aligned workspace are required");
+    const long npix_in = (long)H * W, M = (long)B * npix_in;
+    EMD_REQUIRE(!images || npix_in % 128 == 0, EMD_E_UNSUPPORTED,
+                "emd_deconv3x3s2_stats_f32: per-image statistics need H * W % 128 == 0 (a 128-row tile must not straddle two images)");
+    const int n_mt = (int)((M + 127) / 128);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int ph = 0; ph < 4; ++ph) {
+        GemmParams p{};
+        int ky[4], kx[4];
+        p.ntaps = emd_deconv_phase_taps(ph, ky, kx);
+        p.A = x; p.Whi = whi[ph]; p.Wlo = wlo ? wlo[ph] : nullptr; p.C = y; p.res = nullptr;
+        p.scale1 = ones; p.shift1 = zeros; p.scale2 = p.shift2 = nullptr;
+        p.N = Cout; p.Cin = Cin; p.Cpad = (Cin + kBK - 1) / kBK * kBK;
+        p.lda = ldx; p.ldc = ldy; p.ldres = 0; p.act = 0;
+        p.M = M;
+        p.flat = 0;
+        p.Hg = H; p.Wg = W; p.Ha = H; p.Wa = W; p.Hc = 2 * H; p.Wc = 2 * W; p.sa = 1; p.sc = 2;
+        p.py = ph >> 1; p.px = ph & 1;
+        int dy[4], dx[4];
+        for (int t = 0; t < p.ntaps; ++t) {
+            dy[t] = ky[t] == 2 ? -1 : 0;
+            dx[t] = kx[t] == 2 ? -1 : 0;
+        }
+        set_taps(p, p.ntaps, dy, dx);
+        p.stats_part = static_cast<double*>(workspace);
+        p.stats_nph = 4; p.stats_ph = ph; p.stats_tpi = images ? (int)(npix_in / 128) : n_mt;
+        int rc = dispatch(p, precision, st);
+        if (rc != EMD_OK) return rc;
+    }
+    if (images)
+        return emd::launch_bn_stats_final(static_cast<const double*>(workspace), 4 * (int)(npix_in / 128), Cout, 4 * npix_in, mean, var, st, nullptr,
+                                          nullptr, 0.f, nullptr, nullptr, B);
+    return emd::launch_bn_stats_final(static_cast<const double*>(workspace), 4 * n_mt, Cout, 4 * M, mean, var, st);
 }
 
 // Data gradient of the stride-2 1x1 convolution: dx[b, 2i, 2j, :] (+)= dy[b, i, j, :] * W^T, the other pixels of dx

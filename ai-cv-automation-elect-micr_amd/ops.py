@@ -149,6 +149,26 @@ def conv_stats(x: Act, w: PackedWeights, ones, zeros, out: Act, stride=1, rate=1
     return mean, var
 
 
+def deconv_stats(x: Act, w_phases, ones, zeros, out: Act, images=False, precision=PREC_BF16X3, stream=None):
+    """out = deconv3x3s2(x), no affine, no activation, and the batch statistics of out from the four phase GEMMs' epilogues
+    (emd_deconv3x3s2_stats_f32) -> (mean, var): [Cout], or [B][Cout] flattened with images=True (needs x.H * x.W % 128 == 0)."""
+    import torch
+
+    lib = _lib.load()
+    cout = w_phases[0].cout
+    assert len(w_phases) == 4 and (out.B, out.H, out.W, out.C) == (x.B, 2 * x.H, 2 * x.W, cout)
+    hi = (C.c_void_p * 4)(*[w.hi.data_ptr() for w in w_phases])
+    lo = (C.c_void_p * 4)(*[w.lo.data_ptr() for w in w_phases])
+    n = x.B * cout if images else cout
+    mean = torch.empty(n, dtype=torch.float32, device=x.buf.device)
+    var = torch.empty_like(mean)
+    ws = torch.empty(max(lib.emd_conv_stats_workspace_bytes(4 * x.B * x.H * x.W, cout) // 8, 1), dtype=torch.float64, device=x.buf.device)
+    rc = lib.emd_deconv3x3s2_stats_f32(x.ptr, x.ld, hi, lo, _p(ones), _p(zeros), out.ptr, out.ld, x.B, x.H, x.W, x.C, cout, precision,
+                                       1 if images else 0, _p(mean), _p(var), _p(ws), _lib.stream_ptr(stream))
+    _lib.check(rc, "emd_deconv3x3s2_stats_f32")
+    return mean, var
+
+
 def avgpool2x2(x: Act, out: Act, stream=None):
     lib = _lib.load()
     assert (out.B, out.H, out.W, out.C) == (x.B, -(-x.H // 2), -(-x.W // 2), x.C)

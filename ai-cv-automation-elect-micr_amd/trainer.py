@@ -402,10 +402,15 @@ class DenoiserTrainer:
 
     def _deconv_fwd(self, key, x, out):
         L = self.layers[key]
-        r = ops.deconv3x3s2(x, self.pk_f[key], self.ones, self.zeros, self._E(x.B, 2 * x.H, 2 * x.W, L.cout), act=False,
-                            precision=self.precision)
+        stats = None
+        if self._fuse_stats(x):    # the batch statistics of r from the four phase GEMMs' epilogues (per image: whole 128-row tiles of the INPUT grid)
+            r = self._E(x.B, 2 * x.H, 2 * x.W, L.cout)
+            stats = ops.deconv_stats(x, self.pk_f[key], self.ones, self.zeros, r, images=self._per_image, precision=self.precision)
+        else:
+            r = ops.deconv3x3s2(x, self.pk_f[key], self.ones, self.zeros, self._E(x.B, 2 * x.H, 2 * x.W, L.cout), act=False,
+                                precision=self.precision)
         self._force(r, L.scope, "r")
-        fold = self._bn(key, r, L.scope + "/" + L.bname)
+        fold = self._bn(key, r, L.scope + "/" + L.bname, stats=stats)
         self._affine(r, fold, out, ops.ACT_RELU6)
         return out, {"x": x, "r": r, "fold": fold}
 

@@ -332,6 +332,13 @@ int emd_conv1x1_stats_f32(const float* x, int ldx, const uint16_t* whi, const ui
 int emd_conv3x3_stats_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones, const float* zeros,
                           float* y, int ldy, int B, int H, int W, int Cin, int Cout, int rate, int precision, int images,
                           float* mean, float* var, void* workspace, emd_stream_t stream);
+/* The transposed 3x3 stride-2 conv of a training forward pass (emd_deconv3x3s2_f32, no affine, no activation; machine_learning/
+ * denoiser.py:141-148 under phase = True) + the batch statistics of its output from the four phase GEMMs' epilogues: mean / var [Cout]
+ * over all B * 2H * 2W output pixels, or images != 0: [B][Cout] per image (needs H * W % 128 == 0: EMD_E_UNSUPPORTED otherwise).
+ * workspace: emd_conv_stats_workspace_bytes(4 * B * H * W, Cout) bytes. */
+int emd_deconv3x3s2_stats_f32(const float* x, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4], const float* ones,
+                              const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int precision, int images,
+                              float* mean, float* var, void* workspace, emd_stream_t stream);
 int emd_affine_act_images_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
                               float* y, int ldy, int B, long npix_img, int C, int act, emd_stream_t stream);
 /* y = act(x*scale + shift) + res_act(res*res_scale + res_shift): the residual operand given BEFORE its own affine + activation (round 4,

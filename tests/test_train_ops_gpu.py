@@ -691,3 +691,29 @@ def test_affine_with_the_residual_before_its_own_affine(B, H, W, Cc, images):
     got = ops.affine_act_res_pre(r, sc, sh, out, ops.PreAct(r2, sc2, sh2, images=images, act=ops.ACT_RELU6), act=ops.ACT_RELU6)
     torch.cuda.synchronize()
     assert torch.equal(got.buf, want.buf)
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,images", [(2, 16, 16, 64, 64, True), (3, 8, 12, 128, 32, False), (2, 16, 8, 256, 128, True)])
+def test_deconv_stats_equals_deconv_then_statistics(B, H, W, ci, co, images):
+    """emd_deconv3x3s2_stats_f32 (round 4: the transposed conv of the training forward with the batch statistics of its output from the
+    four phase GEMMs' epilogues): y bit for bit emd_deconv3x3s2_f32's, mean / var equal to emd_bn_stats[_images]_f32 of y to float32
+    rounding (double sums, other slabs); image 1's statistics do not depend on the batch it came in."""
+    from emdenoise import ops
+
+    x = rnd((B, H, W, ci), 720, positive=True)
+    w = rnd((3, 3, co, ci), 721, scale=(2.0 / (9 * ci + co)) ** 0.5)
+    ph = ops.pack_deconv(w, dev())
+    ones, zeros = torch.ones(co, device=dev()), torch.zeros(co, device=dev())
+    xa = to_act(x, ld=ci + 8, c0=4)
+    y1, y2 = out_act(B, 2 * H, 2 * W, co, ld=co + 4, c0=0), out_act(B, 2 * H, 2 * W, co, ld=co + 4, c0=0)
+    mean, var = ops.deconv_stats(xa, ph, ones, zeros, y1, images=images)
+    ops.deconv3x3s2(xa, ph, ones, zeros, y2, act=False)
+    m2, v2 = ops.bn_batch_stats_images(y2) if images else ops.bn_batch_stats(y2)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.torch(), y2.torch())
+    assert rel_l2(mean.cpu().numpy(), m2.cpu().numpy()) < 2e-7 and rel_l2(var.cpu().numpy(), v2.cpu().numpy()) < 2e-6
+    if images:
+        xb = to_act(x[1:2], ld=ci + 8, c0=4)
+        mo, vo = ops.deconv_stats(xb, ph, ones, zeros, out_act(1, 2 * H, 2 * W, co), images=True)
+        torch.cuda.synchronize()
+        assert torch.equal(mo, mean[co:2 * co]) and torch.equal(vo, var[co:2 * co])
