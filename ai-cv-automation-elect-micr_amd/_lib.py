@@ -199,12 +199,12 @@ SIGNATURES = {
     # x ldx dy ldd dw B H W C stride rate stream
     "emd_dw3x3_wgrad_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p] + [C.c_int] * 6 + [C.c_void_p]),
     "emd_dw3x3_bn_bwd_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
-    # dd ldd w_flipped r ldr mean rstd mscale mshift mask images B H W C s1 s2 dw_consumer workspace stream
-    "emd_dw3x3_bn_bwd_reduce_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [_c_float_p] * 4 + [C.c_int] * 6
+    # dd ldd w_flipped r ldr mean rstd mscale mshift mask images B H W C stride rate s1 s2 dw_consumer workspace stream
+    "emd_dw3x3_bn_bwd_reduce_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [_c_float_p] * 4 + [C.c_int] * 8
                                     + [_c_float_p, _c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
-    # dd ldd w_flipped r ldr K m1 mean m2 mscale mshift mask images dr ldo B H W C stream
+    # dd ldd w_flipped r ldr K m1 mean m2 mscale mshift mask images dr ldo B H W C stride rate stream
     "emd_dw3x3_bn_bwd_apply_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [_c_float_p] * 6 + [C.c_int] * 2
-                                   + [_c_float_p] + [C.c_int] * 5 + [C.c_void_p]),
+                                   + [_c_float_p] + [C.c_int] * 7 + [C.c_void_p]),
     # r ldx pre_scale pre_shift pre_images act dy ldd dw B H W C stride rate stream
     "emd_dw3x3_wgrad_pre_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, C.c_int, _c_float_p, C.c_int, _c_float_p]
                                 + [C.c_int] * 6 + [C.c_void_p]),

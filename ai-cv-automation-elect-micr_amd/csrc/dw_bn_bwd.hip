@@ -204,13 +204,146 @@ __global__ __launch_bounds__(256) void dw_bn_bwd_kernel(const DwBnArgs a) {
     }
 }
 
+// Any stride / dilation (the stride-2 consumers cnn*_strided; same passes, gather form): a thread walks every 16th pixel q of its slab of
+// one image for one channel quad and gathers dy[q] = sum over the output pixels whose window holds q, in dw_bwd_data_kernel's order
+// (bwd_misc.hip: its bits); WG adds x[q] * dd[that output pixel] into the tap's weight-gradient accumulator in the same loop.
+// Grid (ceil(C / 64), slabs per image, B); a.H, a.W: the grid of r (the consumer's INPUT); dd is [B, Ho, Wo, C].
+template <int EPI, bool WG>
+__global__ __launch_bounds__(256) void dw_bn_bwd_gen_kernel(const DwBnArgs a, int Ho, int Wo, int st, int rate, int pt, int pl, long pps) {
+    const int H = a.H, W = a.W, C = a.C4 * 4;
+    const int cl = (threadIdx.x & 15) * 4, plane = threadIdx.x >> 4;
+    const int c0 = blockIdx.x * 64 + cl;
+    const bool live = c0 < C;
+    const int c = live ? c0 : C - 4;
+    const long b = blockIdx.z, npix = (long)H * W;
+    const long p0 = (long)blockIdx.y * pps, p1 = p0 + pps < npix ? p0 + pps : npix;
+    const long vo = b * a.vld + c;
+    const float4 mu = *reinterpret_cast<const float4*>(a.mean + vo);
+    float4 ms = f4zero(), mh = f4zero();
+    if (a.mask) {
+        ms = *reinterpret_cast<const float4*>(a.ms + vo);
+        mh = *reinterpret_cast<const float4*>(a.mh + vo);
+    }
+    float4 e0 = f4zero(), e1 = f4zero(), e2 = f4zero();
+    if (EPI == 1) {
+        e0 = *reinterpret_cast<const float4*>(a.rstd + vo);
+    } else {
+        e0 = *reinterpret_cast<const float4*>(a.K + vo);
+        e1 = *reinterpret_cast<const float4*>(a.m1 + vo);
+        e2 = *reinterpret_cast<const float4*>(a.m2 + vo);
+    }
+    const float* ddb = a.dd + (b * Ho) * (long)Wo * a.ldd + c;
+    const float* rb = a.r + b * npix * a.ldr + c;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    float4 wa[WG ? 9 : 1];
+#pragma unroll
+    for (int k = 0; k < (WG ? 9 : 1); ++k) wa[k] = f4zero();
+    if (live) {
+        for (long p = p0 + plane; p < p1; p += 16) {
+            const int ix = (int)(p % W), iy = (int)(p / W);
+            const float4 rv = *reinterpret_cast<const float4*>(rb + p * a.ldr);
+            const float rk[4] = {rv.x, rv.y, rv.z, rv.w};
+            const float msk[4] = {ms.x, ms.y, ms.z, ms.w}, mhk[4] = {mh.x, mh.y, mh.z, mh.w}, muk[4] = {mu.x, mu.y, mu.z, mu.w};
+            float4 x = f4zero();
+            if constexpr (WG)
+                x = make_float4(fminf(fmaxf(fmaf(rk[0], msk[0], mhk[0]), 0.f), 6.f), fminf(fmaxf(fmaf(rk[1], msk[1], mhk[1]), 0.f), 6.f),
+                                fminf(fmaxf(fmaf(rk[2], msk[2], mhk[2]), 0.f), 6.f), fminf(fmaxf(fmaf(rk[3], msk[3], mhk[3]), 0.f), 6.f));
+            float4 acc = f4zero();
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int ny = iy + pt - ky * rate;
+                if (ny < 0 || ny % st != 0 || ny / st >= Ho) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int nx = ix + pl - kx * rate;
+                    if (nx < 0 || nx % st != 0 || nx / st >= Wo) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(ddb + ((long)(ny / st) * Wo + nx / st) * a.ldd);
+                    acc = fma4(v, *reinterpret_cast<const float4*>(a.w + (8 - (ky * 3 + kx)) * C + c), acc);   // a.w holds the taps reversed
+                    if constexpr (WG) wa[ky * 3 + kx] = fma4(x, v, wa[ky * 3 + kx]);
+                }
+            }
+            const float dyk[4] = {acc.x, acc.y, acc.z, acc.w};
+            const float e0k[4] = {e0.x, e0.y, e0.z, e0.w}, e1k[4] = {e1.x, e1.y, e1.z, e1.w}, e2k[4] = {e2.x, e2.y, e2.z, e2.w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g = grad_mask(dyk[k], fmaf(rk[k], msk[k], mhk[k]), a.mask);
+                if (EPI == 1) {
+                    s[k] += (double)g;
+                    q[k] += (double)g * (double)((rk[k] - muk[k]) * e0k[k]);
+                } else {
+                    o[k] = e0k[k] * (g - e1k[k] - (rk[k] - muk[k]) * e2k[k]);
+                }
+            }
+            if (EPI == 2) *reinterpret_cast<float4*>(a.dr + (b * npix + p) * a.ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if constexpr (WG) {
+        __shared__ float red[16][9][64 + 1];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            red[plane][t][cl + 0] = wa[t].x; red[plane][t][cl + 1] = wa[t].y;
+            red[plane][t][cl + 2] = wa[t].z; red[plane][t][cl + 3] = wa[t].w;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+            const int t = i / 64, lc = i % 64;
+            const int cc = blockIdx.x * 64 + lc;
+            if (cc >= C) continue;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += red[k][t][lc];
+            atomicAdd(a.dwg + (long)t * C + cc, sum);
+        }
+    }
+    if (EPI == 1) {
+        __shared__ double sm[2][16][64 + 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sm[0][plane][cl + k] = s[k];
+            sm[1][plane][cl + k] = q[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, lc = threadIdx.x & 63;
+            const int cc = blockIdx.x * 64 + lc;
+            if (cc < C) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t += sm[which][k][lc];
+                a.part[((b * gridDim.y + blockIdx.y) * 2 + which) * C + cc] = t;
+            }
+        }
+    }
+}
+
 int strip_height(int H) { return H >= 64 ? 16 : 8; }
+constexpr long kGenPps = 512;    // pixels per slab of the gather form
+inline int gen_slabs(long npix) { return (int)((npix + kGenPps - 1) / kGenPps); }
+inline int same_pad_before(int n, int s, int r) {  // TF SAME, k = 3 (bwd_misc.hip)
+    const int o = (n + s - 1) / s;
+    int total = (o - 1) * s + 2 * r + 1 - n;
+    if (total < 0) total = 0;
+    return total / 2;
+}
 
 bool args_ok(const float* p, int ld, int C) { return p && C >= 4 && C % 4 == 0 && ld % 4 == 0 && ld >= C && emd::aligned16(p); }
 
 template <int EPI>
-int launch(const DwBnArgs& a0, int B, hipStream_t st) {
+int launch(const DwBnArgs& a0, int B, hipStream_t st, int stride = 1, int rate = 1) {
     DwBnArgs a = a0;
+    if (stride != 1 || rate != 1) {   // the gather form
+        const int Ho = (a.H + stride - 1) / stride, Wo = (a.W + stride - 1) / stride;
+        const int pt = same_pad_before(a.H, stride, rate), pl = same_pad_before(a.W, stride, rate);
+        const dim3 grid((a.C4 * 4 + 63) / 64, gen_slabs((long)a.H * a.W), B);
+        if constexpr (EPI == 1) {
+            if (a.dwg) hipLaunchKernelGGL((dw_bn_bwd_gen_kernel<1, true>), grid, dim3(256), 0, st, a, Ho, Wo, stride, rate, pt, pl, kGenPps);
+            else hipLaunchKernelGGL((dw_bn_bwd_gen_kernel<1, false>), grid, dim3(256), 0, st, a, Ho, Wo, stride, rate, pt, pl, kGenPps);
+        } else {
+            hipLaunchKernelGGL((dw_bn_bwd_gen_kernel<2, false>), grid, dim3(256), 0, st, a, Ho, Wo, stride, rate, pt, pl, kGenPps);
+        }
+        return emd::check_launch("dw_bn_bwd_gen_kernel");
+    }
     const int TH = strip_height(a.H);
     a.nstrip = (a.H + TH - 1) / TH;
     const long nb = (long)B * a.nstrip * ((a.W + 15) / 16) * ((a.C4 + 15) / 16);
@@ -232,7 +365,8 @@ int launch(const DwBnArgs& a0, int B, hipStream_t st) {
 extern "C" size_t emd_dw3x3_bn_bwd_workspace_bytes(int B, int H, int W, int C) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
     const int TH = strip_height(H);
-    return (size_t)B * ((H + TH - 1) / TH) * ((W + 15) / 16) * 2 * C * sizeof(double);
+    const long roll = (long)((H + TH - 1) / TH) * ((W + 15) / 16), gen = gen_slabs((long)H * W);   // slabs per image, either form
+    return (size_t)B * (roll > gen ? roll : gen) * 2 * C * sizeof(double);
 }
 
 // s1[c] = sum g, s2[c] = sum g * (r - mean) * rstd with g = dw3x3(dd, w_flipped) * mask(r * mscale + mshift): emd_dw3x3_f32(stride 1) followed
@@ -241,7 +375,9 @@ extern "C" size_t emd_dw3x3_bn_bwd_workspace_bytes(int B, int H, int W, int C) {
 // relu6, dd) -- the pass reads exactly its operands.
 extern "C" int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* mean,
                                            const float* rstd, const float* mscale, const float* mshift, int mask, int images, int B, int H,
-                                           int W, int C, float* s1, float* s2, float* dw_consumer, void* workspace, emd_stream_t stream) {
+                                           int W, int C, int stride, int rate, float* s1, float* s2, float* dw_consumer, void* workspace,
+                                           emd_stream_t stream) {
+    EMD_REQUIRE((stride == 1 || stride == 2) && rate >= 1 && (rate == 1 || stride == 1), EMD_E_INVALID, "emd_dw3x3_bn_bwd_reduce_f32: stride 1 or 2; rate > 1 needs stride 1");
     EMD_REQUIRE(!dw_consumer || mask == 1, EMD_E_INVALID, "emd_dw3x3_bn_bwd_reduce_f32: the consumer's weight gradient needs the relu6 mask (x = relu6(r*mscale + mshift))");
     EMD_REQUIRE(w_flipped && mean && rstd && s1 && s2 && workspace, EMD_E_INVALID, "emd_dw3x3_bn_bwd_reduce_f32: null pointer");
     EMD_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && mask >= 0 && mask <= 3 && (!mask || (mscale && mshift)), EMD_E_INVALID,
@@ -254,10 +390,10 @@ extern "C" int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float
     a.dwg = dw_consumer;
     a.ldd = ldd; a.ldr = ldr; a.H = H; a.W = W; a.C4 = C / 4; a.mask = mask; a.vld = images ? C : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = launch<1>(a, B, st);
+    int rc = launch<1>(a, B, st, stride, rate);
     if (rc != EMD_OK) return rc;
     const int TH = strip_height(H);
-    const int nslab = ((H + TH - 1) / TH) * ((W + 15) / 16);
+    const int nslab = (stride != 1 || rate != 1) ? gen_slabs((long)H * W) : ((H + TH - 1) / TH) * ((W + 15) / 16);
     if (images) return emd::launch_chan_reduce_final(a.part, nslab, C, B, s1, s2, st);
     // batch statistics: the B images' slabs are one list
     return emd::launch_chan_reduce_final(a.part, nslab * B, C, 1, s1, s2, st);
@@ -266,7 +402,9 @@ extern "C" int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float
 // dr = K * (g - m1 - (r - mean) * m2), g as above: emd_dw3x3_f32(stride 1) followed by emd_bn_bwd_apply[_images]_f32; dr may be r.
 extern "C" int emd_dw3x3_bn_bwd_apply_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* K,
                                           const float* m1, const float* mean, const float* m2, const float* mscale, const float* mshift,
-                                          int mask, int images, float* dr, int ldo, int B, int H, int W, int C, emd_stream_t stream) {
+                                          int mask, int images, float* dr, int ldo, int B, int H, int W, int C, int stride, int rate,
+                                          emd_stream_t stream) {
+    EMD_REQUIRE((stride == 1 || stride == 2) && rate >= 1 && (rate == 1 || stride == 1), EMD_E_INVALID, "emd_dw3x3_bn_bwd_apply_f32: stride 1 or 2; rate > 1 needs stride 1");
     EMD_REQUIRE(w_flipped && K && m1 && mean && m2 && dr, EMD_E_INVALID, "emd_dw3x3_bn_bwd_apply_f32: null pointer");
     EMD_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && mask >= 0 && mask <= 3 && (!mask || (mscale && mshift)), EMD_E_INVALID,
                 "emd_dw3x3_bn_bwd_apply_f32: bad argument");
@@ -276,5 +414,5 @@ extern "C" int emd_dw3x3_bn_bwd_apply_f32(const float* dd, int ldd, const float*
     DwBnArgs a{};
     a.dd = dd; a.w = w_flipped; a.r = r; a.dr = dr; a.mean = mean; a.ms = mscale; a.mh = mshift; a.K = K; a.m1 = m1; a.m2 = m2;
     a.ldd = ldd; a.ldr = ldr; a.ldo = ldo; a.H = H; a.W = W; a.C4 = C / 4; a.mask = mask; a.vld = images ? C : 0;
-    return launch<2>(a, B, static_cast<hipStream_t>(stream));
+    return launch<2>(a, B, static_cast<hipStream_t>(stream), stride, rate);
 }

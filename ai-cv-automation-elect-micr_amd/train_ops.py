@@ -245,18 +245,22 @@ def bn_backward(dy: Act, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MA
 
 
 class DwGrad:
-    """A gradient that was never written: dy = dw3x3(dd, w_flipped) (stride 1, rate 1) -- the data gradient of a separable conv's
-    depthwise stage, the ONLY contribution to the gradient of its input.  bn_backward forms it on the fly (emd_dw3x3_bn_bwd_*_f32)."""
+    """A gradient that was never written: dy = the data gradient of a separable conv's depthwise stage (dw3x3(dd, w_flipped) at stride 1;
+    dw3x3_bwd_data's gather at stride 2 / with dilation), the ONLY contribution to the gradient of its input.  bn_backward forms it on
+    the fly (emd_dw3x3_bn_bwd_*_f32)."""
 
-    __slots__ = ("dd", "w", "gdw", "B", "H", "W", "C")
+    __slots__ = ("dd", "w", "gdw", "stride", "rate", "B", "H", "W", "C")
 
-    def __init__(self, dd: Act, w_flipped, gdw=None):
+    def __init__(self, dd: Act, w_flipped, gdw=None, stride=1, rate=1, hw=None):
         """gdw: the consumer's depthwise weight-gradient slice [9][C] when bn_backward_dw is to add that gradient too (its reduction pass
         reads exactly the operands: dd and the r behind the consumer's never-written input) -- the consumer then skips its own launch."""
         assert w_flipped.is_contiguous() and w_flipped.numel() == 9 * dd.C
         assert gdw is None or (gdw.is_contiguous() and gdw.numel() == 9 * dd.C)
-        self.dd, self.w, self.gdw = dd, w_flipped, gdw
-        self.B, self.H, self.W, self.C = dd.B, dd.H, dd.W, dd.C
+        self.dd, self.w, self.gdw, self.stride, self.rate = dd, w_flipped, gdw, stride, rate
+        # shape of the gradient = the consumer's INPUT grid (hw: needed with stride 2, where dd is the smaller OUTPUT grid)
+        self.B, self.C = dd.B, dd.C
+        self.H, self.W = hw if hw is not None else (dd.H, dd.W)
+        assert (dd.H, dd.W) == (-(-self.H // stride), -(-self.W // stride))
 
 
 def bn_backward_dw(dy: DwGrad, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MASK_RELU6, gamma1=None, dgamma1=None, eps=BN_EPS,
@@ -277,7 +281,7 @@ def bn_backward_dw(dy: DwGrad, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, m
     ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
     ws = torch.empty(max(lib.emd_dw3x3_bn_bwd_workspace_bytes(dy.B, dy.H, dy.W, Cc) // 8, 1), dtype=torch.float64, device=dev)
     _lib.check(lib.emd_dw3x3_bn_bwd_reduce_f32(dd.ptr, dd.ld, _p(dy.w), r.ptr, r.ld, _p(fold["mean"]), _p(fold["rstd1"]), _p(ms), _p(mh), mask,
-                                               1 if images else 0, dy.B, dy.H, dy.W, Cc, _p(s1), _p(t), _p(dy.gdw), _p(ws),
+                                               1 if images else 0, dy.B, dy.H, dy.W, Cc, dy.stride, dy.rate, _p(s1), _p(t), _p(dy.gdw), _p(ws),
                                                _lib.stream_ptr(stream)),
                "emd_dw3x3_bn_bwd_reduce_f32")
     K, m1, m2 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
@@ -290,7 +294,8 @@ def bn_backward_dw(dy: DwGrad, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, m
                                            C.c_float(eps), C.c_long(npix), Cc, _p(K), _p(m1), _p(m2), _p(dgamma1), _p(dgamma2),
                                            _p(dbeta2), _lib.stream_ptr(stream)), "emd_bn_bwd_prep_f32")
     _lib.check(lib.emd_dw3x3_bn_bwd_apply_f32(dd.ptr, dd.ld, _p(dy.w), r.ptr, r.ld, _p(K), _p(m1), _p(fold["mean"]), _p(m2), _p(ms), _p(mh),
-                                              mask, 1 if images else 0, dr.ptr, dr.ld, dy.B, dy.H, dy.W, Cc, _lib.stream_ptr(stream)),
+                                              mask, 1 if images else 0, dr.ptr, dr.ld, dy.B, dy.H, dy.W, Cc, dy.stride, dy.rate,
+                                              _lib.stream_ptr(stream)),
                "emd_dw3x3_bn_bwd_apply_f32")
     return dr
 

@@ -127,6 +127,9 @@ class DenoiserTrainer:
         # ... and the gradient of such a never-written activation is never written either: the producer's BN backward forms it from the
         # consumer's depthwise data gradient on the fly (TO.DwGrad / bn_backward_dw; round 4)
         self.fuse_dw_bn_bwd = os.environ.get("EMD_T_DW_BN_BWD", "1") == "1"
+        # ... also behind a stride-2 (or dilated) consumer (gather form): correct and tested, but measured SLOWER (44.76 / 44.83 ms per step
+        # against 44.43 / 44.41: the gather's per-pixel index arithmetic costs more than the two passes it saves on four layers); opt-in
+        self.fuse_dw_bn_bwd_s2 = os.environ.get("EMD_T_DW_BN_BWD_S2", "0") == "1"
         self.fuse_dw_wgrad = os.environ.get("EMD_T_DW_WGRAD", "1") == "1"   # ... whose reduction pass also adds the consumer's depthwise weight gradient
         self.fuse_stats = os.environ.get("EMD_T_FUSE_STATS", "1") == "1"   # batch statistics from the producing GEMM's epilogue (ops.conv_stats)
         self.teacher = None   # test hook: scope -> {"d": ..., "r": ...} reference tensors that REPLACE the forward's conv outputs (see _force)
@@ -173,12 +176,12 @@ class DenoiserTrainer:
                     pb.add(self.pk_b[key], w, 9, cout_major=False)
             self._pack_batch = pb
         self._pack_batch.run()
-        # taps reversed for the stride-1 data gradients: one gather from the flat parameter vector into one buffer that the per-layer
+        # taps reversed for the depthwise data gradients (stride 1: the forward kernel on them; every stride: TO.DwGrad): one gather from the flat parameter vector into one buffer that the per-layer
         # [9][C] views point into; updated IN PLACE (a captured hipGraph keeps the pointers)
         import torch
 
         if self._flip_idx is None:
-            keys = [k for k, L in self.layers.items() if L.kind == "sep" and L.stride == 1 and L.cin > 1]
+            keys = [k for k, L in self.layers.items() if L.kind == "sep" and L.cin > 1]
             idx, off = [], 0
             for k in keys:
                 w = self._dw(k)
@@ -471,13 +474,15 @@ class DenoiserTrainer:
         # the data gradient lands on d -- unless the weight gradient above may still be reading d on its side stream
         dd_buf = d if self._wg_side is None else self._E(d.B, d.H, d.W, d.C)
         dd = ops.conv1x1(dr, self.pk_b[key], self.ones, self.zeros, dd_buf, act=False, precision=self.precision)
-        deferred = (isinstance(x, ops.PreAct) and need_dx and self.fuse_dw_bn_bwd and L.stride == 1 and L.rate == 1 and self._wg_side is None
+        deferred = (isinstance(x, ops.PreAct) and need_dx and self.fuse_dw_bn_bwd and self._wg_side is None
+                    and (self.fuse_dw_bn_bwd_s2 or (L.stride == 1 and L.rate == 1))
                     and self._gkey(x) not in gslot and id(x.buf) not in self._gparent and x.C % 4 == 0)
         if deferred:
             # x was never written and this layer is its only consumer: its gradient is this depthwise data gradient and nothing else,
             # so it is not written either -- the producer's BN backward recomputes it from dd in both of its passes (TO.bn_backward_dw),
             # and its reduction pass, which streams dd and the r behind x, adds THIS layer's depthwise weight gradient on the way
-            g = TO.DwGrad(dd, self.dw_flip[key], self._gdw(key) if (self.fuse_dw_wgrad and x.act == ops.ACT_RELU6) else None)
+            g = TO.DwGrad(dd, self.dw_flip[key], self._gdw(key) if (self.fuse_dw_wgrad and x.act == ops.ACT_RELU6) else None,
+                          stride=L.stride, rate=L.rate, hw=(x.H, x.W))
             gslot[self._gkey(x)] = g
             if g.gdw is None:
                 TO.dw3x3_wgrad_pre(x, dd, self._gdw(key), stride=L.stride, rate=L.rate)

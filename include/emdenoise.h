@@ -481,15 +481,17 @@ int emd_dw3x3_bwd_data_f32(const float* dy, int ldd, const float* w, float* dx, 
  *   emd_dw3x3_bn_bwd_apply_f32  = emd_dw3x3_f32 + emd_bn_bwd_apply[_images]_f32 (dr = K * (g - m1 - (r - mean) * m2); dr may be r)
  * dw_consumer (or NULL; needs mask = relu6): [9][C] += the CONSUMER's depthwise weight gradient = emd_dw3x3_wgrad_pre_f32(r, mscale,
  * mshift, relu6, dd): the reduction pass streams exactly its operands.
- * dd, r, dr [B,H,W,C]; w_flipped [9][C] = the consumer's depthwise taps reversed (tap t = original tap 8 - t); images != 0: every
+ * r, dr [B,H,W,C] (the consumer's INPUT grid); dd [B,ceil(H/stride),ceil(W/stride),C]; stride 1 or 2, rate (dilation, stride 1 only) as
+ * emd_dw3x3_f32 (stride 1, rate 1: the rolling-window form; else a gather form = emd_dw3x3_bwd_data_f32's arithmetic);
+ * w_flipped [9][C] = the consumer's depthwise taps reversed (tap t = original tap 8 - t); images != 0: every
  * per-channel vector is [B][C] (per-image statistics).  (tf.gradients of machine_learning/denoiser.py:110-136 with phase = True.) */
 size_t emd_dw3x3_bn_bwd_workspace_bytes(int B, int H, int W, int C);
 int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* mean,
                                 const float* rstd, const float* mscale, const float* mshift, int mask, int images, int B, int H, int W,
-                                int C, float* s1, float* s2, float* dw_consumer, void* workspace, emd_stream_t stream);
+                                int C, int stride, int rate, float* s1, float* s2, float* dw_consumer, void* workspace, emd_stream_t stream);
 int emd_dw3x3_bn_bwd_apply_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* K, const float* m1,
                                const float* mean, const float* m2, const float* mscale, const float* mshift, int mask, int images,
-                               float* dr, int ldo, int B, int H, int W, int C, emd_stream_t stream);
+                               float* dr, int ldo, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream);
 /* emd_dw3x3_wgrad_f32 with the layer's input given as the pre-activation tensor r of the layer before it (the forward pass ran
  * emd_dw3x3_pre_act_f32 on it and never wrote x = act(r * pre_scale + pre_shift)): x is rebuilt in the loads.  Arguments as there. */
 int emd_dw3x3_wgrad_pre_f32(const float* r, int ldx, const float* pre_scale, const float* pre_shift, int pre_images, int act,

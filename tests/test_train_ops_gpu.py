@@ -624,13 +624,16 @@ def test_dw3x3_wgrad_pre_equals_affine_then_weight_gradient(B, H, W, Cc, stride,
     assert (got.double().cpu() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("B,H,W,Cc,images,double_bn,mask", [
-    (2, 32, 32, 728, True, True, 1),      # the 1/16-resolution flow, a pair of one-image towers
-    (2, 72, 80, 64, True, False, 1),      # 16-row strips, a ragged last strip
-    (3, 20, 24, 24, False, True, 1),      # batch statistics; W, C not multiples of the workgroup's 16 columns / 64 channels
-    (1, 16, 16, 128, False, False, 0),    # no activation mask
+@pytest.mark.parametrize("B,H,W,Cc,images,double_bn,mask,stride,rate", [
+    (2, 32, 32, 728, True, True, 1, 1, 1),      # the 1/16-resolution flow, a pair of one-image towers
+    (2, 72, 80, 64, True, False, 1, 1, 1),      # 16-row strips, a ragged last strip
+    (3, 20, 24, 24, False, True, 1, 1, 1),      # batch statistics; W, C not multiples of the workgroup's 16 columns / 64 channels
+    (1, 16, 16, 128, False, False, 0, 1, 1),    # no activation mask
+    (2, 64, 64, 64, True, True, 1, 2, 1),       # a stride-2 consumer (cnn0_last -> cnn0_strided): the gather form
+    (3, 22, 18, 24, False, False, 1, 2, 1),     # ... ragged, batch statistics
+    (2, 16, 16, 128, True, True, 1, 1, 2),      # a dilated consumer
 ])
-def test_bn_backward_of_a_never_written_gradient(B, H, W, Cc, images, double_bn, mask):
+def test_bn_backward_of_a_never_written_gradient(B, H, W, Cc, images, double_bn, mask, stride, rate):
     """TO.bn_backward_dw (emd_dw3x3_bn_bwd_reduce_f32 / _apply_f32: dy = dw3x3(dd, flipped taps) formed on the fly in both passes) ==
     ops.dw3x3 written out, then TO.bn_backward: dr and the parameter gradients to the rounding of the re-cut double sums."""
     from emdenoise import ops, train_ops as TO
@@ -638,8 +641,10 @@ def test_bn_backward_of_a_never_written_gradient(B, H, W, Cc, images, double_bn,
     g = torch.Generator(device=dev()).manual_seed(7)
     rn = lambda *sh: torch.randn(*sh, device=dev(), generator=g)
     r0 = rn(B, H, W, Cc) * 2
-    dd = ops.Act(rn(B, H, W, Cc))
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    dd = ops.Act(rn(B, Ho, Wo, Cc))
     wf = rn(9, Cc) * 0.3
+    w0 = wf.flip(0).contiguous()      # the consumer's own taps (wf = reversed)
     gamma2, beta2 = torch.rand(Cc, device=dev(), generator=g) + 0.5, rn(Cc)
     gamma1, beta1 = (torch.rand(Cc, device=dev(), generator=g) + 0.5, rn(Cc)) if double_bn else (None, None)
     rA = ops.Act(r0.clone())
@@ -654,11 +659,15 @@ def test_bn_backward_of_a_never_written_gradient(B, H, W, Cc, images, double_bn,
         dg1 = torch.zeros(Cc, device=dev()) if double_bn else None
         gdw = torch.zeros(9, Cc, device=dev())
         if fused:
-            TO.bn_backward_dw(TO.DwGrad(dd, wf, gdw if wg else None), r, fold, gamma2, dg2, db2, r, mask=mask, gamma1=gamma1, dgamma1=dg1)
+            TO.bn_backward_dw(TO.DwGrad(dd, wf, gdw if wg else None, stride=stride, rate=rate, hw=(H, W)), r, fold, gamma2, dg2, db2, r, mask=mask,
+                              gamma1=gamma1, dgamma1=dg1)
         else:
             if wg:
-                TO.dw3x3_wgrad_pre(ops.PreAct(r, fold["scale"], fold["shift"], images=images, act=ops.ACT_RELU6), dd, gdw)
-            dy = ops.dw3x3(dd, wf, ops.Act.empty(B, H, W, Cc, dev()))
+                TO.dw3x3_wgrad_pre(ops.PreAct(r, fold["scale"], fold["shift"], images=images, act=ops.ACT_RELU6), dd, gdw, stride=stride, rate=rate)
+            if stride == 1:
+                dy = ops.dw3x3(dd, wf, ops.Act.empty(B, H, W, Cc, dev()), rate=rate)
+            else:
+                dy = TO.dw3x3_bwd_data(dd, w0, ops.Act.empty(B, H, W, Cc, dev()), stride=stride, rate=rate)
             TO.bn_backward(dy, r, fold, gamma2, dg2, db2, r, mask=mask, gamma1=gamma1, dgamma1=dg1)
         torch.cuda.synchronize()
         outs[fused] = (r.buf.clone(), dg2, db2, dg1, gdw)
