@@ -198,6 +198,9 @@ SIGNATURES = {
                                    [C.c_int, _c_float_p, _c_float_p, C.c_float] + [_c_float_p] * 4 + [C.c_int, C.c_void_p]),
     # x ldx dy ldd dw B H W C stride rate stream
     "emd_dw3x3_wgrad_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p] + [C.c_int] * 6 + [C.c_void_p]),
+    # dd ldd w_flipped x ldx dx ldo dw B H W C stream
+    "emd_dw3x3_bwd_both_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p] + [C.c_int] * 4
+                               + [C.c_void_p]),
     "emd_dw3x3_bn_bwd_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     # dd ldd w_flipped r ldr mean rstd mscale mshift mask images B H W C stride rate s1 s2 dw_consumer workspace stream
     "emd_dw3x3_bn_bwd_reduce_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [_c_float_p] * 4 + [C.c_int] * 8

@@ -45,9 +45,13 @@ struct DwBnArgs {
 // which x = relu6(r*ms + mh) is the mask's own argument clamped -- so that gradient is accumulated here too (the raw 3 x 3 window of dd
 // around the pixel is kept beside the window sums): dW[3ky + kx] += x[q] * dd[q - (ky-1, kx-1)], 16 columns summed through LDS, one
 // float atomic per (tap, channel) and workgroup as in dw_wgrad_roll_kernel (bwd_misc.hip).  emd_dw3x3_wgrad_pre_f32's launch is gone.
+// EPI = 0 (always with WG): no batch norm at all -- the depthwise stage's two gradients in ONE pass for a consumer whose input x WAS written
+// (a block's first separable conv): dx = dw3x3(dd, flipped taps) stored to a.dr, dW += sum x[q] * dd[q - tap] with x = a.r as it is
+// (emd_dw3x3_f32 on the reversed taps + emd_dw3x3_wgrad_f32, which read dd twice).
 template <int TH, int EPI, bool WG = false>
 __global__ __launch_bounds__(256) void dw_bn_bwd_kernel(const DwBnArgs a) {
-    static_assert(!WG || EPI == 1, "the weight gradient rides in the reduction pass");
+    static_assert(!WG || EPI <= 1, "the weight gradient rides in the reduction pass (or in the plain data-gradient pass)");
+    static_assert(EPI != 0 || WG, "EPI 0 is the two depthwise gradients in one pass");
     const int ncb = (a.C4 + 15) >> 4, npb = (a.W + 15) >> 4;
     int bidx = blockIdx.x;
     const int cblk = bidx % ncb;
@@ -67,14 +71,15 @@ __global__ __launch_bounds__(256) void dw_bn_bwd_kernel(const DwBnArgs a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(a.w + k * C + c4 * 4);
     const long vo = b * a.vld + c4 * 4;
-    const float4 mu = *reinterpret_cast<const float4*>(a.mean + vo);
-    float4 ms = f4zero(), mh = f4zero();
-    if (a.mask) {
+    float4 mu = f4zero(), ms = f4zero(), mh = f4zero();
+    if (EPI != 0) mu = *reinterpret_cast<const float4*>(a.mean + vo);
+    if (EPI != 0 && a.mask) {
         ms = *reinterpret_cast<const float4*>(a.ms + vo);
         mh = *reinterpret_cast<const float4*>(a.mh + vo);
     }
     float4 e0 = f4zero(), e1 = f4zero(), e2 = f4zero();   // EPI 1: rstd; EPI 2: K, m1, m2
-    if (EPI == 1) {
+    if (EPI == 0) {
+    } else if (EPI == 1) {
         e0 = *reinterpret_cast<const float4*>(a.rstd + vo);
     } else {
         e0 = *reinterpret_cast<const float4*>(a.K + vo);
@@ -135,8 +140,9 @@ __global__ __launch_bounds__(256) void dw_bn_bwd_kernel(const DwBnArgs a) {
                 const float msk[4] = {ms.x, ms.y, ms.z, ms.w}, mhk[4] = {mh.x, mh.y, mh.z, mh.w}, muk[4] = {mu.x, mu.y, mu.z, mu.w};
                 const float e0k[4] = {e0.x, e0.y, e0.z, e0.w}, e1k[4] = {e1.x, e1.y, e1.z, e1.w}, e2k[4] = {e2.x, e2.y, e2.z, e2.w};
                 float o[4];
+                if (EPI == 0) *reinterpret_cast<float4*>(a.dr + pix * a.ldo + c4 * 4) = dyv;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < (EPI == 0 ? 0 : 4); ++k) {
                     const float g = grad_mask(dyk[k], fmaf(rk[k], msk[k], mhk[k]), a.mask);
                     if (EPI == 1) {     // chan_reduce_partial_v4's terms
                         s[k] += (double)g;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256) void dw_bn_bwd_kernel(const DwBnArgs a) {
                 }
                 if (EPI == 2) *reinterpret_cast<float4*>(a.dr + pix * a.ldo + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
                 if constexpr (WG) {   // x = relu6(r*ms + mh): affine_relu6_kernel's bits (what the forward's loads rebuilt); window rows 0, 1, 2 = tt - 2, tt - 1, tt
-                    const float4 x = make_float4(fminf(fmaxf(fmaf(rk[0], msk[0], mhk[0]), 0.f), 6.f), fminf(fmaxf(fmaf(rk[1], msk[1], mhk[1]), 0.f), 6.f),
+                    const float4 x = EPI == 0 ? rv : make_float4(fminf(fmaxf(fmaf(rk[0], msk[0], mhk[0]), 0.f), 6.f), fminf(fmaxf(fmaf(rk[1], msk[1], mhk[1]), 0.f), 6.f),
                                                  fminf(fmaxf(fmaf(rk[2], msk[2], mhk[2]), 0.f), 6.f), fminf(fmaxf(fmaf(rk[3], msk[3], mhk[3]), 0.f), 6.f));
                     wa[0] = fma4(x, r, wa[0]);   wa[1] = fma4(x, c, wa[1]);   wa[2] = fma4(x, l, wa[2]);      // ky = 0: window row 2
                     wa[3] = fma4(x, pr1, wa[3]); wa[4] = fma4(x, pc1, wa[4]); wa[5] = fma4(x, pl1, wa[5]);    // ky = 1: row 1
@@ -329,6 +335,17 @@ inline int same_pad_before(int n, int s, int r) {  // TF SAME, k = 3 (bwd_misc.h
 
 bool args_ok(const float* p, int ld, int C) { return p && C >= 4 && C % 4 == 0 && ld % 4 == 0 && ld >= C && emd::aligned16(p); }
 
+int launch_plain(const DwBnArgs& a0, int B, hipStream_t st) {   // EPI 0: stride 1, rate 1
+    DwBnArgs a = a0;
+    const int TH = a.H >= 64 ? 16 : 8;
+    a.nstrip = (a.H + TH - 1) / TH;
+    const long nb = (long)B * a.nstrip * ((a.W + 15) / 16) * ((a.C4 + 15) / 16);
+    EMD_REQUIRE(nb >= 1 && nb <= 0x7fffffffL, EMD_E_UNSUPPORTED, "emd_dw3x3_bwd_both_f32: grid too large");
+    if (TH == 16) hipLaunchKernelGGL((dw_bn_bwd_kernel<16, 0, true>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dw_bn_bwd_kernel<8, 0, true>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    return emd::check_launch("dw_bn_bwd_kernel<both depthwise gradients>");
+}
+
 template <int EPI>
 int launch(const DwBnArgs& a0, int B, hipStream_t st, int stride = 1, int rate = 1) {
     DwBnArgs a = a0;
@@ -415,4 +432,19 @@ extern "C" int emd_dw3x3_bn_bwd_apply_f32(const float* dd, int ldd, const float*
     a.dd = dd; a.w = w_flipped; a.r = r; a.dr = dr; a.mean = mean; a.ms = mscale; a.mh = mshift; a.K = K; a.m1 = m1; a.m2 = m2;
     a.ldd = ldd; a.ldr = ldr; a.ldo = ldo; a.H = H; a.W = W; a.C4 = C / 4; a.mask = mask; a.vld = images ? C : 0;
     return launch<2>(a, B, static_cast<hipStream_t>(stream), stride, rate);
+}
+
+// Both gradients of a stride-1 depthwise 3x3 in one pass: dx = emd_dw3x3_f32(dd, w_flipped) and dw[9][C] += emd_dw3x3_wgrad_f32(x, dd) -- dd is
+// read once (with its halo) instead of twice, one launch instead of two.  dx has emd_dw3x3_f32's bits.
+extern "C" int emd_dw3x3_bwd_both_f32(const float* dd, int ldd, const float* w_flipped, const float* x, int ldx, float* dx, int ldo, float* dw,
+                                      int B, int H, int W, int C, emd_stream_t stream) {
+    EMD_REQUIRE(w_flipped && dw, EMD_E_INVALID, "emd_dw3x3_bwd_both_f32: null pointer");
+    EMD_REQUIRE(B >= 0 && B <= 65535 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_dw3x3_bwd_both_f32: bad shape");
+    EMD_REQUIRE(args_ok(dd, ldd, C) && args_ok(x, ldx, C) && args_ok(dx, ldo, C) && emd::aligned16(w_flipped), EMD_E_ALIGN,
+                "emd_dw3x3_bwd_both_f32: C, pitches multiples of 4; 16-byte aligned tensors");
+    if (B == 0) return EMD_OK;
+    DwBnArgs a{};
+    a.dd = dd; a.w = w_flipped; a.r = x; a.dr = dx; a.dwg = dw;
+    a.ldd = ldd; a.ldr = ldx; a.ldo = ldo; a.H = H; a.W = W; a.C4 = C / 4;
+    return launch_plain(a, B, static_cast<hipStream_t>(stream));
 }

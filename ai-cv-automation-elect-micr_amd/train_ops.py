@@ -307,6 +307,15 @@ def dw3x3_wgrad(x: Act, dy: Act, dw_dev, stride=1, rate=1, stream=None):
                                                _lib.stream_ptr(stream)), "emd_dw3x3_wgrad_f32")
 
 
+def dw3x3_bwd_both(dd: Act, w_flipped, x: Act, dx: Act, dw_dev, stream=None):
+    """Both gradients of a stride-1 depthwise 3x3 in one pass (emd_dw3x3_bwd_both_f32): dx = dw3x3(dd, w_flipped), dw_dev += wgrad(x, dd)."""
+    assert dw_dev.is_contiguous() and dw_dev.numel() == 9 * x.C and w_flipped.is_contiguous() and w_flipped.numel() == 9 * x.C
+    assert (dd.B, dd.H, dd.W, dd.C) == (x.B, x.H, x.W, x.C) == (dx.B, dx.H, dx.W, dx.C)
+    _lib.check(_lib.load().emd_dw3x3_bwd_both_f32(dd.ptr, dd.ld, _p(w_flipped), x.ptr, x.ld, dx.ptr, dx.ld, _p(dw_dev), x.B, x.H, x.W, x.C,
+                                                  _lib.stream_ptr(stream)), "emd_dw3x3_bwd_both_f32")
+    return dx
+
+
 def dw3x3_wgrad_pre(x, dy: Act, dw_dev, stride=1, rate=1, stream=None):
     """dw3x3_wgrad with the layer's input given as an ops.PreAct (never written; rebuilt from its r in the loads)."""
     r = x.r

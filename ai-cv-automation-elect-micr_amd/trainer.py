@@ -130,6 +130,7 @@ class DenoiserTrainer:
         # ... also behind a stride-2 (or dilated) consumer (gather form): correct and tested, but measured SLOWER (44.76 / 44.83 ms per step
         # against 44.43 / 44.41: the gather's per-pixel index arithmetic costs more than the two passes it saves on four layers); opt-in
         self.fuse_dw_bn_bwd_s2 = os.environ.get("EMD_T_DW_BN_BWD_S2", "0") == "1"
+        self.fuse_dw_both = os.environ.get("EMD_T_DW_BOTH", "1") == "1"     # a written input: the depthwise stage's two gradients in one pass over dd
         self.fuse_dw_wgrad = os.environ.get("EMD_T_DW_WGRAD", "1") == "1"   # ... whose reduction pass also adds the consumer's depthwise weight gradient
         self.fuse_stats = os.environ.get("EMD_T_FUSE_STATS", "1") == "1"   # batch statistics from the producing GEMM's epilogue (ops.conv_stats)
         self.teacher = None   # test hook: scope -> {"d": ..., "r": ...} reference tensors that REPLACE the forward's conv outputs (see _force)
@@ -486,6 +487,11 @@ class DenoiserTrainer:
             gslot[self._gkey(x)] = g
             if g.gdw is None:
                 TO.dw3x3_wgrad_pre(x, dd, self._gdw(key), stride=L.stride, rate=L.rate)
+            return
+        if (self.fuse_dw_both and not isinstance(x, ops.PreAct) and need_dx and L.stride == 1 and L.rate == 1 and self._wg_side is None
+                and x.C % 4 == 0 and L.cin > 1):
+            # a written input (a block's first separable conv): data gradient and weight gradient in one pass over dd
+            self._put(gslot, x, lambda dst: TO.dw3x3_bwd_both(dd, self.dw_flip[key], x, dst, self._gdw(key)))
             return
         if isinstance(x, ops.PreAct):    # the input was never written: rebuilt from the previous layer's r in the loads
             self._wg(lambda: TO.dw3x3_wgrad_pre(x, dd, self._gdw(key), stride=L.stride, rate=L.rate), dd)

@@ -492,6 +492,10 @@ int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float* w_flipped
 int emd_dw3x3_bn_bwd_apply_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* K, const float* m1,
                                const float* mean, const float* m2, const float* mscale, const float* mshift, int mask, int images,
                                float* dr, int ldo, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream);
+/* Both gradients of a stride-1 depthwise 3x3 in one pass (round 4): dx = emd_dw3x3_f32(dd, w_flipped) -- the data gradient, its bits -- and
+ * dw[9][C] += emd_dw3x3_wgrad_f32(x, dd); dd is read once instead of twice.  x, dx, dd [B,H,W,C]; w_flipped = the taps reversed. */
+int emd_dw3x3_bwd_both_f32(const float* dd, int ldd, const float* w_flipped, const float* x, int ldx, float* dx, int ldo, float* dw, int B,
+                           int H, int W, int C, emd_stream_t stream);
 /* emd_dw3x3_wgrad_f32 with the layer's input given as the pre-activation tensor r of the layer before it (the forward pass ran
  * emd_dw3x3_pre_act_f32 on it and never wrote x = act(r * pre_scale + pre_shift)): x is rebuilt in the loads.  Arguments as there. */
 int emd_dw3x3_wgrad_pre_f32(const float* r, int ldx, const float* pre_scale, const float* pre_shift, int pre_images, int act,

@@ -326,8 +326,9 @@ def test_affine_in_the_consumers_loads_changes_nothing():
         # its reduction pass): the default, each step back, all written out
         for mode in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)):
             tr = TR.DenoiserTrainer(w, dev())
-            assert tr.lazy_affine and tr.fuse_dw_bn_bwd and tr.fuse_dw_wgrad
+            assert tr.lazy_affine and tr.fuse_dw_bn_bwd and tr.fuse_dw_wgrad and tr.fuse_dw_both
             tr.lazy_affine, tr.fuse_dw_bn_bwd, tr.fuse_dw_wgrad = mode
+            tr.fuse_dw_both = mode[0]     # (the two depthwise gradients of a written input in one pass: on with the default only)
             tr.zero_grad()
             o, r = tr.tower(x, t, update_moving=True, per_image=per_image)
             torch.cuda.synchronize()

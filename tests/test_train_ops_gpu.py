@@ -726,3 +726,28 @@ def test_deconv_stats_equals_deconv_then_statistics(B, H, W, ci, co, images):
         mo, vo = ops.deconv_stats(xb, ph, ones, zeros, out_act(1, 2 * H, 2 * W, co), images=True)
         torch.cuda.synchronize()
         assert torch.equal(mo, mean[co:2 * co]) and torch.equal(vo, var[co:2 * co])
+
+
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 32, 32, 728), (1, 72, 80, 64), (3, 20, 24, 24)])
+def test_both_depthwise_gradients_in_one_pass(B, H, W, Cc):
+    """emd_dw3x3_bwd_both_f32: dx bit for bit emd_dw3x3_f32 on the reversed taps, dw == emd_dw3x3_wgrad_f32 to the spread of its float
+    atomics; x is padded into a wider buffer (pitches)."""
+    from emdenoise import ops, train_ops as TO
+
+    g = torch.Generator(device=dev()).manual_seed(11)
+    rn = lambda *sh: torch.randn(*sh, device=dev(), generator=g)
+    xbuf = torch.full((B, H, W, Cc + 8), float("nan"), device=dev())
+    xbuf[..., 4:4 + Cc] = rn(B, H, W, Cc)
+    x = ops.Act(xbuf, Cc, 4)
+    dd = ops.Act(rn(B, H, W, Cc))
+    wf = rn(9, Cc) * 0.3
+    want_dx = ops.dw3x3(dd, wf, ops.Act.empty(B, H, W, Cc, dev()))
+    want_dw = torch.zeros(9, Cc, device=dev())
+    TO.dw3x3_wgrad(x, dd, want_dw)
+    dx = ops.Act.empty(B, H, W, Cc, dev())
+    dx.buf.fill_(float("nan"))
+    got_dw = torch.zeros(9, Cc, device=dev())
+    TO.dw3x3_bwd_both(dd, wf, x, dx, got_dw)
+    torch.cuda.synchronize()
+    assert torch.equal(dx.buf, want_dx.buf)
+    assert (got_dw - want_dw).abs().max().item() < 2e-5 * want_dw.abs().max().item()
