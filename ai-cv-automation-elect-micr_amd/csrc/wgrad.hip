@@ -283,6 +283,37 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const emd_pack_
         else hi = mid - 1;
     }
     const emd_pack_job_t j = jobs[lo];
+    if (!j.cout_major) {
+        // [taps][Cin][Cout] -> [Npad][taps][Cpad] is a transpose: one thread per packed element (below) reads with a stride of Cout floats --
+        // a 32-byte sector per 4-byte value, 2 GB fetched for the model's 160 MB of weights and 450 us at the end of every training step
+        // (round 4: profiles/r04_t_traffic_by_kernel.txt).  Here a block moves a 16 (c) x 16 (n) tile of one tap through LDS: 64-byte
+        // runs on the read side, 32-byte runs on the write side.
+        __shared__ float tile[16][17];
+        const long lb = blk - j.first_block;
+        const int ntc = (j.cpad + 15) >> 4;
+        const int tc = (int)(lb % ntc);
+        const long rest = lb / ntc;
+        const int t = (int)(rest % j.ntaps);
+        const int tn = (int)(rest / j.ntaps);
+        const int npad = (int)(j.total / ((long)j.ntaps * j.cpad));
+        const int i = threadIdx.x >> 4, jj = threadIdx.x & 15;
+        {
+            const int c = tc * 16 + i, n = tn * 16 + jj;
+            const long st = (long)((j.tap_sel >> (4 * t)) & 15);
+            tile[i][jj] = (c < j.cin && n < j.cout) ? j.w[(st * j.cin + c) * j.cout + n] : 0.f;
+        }
+        __syncthreads();
+        const int n = tn * 16 + i, c = tc * 16 + jj;
+        if (n < npad && c < j.cpad) {
+            const float v = tile[jj][i];
+            const long o = ((long)n * j.ntaps + t) * j.cpad + c;
+            const __bf16 h = (__bf16)v;
+            const __bf16 l = (__bf16)(v - (float)h);
+            j.hi[o] = __builtin_bit_cast(uint16_t, h);
+            j.lo[o] = __builtin_bit_cast(uint16_t, l);
+        }
+        return;
+    }
     const long idx = (blk - j.first_block) * 256 + threadIdx.x;
     if (idx >= j.total) return;
     const int c = (int)(idx % j.cpad);
@@ -401,7 +432,8 @@ extern "C" int emd_pack_job_fill(emd_pack_job_t* job, const float* w, int src_ta
     job->w = w; job->hi = hi; job->lo = lo; job->tap_sel = sel;
     job->total = npad * ntaps * cpad;
     job->first_block = 0;
-    job->n_blocks = (job->total + 255) / 256;
+    // cout_major: one thread per packed element; else 16 x 16 (n, c) tiles per tap (see pack_weights_batch_kernel)
+    job->n_blocks = cout_major ? (job->total + 255) / 256 : (long)ntaps * ((npad + 15) / 16) * ((cpad + 15) / 16);
     job->ntaps = ntaps; job->cin = Cin; job->cout = Cout; job->cout_major = cout_major ? 1 : 0; job->cpad = cpad; job->pad_ = 0;
     return EMD_OK;
 }

@@ -390,7 +390,8 @@ typedef struct emd_pack_job {
     unsigned long long tap_sel;   /* 4 bits per packed tap: its source tap */
     long total;                   /* packed elements of one plane */
     long first_block;             /* caller-assigned */
-    long n_blocks;                /* ceil(total / 256) */
+    long n_blocks;                /* workgroups of this job in the batch launch (set by emd_pack_job_fill: ceil(total / 256), or the 16 x 16
+                                   * tile count of the transposing form) */
     int ntaps, cin, cout, cout_major, cpad, pad_;
 } emd_pack_job_t;
 int emd_pack_job_fill(emd_pack_job_t* job, const float* w, int src_taps, int ntaps, const int* tap_sel, int Cin, int Cout,
