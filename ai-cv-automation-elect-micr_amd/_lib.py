@@ -130,11 +130,17 @@ SIGNATURES = {
     # x ldx whi wlo ones zeros y ldy B H W Cin Cout stride|rate precision images mean var workspace stream
     "emd_conv1x1_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] +
                               [C.c_int] * 8 + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
+    "emd_conv1x1_stats_fold_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] +
+                              [C.c_int] * 8 + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p] + [C.c_void_p]),
     # x ldx whi[4] wlo[4] ones zeros y ldy B H W Cin Cout precision images mean var workspace stream
     "emd_deconv3x3s2_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 7
                                   + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
+    "emd_deconv3x3s2_stats_fold_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] + [C.c_int] * 7
+                                  + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p] + [C.c_void_p]),
     "emd_conv3x3_stats_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] +
                               [C.c_int] * 8 + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
+    "emd_conv3x3_stats_fold_f32": (C.c_int, [_c_float_p, C.c_int, C.c_void_p, C.c_void_p, _c_float_p, _c_float_p, _c_float_p, C.c_int] +
+                              [C.c_int] * 8 + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p] + [C.c_void_p]),
     # x ldx scale shift res ldres y ldy B npix_img C act stream
     # x ldx scale shift res ldres res_scale res_shift res_act y ldy images npix C act stream
     "emd_affine_act_res_affine_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, _c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int,
@@ -202,9 +208,12 @@ SIGNATURES = {
     "emd_dw3x3_bwd_both_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int, _c_float_p, C.c_int, _c_float_p] + [C.c_int] * 4
                                + [C.c_void_p]),
     "emd_dw3x3_bn_bwd_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
-    # dd ldd w_flipped r ldr mean rstd mscale mshift mask images B H W C stride rate s1 s2 dw_consumer workspace stream
+    # dd ldd w_flipped r ldr mean rstd mscale mshift mask images B H W C stride rate s1 s2 dw_consumer workspace prep stream
     "emd_dw3x3_bn_bwd_reduce_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [_c_float_p] * 4 + [C.c_int] * 8
-                                    + [_c_float_p, _c_float_p, _c_float_p, C.c_void_p, C.c_void_p]),
+                                    + [_c_float_p, _c_float_p, _c_float_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # dy ldd x ldx mean rstd mscale mshift mask images npix C s1 s2 workspace prep stream
+    "emd_bn_bwd_reduce_prep_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int] + [_c_float_p] * 4 + [C.c_int, C.c_int, C.c_long, C.c_int]
+                                   + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     # dd ldd w_flipped r ldr K m1 mean m2 mscale mshift mask images dr ldo B H W C stride rate stream
     "emd_dw3x3_bn_bwd_apply_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [_c_float_p] * 6 + [C.c_int] * 2
                                    + [_c_float_p] + [C.c_int] * 7 + [C.c_void_p]),
@@ -363,6 +372,18 @@ def load():
         if lib.emd_debug_knob(k.strip().encode(), int(v)) != 0:
             raise EmdError(f"EMD_KNOBS: unknown knob {k!r}")
     return lib
+
+
+class BnTrainFold(C.Structure):
+    """emd_bn_train_fold_t (include/emdenoise.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("gamma1", "beta1", "gamma2", "beta2", "bias")] + [("eps", C.c_float), ("pad_", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("scale", "shift", "rstd1", "rstd2", "mm1", "mv1", "mm2", "mv2")] + [("decay", C.c_double)]
+
+
+class BnBwdPrep(C.Structure):
+    """emd_bn_bwd_prep_t (include/emdenoise.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("gamma1", "gamma2", "rstd1", "rstd2")] + [("eps", C.c_float), ("pad_", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("K", "m1", "m2", "dgamma1", "dgamma2", "dbeta2")]
 
 
 def knob(name: str, value: int):

@@ -13,6 +13,7 @@
 //              dbeta  = s1, dgamma  = t                                                 (single BN)
 // (a bias added before a training-mode batch norm cancels: its gradient is zero and it only shifts the moving mean).
 #include "emd_common.hpp"
+#include "bn_chain_dev.hpp"
 
 namespace {
 
@@ -126,8 +127,10 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
     }
 }
 
+// do_prep: the per-channel step bn_bwd_prep_kernel would run next (K, m1, m2 and the parameter gradients) in the same launch
 __global__ __launch_bounds__(256) void chan_reduce_final(const double* __restrict__ part, int nslab, int C,
-                                                         float* __restrict__ s1, float* __restrict__ s2, int accumulate) {
+                                                         float* __restrict__ s1, float* __restrict__ s2, int accumulate,
+                                                         int do_prep, emd::BnPrepArgs pa, float inv_n) {
     // 16 channels x 16 slab lanes per workgroup; per-image form: image b = blockIdx.y
     __shared__ double sm[2][16][16 + 1];
     {
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(256) void chan_reduce_final(const double* __restric
     if (accumulate) atomicAdd(s1 + c, (float)s);  // bias gradients: towers on different streams add concurrently
     else s1[c] = (float)s;
     if (s2) s2[c] = (float)q;
+    if (do_prep) emd::bn_bwd_prep_one(pa, (int)blockIdx.y * C + c, c, (float)s, (float)q, inv_n);
 }
 
 // dx = K * ( g - m1 - (x-mean)*m2 ),  g = dy * mask(x*mscale + mshift); dx may alias dy (elementwise).
@@ -225,35 +229,8 @@ __global__ __launch_bounds__(256) void bn_train_fold_kernel(const float* __restr
     // image 0 only (the first tower, misc_py/denoiser-multi-gpu.py:701-707)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= C) return;
-    const int c = i % period;
-    if (i >= period) mm1 = mv1 = mm2 = mv2 = nullptr;
-    const float mu = mean[i], v = var[i];
-    const float r1 = rsqrtf(v + eps);
-    const float bessel = n > 1.f ? n / (n - 1.f) : 1.f;
-    rstd1[i] = r1;
-    if (gamma1) {  // BN1 (gamma1, beta1) then BN2 (gamma2, beta2)
-        const float g1 = gamma1[c];
-        const float var2 = g1 * g1 * v * r1 * r1;
-        const float r2 = rsqrtf(var2 + eps);
-        rstd2[i] = r2;
-        const float sc = g1 * gamma2[c] * r1 * r2;
-        scale[i] = sc;
-        shift[i] = beta2[c] - mu * sc;
-        if (mm1) {
-            mm1[c] -= (mm1[c] - mu) * omd;
-            mv1[c] -= (mv1[c] - v * bessel) * omd;
-            mm2[c] -= (mm2[c] - beta1[c]) * omd;
-            mv2[c] -= (mv2[c] - var2 * bessel) * omd;
-        }
-    } else {       // a single BN (gamma2, beta2) after conv + bias
-        const float sc = gamma2[c] * r1;
-        scale[i] = sc;
-        shift[i] = beta2[c] - mu * sc;
-        if (mm2) {
-            mm2[c] -= (mm2[c] - (mu + (bias ? bias[c] : 0.f))) * omd;
-            mv2[c] -= (mv2[c] - v * bessel) * omd;
-        }
-    }
+    const emd::BnFoldArgs a{gamma1, beta1, gamma2, beta2, bias, eps, omd, scale, shift, rstd1, rstd2, mm1, mv1, mm2, mv2};
+    emd::bn_train_fold_one(a, i, i % period, i < period, mean[i], var[i], n);
 }
 
 // Per-channel step between the backward reduction and the elementwise apply; parameter gradients ACCUMULATE
@@ -267,23 +244,8 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const float* __restric
     // per-image form: C = B * period entries; parameters and their gradients are indexed by the channel i % period
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= C) return;
-    const int c = i % period;
-    const float r1 = rstd1[i], tv = t[i], sv = s1[i];
-    m1[i] = sv * inv_n;
-    atomicAdd(dbeta2 + c, sv);  // parameter gradients: towers on different streams add concurrently
-    if (gamma1) {
-        const float g1 = gamma1[c], g2 = gamma2[c], r2 = rstd2[i];
-        const float a = g1 * r2;
-        const float e2 = eps * r2 * r2;
-        K[i] = g1 * g2 * r1 * r2;
-        m2[i] = r1 * tv * inv_n * (a * a + e2);
-        atomicAdd(dgamma2 + c, a * tv);
-        atomicAdd(dgamma1 + c, g2 * r2 * e2 * tv);
-    } else {
-        K[i] = gamma2[c] * r1;
-        m2[i] = r1 * tv * inv_n;
-        atomicAdd(dgamma2 + c, tv);
-    }
+    const emd::BnPrepArgs a{gamma1, gamma2, rstd1, rstd2, eps, K, m1, m2, dgamma1, dgamma2, dbeta2};
+    emd::bn_bwd_prep_one(a, i, i % period, s1[i], t[i], inv_n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,8 +475,9 @@ extern "C" size_t emd_chan_reduce_workspace_bytes(long npix, int C) {
 // towers (misc_py/denoiser-multi-gpu.py:763) can run as one batched pass with identical arithmetic per image.
 static int bwd_reduce_impl(const float* dy, int ldd, const float* x, int ldx, const float* mean, const float* rstd,
                            const float* mscale, const float* mshift, int mask, int B, long npix, int C, float* s1, float* s2,
-                           int accumulate_s1, void* workspace, emd_stream_t stream) {
+                           int accumulate_s1, void* workspace, emd_stream_t stream, const emd::BnPrepArgs* prep = nullptr) {
     EMD_REQUIRE(dy && s1 && workspace, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: null pointer");
+    EMD_REQUIRE(!prep || (x && !accumulate_s1), EMD_E_INVALID, "emd_bn_bwd_reduce_prep_f32: the per-channel step needs x (both sums)");
     EMD_REQUIRE(B >= 1 && B <= 65535 && npix >= 1 && C >= 1 && mask >= 0 && mask <= 3, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: bad argument");
     EMD_REQUIRE(!x || (mean && rstd && s2), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: x needs mean, rstd and s2");
     EMD_REQUIRE(!mask || (x && mscale && mshift), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: a mask needs x, mscale, mshift");
@@ -529,7 +492,7 @@ static int bwd_reduce_impl(const float* dy, int ldd, const float* x, int ldx, co
         hipLaunchKernelGGL(chan_reduce_partial, dim3((C + 63) / 64, (unsigned)ns, (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, mean,
                            rstd, mscale, mshift, mask, npix, C, rps, ws);
     hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16, (unsigned)B), dim3(256), 0, st, static_cast<const double*>(ws), (int)ns, C, s1,
-                       x ? s2 : nullptr, accumulate_s1);
+                       x ? s2 : nullptr, accumulate_s1, prep ? 1 : 0, prep ? *prep : emd::BnPrepArgs{}, 1.0f / (float)npix);
     return emd::check_launch("chan_reduce");
 }
 
@@ -546,10 +509,48 @@ extern "C" int emd_bn_bwd_reduce_images_f32(const float* dy, int ldd, const floa
 }
 
 // chan_reduce_final on partials another kernel produced in chan_reduce_partial_v4's layout ([image][slab][2][C] doubles): dw_bn_bwd.hip
-int emd::launch_chan_reduce_final(const double* part, int nslab, int C, int B, float* s1, float* s2, hipStream_t st) {
+int emd::launch_chan_reduce_final(const double* part, int nslab, int C, int B, float* s1, float* s2, hipStream_t st,
+                                  const emd::BnPrepArgs* prep, long npix) {
     EMD_REQUIRE(part && s1 && nslab >= 1 && C >= 1 && B >= 1 && B <= 65535, EMD_E_INVALID, "chan_reduce_final: bad argument");
-    hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16, (unsigned)B), dim3(256), 0, st, part, nslab, C, s1, s2, 0);
+    EMD_REQUIRE(!prep || (s2 && npix >= 1), EMD_E_INVALID, "chan_reduce_final: the per-channel step needs both sums and the pixel count");
+    if (prep)
+        hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16, (unsigned)B), dim3(256), 0, st, part, nslab, C, s1, s2, 0, 1, *prep,
+                           1.0f / (float)npix);
+    else
+        hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16, (unsigned)B), dim3(256), 0, st, part, nslab, C, s1, s2, 0, 0, emd::BnPrepArgs{},
+                           0.f);
     return emd::check_launch("chan_reduce_final");
+}
+
+int emd::bn_fold_args(const emd_bn_train_fold_t* p, emd::BnFoldArgs* out) {
+    EMD_REQUIRE(p && p->gamma2 && p->beta2 && p->scale && p->shift && p->rstd1, EMD_E_INVALID, "emd_bn_train_fold_t: null pointer");
+    EMD_REQUIRE((p->gamma1 == nullptr) == (p->beta1 == nullptr) && (!p->gamma1 || p->rstd2), EMD_E_INVALID,
+                "emd_bn_train_fold_t: the double batch norm needs gamma1, beta1 and rstd2");
+    EMD_REQUIRE(!p->mm2 || p->mv2, EMD_E_INVALID, "emd_bn_train_fold_t: moving mean and variance come together");
+    EMD_REQUIRE(!p->gamma1 || ((p->mm1 == nullptr) == (p->mm2 == nullptr) && (!p->mm1 || p->mv1)), EMD_E_INVALID,
+                "emd_bn_train_fold_t: the double batch norm updates both sets of moving statistics or none");
+    *out = emd::BnFoldArgs{p->gamma1, p->beta1, p->gamma2, p->beta2, p->bias, p->eps, (float)(1.0 - p->decay), p->scale, p->shift, p->rstd1,
+                           p->rstd2, p->mm1, p->mv1, p->mm2, p->mv2};
+    return EMD_OK;
+}
+
+// emd_bn_bwd_prep_t -> the device-side argument block, checked
+int emd::bn_prep_args(const emd_bn_bwd_prep_t* p, emd::BnPrepArgs* out) {
+    EMD_REQUIRE(p && p->gamma2 && p->rstd1 && p->K && p->m1 && p->m2 && p->dgamma2 && p->dbeta2, EMD_E_INVALID, "emd_bn_bwd_prep_t: null pointer");
+    EMD_REQUIRE(!p->gamma1 || (p->rstd2 && p->dgamma1), EMD_E_INVALID, "emd_bn_bwd_prep_t: the double batch norm needs rstd2 and dgamma1");
+    *out = emd::BnPrepArgs{p->gamma1, p->gamma2, p->rstd1, p->rstd2, p->eps, p->K, p->m1, p->m2, p->dgamma1, p->dgamma2, p->dbeta2};
+    return EMD_OK;
+}
+
+// emd_bn_bwd_reduce[_images]_f32 + emd_bn_bwd_prep[_images]_f32 in two launches instead of three (round 4: the per-channel step runs in
+// the reduction's final kernel).  images = 0: batch form (vectors [C], npix = all pixels); images = B: per-image form.
+extern "C" int emd_bn_bwd_reduce_prep_f32(const float* dy, int ldd, const float* x, int ldx, const float* mean, const float* rstd,
+                                          const float* mscale, const float* mshift, int mask, int images, long npix, int C, float* s1,
+                                          float* s2, void* workspace, const emd_bn_bwd_prep_t* prep, emd_stream_t stream) {
+    emd::BnPrepArgs pa;
+    int rc = emd::bn_prep_args(prep, &pa);
+    if (rc != EMD_OK) return rc;
+    return bwd_reduce_impl(dy, ldd, x, ldx, mean, rstd, mscale, mshift, mask, images ? images : 1, npix, C, s1, s2, 0, workspace, stream, &pa);
 }
 
 static int bwd_apply_impl(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,

@@ -12,6 +12,7 @@
 // replaces: the gradient of slim.separable_convolution2d's depthwise stage w.r.t. its input followed by the gradient of
 //           _batch_norm_fn(is_training) + relu6 of the previous block (machine_learning/denoiser.py:110-136 under tf.gradients).
 #include "emd_common.hpp"
+#include "bn_chain_dev.hpp"
 
 namespace {
 
@@ -393,7 +394,14 @@ extern "C" size_t emd_dw3x3_bn_bwd_workspace_bytes(int B, int H, int W, int C) {
 extern "C" int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* mean,
                                            const float* rstd, const float* mscale, const float* mshift, int mask, int images, int B, int H,
                                            int W, int C, int stride, int rate, float* s1, float* s2, float* dw_consumer, void* workspace,
-                                           emd_stream_t stream) {
+                                           const emd_bn_bwd_prep_t* prep, emd_stream_t stream) {
+    // prep != NULL: emd_bn_bwd_prep[_images]_f32's per-channel step in the reduction's final kernel (one launch less)
+    emd::BnPrepArgs pa;
+    if (prep) {
+        int rcp = emd::bn_prep_args(prep, &pa);
+        if (rcp != EMD_OK) return rcp;
+    }
+    const emd::BnPrepArgs* pp = prep ? &pa : nullptr;
     EMD_REQUIRE((stride == 1 || stride == 2) && rate >= 1 && (rate == 1 || stride == 1), EMD_E_INVALID, "emd_dw3x3_bn_bwd_reduce_f32: stride 1 or 2; rate > 1 needs stride 1");
     EMD_REQUIRE(!dw_consumer || mask == 1, EMD_E_INVALID, "emd_dw3x3_bn_bwd_reduce_f32: the consumer's weight gradient needs the relu6 mask (x = relu6(r*mscale + mshift))");
     EMD_REQUIRE(w_flipped && mean && rstd && s1 && s2 && workspace, EMD_E_INVALID, "emd_dw3x3_bn_bwd_reduce_f32: null pointer");
@@ -411,9 +419,9 @@ extern "C" int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float
     if (rc != EMD_OK) return rc;
     const int TH = strip_height(H);
     const int nslab = (stride != 1 || rate != 1) ? gen_slabs((long)H * W) : ((H + TH - 1) / TH) * ((W + 15) / 16);
-    if (images) return emd::launch_chan_reduce_final(a.part, nslab, C, B, s1, s2, st);
+    if (images) return emd::launch_chan_reduce_final(a.part, nslab, C, B, s1, s2, st, pp, (long)H * W);
     // batch statistics: the B images' slabs are one list
-    return emd::launch_chan_reduce_final(a.part, nslab * B, C, 1, s1, s2, st);
+    return emd::launch_chan_reduce_final(a.part, nslab * B, C, 1, s1, s2, st, pp, (long)B * H * W);
 }
 
 // dr = K * (g - m1 - (r - mean) * m2), g as above: emd_dw3x3_f32(stride 1) followed by emd_bn_bwd_apply[_images]_f32; dr may be r.

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "mfma_common.hpp"
+#include "bn_chain_dev.hpp"
 
 namespace {
 
@@ -627,12 +628,15 @@ __global__ __launch_bounds__(256) void bn_stats_partial_v4(const float* __restri
 // FOLD: the batch norm that uses these statistics is folded right here as well (scale = gamma / sqrt(var + eps), shift = beta -
 // mean * scale, from the float mean / var exactly as bn_fold_kernel computes them): one launch instead of two between a GEMM
 // and the kernel that applies the norm (graph X has 63 such pairs on its critical path).
-template <bool FOLD>
+// TRAIN (round 4): the training-mode fold of the whole BN chain (bn_train_fold_kernel's step, bn_chain_dev.hpp: scale, shift, rstd1,
+// rstd2 and the moving-average updates from image 0) in the same launch.
+template <bool FOLD, bool TRAIN = false>
 __global__ __launch_bounds__(256) void bn_stats_final(const double* __restrict__ part, int nslab, int C, long npix,
                                                       float* __restrict__ mean, float* __restrict__ var,
                                                       const float* __restrict__ gamma = nullptr,
                                                       const float* __restrict__ beta = nullptr, float eps = 0.f,
-                                                      float* __restrict__ scale = nullptr, float* __restrict__ shift = nullptr) {
+                                                      float* __restrict__ scale = nullptr, float* __restrict__ shift = nullptr,
+                                                      emd::BnFoldArgs fa = emd::BnFoldArgs{}) {
     // 16 channels x 16 slab lanes per workgroup: the <= 512 slabs of a channel are summed by 16 lanes
     __shared__ double sm[2][16][16 + 1];
     part += (long)blockIdx.y * nslab * 2 * C;              // blockIdx.y = image
@@ -666,6 +670,7 @@ __global__ __launch_bounds__(256) void bn_stats_final(const double* __restrict__
         scale[c] = g;
         shift[c] = (beta ? beta[c] : 0.0f) - mf * g;
     }
+    if (TRAIN) emd::bn_train_fold_one(fa, (int)blockIdx.y * C + c, c, blockIdx.y == 0, mf, vf, (float)npix);
 }
 
 // scale = gamma / sqrt(var + eps) (gamma may be NULL = 1), shift = beta - mean*scale: a batch norm as one affine
@@ -792,8 +797,14 @@ int dw3x3_launch(const char* who, const float* x, int ldx, const float* w, float
 // second stage of the batch statistics (sum over `nslab` partials per channel, fixed order), for producers of partials
 // outside this file (the statistics epilogue of gemm_split.hip)
 int emd::launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st,
-                               const float* gamma, const float* beta, float eps, float* scale, float* shift, int images) {
+                               const float* gamma, const float* beta, float eps, float* scale, float* shift, int images,
+                               const emd::BnFoldArgs* train_fold) {
     // images > 1: per-image statistics -- `nslab` partials and `npix` pixels PER IMAGE, part [image][nslab][2][C], mean / var [image][C]
+    if (train_fold) {
+        hipLaunchKernelGGL((bn_stats_final<false, true>), dim3((C + 15) / 16, images > 1 ? images : 1), dim3(256), 0, st, part, nslab, C, npix, mean,
+                           var, nullptr, nullptr, 0.f, nullptr, nullptr, *train_fold);
+        return emd::check_launch("bn_stats_final<training fold>");
+    }
     if (scale)
         hipLaunchKernelGGL(bn_stats_final<true>, dim3((C + 15) / 16), dim3(256), 0, st, part, nslab, C, npix, mean, var, gamma, beta,
                            eps, scale, shift);

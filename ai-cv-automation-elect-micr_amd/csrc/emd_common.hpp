@@ -37,10 +37,16 @@ int launch_dw3x3_reflect_roll(const float* x, int ldx, const float* w, float* y,
 int launch_conv3x3_cout1_reflect_roll(const float* x, int ldx, const float* w, float bias, float* y, int B, int H, int W, int Cin,
                                       hipStream_t st);
 
-int launch_chan_reduce_final(const double* part, int nslab, int C, int B, float* s1, float* s2, hipStream_t st);   // bn_train.hip
+struct BnFoldArgs;   // bn_chain_dev.hpp
+struct BnPrepArgs;
+int bn_prep_args(const emd_bn_bwd_prep_t* p, BnPrepArgs* out);        // bn_train.hip: the public structs -> device argument blocks, checked
+int bn_fold_args(const emd_bn_train_fold_t* p, BnFoldArgs* out);
+// bn_train.hip; prep != NULL: bn_bwd_prep_kernel's per-channel step in the same launch (npix: pixels per reduction)
+int launch_chan_reduce_final(const double* part, int nslab, int C, int B, float* s1, float* s2, hipStream_t st, const BnPrepArgs* prep = nullptr,
+                             long npix = 0);
 int launch_bn_stats_final(const double* part, int nslab, int C, long npix, float* mean, float* var, hipStream_t st,
                           const float* gamma = nullptr, const float* beta = nullptr, float eps = 0.f, float* scale = nullptr,
-                          float* shift = nullptr, int images = 1);   // scale != NULL: the norm is folded in the same launch; images > 1 (no fold): per-image statistics
+                          float* shift = nullptr, int images = 1, const BnFoldArgs* train_fold = nullptr);   // scale != NULL: the norm is folded in the same launch; images > 1 (no fold): per-image statistics
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

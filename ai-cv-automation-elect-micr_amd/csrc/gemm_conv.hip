@@ -32,6 +32,7 @@
 // Block index -> tile mapping is XCD-aware: the N-tiles of one M-tile (which re-read the same
 // activation rows) get consecutive indices inside one XCD's share of the grid.
 #include "mfma_common.hpp"
+#include "bn_chain_dev.hpp"
 
 namespace {
 
@@ -504,7 +505,13 @@ extern "C" size_t emd_conv_stats_workspace_bytes(long M, int Cout) {
 }
 
 static int conv_stats_run(GemmParams& p, int B, long npix_img, int images, float* mean, float* var, void* workspace, int precision,
-                          emd_stream_t stream) {
+                          emd_stream_t stream, const emd_bn_train_fold_t* fold = nullptr) {
+    emd::BnFoldArgs fa;
+    if (fold) {
+        int rcf = emd::bn_fold_args(fold, &fa);
+        if (rcf != EMD_OK) return rcf;
+    }
+    const emd::BnFoldArgs* fp = fold ? &fa : nullptr;
     EMD_REQUIRE(mean && var && workspace && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0, EMD_E_INVALID,
                 "emd_conv*_stats_f32: mean, var and an 8-byte aligned workspace are required");
     EMD_REQUIRE(!images || npix_img % 128 == 0, EMD_E_UNSUPPORTED,
@@ -516,13 +523,14 @@ static int conv_stats_run(GemmParams& p, int B, long npix_img, int images, float
     if (rc != EMD_OK) return rc;
     if (images)
         return emd::launch_bn_stats_final(p.stats_part, (int)(npix_img / 128), p.N, npix_img, mean, var, st, nullptr, nullptr, 0.f, nullptr,
-                                          nullptr, B);
-    return emd::launch_bn_stats_final(p.stats_part, (int)((p.M + 127) / 128), p.N, p.M, mean, var, st);
+                                          nullptr, B, fp);
+    return emd::launch_bn_stats_final(p.stats_part, (int)((p.M + 127) / 128), p.N, p.M, mean, var, st, nullptr, nullptr, 0.f, nullptr, nullptr, 1, fp);
 }
 
-extern "C" int emd_conv1x1_stats_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones,
+static int conv1x1_stats_impl(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones,
                                      const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int stride,
-                                     int precision, int images, float* mean, float* var, void* workspace, emd_stream_t stream) {
+                                     int precision, int images, float* mean, float* var, void* workspace, emd_stream_t stream,
+                                     const emd_bn_train_fold_t* fold) {
     int rc = common_checks("emd_conv1x1_stats_f32", x, whi, wlo, ones, zeros, nullptr, nullptr, nullptr, y, Cin, Cout, ldx, ldy, 0,
                            precision);
     if (rc != EMD_OK) return rc;
@@ -538,12 +546,30 @@ extern "C" int emd_conv1x1_stats_f32(const float* x, int ldx, const uint16_t* wh
     p.flat = stride == 1;
     p.Hg = Ho; p.Wg = Wo; p.Ha = H; p.Wa = W; p.Hc = Ho; p.Wc = Wo; p.sa = stride; p.sc = 1; p.py = p.px = 0;
     set_taps(p, 1, nullptr, nullptr);
-    return conv_stats_run(p, B, (long)Ho * Wo, images, mean, var, workspace, precision, stream);
+    return conv_stats_run(p, B, (long)Ho * Wo, images, mean, var, workspace, precision, stream, fold);
 }
 
-extern "C" int emd_conv3x3_stats_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones,
-                                     const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int rate,
+extern "C" int emd_conv1x1_stats_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones,
+                                     const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int stride,
                                      int precision, int images, float* mean, float* var, void* workspace, emd_stream_t stream) {
+    return conv1x1_stats_impl(x, ldx, whi, wlo, ones, zeros, y, ldy, B, H, W, Cin, Cout, stride, precision, images, mean, var, workspace, stream,
+                              nullptr);
+}
+
+// ... and the training-mode fold of the norm behind it in the statistics' final kernel (emd_bn_train_fold[_images]_f32's step; one launch less)
+extern "C" int emd_conv1x1_stats_fold_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones,
+                                          const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int stride,
+                                          int precision, int images, float* mean, float* var, void* workspace,
+                                          const emd_bn_train_fold_t* fold, emd_stream_t stream) {
+    EMD_REQUIRE(fold, EMD_E_INVALID, "emd_conv1x1_stats_fold_f32: null fold block");
+    return conv1x1_stats_impl(x, ldx, whi, wlo, ones, zeros, y, ldy, B, H, W, Cin, Cout, stride, precision, images, mean, var, workspace, stream,
+                              fold);
+}
+
+static int conv3x3_stats_impl(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones,
+                                     const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int rate,
+                                     int precision, int images, float* mean, float* var, void* workspace, emd_stream_t stream,
+                                     const emd_bn_train_fold_t* fold) {
     int rc = common_checks("emd_conv3x3_stats_f32", x, whi, wlo, ones, zeros, nullptr, nullptr, nullptr, y, Cin, Cout, ldx, ldy, 0,
                            precision);
     if (rc != EMD_OK) return rc;
@@ -564,16 +590,39 @@ extern "C" int emd_conv3x3_stats_f32(const float* x, int ldx, const uint16_t* wh
             dx[ky * 3 + kx] = (kx - 1) * rate;
         }
     set_taps(p, 9, dy, dx);
-    return conv_stats_run(p, B, (long)H * W, images, mean, var, workspace, precision, stream);
+    return conv_stats_run(p, B, (long)H * W, images, mean, var, workspace, precision, stream, fold);
+}
+
+extern "C" int emd_conv3x3_stats_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones,
+                                     const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int rate,
+                                     int precision, int images, float* mean, float* var, void* workspace, emd_stream_t stream) {
+    return conv3x3_stats_impl(x, ldx, whi, wlo, ones, zeros, y, ldy, B, H, W, Cin, Cout, rate, precision, images, mean, var, workspace, stream,
+                              nullptr);
+}
+
+extern "C" int emd_conv3x3_stats_fold_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones,
+                                          const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int rate,
+                                          int precision, int images, float* mean, float* var, void* workspace,
+                                          const emd_bn_train_fold_t* fold, emd_stream_t stream) {
+    EMD_REQUIRE(fold, EMD_E_INVALID, "emd_conv3x3_stats_fold_f32: null fold block");
+    return conv3x3_stats_impl(x, ldx, whi, wlo, ones, zeros, y, ldy, B, H, W, Cin, Cout, rate, precision, images, mean, var, workspace, stream,
+                              fold);
 }
 
 // The transposed 3x3 stride-2 conv of a training forward pass (emd_deconv3x3s2_f32 with no affine, no activation) + the batch statistics of
 // its output from the four phase GEMMs' epilogues: mean / var [Cout] over all B * 2H * 2W output pixels, or images != 0: [B][Cout] per
 // image (needs H * W % 128 == 0).  workspace: emd_conv_stats_workspace_bytes(4 * B * H * W, Cout) bytes.
-extern "C" int emd_deconv3x3s2_stats_f32(const float* x, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4], const float* ones,
+static int deconv_stats_impl(const float* x, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4], const float* ones,
                                          const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int precision,
-                                         int images, float* mean, float* var, void* workspace, emd_stream_t stream) {
+                                         int images, float* mean, float* var, void* workspace, emd_stream_t stream,
+                                         const emd_bn_train_fold_t* fold) {
     EMD_REQUIRE(whi, EMD_E_INVALID, "emd_deconv3x3s2_stats_f32: null weight table");
+    emd::BnFoldArgs fa;
+    if (fold) {
+        int rcf = emd::bn_fold_args(fold, &fa);
+        if (rcf != EMD_OK) return rcf;
+    }
+    const emd::BnFoldArgs* fp = fold ? &fa : nullptr;
     for (int ph = 0; ph < 4; ++ph) {
         int rc = common_checks("emd_deconv3x3s2_stats_f32", x, whi[ph], wlo ? wlo[ph] : nullptr, ones, zeros, nullptr, nullptr, nullptr, y,
                                Cin, Cout, ldx, ldy, 0, precision);
@@ -612,8 +661,23 @@ extern "C" int emd_deconv3x3s2_stats_f32(const float* x, int ldx, const uint16_t
     }
     if (images)
         return emd::launch_bn_stats_final(static_cast<const double*>(workspace), 4 * (int)(npix_in / 128), Cout, 4 * npix_in, mean, var, st, nullptr,
-                                          nullptr, 0.f, nullptr, nullptr, B);
-    return emd::launch_bn_stats_final(static_cast<const double*>(workspace), 4 * n_mt, Cout, 4 * M, mean, var, st);
+                                          nullptr, 0.f, nullptr, nullptr, B, fp);
+    return emd::launch_bn_stats_final(static_cast<const double*>(workspace), 4 * n_mt, Cout, 4 * M, mean, var, st, nullptr, nullptr, 0.f, nullptr,
+                                      nullptr, 1, fp);
+}
+
+extern "C" int emd_deconv3x3s2_stats_f32(const float* x, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4], const float* ones,
+                                         const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int precision,
+                                         int images, float* mean, float* var, void* workspace, emd_stream_t stream) {
+    return deconv_stats_impl(x, ldx, whi, wlo, ones, zeros, y, ldy, B, H, W, Cin, Cout, precision, images, mean, var, workspace, stream, nullptr);
+}
+
+extern "C" int emd_deconv3x3s2_stats_fold_f32(const float* x, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4],
+                                              const float* ones, const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout,
+                                              int precision, int images, float* mean, float* var, void* workspace,
+                                              const emd_bn_train_fold_t* fold, emd_stream_t stream) {
+    EMD_REQUIRE(fold, EMD_E_INVALID, "emd_deconv3x3s2_stats_fold_f32: null fold block");
+    return deconv_stats_impl(x, ldx, whi, wlo, ones, zeros, y, ldy, B, H, W, Cin, Cout, precision, images, mean, var, workspace, stream, fold);
 }
 
 // Data gradient of the stride-2 1x1 convolution: dx[b, 2i, 2j, :] (+)= dy[b, i, j, :] * W^T, the other pixels of dx

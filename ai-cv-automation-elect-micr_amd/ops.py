@@ -125,7 +125,7 @@ def conv_stats_supported(x: Act, stride=1, images=False):
     return (not images) or (Ho * Wo) % 128 == 0
 
 
-def conv_stats(x: Act, w: PackedWeights, ones, zeros, out: Act, stride=1, rate=1, images=False, precision=PREC_BF16X3, stream=None):
+def conv_stats(x: Act, w: PackedWeights, ones, zeros, out: Act, stride=1, rate=1, images=False, precision=PREC_BF16X3, stream=None, fold=None):
     """out = conv(x) (1x1, stride 1 / 2; or dense 3x3 with dilation `rate`: by w.taps), no affine, no activation, and the batch
     statistics of out from the GEMM's epilogue -> (mean, var): [Cout], or [B][Cout] flattened with images=True."""
     import torch
@@ -137,19 +137,26 @@ def conv_stats(x: Act, w: PackedWeights, ones, zeros, out: Act, stride=1, rate=1
     mean = torch.empty(n, dtype=torch.float32, device=x.buf.device)
     var = torch.empty_like(mean)
     ws = torch.empty(max(lib.emd_conv_stats_workspace_bytes(x.B * Ho * Wo, w.cout) // 8, 1), dtype=torch.float64, device=x.buf.device)
+    # fold: a train_ops.FoldRequest -- the training-mode fold of the norm behind the conv runs in the statistics' final kernel too
     if w.taps == 1:
-        rc = lib.emd_conv1x1_stats_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(ones), _p(zeros), out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout,
-                                       stride, precision, 1 if images else 0, _p(mean), _p(var), _p(ws), _lib.stream_ptr(stream))
-        _lib.check(rc, "emd_conv1x1_stats_f32")
+        args = (x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(ones), _p(zeros), out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, stride, precision,
+                1 if images else 0, _p(mean), _p(var), _p(ws))
+        if fold is not None:
+            _lib.check(lib.emd_conv1x1_stats_fold_f32(*args, C.byref(fold.struct), _lib.stream_ptr(stream)), "emd_conv1x1_stats_fold_f32")
+        else:
+            _lib.check(lib.emd_conv1x1_stats_f32(*args, _lib.stream_ptr(stream)), "emd_conv1x1_stats_f32")
     else:
         assert stride == 1
-        rc = lib.emd_conv3x3_stats_f32(x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(ones), _p(zeros), out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout,
-                                       rate, precision, 1 if images else 0, _p(mean), _p(var), _p(ws), _lib.stream_ptr(stream))
-        _lib.check(rc, "emd_conv3x3_stats_f32")
+        args = (x.ptr, x.ld, _p(w.hi), _p(w.lo), _p(ones), _p(zeros), out.ptr, out.ld, x.B, x.H, x.W, x.C, w.cout, rate, precision,
+                1 if images else 0, _p(mean), _p(var), _p(ws))
+        if fold is not None:
+            _lib.check(lib.emd_conv3x3_stats_fold_f32(*args, C.byref(fold.struct), _lib.stream_ptr(stream)), "emd_conv3x3_stats_fold_f32")
+        else:
+            _lib.check(lib.emd_conv3x3_stats_f32(*args, _lib.stream_ptr(stream)), "emd_conv3x3_stats_f32")
     return mean, var
 
 
-def deconv_stats(x: Act, w_phases, ones, zeros, out: Act, images=False, precision=PREC_BF16X3, stream=None):
+def deconv_stats(x: Act, w_phases, ones, zeros, out: Act, images=False, precision=PREC_BF16X3, stream=None, fold=None):
     """out = deconv3x3s2(x), no affine, no activation, and the batch statistics of out from the four phase GEMMs' epilogues
     (emd_deconv3x3s2_stats_f32) -> (mean, var): [Cout], or [B][Cout] flattened with images=True (needs x.H * x.W % 128 == 0)."""
     import torch
@@ -163,9 +170,12 @@ def deconv_stats(x: Act, w_phases, ones, zeros, out: Act, images=False, precisio
     mean = torch.empty(n, dtype=torch.float32, device=x.buf.device)
     var = torch.empty_like(mean)
     ws = torch.empty(max(lib.emd_conv_stats_workspace_bytes(4 * x.B * x.H * x.W, cout) // 8, 1), dtype=torch.float64, device=x.buf.device)
-    rc = lib.emd_deconv3x3s2_stats_f32(x.ptr, x.ld, hi, lo, _p(ones), _p(zeros), out.ptr, out.ld, x.B, x.H, x.W, x.C, cout, precision,
-                                       1 if images else 0, _p(mean), _p(var), _p(ws), _lib.stream_ptr(stream))
-    _lib.check(rc, "emd_deconv3x3s2_stats_f32")
+    args = (x.ptr, x.ld, hi, lo, _p(ones), _p(zeros), out.ptr, out.ld, x.B, x.H, x.W, x.C, cout, precision, 1 if images else 0, _p(mean), _p(var),
+            _p(ws))
+    if fold is not None:
+        _lib.check(lib.emd_deconv3x3s2_stats_fold_f32(*args, C.byref(fold.struct), _lib.stream_ptr(stream)), "emd_deconv3x3s2_stats_fold_f32")
+    else:
+        _lib.check(lib.emd_deconv3x3s2_stats_f32(*args, _lib.stream_ptr(stream)), "emd_deconv3x3s2_stats_f32")
     return mean, var
 
 

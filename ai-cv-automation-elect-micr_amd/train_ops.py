@@ -150,6 +150,43 @@ def bn_train_fold(mean, var, gamma2, beta2, npix, gamma1=None, beta1=None, bias=
     return {"scale": scale, "shift": shift, "rstd1": rstd1, "rstd2": rstd2, "mean": mean}
 
 
+class FoldRequest:
+    """The argument block (emd_bn_train_fold_t) for the convolutions that run bn_train_fold's per-channel step in their statistics' final
+    kernel (ops.conv_stats / ops.deconv_stats with fold=...): outputs allocated here, ``result(mean)`` = the dict bn_train_fold returns."""
+
+    def __init__(self, device, images, Cc, gamma2, beta2, gamma1=None, beta1=None, bias=None, moving=None, eps=BN_EPS, decay=BN_DECAY):
+        import torch
+
+        n = (images or 1) * Cc
+        self.images = images
+        self.scale, self.shift, self.rstd1 = (torch.empty(n, dtype=torch.float32, device=device) for _ in range(3))
+        self.rstd2 = torch.empty(n, dtype=torch.float32, device=device) if gamma1 is not None else None
+        mm1 = mv1 = mm2 = mv2 = None
+        if moving is not None:
+            if gamma1 is not None:
+                mm1, mv1, mm2, mv2 = moving
+            else:
+                mm2, mv2 = moving
+        self._keep = (gamma1, beta1, gamma2, beta2, bias, mm1, mv1, mm2, mv2)
+        q = lambda t: t.data_ptr() if t is not None else None
+        self.struct = _lib.BnTrainFold(q(gamma1), q(beta1), q(gamma2), q(beta2), q(bias), eps, 0.0, q(self.scale), q(self.shift), q(self.rstd1),
+                                       q(self.rstd2), q(mm1), q(mv1), q(mm2), q(mv2), decay)
+
+    def result(self, mean):
+        d = {"scale": self.scale, "shift": self.shift, "rstd1": self.rstd1, "rstd2": self.rstd2, "mean": mean}
+        if self.images:
+            d["B"] = self.images
+        return d
+
+
+FUSE_PREP = __import__("os").environ.get("EMD_T_FUSE_PREP", "1") == "1"   # bn_bwd_prep's per-channel step inside the reduction's final kernel
+
+
+def _prep_struct(fold, gamma1, gamma2, eps, K, m1, m2, dgamma1, dgamma2, dbeta2):
+    q = lambda t: t.data_ptr() if t is not None else None
+    return _lib.BnBwdPrep(q(gamma1), q(gamma2), q(fold["rstd1"]), q(fold["rstd2"]), eps, 0.0, q(K), q(m1), q(m2), q(dgamma1), q(dgamma2), q(dbeta2))
+
+
 def bn_small_supported(r: Act):
     """The one-launch training batch norm (emd_bn_train_fwd_small_f32 / _bwd_small_f32) takes per-image maps of up to 4096 pixels."""
     return bool(_lib.load().emd_bn_train_small_supported(C.c_long(r.H * r.W), r.C)) and r.ld % 4 == 0
@@ -213,34 +250,39 @@ def bn_backward(dy: Act, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MA
     Cc = dy.C
     assert (r.B, r.H, r.W, r.C) == (dy.B, dy.H, dy.W, Cc) and (dr.B, dr.H, dr.W, dr.C) == (dy.B, dy.H, dy.W, Cc)
     dev = dy.buf.device
-    if fold.get("B"):   # per-image statistics: B one-image towers as one batched pass
-        B, npix = dy.B, dy.H * dy.W
-        assert fold["B"] == B
-        s1, t = torch.empty(B * Cc, dtype=torch.float32, device=dev), torch.empty(B * Cc, dtype=torch.float32, device=dev)
-        ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
-        ws = torch.empty(max(B * (lib.emd_chan_reduce_workspace_bytes(npix, Cc) // 8), 1), dtype=torch.float64, device=dev)
-        _lib.check(lib.emd_bn_bwd_reduce_images_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(fold["mean"]), _p(fold["rstd1"]), _p(ms), _p(mh), mask,
-                                                    B, C.c_long(npix), Cc, _p(s1), _p(t), _p(ws), _lib.stream_ptr(stream)),
-                   "emd_bn_bwd_reduce_images_f32")
-        K, m1, m2 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
-        _lib.check(lib.emd_bn_bwd_prep_images_f32(_p(s1), _p(t), _p(gamma1), _p(gamma2), _p(fold["rstd1"]), _p(fold["rstd2"]),
-                                                  C.c_float(eps), C.c_long(npix), B, Cc, _p(K), _p(m1), _p(m2), _p(dgamma1), _p(dgamma2),
-                                                  _p(dbeta2), _lib.stream_ptr(stream)), "emd_bn_bwd_prep_images_f32")
-        _lib.check(lib.emd_bn_bwd_apply_images_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(K), _p(m1), _p(fold["mean"]), _p(m2), _p(ms), _p(mh),
-                                                   mask, dr.ptr, dr.ld, B, C.c_long(npix), Cc, _lib.stream_ptr(stream)),
-                   "emd_bn_bwd_apply_images_f32")
-        return dr
-    npix = dy.B * dy.H * dy.W
-    s1, t = torch.empty(Cc, dtype=torch.float32, device=dev), torch.empty(Cc, dtype=torch.float32, device=dev)
+    images = int(fold.get("B") or 0)   # per-image statistics: B one-image towers as one batched pass
+    assert images in (0, dy.B)
+    n = (images or 1) * Cc
+    npix = dy.H * dy.W if images else dy.B * dy.H * dy.W
+    s1, t = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
     ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
-    chan_reduce(dy, s1, r, fold["mean"], fold["rstd1"], t, ms, mh, mask, stream=stream)
     K, m1, m2 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
-    _lib.check(lib.emd_bn_bwd_prep_f32(_p(s1), _p(t), _p(gamma1), _p(gamma2), _p(fold["rstd1"]), _p(fold["rstd2"]),
-                                       C.c_float(eps), C.c_long(npix), Cc, _p(K), _p(m1), _p(m2), _p(dgamma1), _p(dgamma2),
-                                       _p(dbeta2), _lib.stream_ptr(stream)), "emd_bn_bwd_prep_f32")
-    _lib.check(lib.emd_bn_bwd_apply_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(K), _p(m1), _p(fold["mean"]), _p(m2), _p(ms), _p(mh),
-                                        mask, dr.ptr, dr.ld, C.c_long(npix), Cc, _lib.stream_ptr(stream)),
-               "emd_bn_bwd_apply_f32")
+    ws = torch.empty(max((images or 1) * (lib.emd_chan_reduce_workspace_bytes(npix, Cc) // 8), 1), dtype=torch.float64, device=dev)
+    if FUSE_PREP:   # the per-channel step inside the reduction's final kernel
+        prep = _prep_struct(fold, gamma1, gamma2, eps, K, m1, m2, dgamma1, dgamma2, dbeta2)
+        _lib.check(lib.emd_bn_bwd_reduce_prep_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(fold["mean"]), _p(fold["rstd1"]), _p(ms), _p(mh), mask, images,
+                                                  C.c_long(npix), Cc, _p(s1), _p(t), _p(ws), C.byref(prep), _lib.stream_ptr(stream)),
+                   "emd_bn_bwd_reduce_prep_f32")
+    elif images:
+        _lib.check(lib.emd_bn_bwd_reduce_images_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(fold["mean"]), _p(fold["rstd1"]), _p(ms), _p(mh), mask,
+                                                    images, C.c_long(npix), Cc, _p(s1), _p(t), _p(ws), _lib.stream_ptr(stream)),
+                   "emd_bn_bwd_reduce_images_f32")
+        _lib.check(lib.emd_bn_bwd_prep_images_f32(_p(s1), _p(t), _p(gamma1), _p(gamma2), _p(fold["rstd1"]), _p(fold["rstd2"]),
+                                                  C.c_float(eps), C.c_long(npix), images, Cc, _p(K), _p(m1), _p(m2), _p(dgamma1), _p(dgamma2),
+                                                  _p(dbeta2), _lib.stream_ptr(stream)), "emd_bn_bwd_prep_images_f32")
+    else:
+        chan_reduce(dy, s1, r, fold["mean"], fold["rstd1"], t, ms, mh, mask, stream=stream)
+        _lib.check(lib.emd_bn_bwd_prep_f32(_p(s1), _p(t), _p(gamma1), _p(gamma2), _p(fold["rstd1"]), _p(fold["rstd2"]),
+                                           C.c_float(eps), C.c_long(npix), Cc, _p(K), _p(m1), _p(m2), _p(dgamma1), _p(dgamma2),
+                                           _p(dbeta2), _lib.stream_ptr(stream)), "emd_bn_bwd_prep_f32")
+    if images:
+        _lib.check(lib.emd_bn_bwd_apply_images_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(K), _p(m1), _p(fold["mean"]), _p(m2), _p(ms), _p(mh),
+                                                   mask, dr.ptr, dr.ld, images, C.c_long(npix), Cc, _lib.stream_ptr(stream)),
+                   "emd_bn_bwd_apply_images_f32")
+    else:
+        _lib.check(lib.emd_bn_bwd_apply_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(K), _p(m1), _p(fold["mean"]), _p(m2), _p(ms), _p(mh),
+                                            mask, dr.ptr, dr.ld, C.c_long(npix), Cc, _lib.stream_ptr(stream)),
+                   "emd_bn_bwd_apply_f32")
     return dr
 
 
@@ -280,12 +322,15 @@ def bn_backward_dw(dy: DwGrad, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, m
     s1, t = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
     ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
     ws = torch.empty(max(lib.emd_dw3x3_bn_bwd_workspace_bytes(dy.B, dy.H, dy.W, Cc) // 8, 1), dtype=torch.float64, device=dev)
+    K, m1, m2 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
+    prep = _prep_struct(fold, gamma1, gamma2, eps, K, m1, m2, dgamma1, dgamma2, dbeta2) if FUSE_PREP else None
     _lib.check(lib.emd_dw3x3_bn_bwd_reduce_f32(dd.ptr, dd.ld, _p(dy.w), r.ptr, r.ld, _p(fold["mean"]), _p(fold["rstd1"]), _p(ms), _p(mh), mask,
                                                1 if images else 0, dy.B, dy.H, dy.W, Cc, dy.stride, dy.rate, _p(s1), _p(t), _p(dy.gdw), _p(ws),
-                                               _lib.stream_ptr(stream)),
+                                               C.byref(prep) if prep is not None else None, _lib.stream_ptr(stream)),
                "emd_dw3x3_bn_bwd_reduce_f32")
-    K, m1, m2 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
-    if images:
+    if prep is not None:
+        pass
+    elif images:
         _lib.check(lib.emd_bn_bwd_prep_images_f32(_p(s1), _p(t), _p(gamma1), _p(gamma2), _p(fold["rstd1"]), _p(fold["rstd2"]),
                                                   C.c_float(eps), C.c_long(npix), images, Cc, _p(K), _p(m1), _p(m2), _p(dgamma1), _p(dgamma2),
                                                   _p(dbeta2), _lib.stream_ptr(stream)), "emd_bn_bwd_prep_images_f32")

@@ -132,6 +132,7 @@ class DenoiserTrainer:
         self.fuse_dw_bn_bwd_s2 = os.environ.get("EMD_T_DW_BN_BWD_S2", "0") == "1"
         self.fuse_dw_both = os.environ.get("EMD_T_DW_BOTH", "1") == "1"     # a written input: the depthwise stage's two gradients in one pass over dd
         self.fuse_dw_wgrad = os.environ.get("EMD_T_DW_WGRAD", "1") == "1"   # ... whose reduction pass also adds the consumer's depthwise weight gradient
+        self.fuse_fold = os.environ.get("EMD_T_FUSE_FOLD", "1") == "1"    # the BN fold inside the statistics' final kernel (with fuse_stats)
         self.fuse_stats = os.environ.get("EMD_T_FUSE_STATS", "1") == "1"   # batch statistics from the producing GEMM's epilogue (ops.conv_stats)
         self.teacher = None   # test hook: scope -> {"d": ..., "r": ...} reference tensors that REPLACE the forward's conv outputs (see _force)
         self.repack()
@@ -264,6 +265,8 @@ class DenoiserTrainer:
         var) when the producing convolution has delivered them already (ops.conv_stats: the GEMM's epilogue)."""
         L = self.layers[key]
         img = r.B if self._per_image else 0    # per-image statistics: B one-image towers as one batched pass
+        if stats is not None and len(stats) == 3:   # (mean, var, fold): the conv's final statistics kernel ran the fold too (_fold_req)
+            return stats[2]
         if stats is not None:
             mean, var = stats
             npix = r.H * r.W if img else r.B * r.H * r.W
@@ -284,6 +287,25 @@ class DenoiserTrainer:
         mv = (self.m[b2 + "/moving_mean"], self.m[b2 + "/moving_variance"]) if upd else None
         return TO.bn_train_fold(mean, var, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], npix,
                                 bias=self.v[bias_name] if bias_name else None, moving=mv, images=img)
+
+    def _fold_req(self, key, B, bias_name=None):
+        """The fold of layer `key`'s BN chain as a request to the convolution that delivers its statistics (TO.FoldRequest; round 4: the
+        per-channel step runs in the statistics' final kernel -- one launch less per layer), or None (EMD_T_FUSE_FOLD=0)."""
+        if not self.fuse_fold:
+            return None
+        L = self.layers[key]
+        upd = self._update_moving
+        img = B if self._per_image else 0
+        if len(L.bn) == 2:
+            b1, b2 = L.bn
+            mv = (self.m[b1 + "/moving_mean"], self.m[b1 + "/moving_variance"], self.m[b2 + "/moving_mean"],
+                  self.m[b2 + "/moving_variance"]) if upd else None
+            return TO.FoldRequest(self.device, img, L.cout, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], gamma1=self.v[b1 + "/gamma"],
+                                  beta1=self.v[b1 + "/beta"], moving=mv)
+        (b2,) = L.bn
+        mv = (self.m[b2 + "/moving_mean"], self.m[b2 + "/moving_variance"]) if upd else None
+        return TO.FoldRequest(self.device, img, L.cout, self.v[b2 + "/gamma"], self.v[b2 + "/beta"],
+                              bias=self.v[bias_name] if bias_name else None, moving=mv)
 
     def _bn_small_shape(self, npix_img, cout, B):
         """The one-launch forms of the norm (train_ops.bn_train_fwd_small / bn_backward_small) for the small per-image maps (32 x 32,
@@ -358,7 +380,10 @@ class DenoiserTrainer:
         small = self._bn_small_shape(Ho * Wo, L.cout, x.B)   # the one-launch norm takes its own statistics
         if not small and self._fuse_stats(d):     # the batch statistics of r from the pointwise GEMM's epilogue: no second pass over r
             r = self._E(x.B, Ho, Wo, L.cout)
-            stats = ops.conv_stats(d, self.pk_f[key], self.ones, self.zeros, r, images=self._per_image, precision=self.precision)
+            fq = self._fold_req(key, x.B)
+            stats = ops.conv_stats(d, self.pk_f[key], self.ones, self.zeros, r, images=self._per_image, precision=self.precision, fold=fq)
+            if fq is not None:
+                stats = (stats[0], stats[1], fq.result(stats[0]))
         else:
             r = ops.conv1x1(d, self.pk_f[key], self.ones, self.zeros, self._E(x.B, Ho, Wo, L.cout), act=False,
                             precision=self.precision)
@@ -386,8 +411,11 @@ class DenoiserTrainer:
         stats = None
         small = has_bn and self._bn_small_shape(Ho * Wo, L.cout, x.B)
         if has_bn and not small and (L.k == 1 or L.stride == 1) and self._fuse_stats(x, L.stride):
+            fq = self._fold_req(key, x.B, L.scope + "/" + L.bname)
             stats = ops.conv_stats(x, self.pk_f[key], self.ones, self.zeros, tgt, stride=L.stride, rate=L.rate, images=self._per_image,
-                                   precision=self.precision)
+                                   precision=self.precision, fold=fq)
+            if fq is not None:
+                stats = (stats[0], stats[1], fq.result(stats[0]))
         elif L.k == 1:
             ops.conv1x1(x, self.pk_f[key], self.ones, shift, tgt, stride=L.stride, act=False, precision=self.precision)
         else:
@@ -409,7 +437,10 @@ class DenoiserTrainer:
         stats = None
         if self._fuse_stats(x):    # the batch statistics of r from the four phase GEMMs' epilogues (per image: whole 128-row tiles of the INPUT grid)
             r = self._E(x.B, 2 * x.H, 2 * x.W, L.cout)
-            stats = ops.deconv_stats(x, self.pk_f[key], self.ones, self.zeros, r, images=self._per_image, precision=self.precision)
+            fq = self._fold_req(key, x.B, L.scope + "/" + L.bname)
+            stats = ops.deconv_stats(x, self.pk_f[key], self.ones, self.zeros, r, images=self._per_image, precision=self.precision, fold=fq)
+            if fq is not None:
+                stats = (stats[0], stats[1], fq.result(stats[0]))
         else:
             r = ops.deconv3x3s2(x, self.pk_f[key], self.ones, self.zeros, self._E(x.B, 2 * x.H, 2 * x.W, L.cout), act=False,
                                 precision=self.precision)

@@ -96,6 +96,26 @@ int emd_kernel_denoise_f32(const float* x, float* y, int B, int H, int W, int wi
 #define EMD_ACT_LEAKY 4 /* tf.nn.leaky_relu, alpha 0.2: misc_py/gan-infilling-100.py:178 (matrix-core epilogues, emd_affine_act_f32) */
 #define EMD_ACT_RELU6_CLIP01 3 /* relu6 then tf.clip_by_value(.,0,1), misc_py/denoiser-multi-gpu.py:534-538 (emd_affine_act_f32 only) */
 
+/* Round 4: the two per-channel steps of the chain can run inside the kernel that finishes the reduction in front of them (one launch
+ * less per layer and direction: ~700 launches of 4-5 us per training step, each a link in its stream's dependent chain).  The argument
+ * blocks (host structs; every pointer a device pointer; [C], or [B][C] in the per-image forms, exactly as the separate calls take them):
+ *   emd_bn_train_fold_t: emd_bn_train_fold[_images]_f32's parameters and outputs  -> emd_conv1x1_stats_fold_f32, emd_conv3x3_stats_fold_f32,
+ *                        emd_deconv3x3s2_stats_fold_f32 (the conv, its output's statistics AND the fold: mean / var are still written)
+ *   emd_bn_bwd_prep_t:   emd_bn_bwd_prep[_images]_f32's                            -> emd_bn_bwd_reduce_prep_f32, emd_dw3x3_bn_bwd_reduce_f32 */
+typedef struct {
+    const float *gamma1, *beta1, *gamma2, *beta2, *bias;   /* gamma1 / beta1 NULL: a single norm; bias NULL or the conv bias in front of it */
+    float eps, pad_;
+    float *scale, *shift, *rstd1, *rstd2;                  /* outputs (rstd2: the double norm only) */
+    float *mm1, *mv1, *mm2, *mv2;                          /* moving statistics to update from image 0 / the batch, or all NULL */
+    double decay;
+} emd_bn_train_fold_t;
+typedef struct {
+    const float *gamma1, *gamma2, *rstd1, *rstd2;
+    float eps, pad_;
+    float *K, *m1, *m2;                                    /* outputs for the apply step */
+    float *dgamma1, *dgamma2, *dbeta2;                     /* parameter gradients, ADDED into */
+} emd_bn_bwd_prep_t;
+
 /* Host-side weight packing for the matrix-core kernels (all pointers are HOST pointers).
  * w_host : taps x Cin x Cout float32 in TensorFlow order, [taps][Cin][Cout] (slim.conv2d /
  *          pointwise_weights, cout_major = 0) or [taps][Cout][Cin] (slim.conv2d_transpose, cout_major = 1).
@@ -339,6 +359,17 @@ int emd_conv3x3_stats_f32(const float* x, int ldx, const uint16_t* whi, const ui
 int emd_deconv3x3s2_stats_f32(const float* x, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4], const float* ones,
                               const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int precision, int images,
                               float* mean, float* var, void* workspace, emd_stream_t stream);
+/* The three above with the training-mode fold of the norm behind the conv in the statistics' final kernel (emd_bn_train_fold[_images]_f32's
+ * step: scale, shift, rstd1, rstd2, moving-average updates; mean / var are written as well): one launch less per layer. */
+int emd_conv1x1_stats_fold_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones, const float* zeros, float* y,
+                               int ldy, int B, int H, int W, int Cin, int Cout, int stride, int precision, int images, float* mean, float* var,
+                               void* workspace, const emd_bn_train_fold_t* fold, emd_stream_t stream);
+int emd_conv3x3_stats_fold_f32(const float* x, int ldx, const uint16_t* whi, const uint16_t* wlo, const float* ones, const float* zeros, float* y,
+                               int ldy, int B, int H, int W, int Cin, int Cout, int rate, int precision, int images, float* mean, float* var,
+                               void* workspace, const emd_bn_train_fold_t* fold, emd_stream_t stream);
+int emd_deconv3x3s2_stats_fold_f32(const float* x, int ldx, const uint16_t* const whi[4], const uint16_t* const wlo[4], const float* ones,
+                                   const float* zeros, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int precision, int images,
+                                   float* mean, float* var, void* workspace, const emd_bn_train_fold_t* fold, emd_stream_t stream);
 int emd_affine_act_images_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
                               float* y, int ldy, int B, long npix_img, int C, int act, emd_stream_t stream);
 /* y = act(x*scale + shift) + res_act(res*res_scale + res_shift): the residual operand given BEFORE its own affine + activation (round 4,
@@ -415,6 +446,9 @@ int emd_conv1x1_s2_bwd_data_f32(const float* dy, int ldd, const uint16_t* whi, c
  *   accumulate_s1 != 0: s1 += (bias gradients).  workspace: emd_chan_reduce_workspace_bytes(npix, C) bytes.
  * emd_bn_bwd_prep_f32: (s1, t=s2) -> K, m1, m2 for the apply step; dgamma1, dgamma2, dbeta2 += .
  * emd_bn_bwd_apply_f32: dx = K*(g - m1 - (x-mean)*m2); dx may be dy.  C = 1 is allowed (the final layer). */
+int emd_bn_bwd_reduce_prep_f32(const float* dy, int ldd, const float* x, int ldx, const float* mean, const float* rstd, const float* mscale,
+                               const float* mshift, int mask, int images, long npix, int C, float* s1, float* s2, void* workspace,
+                               const emd_bn_bwd_prep_t* prep, emd_stream_t stream);
 size_t emd_chan_reduce_workspace_bytes(long npix, int C);
 int emd_bn_train_fold_f32(const float* mean, const float* var, const float* gamma1, const float* beta1, const float* gamma2,
                           const float* beta2, const float* bias, float eps, long npix, int C, float* scale, float* shift,
@@ -489,7 +523,8 @@ int emd_dw3x3_bwd_data_f32(const float* dy, int ldd, const float* w, float* dx, 
 size_t emd_dw3x3_bn_bwd_workspace_bytes(int B, int H, int W, int C);
 int emd_dw3x3_bn_bwd_reduce_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* mean,
                                 const float* rstd, const float* mscale, const float* mshift, int mask, int images, int B, int H, int W,
-                                int C, int stride, int rate, float* s1, float* s2, float* dw_consumer, void* workspace, emd_stream_t stream);
+                                int C, int stride, int rate, float* s1, float* s2, float* dw_consumer, void* workspace,
+                                const emd_bn_bwd_prep_t* prep /* or NULL */, emd_stream_t stream);
 int emd_dw3x3_bn_bwd_apply_f32(const float* dd, int ldd, const float* w_flipped, const float* r, int ldr, const float* K, const float* m1,
                                const float* mean, const float* m2, const float* mscale, const float* mshift, int mask, int images,
                                float* dr, int ldo, int B, int H, int W, int C, int stride, int rate, emd_stream_t stream);

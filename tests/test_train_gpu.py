@@ -314,7 +314,7 @@ def test_affine_in_the_consumers_loads_changes_nothing():
     (lazy_affine = False): outputs, losses and moving statistics bit for bit (the loads rebuild affine_relu6_kernel's bits), the
     accumulated gradient to the run-to-run spread of its float atomics.  A tower of several images (batch statistics) and a batched
     pass of one-image towers (per-image statistics)."""
-    from emdenoise import trainer as TR
+    from emdenoise import train_ops as TO, trainer as TR
 
     S, B = 64, 3
     w = weights()
@@ -329,9 +329,16 @@ def test_affine_in_the_consumers_loads_changes_nothing():
             assert tr.lazy_affine and tr.fuse_dw_bn_bwd and tr.fuse_dw_wgrad and tr.fuse_dw_both
             tr.lazy_affine, tr.fuse_dw_bn_bwd, tr.fuse_dw_wgrad = mode
             tr.fuse_dw_both = mode[0]     # (the two depthwise gradients of a written input in one pass: on with the default only)
-            tr.zero_grad()
-            o, r = tr.tower(x, t, update_moving=True, per_image=per_image)
-            torch.cuda.synchronize()
+            # the per-channel steps of the BN chain inside the kernels that finish the reductions in front of them (emd_*_stats_fold_f32,
+            # emd_bn_bwd_reduce_prep_f32): off in the all-written-out form
+            assert tr.fuse_fold and TO.FUSE_PREP
+            tr.fuse_fold = TO.FUSE_PREP = mode[0]
+            try:
+                tr.zero_grad()
+                o, r = tr.tower(x, t, update_moving=True, per_image=per_image)
+                torch.cuda.synchronize()
+            finally:
+                TO.FUSE_PREP = True
             res[mode] = (o.clone(), r.clone(), tr.moving.clone(), tr.grads.detach().cpu().numpy().astype(np.float64))
         ref = res[(False, False, False)]
         for mode in ((True, True, True), (True, True, False), (True, False, False)):
