@@ -211,6 +211,12 @@ SIGNATURES = {
     # dd ldd w_flipped r ldr mean rstd mscale mshift mask images B H W C stride rate s1 s2 dw_consumer workspace prep stream
     "emd_dw3x3_bn_bwd_reduce_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, _c_float_p, C.c_int] + [_c_float_p] * 4 + [C.c_int] * 8
                                     + [_c_float_p, _c_float_p, _c_float_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # g1 w9 B H W x ldx mean rstd mscale mshift mask images C s1 s2 workspace prep stream
+    "emd_bn_bwd_reduce_prep_cout1_f32": (C.c_int, [_c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int, _c_float_p, C.c_int] + [_c_float_p] * 4
+                                         + [C.c_int] * 3 + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # g1 w9 B H W x ldx K m1 mean m2 mscale mshift mask images dx ldo C stream
+    "emd_bn_bwd_apply_cout1_f32": (C.c_int, [_c_float_p, _c_float_p, C.c_int, C.c_int, C.c_int, _c_float_p, C.c_int] + [_c_float_p] * 6
+                                   + [C.c_int, C.c_int, _c_float_p, C.c_int, C.c_int, C.c_void_p]),
     # dy ldd x ldx mean rstd mscale mshift mask images npix C s1 s2 workspace prep stream
     "emd_bn_bwd_reduce_prep_f32": (C.c_int, [_c_float_p, C.c_int, _c_float_p, C.c_int] + [_c_float_p] * 4 + [C.c_int, C.c_int, C.c_long, C.c_int]
                                    + [_c_float_p, _c_float_p, C.c_void_p, C.c_void_p, C.c_void_p]),

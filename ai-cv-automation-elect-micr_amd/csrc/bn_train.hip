@@ -24,6 +24,35 @@ __device__ __forceinline__ float grad_mask(float dy, float z, int mask) {
     return dy;
 }
 
+// Round 4: dy given as the data gradient of a 3x3 conv to ONE output channel (the network's final conv: dy[p][c] = sum_taps g1[p + (1-ky,
+// 1-kx)] * w9[ky*3+kx][c], TF SAME) -- never written; formed here from the 1-channel image g1 in dw_bwd_data_kernel<true>'s order (its bits).
+struct Cout1Src {
+    const float* g1;   // [images][H*W] (NULL: dy is a tensor)
+    const float* w9;   // [9][C]
+    int H, W;
+};
+__device__ __forceinline__ float4 cout1_dy(const Cout1Src& s, const float4 (&wk)[9], long r) {
+    const long HW = (long)s.H * s.W;
+    const long img = r / HW;
+    const int rem = (int)(r - img * HW), iy = rem / s.W, ix = rem - iy * s.W;
+    const float* gi = s.g1 + img * HW;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ny = iy + 1 - ky;
+        if (ny < 0 || ny >= s.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int nx = ix + 1 - kx;
+            if (nx < 0 || nx >= s.W) continue;
+            const float g = gi[(long)ny * s.W + nx];
+            const float4 w = wk[ky * 3 + kx];
+            acc = make_float4(fmaf(w.x, g, acc.x), fmaf(w.y, g, acc.y), fmaf(w.z, g, acc.z), fmaf(w.w, g, acc.w));
+        }
+    }
+    return acc;
+}
+
 // s1[c] = sum_pix g,  s2[c] = sum_pix g * (x-mean[c])*rstd[c];  g = dy * mask(x*mscale[c] + mshift[c]).
 // Two passes, double accumulation (as the forward statistics in dw_misc.hip).
 __global__ __launch_bounds__(256) void chan_reduce_partial(const float* __restrict__ dy, int ldd,
@@ -72,11 +101,12 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ mscale, const float* __restrict__ mshift,
                                                               int mask, long npix, int C, long rows_per_slab,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, Cout1Src c1 = Cout1Src{nullptr, nullptr, 0, 0}) {
     // per-image form (gridDim.z images of npix pixels each, per-image statistics vectors [B][C]): image b = blockIdx.z
     {
         const long b = blockIdx.z;
-        dy += b * npix * ldd;
+        if (c1.g1) c1.g1 += b * npix;
+        else dy += b * npix * ldd;
         if (x) { x += b * npix * ldx; mean += b * C; rstd += b * C; }
         if (mask) { mscale += b * C; mshift += b * C; }
         part += b * (long)gridDim.y * 2 * C;
@@ -95,9 +125,14 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
             if (x) { mu[k] = mean[c + k]; rs[k] = rstd[c + k]; }
             if (mask) { ms[k] = mscale[c + k]; mh[k] = mshift[c + k]; }
         }
+        float4 wk[9];
+        if (c1.g1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(c1.w9 + k * C + c);
+        }
 #pragma unroll 4
         for (long r = r0 + rl; r < r1; r += 16) {
-            const float4 d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
+            const float4 d = c1.g1 ? cout1_dy(c1, wk, r) : *reinterpret_cast<const float4*>(dy + r * ldd + c);
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (x) xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
             const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -170,11 +205,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
                                                            const float* __restrict__ K, const float* __restrict__ m1,
                                                            const float* __restrict__ mean, const float* __restrict__ m2,
                                                            const float* __restrict__ mscale, const float* __restrict__ mshift,
-                                                           int mask, float* dx, int ldo, long npix, int CV) {
+                                                           int mask, float* dx, int ldo, long npix, int CV,
+                                                           Cout1Src c1 = Cout1Src{nullptr, nullptr, 0, 0}) {
     constexpr int ROWS = V == 4 ? 8 : 1;
     {   // per-image form: image b = blockIdx.y, npix pixels per image, per-image vectors [B][C]
         const long b = blockIdx.y;
-        dy += b * npix * ldd; x += b * npix * ldx; dx += b * npix * ldo;
+        if (c1.g1) c1.g1 += b * npix;
+        else dy += b * npix * ldd;
+        x += b * npix * ldx; dx += b * npix * ldo;
         K += b * CV * V; m1 += b * CV * V; mean += b * CV * V; m2 += b * CV * V;
         if (mask) { mscale += b * CV * V; mshift += b * CV * V; }
     }
@@ -189,13 +227,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
         kk[k] = K[c + k]; mm1[k] = m1[c + k]; mu[k] = mean[c + k]; mm2[k] = m2[c + k];
         ms[k] = mask ? mscale[c + k] : 0.f; mh[k] = mask ? mshift[c + k] : 0.f;
     }
+    float4 wk[9];
+    if constexpr (V == 4) {
+        if (c1.g1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(c1.w9 + k * (CV * 4) + c);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
         const long r = r0 + i;
         if (r >= npix) break;
         float dd[V], xx[V], o[V];
         if constexpr (V == 4) {
-            const float4 d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
+            const float4 d = c1.g1 ? cout1_dy(c1, wk, r) : *reinterpret_cast<const float4*>(dy + r * ldd + c);
             const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
             dd[0] = d.x; dd[1] = d.y; dd[2] = d.z; dd[3] = d.w;
             xx[0] = xv.x; xx[1] = xv.y; xx[2] = xv.z; xx[3] = xv.w;
@@ -475,8 +520,11 @@ extern "C" size_t emd_chan_reduce_workspace_bytes(long npix, int C) {
 // towers (misc_py/denoiser-multi-gpu.py:763) can run as one batched pass with identical arithmetic per image.
 static int bwd_reduce_impl(const float* dy, int ldd, const float* x, int ldx, const float* mean, const float* rstd,
                            const float* mscale, const float* mshift, int mask, int B, long npix, int C, float* s1, float* s2,
-                           int accumulate_s1, void* workspace, emd_stream_t stream, const emd::BnPrepArgs* prep = nullptr) {
-    EMD_REQUIRE(dy && s1 && workspace, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: null pointer");
+                           int accumulate_s1, void* workspace, emd_stream_t stream, const emd::BnPrepArgs* prep = nullptr,
+                           Cout1Src c1 = Cout1Src{nullptr, nullptr, 0, 0}) {
+    EMD_REQUIRE((dy || c1.g1) && s1 && workspace, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: null pointer");
+    EMD_REQUIRE(!c1.g1 || (c1.w9 && x && C % 4 == 0 && ldx % 4 == 0 && emd::aligned16(x) && emd::aligned16(c1.w9) && c1.H >= 1 && c1.W >= 1 &&
+                           npix % ((long)c1.H * c1.W) == 0), EMD_E_INVALID, "emd_bn_bwd_reduce_prep_cout1_f32: bad argument");
     EMD_REQUIRE(!prep || (x && !accumulate_s1), EMD_E_INVALID, "emd_bn_bwd_reduce_prep_f32: the per-channel step needs x (both sums)");
     EMD_REQUIRE(B >= 1 && B <= 65535 && npix >= 1 && C >= 1 && mask >= 0 && mask <= 3, EMD_E_INVALID, "emd_bn_bwd_reduce_f32: bad argument");
     EMD_REQUIRE(!x || (mean && rstd && s2), EMD_E_INVALID, "emd_bn_bwd_reduce_f32: x needs mean, rstd and s2");
@@ -485,9 +533,9 @@ static int bwd_reduce_impl(const float* dy, int ldd, const float* x, int ldx, co
     const long ns = emd::reduce_slabs(npix), rps = emd::reduce_rows_per_slab(npix);
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
-    if (C % 4 == 0 && ldd % 4 == 0 && (!x || ldx % 4 == 0) && emd::aligned16(dy) && (!x || emd::aligned16(x)))
+    if (c1.g1 || (C % 4 == 0 && ldd % 4 == 0 && (!x || ldx % 4 == 0) && emd::aligned16(dy) && (!x || emd::aligned16(x))))
         hipLaunchKernelGGL(chan_reduce_partial_v4, dim3((C + 63) / 64, (unsigned)ns, (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, mean,
-                           rstd, mscale, mshift, mask, npix, C, rps, ws);
+                           rstd, mscale, mshift, mask, npix, C, rps, ws, c1);
     else
         hipLaunchKernelGGL(chan_reduce_partial, dim3((C + 63) / 64, (unsigned)ns, (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, mean,
                            rstd, mscale, mshift, mask, npix, C, rps, ws);
@@ -555,17 +603,21 @@ extern "C" int emd_bn_bwd_reduce_prep_f32(const float* dy, int ldd, const float*
 
 static int bwd_apply_impl(const float* dy, int ldd, const float* x, int ldx, const float* K, const float* m1,
                           const float* mean, const float* m2, const float* mscale, const float* mshift,
-                          int mask, float* dx, int ldo, int B, long npix, int C, emd_stream_t stream) {
-    EMD_REQUIRE(dy && x && K && m1 && mean && m2 && dx, EMD_E_INVALID, "emd_bn_bwd_apply_f32: null pointer");
+                          int mask, float* dx, int ldo, int B, long npix, int C, emd_stream_t stream,
+                          Cout1Src c1 = Cout1Src{nullptr, nullptr, 0, 0}) {
+    EMD_REQUIRE((dy || c1.g1) && x && K && m1 && mean && m2 && dx, EMD_E_INVALID, "emd_bn_bwd_apply_f32: null pointer");
+    EMD_REQUIRE(!c1.g1 || (c1.w9 && C % 4 == 0 && emd::aligned16(c1.w9) && c1.H >= 1 && c1.W >= 1 && npix % ((long)c1.H * c1.W) == 0),
+                EMD_E_INVALID, "emd_bn_bwd_apply_cout1_f32: bad argument");
     EMD_REQUIRE(B >= 1 && B <= 65535 && npix >= 1 && C >= 1 && mask >= 0 && mask <= 3 && (!mask || (mscale && mshift)), EMD_E_INVALID,
                 "emd_bn_bwd_apply_f32: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (C % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && emd::aligned16(dy) && emd::aligned16(x) &&
+    if (C % 4 == 0 && (c1.g1 || (ldd % 4 == 0 && emd::aligned16(dy))) && ldx % 4 == 0 && ldo % 4 == 0 && emd::aligned16(x) &&
         emd::aligned16(dx)) {
         const long n = ((npix + 7) / 8) * (C / 4);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, K,
-                           m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C / 4);
+                           m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C / 4, c1);
     } else {
+        EMD_REQUIRE(!c1.g1, EMD_E_ALIGN, "emd_bn_bwd_apply_cout1_f32: C, pitches multiples of 4; 16-byte aligned tensors");
         const long n = npix * C;
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, K,
                            m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C);
@@ -583,6 +635,29 @@ extern "C" int emd_bn_bwd_apply_images_f32(const float* dy, int ldd, const float
                                            const float* mean, const float* m2, const float* mscale, const float* mshift,
                                            int mask, float* dx, int ldo, int B, long npix, int C, emd_stream_t stream) {
     return bwd_apply_impl(dy, ldd, x, ldx, K, m1, mean, m2, mscale, mshift, mask, dx, ldo, B, npix, C, stream);
+}
+
+// The two passes for a gradient that is the data gradient of a 3x3 conv to one output channel (the final conv): dy never exists.
+// g1 [B][H][W] (images = B: per-image vectors, else one reduction over all B images), w9 [9][C] the conv's weights.
+extern "C" int emd_bn_bwd_reduce_prep_cout1_f32(const float* g1, const float* w9, int B, int H, int W, const float* x, int ldx, const float* mean,
+                                                const float* rstd, const float* mscale, const float* mshift, int mask, int images, int C,
+                                                float* s1, float* s2, void* workspace, const emd_bn_bwd_prep_t* prep, emd_stream_t stream) {
+    EMD_REQUIRE(g1 && B >= 1 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_bn_bwd_reduce_prep_cout1_f32: bad argument");
+    emd::BnPrepArgs pa;
+    int rc = emd::bn_prep_args(prep, &pa);
+    if (rc != EMD_OK) return rc;
+    const long hw = (long)H * W;
+    return bwd_reduce_impl(nullptr, 0, x, ldx, mean, rstd, mscale, mshift, mask, images ? B : 1, images ? hw : hw * B, C, s1, s2, 0, workspace, stream,
+                           &pa, Cout1Src{g1, w9, H, W});
+}
+
+extern "C" int emd_bn_bwd_apply_cout1_f32(const float* g1, const float* w9, int B, int H, int W, const float* x, int ldx, const float* K,
+                                          const float* m1, const float* mean, const float* m2, const float* mscale, const float* mshift,
+                                          int mask, int images, float* dx, int ldo, int C, emd_stream_t stream) {
+    EMD_REQUIRE(g1 && B >= 1 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_bn_bwd_apply_cout1_f32: bad argument");
+    const long hw = (long)H * W;
+    return bwd_apply_impl(nullptr, 0, x, ldx, K, m1, mean, m2, mscale, mshift, mask, dx, ldo, images ? B : 1, images ? hw : hw * B, C, stream,
+                          Cout1Src{g1, w9, H, W});
 }
 
 static int train_fold_impl(const float* mean, const float* var, const float* gamma1, const float* beta1,

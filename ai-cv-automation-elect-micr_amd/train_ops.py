@@ -249,7 +249,7 @@ def bn_backward(dy: Act, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MA
     lib = _lib.load()
     Cc = dy.C
     assert (r.B, r.H, r.W, r.C) == (dy.B, dy.H, dy.W, Cc) and (dr.B, dr.H, dr.W, dr.C) == (dy.B, dy.H, dy.W, Cc)
-    dev = dy.buf.device
+    dev = r.buf.device
     images = int(fold.get("B") or 0)   # per-image statistics: B one-image towers as one batched pass
     assert images in (0, dy.B)
     n = (images or 1) * Cc
@@ -258,6 +258,15 @@ def bn_backward(dy: Act, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MA
     ms, mh = (fold["scale"], fold["shift"]) if mask else (None, None)
     K, m1, m2 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
     ws = torch.empty(max((images or 1) * (lib.emd_chan_reduce_workspace_bytes(npix, Cc) // 8), 1), dtype=torch.float64, device=dev)
+    if isinstance(dy, Cout1Grad):
+        prep = _prep_struct(fold, gamma1, gamma2, eps, K, m1, m2, dgamma1, dgamma2, dbeta2)
+        _lib.check(lib.emd_bn_bwd_reduce_prep_cout1_f32(_p(dy.g1), _p(dy.w9), dy.B, dy.H, dy.W, r.ptr, r.ld, _p(fold["mean"]), _p(fold["rstd1"]),
+                                                        _p(ms), _p(mh), mask, 1 if images else 0, Cc, _p(s1), _p(t), _p(ws), C.byref(prep),
+                                                        _lib.stream_ptr(stream)), "emd_bn_bwd_reduce_prep_cout1_f32")
+        _lib.check(lib.emd_bn_bwd_apply_cout1_f32(_p(dy.g1), _p(dy.w9), dy.B, dy.H, dy.W, r.ptr, r.ld, _p(K), _p(m1), _p(fold["mean"]), _p(m2),
+                                                  _p(ms), _p(mh), mask, 1 if images else 0, dr.ptr, dr.ld, Cc, _lib.stream_ptr(stream)),
+                   "emd_bn_bwd_apply_cout1_f32")
+        return dr
     if FUSE_PREP:   # the per-channel step inside the reduction's final kernel
         prep = _prep_struct(fold, gamma1, gamma2, eps, K, m1, m2, dgamma1, dgamma2, dbeta2)
         _lib.check(lib.emd_bn_bwd_reduce_prep_f32(dy.ptr, dy.ld, r.ptr, r.ld, _p(fold["mean"]), _p(fold["rstd1"]), _p(ms), _p(mh), mask, images,
@@ -284,6 +293,18 @@ def bn_backward(dy: Act, r: Act, fold, gamma2, dgamma2, dbeta2, dr: Act, mask=MA
                                             mask, dr.ptr, dr.ld, C.c_long(npix), Cc, _lib.stream_ptr(stream)),
                    "emd_bn_bwd_apply_f32")
     return dr
+
+
+class Cout1Grad:
+    """A gradient that was never written: the data gradient of the 3x3 conv to one output channel (the final conv), dy[p][c] = sum_taps
+    g1[p + (1-ky, 1-kx)] * w9[tap][c]; bn_backward forms it from the 1-channel image g1 [B,H,W,1] in both of its passes."""
+
+    __slots__ = ("g1", "w9", "B", "H", "W", "C")
+
+    def __init__(self, g1, w9):
+        assert g1.dim() == 4 and g1.shape[3] == 1 and g1.is_contiguous() and w9.is_contiguous() and w9.shape[0] == 9
+        self.g1, self.w9 = g1, w9
+        self.B, self.H, self.W, self.C = g1.shape[0], g1.shape[1], g1.shape[2], w9.shape[1]
 
 
 class DwGrad:

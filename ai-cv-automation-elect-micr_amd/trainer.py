@@ -132,6 +132,10 @@ class DenoiserTrainer:
         self.fuse_dw_bn_bwd_s2 = os.environ.get("EMD_T_DW_BN_BWD_S2", "0") == "1"
         self.fuse_dw_both = os.environ.get("EMD_T_DW_BOTH", "1") == "1"     # a written input: the depthwise stage's two gradients in one pass over dd
         self.fuse_dw_wgrad = os.environ.get("EMD_T_DW_WGRAD", "1") == "1"   # ... whose reduction pass also adds the consumer's depthwise weight gradient
+        # the final conv's data gradient formed on the fly in its two consumers' BN backward (TO.Cout1Grad): correct, tested, and measured
+        # SLOWER (44.4-44.5 ms per step against 43.0-43.2: nine conditional scalar loads per pixel, four times, cost more than the five
+        # passes over a 64-channel 512^2 tensor they replace); opt-in
+        self.fuse_cout1_grad = os.environ.get("EMD_T_COUT1_GRAD", "0") == "1"
         self.fuse_fold = os.environ.get("EMD_T_FUSE_FOLD", "1") == "1"    # the BN fold inside the statistics' final kernel (with fuse_stats)
         self.fuse_stats = os.environ.get("EMD_T_FUSE_STATS", "1") == "1"   # batch statistics from the producing GEMM's epilogue (ops.conv_stats)
         self.teacher = None   # test hook: scope -> {"d": ..., "r": ...} reference tensors that REPLACE the forward's conv outputs (see _force)
@@ -752,7 +756,11 @@ class DenoiserTrainer:
                              self.g[Lf.bn[0] + "/beta"], st.rfa, mask=TO.MASK_RELU6_CLIP)
         deconv0 = st.deconv0
         self._wg(lambda: TO.conv3x3_cout1_wgrad(deconv0, drf.buf, self.g[Lf.scope + "/" + Lf.wname].view(9, f0)))
-        self._put(G, deconv0, lambda dst: TO.conv3x3_cout1_bwd_data(drf.buf, st.wf, dst))
+        if self.fuse_cout1_grad and self.teacher is None and self._wg_side is None and not self.fuse_bn_small:
+            # the final conv's data gradient is never written: deconv0_b's and residual0_d's BN backward form it from drf (TO.Cout1Grad)
+            G[self._gkey(deconv0)] = TO.Cout1Grad(drf.buf, st.wf)
+        else:
+            self._put(G, deconv0, lambda dst: TO.conv3x3_cout1_bwd_data(drf.buf, st.wf, dst))
         # decoder 0: deconv0 = sep_b(sep_a(deconv1to0)) + residual0_d(deconv1to0)
         g = grad(deconv0)
         self._sep_bwd("deconv0_b", g, C["deconv0_b"], G)

@@ -449,6 +449,15 @@ int emd_conv1x1_s2_bwd_data_f32(const float* dy, int ldd, const uint16_t* whi, c
 int emd_bn_bwd_reduce_prep_f32(const float* dy, int ldd, const float* x, int ldx, const float* mean, const float* rstd, const float* mscale,
                                const float* mshift, int mask, int images, long npix, int C, float* s1, float* s2, void* workspace,
                                const emd_bn_bwd_prep_t* prep, emd_stream_t stream);
+/* The reduction (+ per-channel step) and the apply pass for a gradient that is the data gradient of a 3x3 conv to ONE output channel (the
+ * network's final conv, :528-532): dy[p][c] = sum_taps g1[p + (1-ky, 1-kx)] * w9[3ky+kx][c] is formed from the 1-channel image g1 [B][H][W]
+ * in both passes and never written (emd_conv3x3_cout1_bwd_data_f32's arithmetic).  images != 0: per-image vectors [B][C]. */
+int emd_bn_bwd_reduce_prep_cout1_f32(const float* g1, const float* w9, int B, int H, int W, const float* x, int ldx, const float* mean,
+                                     const float* rstd, const float* mscale, const float* mshift, int mask, int images, int C, float* s1,
+                                     float* s2, void* workspace, const emd_bn_bwd_prep_t* prep, emd_stream_t stream);
+int emd_bn_bwd_apply_cout1_f32(const float* g1, const float* w9, int B, int H, int W, const float* x, int ldx, const float* K, const float* m1,
+                               const float* mean, const float* m2, const float* mscale, const float* mshift, int mask, int images, float* dx,
+                               int ldo, int C, emd_stream_t stream);
 size_t emd_chan_reduce_workspace_bytes(long npix, int C);
 int emd_bn_train_fold_f32(const float* mean, const float* var, const float* gamma1, const float* beta1, const float* gamma2,
                           const float* beta2, const float* bias, float eps, long npix, int C, float* scale, float* shift,

@@ -331,8 +331,9 @@ def test_affine_in_the_consumers_loads_changes_nothing():
             tr.fuse_dw_both = mode[0]     # (the two depthwise gradients of a written input in one pass: on with the default only)
             # the per-channel steps of the BN chain inside the kernels that finish the reductions in front of them (emd_*_stats_fold_f32,
             # emd_bn_bwd_reduce_prep_f32): off in the all-written-out form
-            assert tr.fuse_fold and TO.FUSE_PREP
+            assert tr.fuse_fold and TO.FUSE_PREP and not tr.fuse_cout1_grad
             tr.fuse_fold = TO.FUSE_PREP = mode[0]
+            tr.fuse_cout1_grad = mode == (True, True, False)     # (opt-in: the final conv's data gradient never written, TO.Cout1Grad)
             try:
                 tr.zero_grad()
                 o, r = tr.tower(x, t, update_moving=True, per_image=per_image)

@@ -751,3 +751,39 @@ def test_both_depthwise_gradients_in_one_pass(B, H, W, Cc):
     torch.cuda.synchronize()
     assert torch.equal(dx.buf, want_dx.buf)
     assert (got_dw - want_dw).abs().max().item() < 2e-5 * want_dw.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,W,Cc,images,double_bn", [(2, 24, 40, 64, True, True), (3, 16, 16, 24, False, False)])
+def test_bn_backward_of_the_final_convs_data_gradient(B, H, W, Cc, images, double_bn):
+    """TO.bn_backward on a TO.Cout1Grad (emd_bn_bwd_reduce_prep_cout1_f32 / emd_bn_bwd_apply_cout1_f32: the 3x3-to-one-channel conv's data
+    gradient formed from the 1-channel image in both passes) == emd_conv3x3_cout1_bwd_data_f32 written out, then TO.bn_backward: dr bit for
+    bit where the sums agree (same slabs, same order: they do), parameter gradients to the atomics' spread."""
+    from emdenoise import ops, train_ops as TO
+
+    g = torch.Generator(device=dev()).manual_seed(13)
+    rn = lambda *sh: torch.randn(*sh, device=dev(), generator=g)
+    r0 = rn(B, H, W, Cc) * 2
+    g1 = rn(B, H, W, 1).contiguous()
+    w9 = (rn(9, Cc) * 0.3).contiguous()
+    gamma2, beta2 = torch.rand(Cc, device=dev(), generator=g) + 0.5, rn(Cc)
+    gamma1, beta1 = (torch.rand(Cc, device=dev(), generator=g) + 0.5, rn(Cc)) if double_bn else (None, None)
+    mean, var = (ops.bn_batch_stats_images if images else ops.bn_batch_stats)(ops.Act(r0.clone()))
+    fold = TO.bn_train_fold(mean, var, gamma2, beta2, H * W if images else B * H * W, gamma1=gamma1, beta1=beta1, images=B if images else 0)
+    outs = {}
+    for fused in (False, True):
+        r = ops.Act(r0.clone())
+        dg2, db2 = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
+        dg1 = torch.zeros(Cc, device=dev()) if double_bn else None
+        if fused:
+            dy = TO.Cout1Grad(g1, w9)
+        else:
+            dy = TO.conv3x3_cout1_bwd_data(g1, w9, ops.Act.empty(B, H, W, Cc, dev()))
+        TO.bn_backward(dy, r, fold, gamma2, dg2, db2, r, mask=TO.MASK_RELU6, gamma1=gamma1, dgamma1=dg1)
+        torch.cuda.synchronize()
+        outs[fused] = (r.buf.clone(), dg2, db2, dg1)
+    a, b = outs[True], outs[False]
+    assert not torch.isnan(a[0]).any()
+    assert torch.equal(a[0], b[0])
+    for u, v in zip(a[1:], b[1:]):
+        if u is not None:
+            assert (u - v).abs().max().item() < 1e-5 * max(v.abs().max().item(), 1e-3)
