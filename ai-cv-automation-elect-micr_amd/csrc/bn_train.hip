@@ -162,29 +162,51 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
     }
 }
 
-// do_prep: the per-channel step bn_bwd_prep_kernel would run next (K, m1, m2 and the parameter gradients) in the same launch
+// do_prep: the per-channel step bn_bwd_prep_kernel would run next (K, m1, m2 and the parameter gradients) in the same launch.
+// CL channels x (256 / CL) slab lanes per workgroup (16 x 16 originally; 4 / 1 channels for the long partial lists of the large maps: the
+// fused depthwise-gradient reduction delivers 1 024 per 512^2 image and a 64-channel layer had four workgroups; see bn_stats_final).
+inline int reduce_final_cl(int nslab) { return nslab < 128 ? 16 : (nslab < 1024 ? 4 : 1); }
+template <int CL>
 __global__ __launch_bounds__(256) void chan_reduce_final(const double* __restrict__ part, int nslab, int C,
                                                          float* __restrict__ s1, float* __restrict__ s2, int accumulate,
                                                          int do_prep, emd::BnPrepArgs pa, float inv_n) {
-    // 16 channels x 16 slab lanes per workgroup; per-image form: image b = blockIdx.y
-    __shared__ double sm[2][16][16 + 1];
-    {
+    constexpr int SL = 256 / CL;
+    __shared__ double sm[2][SL][CL + 1];
+    {   // per-image form: image b = blockIdx.y
         const long b = blockIdx.y;
         part += b * (long)nslab * 2 * C;
         s1 += b * C;
         if (s2) s2 += b * C;
     }
-    const int l = threadIdx.x & 15, k0 = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + l;
+    const int l = threadIdx.x % CL, k0 = threadIdx.x / CL;
+    const int c = blockIdx.x * CL + l;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int k = k0; k < nslab; k += 16) {
+        for (int k = k0; k < nslab; k += SL) {
             s += part[((long)k * 2 + 0) * C + c];
             q += part[((long)k * 2 + 1) * C + c];
         }
     sm[0][k0][l] = s;
     sm[1][k0][l] = q;
     __syncthreads();
+    if constexpr (SL > 16) {
+        if (k0 < 16) {
+            double s2v = 0.0, q2v = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < SL / 16; ++k) {
+                s2v += sm[0][k0 * (SL / 16) + k][l];
+                q2v += sm[1][k0 * (SL / 16) + k][l];
+            }
+            s = s2v;
+            q = q2v;
+        }
+        __syncthreads();
+        if (k0 < 16) {
+            sm[0][k0][l] = s;
+            sm[1][k0][l] = q;
+        }
+        __syncthreads();
+    }
     if (k0 != 0 || c >= C) return;
     s = q = 0.0;
 #pragma unroll
@@ -196,6 +218,19 @@ __global__ __launch_bounds__(256) void chan_reduce_final(const double* __restric
     else s1[c] = (float)s;
     if (s2) s2[c] = (float)q;
     if (do_prep) emd::bn_bwd_prep_one(pa, (int)blockIdx.y * C + c, c, (float)s, (float)q, inv_n);
+}
+
+static void launch_final(const double* part, int nslab, int C, int B, float* s1, float* s2, int accumulate, const emd::BnPrepArgs* prep, float inv_n,
+                         hipStream_t st) {
+    const int cl = reduce_final_cl(nslab);
+    const emd::BnPrepArgs pa = prep ? *prep : emd::BnPrepArgs{};
+    const int dp = prep ? 1 : 0;
+    if (cl == 16)
+        hipLaunchKernelGGL(chan_reduce_final<16>, dim3((C + 15) / 16, (unsigned)B), dim3(256), 0, st, part, nslab, C, s1, s2, accumulate, dp, pa, inv_n);
+    else if (cl == 4)
+        hipLaunchKernelGGL(chan_reduce_final<4>, dim3((C + 3) / 4, (unsigned)B), dim3(256), 0, st, part, nslab, C, s1, s2, accumulate, dp, pa, inv_n);
+    else
+        hipLaunchKernelGGL(chan_reduce_final<1>, dim3(C, (unsigned)B), dim3(256), 0, st, part, nslab, C, s1, s2, accumulate, dp, pa, inv_n);
 }
 
 // dx = K * ( g - m1 - (x-mean)*m2 ),  g = dy * mask(x*mscale + mshift); dx may alias dy (elementwise).
@@ -539,8 +574,7 @@ static int bwd_reduce_impl(const float* dy, int ldd, const float* x, int ldx, co
     else
         hipLaunchKernelGGL(chan_reduce_partial, dim3((C + 63) / 64, (unsigned)ns, (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, mean,
                            rstd, mscale, mshift, mask, npix, C, rps, ws);
-    hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16, (unsigned)B), dim3(256), 0, st, static_cast<const double*>(ws), (int)ns, C, s1,
-                       x ? s2 : nullptr, accumulate_s1, prep ? 1 : 0, prep ? *prep : emd::BnPrepArgs{}, 1.0f / (float)npix);
+    launch_final(static_cast<const double*>(ws), (int)ns, C, B, s1, x ? s2 : nullptr, accumulate_s1, prep, 1.0f / (float)npix, st);
     return emd::check_launch("chan_reduce");
 }
 
@@ -561,12 +595,7 @@ int emd::launch_chan_reduce_final(const double* part, int nslab, int C, int B, f
                                   const emd::BnPrepArgs* prep, long npix) {
     EMD_REQUIRE(part && s1 && nslab >= 1 && C >= 1 && B >= 1 && B <= 65535, EMD_E_INVALID, "chan_reduce_final: bad argument");
     EMD_REQUIRE(!prep || (s2 && npix >= 1), EMD_E_INVALID, "chan_reduce_final: the per-channel step needs both sums and the pixel count");
-    if (prep)
-        hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16, (unsigned)B), dim3(256), 0, st, part, nslab, C, s1, s2, 0, 1, *prep,
-                           1.0f / (float)npix);
-    else
-        hipLaunchKernelGGL(chan_reduce_final, dim3((C + 15) / 16, (unsigned)B), dim3(256), 0, st, part, nslab, C, s1, s2, 0, 0, emd::BnPrepArgs{},
-                           0.f);
+    launch_final(part, nslab, C, B, s1, s2, 0, prep, prep ? 1.0f / (float)npix : 0.f, st);
     return emd::check_launch("chan_reduce_final");
 }
 

@@ -630,29 +630,53 @@ __global__ __launch_bounds__(256) void bn_stats_partial_v4(const float* __restri
 // and the kernel that applies the norm (graph X has 63 such pairs on its critical path).
 // TRAIN (round 4): the training-mode fold of the whole BN chain (bn_train_fold_kernel's step, bn_chain_dev.hpp: scale, shift, rstd1,
 // rstd2 and the moving-average updates from image 0) in the same launch.
-template <bool FOLD, bool TRAIN = false>
+inline int final_cl(int nslab) { return nslab < 128 ? 16 : (nslab < 1024 ? 4 : 1); }   // channels per workgroup of bn_stats_final
+// CL channels x (256 / CL) slab lanes per workgroup.  CL = 16 is the original geometry (<= 512 slabs of a channel summed by 16 lanes); the
+// statistics epilogues of the GEMMs deliver one partial per 128-row tile -- 2 048 per 512^2 image -- and with 16 channels per workgroup a
+// 64-channel layer had FOUR workgroups walking 128-256 dependent rounds: 87 us behind a 53 us GEMM (tools/small_gemm_bench.py, round 4).
+// CL = 4 / 1 (launch rule: final_cl) give those layers 16 / 64 workgroups of 64 / 256 lanes.  The order of the sum depends on CL, which
+// depends on nslab only: an image alone and the same image in a batch still get the same bits.
+template <bool FOLD, bool TRAIN = false, int CL = 16>
 __global__ __launch_bounds__(256) void bn_stats_final(const double* __restrict__ part, int nslab, int C, long npix,
                                                       float* __restrict__ mean, float* __restrict__ var,
                                                       const float* __restrict__ gamma = nullptr,
                                                       const float* __restrict__ beta = nullptr, float eps = 0.f,
                                                       float* __restrict__ scale = nullptr, float* __restrict__ shift = nullptr,
                                                       emd::BnFoldArgs fa = emd::BnFoldArgs{}) {
-    // 16 channels x 16 slab lanes per workgroup: the <= 512 slabs of a channel are summed by 16 lanes
-    __shared__ double sm[2][16][16 + 1];
+    constexpr int SL = 256 / CL;
+    __shared__ double sm[2][SL][CL + 1];
     part += (long)blockIdx.y * nslab * 2 * C;              // blockIdx.y = image
     mean += (long)blockIdx.y * C;
     var += (long)blockIdx.y * C;
-    const int l = threadIdx.x & 15, k0 = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + l;
+    const int l = threadIdx.x % CL, k0 = threadIdx.x / CL;
+    const int c = blockIdx.x * CL + l;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int k = k0; k < nslab; k += 16) {
+        for (int k = k0; k < nslab; k += SL) {
             s += part[((long)k * 2 + 0) * C + c];
             q += part[((long)k * 2 + 1) * C + c];
         }
     sm[0][k0][l] = s;
     sm[1][k0][l] = q;
     __syncthreads();
+    if constexpr (SL > 16) {   // SL lanes -> 16 (lane j takes the SL / 16 consecutive entries from j * SL / 16), then as before
+        if (k0 < 16) {
+            double s2 = 0.0, q2 = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < SL / 16; ++k) {
+                s2 += sm[0][k0 * (SL / 16) + k][l];
+                q2 += sm[1][k0 * (SL / 16) + k][l];
+            }
+            s = s2;
+            q = q2;
+        }
+        __syncthreads();
+        if (k0 < 16) {
+            sm[0][k0][l] = s;
+            sm[1][k0][l] = q;
+        }
+        __syncthreads();
+    }
     if (k0 != 0 || c >= C) return;
     s = q = 0.0;
 #pragma unroll
@@ -800,16 +824,22 @@ int emd::launch_bn_stats_final(const double* part, int nslab, int C, long npix, 
                                const float* gamma, const float* beta, float eps, float* scale, float* shift, int images,
                                const emd::BnFoldArgs* train_fold) {
     // images > 1: per-image statistics -- `nslab` partials and `npix` pixels PER IMAGE, part [image][nslab][2][C], mean / var [image][C]
+    const int cl = final_cl(nslab);
+    const unsigned ni = images > 1 ? images : 1;
+    const emd::BnFoldArgs fa = train_fold ? *train_fold : emd::BnFoldArgs{};
+#define EMD_FINAL(FOLD, TRAIN, CLV, GY) \
+    hipLaunchKernelGGL((bn_stats_final<FOLD, TRAIN, CLV>), dim3((C + CLV - 1) / CLV, GY), dim3(256), 0, st, part, nslab, C, npix, mean, var, gamma, \
+                       beta, eps, scale, shift, fa)
     if (train_fold) {
-        hipLaunchKernelGGL((bn_stats_final<false, true>), dim3((C + 15) / 16, images > 1 ? images : 1), dim3(256), 0, st, part, nslab, C, npix, mean,
-                           var, nullptr, nullptr, 0.f, nullptr, nullptr, *train_fold);
+        if (cl == 16) EMD_FINAL(false, true, 16, ni); else if (cl == 4) EMD_FINAL(false, true, 4, ni); else EMD_FINAL(false, true, 1, ni);
         return emd::check_launch("bn_stats_final<training fold>");
     }
-    if (scale)
-        hipLaunchKernelGGL(bn_stats_final<true>, dim3((C + 15) / 16), dim3(256), 0, st, part, nslab, C, npix, mean, var, gamma, beta,
-                           eps, scale, shift);
-    else
-        hipLaunchKernelGGL(bn_stats_final<false>, dim3((C + 15) / 16, images > 1 ? images : 1), dim3(256), 0, st, part, nslab, C, npix, mean, var);
+    if (scale) {
+        if (cl == 16) EMD_FINAL(true, false, 16, 1); else if (cl == 4) EMD_FINAL(true, false, 4, 1); else EMD_FINAL(true, false, 1, 1);
+    } else {
+        if (cl == 16) EMD_FINAL(false, false, 16, ni); else if (cl == 4) EMD_FINAL(false, false, 4, ni); else EMD_FINAL(false, false, 1, ni);
+    }
+#undef EMD_FINAL
     return emd::check_launch("bn_stats_final");
 }
 
@@ -1059,9 +1089,7 @@ extern "C" int emd_bn_stats_f32(const float* x, int ldx, long npix, int C, float
     else
         hipLaunchKernelGGL(bn_stats_partial, dim3((C + 63) / 64, (unsigned)nslab), dim3(256), 0, st, x, ldx, npix, C,
                            rows_per_slab, ws);
-    hipLaunchKernelGGL(bn_stats_final<false>, dim3((C + 15) / 16), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
-                       npix, mean, var);
-    return emd::check_launch("bn_stats");
+    return emd::launch_bn_stats_final(static_cast<const double*>(ws), (int)nslab, C, npix, mean, var, st);
 }
 
 // Per-image statistics of a batch [B][npix_img][C] in one pair of launches (instance norms; the batch-statistics norms of
@@ -1083,9 +1111,7 @@ extern "C" int emd_bn_stats_images_f32(const float* x, int ldx, int B, long npix
     else
         hipLaunchKernelGGL(bn_stats_partial, dim3((C + 63) / 64, (unsigned)nslab, B), dim3(256), 0, st, x, ldx, npix_img, C,
                            rows_per_slab, ws);
-    hipLaunchKernelGGL(bn_stats_final<false>, dim3((C + 15) / 16, B), dim3(256), 0, st, static_cast<const double*>(ws), (int)nslab, C,
-                       npix_img, mean, var);
-    return emd::check_launch("bn_stats (images)");
+    return emd::launch_bn_stats_final(static_cast<const double*>(ws), (int)nslab, C, npix_img, mean, var, st, nullptr, nullptr, 0.f, nullptr, nullptr, B);
 }
 
 // y = act(x*scale[image] + shift[image]) [+ res]: emd_affine_act_f32 with per-image scale / shift vectors [B][C].
