@@ -389,15 +389,15 @@ struct XRun {
             ar->release(ws);
         } else {
             T4 tmp = E(Ho, Wo, d.cin);
-            void* ws = raw(emd_bn_stats_workspace_bytes(M, d.cout));
+            void* ws = raw(emd_conv_stats_workspace_bytes(M, d.cout));
             if (live()) {
                 if (a.pre_s)
                     call(emd_dw3x3_pre_f32(a.t.ptr(), a.t.ld, a.pre_s, a.pre_t, p.dw, tmp.ptr(), tmp.ld, B, H, W, d.cin, d.stride, 1, st));
                 else
                     call(emd_dw3x3_f32(a.t.ptr(), a.t.ld, p.dw, tmp.ptr(), tmp.ld, B, H, W, d.cin, d.stride, 1, st));
-                call(emd_conv1x1_f32(tmp.ptr(), tmp.ld, p.pw.hi, p.pw.lo, p.one, p.zero, nullptr, nullptr, nullptr, 0, y.t.ptr(), y.t.ld, B, Ho, Wo, d.cin,
-                                     d.cout, 1, EMD_ACT_NONE, EMD_PREC_BF16X3, st));
-                call(emd_bn_stats_f32(y.t.ptr(), y.t.ld, M, d.cout, mean, var, ws, st));
+                // the statistics from the fp32 GEMM's epilogue (round 4; xception.py's sep does the same: identical bits)
+                call(emd_conv1x1_stats_f32(tmp.ptr(), tmp.ld, p.pw.hi, p.pw.lo, p.one, p.zero, y.t.ptr(), y.t.ld, B, Ho, Wo, d.cin, d.cout, 1,
+                                           EMD_PREC_BF16X3, 0, mean, var, ws, st));
                 call(emd_bn_fold_f32(mean, var, nullptr, p.beta, (float)BN_EPS_X, scale, shift, d.cout, st));
             }
             ar->release(tmp.buf);

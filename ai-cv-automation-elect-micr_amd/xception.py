@@ -347,9 +347,15 @@ class XceptionEngine:
                                                    act=ops.ACT_NONE, pre=pre, stats=True)
                     scale, shift = ops.bn_fold(mean, var, None, p["beta"], BN_EPS)
             else:
+                # (the narrow entry-flow layers at 256^2: no split32 form) -- the statistics come out of the fp32 GEMM's epilogue all the same
+                # (emd_conv1x1_stats_f32, round 4: built for the training step; a pass over y less)
                 tmp = ops.dw3x3(a, p["dw"], E(Ho, Wo, L.cin), stride=L.stride, pre=pre)
-                y = ops.conv1x1(tmp, p["pw"], p["one"], p["zero"], E(Ho, Wo, L.cout), act=ops.ACT_NONE, precision=prec)
-                mean, var = ops.bn_batch_stats(y)
+                y = E(Ho, Wo, L.cout)
+                if os.environ.get("EMD_X_CONV_STATS", "1") != "0":
+                    mean, var = ops.conv_stats(tmp, p["pw"], p["one"], p["zero"], y, precision=prec)
+                else:   # (dev: the two-launch form; the native executor has the epilogue form only, so its bit-identity test needs the default)
+                    ops.conv1x1(tmp, p["pw"], p["one"], p["zero"], y, act=ops.ACT_NONE, precision=prec)
+                    mean, var = ops.bn_batch_stats(y)
                 scale, shift = ops.bn_fold(mean, var, None, p["beta"], BN_EPS)
             if trace is not None:   # the oracle traces the SEP output before the residual add
                 tr_out = ops.affine_act(y, scale, shift, E(Ho, Wo, L.cout), act=RELU)
