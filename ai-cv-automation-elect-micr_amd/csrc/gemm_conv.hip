@@ -193,21 +193,9 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmParams p) {
                 for (int q = 0; q < A_PASSES; ++q) aoff[q] = rowA[a_row + q * 16];
             }
             const bool kok = c0 + a_col < p.Cin;  // Cin % 4 == 0: a float4 is all inside or all outside
-            if (FLAT) {
-                // 1x1 forms: every tile but the last is all real rows; plain loads there (block-uniform)
-                if (rows_all_valid && c0 + BK <= p.Cin) {
-#pragma unroll
-                    for (int q = 0; q < A_PASSES; ++q) areg[q] = *reinterpret_cast<const f32x4*>(Ab + aoff[q] + c0);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < A_PASSES; ++q) {
-                        // branch-free: an invalid row / K-tail chunk reads the tensor's first 16 bytes and is zeroed
-                        const bool ok = aoff[q] >= 0 && kok;
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? Ab + aoff[q] + c0 : p.A);
-                        areg[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-            } else {
+            {   // (round 4: the plain 1x1 forms had a fast path -- all rows real, plain loads -- beside a masked one that selected on the LOADED
+                // value; the compiler joined the two with copies of the loaded registers, i.e. uses: s_waitcnt vmcnt(0) right behind the
+                // loads in the steady state, the next K step's latency exposed in front of this step's MFMAs.  One path, select on the address.)
                 // forms with taps / strides: a row without a source pixel for this tap (padding) or a channel group beyond Cin
                 // reads 16 zero bytes.  The select is on the ADDRESS -- a select on the loaded value makes the wave wait for the
                 // load right here instead of a whole MFMA phase later (measured: the 3x3 / transposed-conv phases of graph D

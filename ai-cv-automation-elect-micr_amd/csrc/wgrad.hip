@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // mfma_f32_32x32x16_bf16 per fragment pair (lo*hi + hi*lo + hi*hi), fp32 accumulators.  Block = 4 waves, each a
 // 64x64 sub-tile; the next chunk's 16 global loads per thread are in flight during the MFMA phase.  The M range is
 // split over blockIdx.z and combined with float atomics, as above.
+__device__ __attribute__((aligned(16))) float g_zero_w[4];   // what the pixels past a slice's end and the padded taps load
 template <int UA, int UD>  // tile = 64*UA channels of A x 64*UD channels of dY
 __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(const WgradParams p) {
     constexpr int TK = 64 * UA, TN = 64 * UD, MC = 64;
@@ -145,44 +146,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(const WgradPara
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     f32x4 ra[UA][4], rd[UD][4];  // staging registers: [channel quad][pixel]
+    // ONE straight-line path (round 4): every load is issued unconditionally from an address that is either the element's or a 16-byte
+    // zero buffer's.  The first version had a fast path (full, ungathered chunk) and a masked path (zero, then load under `if`): the
+    // compiler joined them with register copies, and a copy of a loaded register is a use -- s_waitcnt vmcnt right behind the loads, the
+    // whole latency of the NEXT chunk's loads exposed in front of this chunk's MFMAs (in-kernel stamps: 38 % of the kernel; same
+    // disease and cure as gemm_conv.hip's loader).
     auto load_chunk = [&](int mc) {
-        if (p.flat && mc + MC <= mend) {
-            const float* ap = p.A + (long)(mc + 4 * pq) * p.lda;
-            const float* dp = p.dY + (long)(mc + 4 * pq) * p.ldd;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int u = 0; u < UA; ++u) ra[u][j] = *reinterpret_cast<const f32x4*>(ap + (long)j * p.lda + ca[u]);
-#pragma unroll
-                for (int u = 0; u < UD; ++u) rd[u][j] = *reinterpret_cast<const f32x4*>(dp + (long)j * p.ldd + cd[u]);
-            }
-            return;
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = mc + 4 * pq + j;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < UA; ++u) ra[u][j] = z;
-#pragma unroll
-            for (int u = 0; u < UD; ++u) rd[u][j] = z;
-            if (m < mend) {
-                long src = m;
-                if (!p.flat) {
-                    const unsigned um = (unsigned)m, jx = um % (unsigned)p.Wg, t = um / (unsigned)p.Wg;
-                    const int iy = (int)(t % (unsigned)p.Hg) * p.sa + dyo, ix = (int)jx * p.sa + dxo;
-                    src = (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa)
-                              ? ((long)(t / (unsigned)p.Hg) * p.Ha + iy) * (long)p.Wa + ix : -1;
-                }
-                if (src >= 0) {
-                    const float* ap = p.A + src * p.lda;
-#pragma unroll
-                    for (int u = 0; u < UA; ++u) ra[u][j] = *reinterpret_cast<const f32x4*>(ap + ca[u]);
-                }
-                const float* dp = p.dY + (long)m * p.ldd;
-#pragma unroll
-                for (int u = 0; u < UD; ++u) rd[u][j] = *reinterpret_cast<const f32x4*>(dp + cd[u]);
+            const bool in = m < mend;
+            long src = m;
+            if (!p.flat) {   // kernel-uniform; integer arithmetic only
+                const unsigned um = (unsigned)(in ? m : mbeg), jx = um % (unsigned)p.Wg, t = um / (unsigned)p.Wg;
+                const int iy = (int)(t % (unsigned)p.Hg) * p.sa + dyo, ix = (int)jx * p.sa + dxo;
+                src = (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) ? ((long)(t / (unsigned)p.Hg) * p.Ha + iy) * (long)p.Wa + ix : -1;
             }
+            const bool oka = in && src >= 0;
+            const float* ap = p.A + (oka ? src : 0) * p.lda;
+            const float* dp = p.dY + (long)(in ? m : 0) * p.ldd;
+#pragma unroll
+            for (int u = 0; u < UA; ++u) ra[u][j] = *reinterpret_cast<const f32x4*>(oka ? ap + ca[u] : g_zero_w);
+#pragma unroll
+            for (int u = 0; u < UD; ++u) rd[u][j] = *reinterpret_cast<const f32x4*>(in ? dp + cd[u] : g_zero_w);
         }
     };
     // 4 pixels of one channel -> 4 bf16 hi + 4 bf16 lo, one ds_write_b64 each
