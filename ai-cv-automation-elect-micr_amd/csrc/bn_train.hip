@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void chan_reduce_partial(const float* __restri
     }
 }
 
-// The same for C % 4 == 0: 16 channel quads x 16 row lanes per workgroup, 16-byte loads.
+// The same for C % 4 == 0: 16 channel quads x 16 row lanes per workgroup, 16-byte loads.  C1: dy from a Cout1Src (a template parameter: a
+// run-time test inside the unrolled loop kept its loads from being batched).
+template <bool C1 = false>
 __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __restrict__ dy, int ldd,
                                                               const float* __restrict__ x, int ldx,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
     // per-image form (gridDim.z images of npix pixels each, per-image statistics vectors [B][C]): image b = blockIdx.z
     {
         const long b = blockIdx.z;
-        if (c1.g1) c1.g1 += b * npix;
+        if (C1) c1.g1 += b * npix;
         else dy += b * npix * ldd;
         if (x) { x += b * npix * ldx; mean += b * C; rstd += b * C; }
         if (mask) { mscale += b * C; mshift += b * C; }
@@ -125,14 +127,16 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
             if (x) { mu[k] = mean[c + k]; rs[k] = rstd[c + k]; }
             if (mask) { ms[k] = mscale[c + k]; mh[k] = mshift[c + k]; }
         }
-        float4 wk[9];
-        if (c1.g1) {
+        float4 wk[C1 ? 9 : 1];
+        if constexpr (C1) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(c1.w9 + k * C + c);
         }
 #pragma unroll 4
         for (long r = r0 + rl; r < r1; r += 16) {
-            const float4 d = c1.g1 ? cout1_dy(c1, wk, r) : *reinterpret_cast<const float4*>(dy + r * ldd + c);
+            float4 d;
+            if constexpr (C1) d = cout1_dy(c1, wk, r);
+            else d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (x) xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
             const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -235,7 +239,7 @@ static void launch_final(const double* part, int nslab, int C, int B, float* s1,
 
 // dx = K * ( g - m1 - (x-mean)*m2 ),  g = dy * mask(x*mscale + mshift); dx may alias dy (elementwise).
 // V = 4: a thread keeps the six per-channel vectors of its channel quad in registers and walks ROWS rows with them.
-template <int V>
+template <int V, bool C1 = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int ldd, const float* __restrict__ x, int ldx,
                                                            const float* __restrict__ K, const float* __restrict__ m1,
                                                            const float* __restrict__ mean, const float* __restrict__ m2,
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
     constexpr int ROWS = V == 4 ? 8 : 1;
     {   // per-image form: image b = blockIdx.y, npix pixels per image, per-image vectors [B][C]
         const long b = blockIdx.y;
-        if (c1.g1) c1.g1 += b * npix;
+        if (C1) c1.g1 += b * npix;
         else dy += b * npix * ldd;
         x += b * npix * ldx; dx += b * npix * ldo;
         K += b * CV * V; m1 += b * CV * V; mean += b * CV * V; m2 += b * CV * V;
@@ -262,12 +266,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
         kk[k] = K[c + k]; mm1[k] = m1[c + k]; mu[k] = mean[c + k]; mm2[k] = m2[c + k];
         ms[k] = mask ? mscale[c + k] : 0.f; mh[k] = mask ? mshift[c + k] : 0.f;
     }
-    float4 wk[9];
-    if constexpr (V == 4) {
-        if (c1.g1) {
+    float4 wk[C1 ? 9 : 1];
+    if constexpr (V == 4 && C1) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(c1.w9 + k * (CV * 4) + c);
-        }
+        for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(c1.w9 + k * (CV * 4) + c);
     }
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
@@ -275,7 +277,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
         if (r >= npix) break;
         float dd[V], xx[V], o[V];
         if constexpr (V == 4) {
-            const float4 d = c1.g1 ? cout1_dy(c1, wk, r) : *reinterpret_cast<const float4*>(dy + r * ldd + c);
+            float4 d;
+            if constexpr (C1) d = cout1_dy(c1, wk, r);
+            else d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
             const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
             dd[0] = d.x; dd[1] = d.y; dd[2] = d.z; dd[3] = d.w;
             xx[0] = xv.x; xx[1] = xv.y; xx[2] = xv.z; xx[3] = xv.w;
@@ -569,8 +573,12 @@ static int bwd_reduce_impl(const float* dy, int ldd, const float* x, int ldx, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
     if (c1.g1 || (C % 4 == 0 && ldd % 4 == 0 && (!x || ldx % 4 == 0) && emd::aligned16(dy) && (!x || emd::aligned16(x))))
-        hipLaunchKernelGGL(chan_reduce_partial_v4, dim3((C + 63) / 64, (unsigned)ns, (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, mean,
-                           rstd, mscale, mshift, mask, npix, C, rps, ws, c1);
+        if (c1.g1)
+            hipLaunchKernelGGL(chan_reduce_partial_v4<true>, dim3((C + 63) / 64, (unsigned)ns, (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, mean,
+                               rstd, mscale, mshift, mask, npix, C, rps, ws, c1);
+        else
+            hipLaunchKernelGGL(chan_reduce_partial_v4<false>, dim3((C + 63) / 64, (unsigned)ns, (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, mean,
+                               rstd, mscale, mshift, mask, npix, C, rps, ws, c1);
     else
         hipLaunchKernelGGL(chan_reduce_partial, dim3((C + 63) / 64, (unsigned)ns, (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, mean,
                            rstd, mscale, mshift, mask, npix, C, rps, ws);
@@ -643,8 +651,12 @@ static int bwd_apply_impl(const float* dy, int ldd, const float* x, int ldx, con
     if (C % 4 == 0 && (c1.g1 || (ldd % 4 == 0 && emd::aligned16(dy))) && ldx % 4 == 0 && ldo % 4 == 0 && emd::aligned16(x) &&
         emd::aligned16(dx)) {
         const long n = ((npix + 7) / 8) * (C / 4);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, K,
-                           m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C / 4, c1);
+        if (c1.g1)
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, K,
+                               m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C / 4, c1);
+        else
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, dy, ldd, x, ldx, K,
+                               m1, mean, m2, mscale, mshift, mask, dx, ldo, npix, C / 4, c1);
     } else {
         EMD_REQUIRE(!c1.g1, EMD_E_ALIGN, "emd_bn_bwd_apply_cout1_f32: C, pitches multiples of 4; 16-byte aligned tensors");
         const long n = npix * C;

@@ -1,2 +1,2 @@
-timeout -k 10 300 python -m pytest tests/test_train_ops_gpu.py -x -q -m gpu -k "wgrad or weight_grad" 2>&1 | tail -2
-timeout -k 10 200 python tools/small_gemm_bench.py 2>&1 | grep wgrad
+timeout -k 10 600 python -m pytest tests/test_train_ops_gpu.py tests/test_train_gpu.py tests/test_gan_train_gpu.py -x -q -m gpu 2>&1 | tail -2
+for i in 1 2; do timeout -k 10 300 python bench.py --workload T --no-cpu-baseline --no-riders 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('T', d['ms_per_step'])"; done
