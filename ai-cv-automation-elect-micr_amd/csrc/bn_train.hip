@@ -122,23 +122,22 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
     if (c < C) {
         float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, ms[4] = {0.f, 0.f, 0.f, 0.f}, mh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (x) { mu[k] = mean[c + k]; rs[k] = rstd[c + k]; }
-            if (mask) { ms[k] = mscale[c + k]; mh[k] = mshift[c + k]; }
+        if (x) {
+            const float4 a = *reinterpret_cast<const float4*>(mean + c), b4 = *reinterpret_cast<const float4*>(rstd + c);
+            mu[0] = a.x; mu[1] = a.y; mu[2] = a.z; mu[3] = a.w;
+            rs[0] = b4.x; rs[1] = b4.y; rs[2] = b4.z; rs[3] = b4.w;
+        }
+        if (mask) {
+            const float4 a = *reinterpret_cast<const float4*>(mscale + c), b4 = *reinterpret_cast<const float4*>(mshift + c);
+            ms[0] = a.x; ms[1] = a.y; ms[2] = a.z; ms[3] = a.w;
+            mh[0] = b4.x; mh[1] = b4.y; mh[2] = b4.z; mh[3] = b4.w;
         }
         float4 wk[C1 ? 9 : 1];
         if constexpr (C1) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(c1.w9 + k * C + c);
         }
-#pragma unroll 4
-        for (long r = r0 + rl; r < r1; r += 16) {
-            float4 d;
-            if constexpr (C1) d = cout1_dy(c1, wk, r);
-            else d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
-            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (x) xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        auto term = [&](const float4 d, const float4 xv) {
             const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -146,6 +145,29 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_v4(const float* __res
                 s[k] += (double)g;
                 q[k] += (double)g * (double)((xx[k] - mu[k]) * rs[k]);
             }
+        };
+        long r = r0 + rl;
+        if constexpr (!C1) {
+            if (x) {   // four rows' loads in flight at a time (same rows, same order of the sums: same bits)
+                for (; r + 48 < r1; r += 64) {
+                    float4 d4[4], x4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        d4[u] = *reinterpret_cast<const float4*>(dy + (r + 16 * u) * ldd + c);
+                        x4[u] = *reinterpret_cast<const float4*>(x + (r + 16 * u) * ldx + c);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) term(d4[u], x4[u]);
+                }
+            }
+        }
+        for (; r < r1; r += 16) {
+            float4 d;
+            if constexpr (C1) d = cout1_dy(c1, wk, r);
+            else d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x) xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            term(d, xv);
         }
     }
 #pragma unroll
@@ -261,22 +283,54 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
     const int c = (int)(tid % CV) * V;
     const long r0 = (tid / CV) * ROWS;
     float kk[V], mm1[V], mu[V], mm2[V], ms[V], mh[V];
+    if constexpr (V == 4) {   // six 16-byte loads (the vectors are 16-byte aligned device allocations, C % 4 == 0), not twenty-four
+        const float4 a = *reinterpret_cast<const float4*>(K + c), b4 = *reinterpret_cast<const float4*>(m1 + c);
+        const float4 d4 = *reinterpret_cast<const float4*>(mean + c), e = *reinterpret_cast<const float4*>(m2 + c);
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f), g4 = f;
+        if (mask) {
+            f = *reinterpret_cast<const float4*>(mscale + c);
+            g4 = *reinterpret_cast<const float4*>(mshift + c);
+        }
+        kk[0] = a.x; kk[1] = a.y; kk[2] = a.z; kk[3] = a.w;
+        mm1[0] = b4.x; mm1[1] = b4.y; mm1[2] = b4.z; mm1[3] = b4.w;
+        mu[0] = d4.x; mu[1] = d4.y; mu[2] = d4.z; mu[3] = d4.w;
+        mm2[0] = e.x; mm2[1] = e.y; mm2[2] = e.z; mm2[3] = e.w;
+        ms[0] = f.x; ms[1] = f.y; ms[2] = f.z; ms[3] = f.w;
+        mh[0] = g4.x; mh[1] = g4.y; mh[2] = g4.z; mh[3] = g4.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-        kk[k] = K[c + k]; mm1[k] = m1[c + k]; mu[k] = mean[c + k]; mm2[k] = m2[c + k];
-        ms[k] = mask ? mscale[c + k] : 0.f; mh[k] = mask ? mshift[c + k] : 0.f;
+        for (int k = 0; k < V; ++k) {
+            kk[k] = K[c + k]; mm1[k] = m1[c + k]; mu[k] = mean[c + k]; mm2[k] = m2[c + k];
+            ms[k] = mask ? mscale[c + k] : 0.f; mh[k] = mask ? mshift[c + k] : 0.f;
+        }
     }
     float4 wk[C1 ? 9 : 1];
     if constexpr (V == 4 && C1) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(c1.w9 + k * (CV * 4) + c);
     }
+    // (V == 4, dy a tensor: all sixteen loads of the thread's eight rows first -- rows past the end re-read the last one --, then the
+    // arithmetic and the stores: with a load, a wait and a break per row the small maps of the 1/16-resolution flow, a handful of waves
+    // per CU, paid eight dependent round trips per thread)
+    float4 dpre[(V == 4 && !C1) ? ROWS : 1], xpre[(V == 4 && !C1) ? ROWS : 1];
+    if constexpr (V == 4 && !C1) {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const long r = r0 + i < npix ? r0 + i : npix - 1;
+            dpre[i] = *reinterpret_cast<const float4*>(dy + r * ldd + c);
+            xpre[i] = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
         const long r = r0 + i;
         if (r >= npix) break;
         float dd[V], xx[V], o[V];
-        if constexpr (V == 4) {
+        if constexpr (V == 4 && !C1) {
+            const float4 d = dpre[i], xv = xpre[i];
+            dd[0] = d.x; dd[1] = d.y; dd[2] = d.z; dd[3] = d.w;
+            xx[0] = xv.x; xx[1] = xv.y; xx[2] = xv.z; xx[3] = xv.w;
+        } else if constexpr (V == 4) {
             float4 d;
             if constexpr (C1) d = cout1_dy(c1, wk, r);
             else d = *reinterpret_cast<const float4*>(dy + r * ldd + c);
