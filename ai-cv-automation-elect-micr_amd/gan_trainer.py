@@ -174,9 +174,9 @@ class DiscriminatorTrainer:
             for lay in self.L[br]["layers"]:
                 Ho, Wo = -(-x.H // 2), -(-x.W // 2)
                 d = ops.dw3x3(x, self._dw(lay), self._E(1, Ho, Wo, x.C), stride=2)
-                r = ops.conv1x1(d, lay["pk_f"], self.ones, self.zeros, self._E(1, Ho, Wo, lay["cout"]), act=False,
-                                precision=self.precision)
-                mean, var = ops.bn_batch_stats(r)
+                # (round 4: the batch statistics from the GEMM's epilogue, emd_conv1x1_stats_f32 -- no pass over r of their own)
+                r = self._E(1, Ho, Wo, lay["cout"])
+                mean, var = ops.conv_stats(d, lay["pk_f"], self.ones, self.zeros, r, precision=self.precision)
                 b = lay["scope"] + "/BatchNorm"
                 f = lay["cout"]
                 mv = (self.m[b + "/moving_mean"], self.m[b + "/moving_variance"], self.scratch[2 * features5: 2 * features5 + f],
@@ -446,16 +446,18 @@ class GeneratorTrainer:
                 ops.dw3x3_reflect(x, self._dw(key), d, stride=L.stride)
             else:
                 ops.dw3x3(x, self._dw(key), d, stride=L.stride)
-        r = ops.conv1x1(d, self.pk_f[key], self.ones, self.zeros, self._E(d.B, Ho, Wo, L.cout), act=False, precision=self.precision)
         if self._batch_stats:
             # the train op's update ops (update_moving_statistics): both norms of the block on the BATCH statistics of this tower's
             # image (the second norm's follow analytically from the first's, as in graph D'), moving averages assigned in the same launch
             b1, b2 = L.scope + "/BatchNorm", L.outer_bn
-            mean, var = ops.bn_batch_stats(r)
+            r = self._E(d.B, Ho, Wo, L.cout)
+            mean, var = ops.conv_stats(d, self.pk_f[key], self.ones, self.zeros, r, precision=self.precision)   # statistics from the GEMM's epilogue
             f = TO.bn_train_fold(mean, var, self.v[b2 + "/gamma"], self.v[b2 + "/beta"], d.B * Ho * Wo, gamma1=self.v[b1 + "/gamma"],
                                  beta1=self.v[b1 + "/beta"], eps=BN_EPS_GEN, decay=BN_DECAY_GEN,
                                  moving=(self.m[b1 + "/moving_mean"], self.m[b1 + "/moving_variance"], self.m[b2 + "/moving_mean"],
                                          self.m[b2 + "/moving_variance"]))
+        else:
+            r = ops.conv1x1(d, self.pk_f[key], self.ones, self.zeros, self._E(d.B, Ho, Wo, L.cout), act=False, precision=self.precision)
         y = ops.affine_act(r, f["scale"], f["shift"], self._E(d.B, Ho, Wo, L.cout), act=ops.ACT_LEAKY, res=res)
         return y, {"x": x, "d": d, "r": r, "x_img": x_img}
 
