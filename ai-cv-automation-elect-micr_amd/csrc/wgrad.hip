@@ -27,6 +27,8 @@ struct WgradParams {
     unsigned long long dyp, dxp;
 };
 
+__device__ __attribute__((aligned(16))) float g_zero_w[4];   // what the pixels past a slice's end and the padded taps load
+
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int TK = 64, TN = 64, MC = 32;
     __shared__ __attribute__((aligned(16))) float As[MC][TK + 4];
@@ -91,6 +93,68 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
+// K = 4 (the network's first pointwise convs: a 1-channel image padded to 4 channels, cnn0 and residual0 of graph D'): the 64 x 64 tile
+// above is 1/16 full there and walks M in 32-pixel chunks between barriers -- 214 us for a pair of 512^2 images whose dY a stream
+// kernel reads in 30 (round 4 profile: 2.1 ms of the step's kernel time, at the very end of every tower's reverse pass).  Here a thread
+// owns four output columns and every 16th pixel of its slab: one 16-byte load of A, one of dY, sixteen FMAs per pixel, four pixels' loads
+// in flight; 16 pixel lanes -> LDS -> one float atomic per (k, n) and workgroup.  One tap, any stride (row map as above).
+__global__ __launch_bounds__(256) void conv_wgrad_k4_kernel(const WgradParams p, long pix_per_slab) {
+    const int nq = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int n = blockIdx.x * 64 + nq * 4;
+    const bool live = n < p.N;
+    const int nc = live ? n : 0;
+    const long p0 = (long)blockIdx.y * pix_per_slab, p1 = p0 + pix_per_slab < p.M ? p0 + pix_per_slab : p.M;
+    const int dyo = (int)(p.dyp & 127) - 64, dxo = (int)(p.dxp & 127) - 64;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    auto src_of = [&](long m) -> long {
+        if (p.flat) return m;
+        const int j = (int)(m % p.Wg);
+        const long t = m / p.Wg;
+        const int iy = (int)(t % p.Hg) * p.sa + dyo, ix = j * p.sa + dxo;
+        return (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) ? ((t / p.Hg) * p.Ha + iy) * (long)p.Wa + ix : -1;
+    };
+    auto fma16 = [&](const f32x4 a, const f32x4 d) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], d[j], acc[i][j]);
+    };
+    long m = p0 + lane;
+    for (; m + 48 < p1; m += 64) {
+        f32x4 a[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long mm = m + 16 * u, src = src_of(mm);
+            a[u] = *reinterpret_cast<const f32x4*>(src >= 0 ? p.A + src * p.lda : g_zero_w);
+            d[u] = *reinterpret_cast<const f32x4*>(p.dY + mm * p.ldd + nc);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fma16(a[u], d[u]);
+    }
+    for (; m < p1; m += 16) {
+        const long src = src_of(m);
+        fma16(*reinterpret_cast<const f32x4*>(src >= 0 ? p.A + src * p.lda : g_zero_w), *reinterpret_cast<const f32x4*>(p.dY + m * p.ldd + nc));
+    }
+    __shared__ float red[16][4][64 + 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[lane][i][nq * 4 + j] = acc[i][j];
+    __syncthreads();
+    const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const int nn = blockIdx.x * 64 + c;
+    if (nn < p.N && k < p.K) {
+        float sum = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) sum += red[l][k][c];
+        atomicAdd(p.dW + (long)k * p.N + nn, sum);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The same weight gradient on the matrix cores (the default path; the VALU kernel above remains for K or N < 32,
 // where a 128x128 tile would be nearly empty).  dW[k][n] = sum_m A[m][k] * dY[m][n]: the CONTRACTION runs over
@@ -101,7 +165,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // mfma_f32_32x32x16_bf16 per fragment pair (lo*hi + hi*lo + hi*hi), fp32 accumulators.  Block = 4 waves, each a
 // 64x64 sub-tile; the next chunk's 16 global loads per thread are in flight during the MFMA phase.  The M range is
 // split over blockIdx.z and combined with float atomics, as above.
-__device__ __attribute__((aligned(16))) float g_zero_w[4];   // what the pixels past a slice's end and the padded taps load
 template <int UA, int UD>  // tile = 64*UA channels of A x 64*UD channels of dY
 __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(const WgradParams p) {
     constexpr int TK = 64 * UA, TN = 64 * UD, MC = 64;
@@ -376,6 +439,14 @@ extern "C" int emd_conv_wgrad_f32(const float* a, int lda, const float* dy, int 
         else if (tn == 128) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 1>), grid, dim3(256), 0, st, p);
         return emd::check_launch("conv_wgrad_mfma_kernel");
+    }
+    if (K == 4 && ntaps == 1 && lda % 4 == 0 && N % 4 == 0) {
+        long nslab = (p.M + 2047) / 2048;
+        if (nslab > 512) nslab = 512;
+        const long pps = ((p.M + nslab - 1) / nslab + 15) / 16 * 16;
+        hipLaunchKernelGGL(conv_wgrad_k4_kernel, dim3((N + 63) / 64, (unsigned)((p.M + pps - 1) / pps)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           p, pps);
+        return emd::check_launch("conv_wgrad_k4_kernel");
     }
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(kt, nt, ntaps * p.msplit), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return emd::check_launch("conv_wgrad_kernel");

@@ -45,7 +45,9 @@ def leaf(a):
     (1, 512, 512, 128, 64, 1, 1, 1),    # deconv0_a pointwise / residual0_d
     (1, 256, 256, 384, 128, 1, 1, 1),   # deconv1_a pointwise / residual1_d
     (1, 128, 128, 384, 256, 1, 1, 1),   # deconv2_a
-    (1, 512, 512, 4, 128, 1, 2, 1),     # residual0: the zero-padded 1-channel image, stride 2
+    (1, 512, 512, 4, 128, 1, 2, 1),     # residual0: the zero-padded 1-channel image, stride 2 (conv_wgrad_k4_kernel, round 4)
+    (1, 512, 512, 4, 64, 1, 1, 1),      # cnn0's pointwise conv: the same, plain
+    (2, 9, 13, 4, 24, 1, 1, 1),         # ... ragged: a slab tail, a column tail
     (1, 32, 32, 728, 728, 3, 1, 18),    # ASPP rate-18 branch at the tower's 32 x 32: most taps fall into the padding
 ])
 def test_conv_wgrad(B, H, W, ci, co, k, stride, rate):
