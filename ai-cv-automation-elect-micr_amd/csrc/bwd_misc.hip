@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 // a strip of TH output rows keeping the three live input rows x[.][ox-1..ox+1] in registers, so every output pixel
 // costs 4 vector loads (3 of x, 1 of dy) instead of 10; neighbouring lanes share the x loads through L1.
 // Block = 16 channel quads x 16 columns; grid (ceil(C/64), ceil(W/16), B * strips).
-template <int TH, bool PRE = false>
+// SCALAR (round 4): dy has ONE channel -- the weight gradient of the final 3x3 conv to one output channel ran on the generic kernel, nine
+// gathers of x per pixel: 204 us for a pair of 512^2 x 64 maps this form reads once.
+template <int TH, bool PRE = false, bool SCALAR = false>
 __global__ __launch_bounds__(256) void dw_wgrad_roll_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
                                                             int ldd, float* __restrict__ dw, int H, int W, int C, int nstrip,
                                                             const float* __restrict__ pre_s = nullptr, const float* __restrict__ pre_t = nullptr,
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_roll_kernel(const float* __restr
     for (int t = 0; t < 9; ++t) acc[t] = f4zero();
     if (c < C && ox < W) {
         const float* xb = x + ((long)b * H) * W * ldx + c;
-        const float* db = dy + ((long)b * H) * W * ldd + c;
+        const float* db = dy + ((long)b * H) * W * ldd + (SCALAR ? 0 : c);
         const bool hl = ox > 0, hr = ox + 1 < W;
         float4 ps = f4zero(), pq = f4zero();
         if (PRE) {
@@ -149,7 +151,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_roll_kernel(const float* __restr
         const int y1 = y0 + TH < H ? y0 + TH : H;
         for (int oy = y0; oy < y1; ++oy) {
             row(oy + 1, c0, c1, c2);
-            const float4 g = *reinterpret_cast<const float4*>(db + ((long)oy * W + ox) * ldd);
+            float4 g;
+            if constexpr (SCALAR) {
+                const float v = db[(long)oy * W + ox];
+                g = make_float4(v, v, v, v);
+            } else {
+                g = *reinterpret_cast<const float4*>(db + ((long)oy * W + ox) * ldd);
+            }
             acc[0] = fma4(a0, g, acc[0]); acc[1] = fma4(a1, g, acc[1]); acc[2] = fma4(a2, g, acc[2]);
             acc[3] = fma4(b0, g, acc[3]); acc[4] = fma4(b1, g, acc[4]); acc[5] = fma4(b2, g, acc[5]);
             acc[6] = fma4(c0, g, acc[6]); acc[7] = fma4(c1, g, acc[7]); acc[8] = fma4(c2, g, acc[8]);
@@ -208,6 +216,53 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
         }
     }
     *reinterpret_cast<float4*>(dx + ((b * H + iy) * (long)W + ix) * ldx + c) = acc;
+}
+
+// The SCALAR stride-1 case above for the large maps (the final conv's data gradient: 64 channels at 512^2): a thread = four pixels along
+// W x 4 channels, the nine taps' weights and the 3 x 6 window of the 1-channel gradient image in registers -- nine weight loads per four
+// pixels instead of per pixel.  Sums in dw_bwd_data_kernel<true>'s order (ky, then kx): its bits.  W % 4 == 0.
+__global__ __launch_bounds__(256) void cout1_bwd_data_x4_kernel(const float* __restrict__ g1, const float* __restrict__ w, float* __restrict__ dx,
+                                                                int ldx, int H, int W, int C4, long nthreads) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nthreads) return;
+    const int c = (int)(tid % C4) * 4;
+    long q = tid / C4;
+    const int W4 = W >> 2;
+    const int ix0 = (int)(q % W4) * 4;
+    q /= W4;
+    const int iy = (int)(q % H);
+    const long b = q / H;
+    const int C = C4 * 4;
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(w + k * C + c);
+    const float* gi = g1 + b * (long)H * W;
+    // window value (row iy + 1 - ky, column ix + 1 - kx) for output pixel ix = ix0 + j: columns ix0 - 1 .. ix0 + 4
+    float gw[3][6];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ny = iy + 1 - ky;
+        const bool rowok = ny >= 0 && ny < H;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+            const int nx = ix0 - 1 + cc;
+            gw[ky][cc] = (rowok && nx >= 0 && nx < W) ? gi[(long)ny * W + nx] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float4 acc = f4zero();
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int nx = ix0 + j + 1 - kx;       // column of the tap; a padded tap adds nothing in the generic kernel: skip it
+                const int ny = iy + 1 - ky;
+                if (ny < 0 || ny >= H || nx < 0 || nx >= W) continue;
+                acc = fma4s(wk[ky * 3 + kx], gw[ky][j + 2 - kx], acc);
+            }
+        *reinterpret_cast<float4*>(dx + ((b * H + iy) * (long)W + ix0 + j) * ldx + c) = acc;
+    }
 }
 
 // Gradient of the legacy (align_corners=False, no half-pixel) bilinear resize: every INPUT pixel gathers from
@@ -348,11 +403,11 @@ int launch_wgrad(const float* x, int ldx, const float* dy, int ldd, float* dw, i
                  int rate, hipStream_t st, const float* pre_s = nullptr, const float* pre_t = nullptr, long pre_ld = 0, float pre_hi = 0.f) {
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const long npix = (long)B * Ho * Wo;
-    if (!SCALAR && stride == 1 && rate == 1 && H >= 64 && W >= 64) {  // the large maps: rolling-window form
+    if (stride == 1 && rate == 1 && H >= 64 && W >= 64) {  // the large maps: rolling-window form
         constexpr int TH = 32;
         const int nstrip = (H + TH - 1) / TH;
         if ((long)B * nstrip <= 65535 && (W + 15) / 16 <= 65535) {
-            hipLaunchKernelGGL((dw_wgrad_roll_kernel<TH, PRE>), dim3((C + 63) / 64, (W + 15) / 16, B * nstrip), dim3(256), 0, st, x, ldx,
+            hipLaunchKernelGGL((dw_wgrad_roll_kernel<TH, PRE, SCALAR>), dim3((C + 63) / 64, (W + 15) / 16, B * nstrip), dim3(256), 0, st, x, ldx,
                                dy, ldd, dw, H, W, C, nstrip, pre_s, pre_t, pre_ld, pre_hi);
             return emd::check_launch("dw_wgrad_roll_kernel");
         }
@@ -436,6 +491,14 @@ extern "C" int emd_conv3x3_cout1_bwd_data_f32(const float* dy, const float* w, f
     EMD_REQUIRE(B >= 0 && H >= 1 && W >= 1, EMD_E_INVALID, "emd_conv3x3_cout1_bwd_data_f32: bad shape");
     EMD_REQUIRE(dw_args_ok(dx, ldx, Cin) && emd::aligned16(w), EMD_E_ALIGN, "emd_conv3x3_cout1_bwd_data_f32: Cin, ldx multiples of 4, 16-byte aligned");
     if (B == 0) return EMD_OK;
+    if (W % 4 == 0 && (long)H * W >= 64 * 64) {   // the large maps
+        const long nthreads = (long)B * H * (W / 4) * (Cin / 4);
+        unsigned nb;
+        int rc = blocks_for(nthreads, &nb);
+        if (rc != EMD_OK) return rc;
+        hipLaunchKernelGGL(cout1_bwd_data_x4_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), dy, w, dx, ldx, H, W, Cin / 4, nthreads);
+        return emd::check_launch("cout1_bwd_data_x4_kernel");
+    }
     return launch_bwd_data<true>(dy, 1, w, dx, ldx, B, H, W, Cin, 1, 1, static_cast<hipStream_t>(stream));
 }
 

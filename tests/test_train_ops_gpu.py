@@ -222,7 +222,7 @@ def test_dw3x3_backward(B, H, W, Cc, stride):
         assert rel_l2(dx2.torch().cpu().numpy(), gx.numpy()) < TOL_F32
 
 
-@pytest.mark.parametrize("B,H,W,ci", [(2, 12, 16, 64), (1, 5, 7, 128), (2, 64, 64, 64)])
+@pytest.mark.parametrize("B,H,W,ci", [(2, 12, 16, 64), (1, 5, 7, 128), (2, 64, 64, 64), (1, 72, 88, 24)])
 def test_conv3x3_cout1_backward(B, H, W, ci):
     from emdenoise import train_ops as TO
     from oracle import tf_ops as T
