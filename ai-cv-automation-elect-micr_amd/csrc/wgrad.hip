@@ -332,52 +332,74 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const emd_pack_
         else hi = mid - 1;
     }
     const emd_pack_job_t j = jobs[lo];
+    const long lb = blk - j.first_block;
+    auto split_store = [&](long o, const float (&v)[4]) {   // four consecutive packed elements: one 8-byte store per plane
+        unsigned h01, l01, h23, l23;
+        split2(v[0], v[1], h01, l01);
+        split2(v[2], v[3], h23, l23);
+        *reinterpret_cast<u32x2*>(j.hi + o) = u32x2{h01, h23};
+        *reinterpret_cast<u32x2*>(j.lo + o) = u32x2{l01, l23};
+    };
     if (!j.cout_major) {
-        // [taps][Cin][Cout] -> [Npad][taps][Cpad] is a transpose: one thread per packed element (below) reads with a stride of Cout floats --
-        // a 32-byte sector per 4-byte value, 2 GB fetched for the model's 160 MB of weights and 450 us at the end of every training step
-        // (round 4: profiles/r04_t_traffic_by_kernel.txt).  Here a block moves a 16 (c) x 16 (n) tile of one tap through LDS: 64-byte
-        // runs on the read side, 32-byte runs on the write side.
-        __shared__ float tile[16][17];
-        const long lb = blk - j.first_block;
-        const int ntc = (j.cpad + 15) >> 4;
+        // [taps][Cin][Cout] -> [Npad][taps][Cpad] is a transpose: one thread per packed element read with a stride of Cout floats -- a
+        // 32-byte sector per 4-byte value, 2 GB fetched for the model's 160 MB of weights (round 4: profiles/r04_t_traffic_by_kernel.txt).
+        // A block moves a 64 (c) x 16 (n) tile of one tap through LDS: 64-byte runs read (a thread = four consecutive n of one c), 128-byte
+        // runs written (a thread = four consecutive c of one n, 8 bytes per plane).
+        __shared__ float tile[64][17];
+        const int ntc = (j.cpad + 63) >> 6;
         const int tc = (int)(lb % ntc);
         const long rest = lb / ntc;
         const int t = (int)(rest % j.ntaps);
         const int tn = (int)(rest / j.ntaps);
         const int npad = (int)(j.total / ((long)j.ntaps * j.cpad));
-        const int i = threadIdx.x >> 4, jj = threadIdx.x & 15;
+        const long st = (long)((j.tap_sel >> (4 * t)) & 15);
         {
-            const int c = tc * 16 + i, n = tn * 16 + jj;
-            const long st = (long)((j.tap_sel >> (4 * t)) & 15);
-            tile[i][jj] = (c < j.cin && n < j.cout) ? j.w[(st * j.cin + c) * j.cout + n] : 0.f;
+            const int c = tc * 64 + (threadIdx.x >> 2), n = tn * 16 + (threadIdx.x & 3) * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (c < j.cin) {
+                const float* src = j.w + (st * j.cin + c) * j.cout + n;
+                if (n + 3 < j.cout && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {   // (a variable's slice of the flat parameter vector need not be 16-byte aligned)
+                    const float4 q = *reinterpret_cast<const float4*>(src);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (n + k < j.cout) v[k] = src[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tile[threadIdx.x >> 2][(threadIdx.x & 3) * 4 + k] = v[k];
         }
         __syncthreads();
-        const int n = tn * 16 + i, c = tc * 16 + jj;
-        if (n < npad && c < j.cpad) {
-            const float v = tile[jj][i];
-            const long o = ((long)n * j.ntaps + t) * j.cpad + c;
-            const __bf16 h = (__bf16)v;
-            const __bf16 l = (__bf16)(v - (float)h);
-            j.hi[o] = __builtin_bit_cast(uint16_t, h);
-            j.lo[o] = __builtin_bit_cast(uint16_t, l);
+        const int n = tn * 16 + (threadIdx.x >> 4), c = tc * 64 + (threadIdx.x & 15) * 4;
+        if (n < npad && c < j.cpad) {   // cpad % 64 == 0: four packed elements are all inside
+            const float v[4] = {tile[(threadIdx.x & 15) * 4 + 0][threadIdx.x >> 4], tile[(threadIdx.x & 15) * 4 + 1][threadIdx.x >> 4],
+                                tile[(threadIdx.x & 15) * 4 + 2][threadIdx.x >> 4], tile[(threadIdx.x & 15) * 4 + 3][threadIdx.x >> 4]};
+            split_store(((long)n * j.ntaps + t) * j.cpad + c, v);
         }
         return;
     }
-    const long idx = (blk - j.first_block) * 256 + threadIdx.x;
+    // cout_major: source rows are contiguous along c -- a thread packs four consecutive c (cpad % 64 == 0)
+    const long idx = (lb * 256 + threadIdx.x) * 4;
     if (idx >= j.total) return;
     const int c = (int)(idx % j.cpad);
     const long r = idx / j.cpad;
     const int t = (int)(r % j.ntaps);
     const int n = (int)(r / j.ntaps);
-    float v = 0.f;
-    if (c < j.cin && n < j.cout) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < j.cout) {
         const long st = (long)((j.tap_sel >> (4 * t)) & 15);
-        v = j.cout_major ? j.w[(st * j.cout + n) * j.cin + c] : j.w[(st * j.cin + c) * j.cout + n];
+        const float* src = j.w + (st * j.cout + n) * j.cin + c;
+        if (c + 3 < j.cin && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const float4 q = *reinterpret_cast<const float4*>(src);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c + k < j.cin) v[k] = src[k];
+        }
     }
-    const __bf16 h = (__bf16)v;
-    const __bf16 l = (__bf16)(v - (float)h);
-    j.hi[idx] = __builtin_bit_cast(uint16_t, h);
-    j.lo[idx] = __builtin_bit_cast(uint16_t, l);
+    split_store(idx, v);
 }
 
 }  // namespace
@@ -489,8 +511,8 @@ extern "C" int emd_pack_job_fill(emd_pack_job_t* job, const float* w, int src_ta
     job->w = w; job->hi = hi; job->lo = lo; job->tap_sel = sel;
     job->total = npad * ntaps * cpad;
     job->first_block = 0;
-    // cout_major: one thread per packed element; else 16 x 16 (n, c) tiles per tap (see pack_weights_batch_kernel)
-    job->n_blocks = cout_major ? (job->total + 255) / 256 : (long)ntaps * ((npad + 15) / 16) * ((cpad + 15) / 16);
+    // cout_major: a thread per four packed elements; else 16 (n) x 64 (c) tiles per tap (see pack_weights_batch_kernel)
+    job->n_blocks = cout_major ? (job->total / 4 + 255) / 256 : (long)ntaps * ((npad + 15) / 16) * ((cpad + 63) / 64);
     job->ntaps = ntaps; job->cin = Cin; job->cout = Cout; job->cout_major = cout_major ? 1 : 0; job->cpad = cpad; job->pad_ = 0;
     return EMD_OK;
 }
