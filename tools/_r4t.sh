@@ -1,2 +1,3 @@
-timeout -k 10 600 python -m pytest tests/test_train_ops_gpu.py tests/test_train_gpu.py -x -q -m gpu -k "pack or train_steps or checkpoint or gradients_smooth" 2>&1 | tail -2
-for i in 1 2; do timeout -k 10 300 python bench.py --workload T --no-cpu-baseline --no-riders 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('T', d['ms_per_step'])"; done
+for v in 0 1 0 1; do
+  EMD_T_STAGGER=$v timeout -k 10 300 python bench.py --workload T --no-cpu-baseline --no-riders 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('stagger=$v', d['ms_per_step'])"
+done
