@@ -108,7 +108,13 @@ def test_pack_job_struct_layout_matches_the_header():
     assert rc == 0
     assert (job.w, job.hi, job.lo) == (0x1000, 0x2000, 0x3000)
     assert job.tap_sel == (1 | (0 << 4)) and (job.ntaps, job.cin, job.cout, job.cout_major) == (2, 100, 72, 1)
-    assert job.cpad == 128 and job.total == 128 * 2 * 128 and job.n_blocks == (job.total + 255) // 256 and job.first_block == 0
+    # (cout_major: a thread packs four consecutive elements -- round 4)
+    assert job.cpad == 128 and job.total == 128 * 2 * 128 and job.n_blocks == (job.total // 4 + 255) // 256 and job.first_block == 0
+    # the transposing orientation: 16 (n) x 64 (c) tiles per tap
+    rc = lib.emd_pack_job_fill(C.byref(job), C.c_void_p(0x1000), 3, 2, sel, 100, 72, 0, C.c_void_p(0x2000), C.c_void_p(0x3000))
+    assert rc == 0 and job.cout_major == 0 and job.n_blocks == 2 * ((job.total // (2 * job.cpad) + 15) // 16) * ((job.cpad + 63) // 64)
+    rc = lib.emd_pack_job_fill(C.byref(job), C.c_void_p(0x1000), 3, 2, sel, 100, 72, 1, C.c_void_p(0x2000), C.c_void_p(0x3000))
+    assert rc == 0
     assert C.sizeof(_lib.PackJob) == 80
     # a tap subset needs tap_sel; out-of-range selections are refused
     assert lib.emd_pack_job_fill(C.byref(job), C.c_void_p(0x1000), 3, 2, None, 100, 72, 1, C.c_void_p(0x2000), C.c_void_p(0x3000)) != 0
